@@ -1,0 +1,150 @@
+/*
+ * rg.h -- C ABI of the MI355X-native RoarGraph hot path (librg_hip.so).
+ *
+ * Plain pointers and sizes only; no C++ or torch types cross this boundary.
+ * Every entry point names the reference interface it replaces (file:line into
+ * matchyc/RoarGraph @ 2024_10_08).  INTEGRATION.md shows the binding a
+ * maintainer of the reference would add.
+ *
+ * Conventions kept from the reference:
+ *   - smaller score = closer.  Inner product returns -dot (distance.h:223),
+ *     L2 returns the squared distance (distance.h:87), cosine = IP on
+ *     L2-normalised vectors (index_bipartite.cpp:2679-2684).
+ *   - metric codes are efanna2e::Metric values (distance.h:15).
+ *   - vectors are row-major fp32 with a row stride of ceil(dim/8)*8 floats,
+ *     zero padded (util.h:37-75, 191-199).
+ *   - results of rg_search are bit-identical to SearchRoarGraph's for the
+ *     same .index / base / query / L_pq.
+ *
+ * Error handling: no exception crosses the ABI.  Functions return RG_OK or a
+ * negative rg_status; rg_last_error() returns the message (thread local), with
+ * the reference's wording where it has one ("Data file size wrong!",
+ * "not enough results: N, expected: K").
+ *
+ * Pointer suffixes: plain = host memory, d_ = device (HBM) memory on the
+ * index's GPU.  `stream` is a hipStream_t passed as void* (NULL = default).
+ */
+#ifndef RG_H
+#define RG_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef int rg_status;
+enum {
+    RG_OK = 0,
+    RG_ERR_IO = -1,         /* cannot open / short read */
+    RG_ERR_FORMAT = -2,     /* "Data file size wrong!" and friends */
+    RG_ERR_ARG = -3,        /* bad argument (k > L_pq, dim mismatch, ...) */
+    RG_ERR_DEVICE = -4,     /* HIP error, or no gfx950 device */
+    RG_ERR_NOT_ENOUGH = -5, /* "not enough results" (index_bipartite.cpp:2408-2412) */
+    RG_ERR_OOM = -6
+};
+enum { RG_METRIC_L2 = 0, RG_METRIC_IP = 1, RG_METRIC_COSINE = 4 }; /* distance.h:15 */
+
+typedef struct rg_index rg_index;
+
+const char *rg_last_error(void);
+const char *rg_version(void);
+/* number of visible HIP devices (0 on a CPU-only host; never fails) */
+int rg_device_count(void);
+
+/* ------------------------------------------------------------------ formats
+ * Host-side readers/writers with the reference's validation rules. Buffers
+ * returned through ** are malloc'ed by the library; release with rg_free. */
+void rg_free(void *p);
+/* load_meta<float>, util.h:106-127 */
+rg_status rg_fbin_meta(const char *path, uint32_t *npts, uint32_t *dim);
+/* load_data<float> + data_align, util.h:179-211, 37-75: rows at stride ceil(dim/8)*8, zero padded */
+rg_status rg_fbin_load(const char *path, uint32_t *npts, uint32_t *dim, uint32_t *stride, float **data);
+rg_status rg_fbin_save(const char *path, const float *data, uint32_t npts, uint32_t dim, uint32_t stride);
+/* load_gt_meta / load_gt_data_with_dist, util.h:84-105, 129-155 */
+rg_status rg_gt_meta(const char *path, uint32_t *npts, uint32_t *k);
+rg_status rg_gt_load(const char *path, uint32_t *npts, uint32_t *k, uint32_t **ids, float **dists);
+/* writer of the same layout (what compute_groundtruth emits, README.md:70-74) */
+rg_status rg_gt_save(const char *path, const uint32_t *ids, const float *dists, uint32_t npts, uint32_t k);
+/* LoadLearnBaseKNN, index_bipartite.cpp:2622-2642: header + ids only */
+rg_status rg_knn_ids_load(const char *path, uint32_t *npts, uint32_t *k, uint32_t **ids);
+/* LoadProjectionGraph / SaveProjectionGraph, index_bipartite.cpp:2097-2117 / 2606-2619; CSR in memory */
+rg_status rg_graph_load(const char *path, uint32_t *nd, uint32_t *ep, uint64_t **offsets, uint32_t **nbrs);
+rg_status rg_graph_save(const char *path, uint32_t nd, uint32_t ep, const uint64_t *offsets, const uint32_t *nbrs);
+/* ComputeRecall, tests/test_search_roargraph.cpp:23-36 */
+float rg_recall(uint32_t nq, uint32_t k, uint32_t gt_dim, const uint32_t *res, const uint32_t *gt);
+/* normalize<float>, util.h:214-225 (cosine) */
+void rg_normalize_rows(float *data, size_t n, size_t stride, uint32_t dim);
+
+/* ---------------------------------------------------------------- lifecycle
+ * Replaces: IndexBipartite(dim, n, metric, nullptr) (index_bipartite.h:27)
+ *           -> LoadSearchNeededData(base, "")       (index_bipartite.h:62-64, .cpp:2664-2695)
+ *           -> LoadProjectionGraph(file)            (index_bipartite.h:105, .cpp:2097-2117)
+ *           -> InitVisitedListPool(T)               (index_bipartite.h:133)
+ * The index is immutable after open. */
+rg_status rg_index_open(const char *base_fbin, const char *index_path, int metric, int device, rg_index **out);
+/* same from host memory (copied to HBM); offsets has nd+1 entries */
+rg_status rg_index_open_mem(const float *base, uint32_t nd, uint32_t dim, uint32_t stride, const uint64_t *offsets,
+                            const uint32_t *nbrs, uint32_t ep, int metric, int device, rg_index **out);
+/* same from buffers already resident in HBM.  d_base is BORROWED (caller keeps it alive and unchanged);
+ * the graph is converted to the library's own layout, d_offsets/d_nbrs may be freed after the call. */
+rg_status rg_index_open_dev(const float *d_base, uint32_t nd, uint32_t dim, uint32_t stride,
+                            const uint64_t *d_offsets, const uint32_t *d_nbrs, uint32_t ep, int metric, int device,
+                            rg_index **out);
+void rg_index_close(rg_index *idx);
+rg_status rg_index_info(const rg_index *idx, uint32_t *nd, uint32_t *dim, uint32_t *stride, uint32_t *ep,
+                        float *avg_degree, uint32_t *max_degree, int *device);
+/* tuning knobs (do not change results): name in {"waves_per_cu", "rows_per_pass", "layout"} */
+rg_status rg_index_set(rg_index *idx, const char *name, int value);
+
+/* ----------------------------------------------------------------- operator
+ * Replaces: float Distance::compare(const float *a, const float *b, unsigned length) (distance.h:18;
+ * DistanceInnerProduct distance.h:108-225, DistanceL2 distance.h:39-89), batched:
+ *   out[i] == compare(base + ids[i]*stride, query, stride)   bit for bit. */
+rg_status rg_score_batch(rg_index *idx, const float *query, const uint32_t *ids, uint32_t n, float *out);
+rg_status rg_score_batch_dev(rg_index *idx, const float *d_query, const uint32_t *d_ids, uint32_t n, float *d_out,
+                             void *stream);
+
+/* ------------------------------------------------------------------- search
+ * Replaces: the OpenMP loop over IndexBipartite::SearchRoarGraph(query, k, qid, params{L_pq}, indices, res_dists)
+ * (tests/test_search_roargraph.cpp:203-209; index_bipartite.h:100-101, .cpp:2311-2420).
+ *   queries  nq rows, row stride qstride floats (>= the index stride's dim; only dim values are read)
+ *   out_ids  nq*k, out_dists nq*k (first k queue entries, (distance,id) order), out_cmps/out_hops nq
+ *            (the pair SearchRoarGraph returns; either may be NULL)
+ * Errors: RG_ERR_ARG if k > L_pq (the CLI's check, test_search_roargraph.cpp:192-195);
+ *         RG_ERR_NOT_ENOUGH "not enough results: N, expected: K" for the first failing query. */
+rg_status rg_search(rg_index *idx, const float *queries, uint32_t nq, uint32_t qstride, uint32_t k, uint32_t L_pq,
+                    uint32_t *out_ids, float *out_dists, uint32_t *out_cmps, uint32_t *out_hops);
+/* device-resident form; enqueues on `stream` and returns without synchronising.
+ * rg_search_wait() synchronises that stream and reports the deferred RG_ERR_NOT_ENOUGH, if any. */
+rg_status rg_search_dev(rg_index *idx, const float *d_queries, uint32_t nq, uint32_t qstride, uint32_t k,
+                        uint32_t L_pq, uint32_t *d_ids, float *d_dists, uint32_t *d_cmps, uint32_t *d_hops,
+                        void *stream);
+rg_status rg_search_wait(rg_index *idx, void *stream);
+
+/* ------------------------------------------------------------- ground truth
+ * Replaces: the external `compute_groundtruth --data_type float --dist_fn {l2,mips,cosine} --base_file F
+ * --query_file F --gt_file F --K n` (README.md:62-75; thirdparty/DiskANN is an empty submodule in the
+ * reference tree).  Output rows are sorted best first; dists are +inner product for mips
+ * (tests/test_search_bipartite.cpp:46-48) and squared L2 for l2.
+ *
+ * rg_gt_shard_dev: one GPU's part. Scores all nq queries against base rows [0, nb) of this shard and
+ * writes the shard-local top-K (ids offset by id_base) sorted best first.  K <= 1024.
+ * rg_gt_merge_dev: merges nlists sorted K-lists per query (layout [list][nq][K]) into one. */
+rg_status rg_gt_shard_dev(const float *d_base, uint32_t nb, uint32_t bstride, const float *d_queries, uint32_t nq,
+                          uint32_t qstride, uint32_t dim, int metric, uint32_t K, uint32_t id_base, uint32_t *d_ids,
+                          float *d_dists, int device, void *stream);
+rg_status rg_gt_merge_dev(const uint32_t *d_ids_in, const float *d_dists_in, uint32_t nlists, uint32_t nq, uint32_t K,
+                          int metric, uint32_t *d_ids, float *d_dists, int device, void *stream);
+/* host-memory convenience: whole job on `ndev` GPUs of this process (base sharded by rows) */
+rg_status rg_groundtruth_mem(const float *base, uint32_t nb, uint32_t bstride, const float *queries, uint32_t nq,
+                             uint32_t qstride, uint32_t dim, int metric, uint32_t K, uint32_t *out_ids,
+                             float *out_dists, const int *devices, int ndev);
+/* file form: the CLI twin's body */
+rg_status rg_groundtruth(const char *base_fbin, const char *query_fbin, const char *gt_out, int metric, uint32_t K,
+                         const int *devices, int ndev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,278 @@
+"""ctypes front-end of the CPU oracle -- TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import
+this module.  It wraps oracle/librg_oracle.so (plain-C restatement, see
+rg_oracle.h) and, when present, the oracle/_ref/rg_ref binary that is compiled
+from the reference's own headers.
+"""
+import ctypes as C
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "librg_oracle.so")
+REF_BIN = os.path.join(HERE, "_ref", "rg_ref")
+
+METRIC = {"l2": 0, "ip": 1, "cosine": 4}
+
+_lib = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", HERE], stdout=subprocess.DEVNULL)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            build()
+        L = C.CDLL(LIB_PATH)
+        L.rgo_compare.restype = C.c_float
+        L.rgo_compare.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_uint]
+        L.rgo_recall.restype = C.c_float
+        L.rgo_last_error.restype = C.c_char_p
+        L.rgo_queue_trace.restype = C.c_size_t
+        _lib = L
+    return _lib
+
+
+class Graph(C.Structure):
+    _fields_ = [("nd", C.c_uint32), ("ep", C.c_uint32), ("offsets", C.c_void_p), ("nbrs", C.c_void_p)]
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def have_avx512():
+    return bool(lib().rgo_have_avx512())
+
+
+def use_avx512(on):
+    lib().rgo_use_avx512(int(bool(on)))
+
+
+def compare(metric, a, b):
+    a = np.ascontiguousarray(a, np.float32)
+    b = np.ascontiguousarray(b, np.float32)
+    return float(lib().rgo_compare(METRIC[metric], _p(a), _p(b), a.shape[0]))
+
+
+def compare_pairs(metric, a, b):
+    """a, b: [n, d] -> f32[n], row-wise compare."""
+    a = np.ascontiguousarray(a, np.float32)
+    b = np.ascontiguousarray(b, np.float32)
+    n, d = a.shape
+    out = np.empty(n, np.float32)
+    f = lib().rgo_compare
+    m = METRIC[metric]
+    for i in range(n):
+        out[i] = f(m, C.c_void_p(a.ctypes.data + i * d * 4), C.c_void_p(b.ctypes.data + i * d * 4), d)
+    return out
+
+
+def score_batch(base, metric, query, ids):
+    base = np.ascontiguousarray(base, np.float32)
+    query = np.ascontiguousarray(query, np.float32)
+    ids = np.ascontiguousarray(ids, np.uint32)
+    out = np.empty(ids.shape[0], np.float32)
+    lib().rgo_score_batch(_p(base), C.c_size_t(base.shape[1]), C.c_uint(base.shape[1]), METRIC[metric], _p(query),
+                          _p(ids), C.c_size_t(ids.shape[0]), _p(out))
+    return out
+
+
+def queue_trace(cap, ops, ids, dists):
+    ops = np.ascontiguousarray(ops, np.uint8)
+    ids = np.ascontiguousarray(ids, np.uint32)
+    dists = np.ascontiguousarray(dists, np.float32)
+    n = ops.shape[0]
+    oi = np.zeros(cap + 1, np.uint32)
+    od = np.zeros(cap + 1, np.float32)
+    of = np.zeros(cap + 1, np.uint8)
+    pops = np.zeros(n + 1, np.uint32)
+    cur = C.c_size_t(0)
+    size = lib().rgo_queue_trace(C.c_size_t(cap), _p(ops), _p(ids), _p(dists), C.c_size_t(n), _p(oi), _p(od), _p(of),
+                                 _p(pops), C.byref(cur))
+    npop = int((ops == 1).sum())
+    return dict(size=size, cur=cur.value, ids=oi[:size].copy(), dists=od[:size].copy(), flags=of[:size].copy(),
+                pops=pops)
+
+
+def make_graph(offsets, nbrs, ep):
+    offsets = np.ascontiguousarray(offsets, np.uint64)
+    nbrs = np.ascontiguousarray(nbrs, np.uint32)
+    g = Graph(offsets.shape[0] - 1, ep, offsets.ctypes.data, nbrs.ctypes.data)
+    g._keep = (offsets, nbrs)
+    return g
+
+
+def search(base, metric, offsets, nbrs, ep, queries, k, L, nthreads=1, dim=None):
+    """Restated SearchRoarGraph over a batch. Returns ids[nq,k], dists[nq,k], cmps[nq], hops[nq]."""
+    base = np.ascontiguousarray(base, np.float32)
+    queries = np.ascontiguousarray(queries, np.float32)
+    g = make_graph(offsets, nbrs, ep)
+    nq = queries.shape[0]
+    d = dim if dim is not None else base.shape[1]
+    ids = np.zeros((nq, k), np.uint32)
+    dists = np.zeros((nq, k), np.float32)
+    cmps = np.zeros(nq, np.uint32)
+    hops = np.zeros(nq, np.uint32)
+    errq = C.c_uint32(0)
+    rc = lib().rgo_search(_p(base), C.c_size_t(base.shape[1]), C.c_uint(d), METRIC[metric], C.byref(g), _p(queries),
+                          C.c_size_t(queries.shape[1]), C.c_uint32(nq), C.c_uint32(k), C.c_uint32(L), _p(ids),
+                          _p(dists), _p(cmps), _p(hops), C.c_int(nthreads), C.byref(errq))
+    if rc != 0:
+        raise RuntimeError(lib().rgo_last_error().decode())
+    return ids, dists, cmps, hops
+
+
+def recall(res, gt, k):
+    res = np.ascontiguousarray(res, np.uint32)
+    gt = np.ascontiguousarray(gt, np.uint32)
+    return float(lib().rgo_recall(C.c_uint32(res.shape[0]), C.c_uint32(k), C.c_uint32(gt.shape[1]), _p(res), _p(gt)))
+
+
+def groundtruth_f64(base, queries, metric, K, nthreads=8, dim=None):
+    base = np.ascontiguousarray(base, np.float32)
+    queries = np.ascontiguousarray(queries, np.float32)
+    nq = queries.shape[0]
+    d = dim if dim is not None else base.shape[1]
+    ids = np.zeros((nq, K), np.uint32)
+    dists = np.zeros((nq, K), np.float32)
+    s64 = np.zeros((nq, K), np.float64)
+    rc = lib().rgo_groundtruth_f64(_p(base), C.c_size_t(base.shape[1]), C.c_uint32(base.shape[0]), _p(queries),
+                                   C.c_size_t(queries.shape[1]), C.c_uint32(nq), C.c_uint(d), METRIC[metric],
+                                   C.c_uint32(K), _p(ids), _p(dists), _p(s64), C.c_int(nthreads))
+    if rc != 0:
+        raise RuntimeError(lib().rgo_last_error().decode())
+    return ids, dists, s64
+
+
+# ---- file formats through the oracle's loaders (error strings follow the reference) ----
+def fbin_meta(path):
+    n, d = C.c_uint32(), C.c_uint32()
+    if lib().rgo_fbin_meta(path.encode(), C.byref(n), C.byref(d)) != 0:
+        raise RuntimeError(lib().rgo_last_error().decode())
+    return n.value, d.value
+
+
+def fbin_load(path):
+    n, d, s = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    ptr = C.c_void_p()
+    if lib().rgo_fbin_load(path.encode(), C.byref(n), C.byref(d), C.byref(s), C.byref(ptr)) != 0:
+        raise RuntimeError(lib().rgo_last_error().decode())
+    arr = np.ctypeslib.as_array(C.cast(ptr, C.POINTER(C.c_float)), shape=(n.value, s.value)).copy()
+    lib().rgo_free(ptr)
+    return arr, d.value
+
+
+def gt_meta(path):
+    n, k = C.c_uint32(), C.c_uint32()
+    if lib().rgo_gt_meta(path.encode(), C.byref(n), C.byref(k)) != 0:
+        raise RuntimeError(lib().rgo_last_error().decode())
+    return n.value, k.value
+
+
+def gt_load(path):
+    n, k = C.c_uint32(), C.c_uint32()
+    pi, pd = C.c_void_p(), C.c_void_p()
+    if lib().rgo_gt_load(path.encode(), C.byref(n), C.byref(k), C.byref(pi), C.byref(pd)) != 0:
+        raise RuntimeError(lib().rgo_last_error().decode())
+    ids = np.ctypeslib.as_array(C.cast(pi, C.POINTER(C.c_uint32)), shape=(n.value, k.value)).copy()
+    ds = np.ctypeslib.as_array(C.cast(pd, C.POINTER(C.c_float)), shape=(n.value, k.value)).copy()
+    lib().rgo_free(pi)
+    lib().rgo_free(pd)
+    return ids, ds
+
+
+def index_load(path):
+    g = Graph()
+    if lib().rgo_index_load(path.encode(), C.byref(g)) != 0:
+        raise RuntimeError(lib().rgo_last_error().decode())
+    off = np.ctypeslib.as_array(C.cast(g.offsets, C.POINTER(C.c_uint64)), shape=(g.nd + 1,)).copy()
+    nb = np.ctypeslib.as_array(C.cast(g.nbrs, C.POINTER(C.c_uint32)), shape=(max(int(off[-1]), 1),)).copy()[: int(off[-1])]
+    ep = g.ep
+    lib().rgo_graph_free(C.byref(g))
+    return off, nb, ep
+
+
+def index_save(path, offsets, nbrs, ep):
+    g = make_graph(offsets, nbrs, ep)
+    if lib().rgo_index_save(path.encode(), C.byref(g)) != 0:
+        raise RuntimeError(lib().rgo_last_error().decode())
+
+
+# ---- the reference-header driver (oracle/_ref/rg_ref) ----
+def have_ref():
+    if not os.path.exists(REF_BIN):
+        return False
+    try:
+        flags = open("/proc/cpuinfo").read()
+    except OSError:
+        return False
+    return "avx512f" in flags and "avx512dq" in flags
+
+
+def ref_run(*args, check=True):
+    r = subprocess.run([REF_BIN, *map(str, args)], capture_output=True, text=True)
+    if check and r.returncode != 0:
+        raise RuntimeError("rg_ref failed: %s %s" % (r.stdout[-400:], r.stderr[-400:]))
+    return r
+
+
+def ref_dist(metric, a, b):
+    a = np.ascontiguousarray(a, np.float32)
+    b = np.ascontiguousarray(b, np.float32)
+    n, d = a.shape
+    with tempfile.TemporaryDirectory() as td:
+        fin, fout = os.path.join(td, "in"), os.path.join(td, "out")
+        with open(fin, "wb") as f:
+            f.write(np.array([n, d], np.uint32).tobytes())
+            f.write(a.tobytes())
+            f.write(b.tobytes())
+        ref_run("dist", metric, fin, fout)
+        return np.fromfile(fout, np.float32)
+
+
+def ref_queue(cap, ops, ids, dists):
+    ops = np.ascontiguousarray(ops, np.uint8)
+    with tempfile.TemporaryDirectory() as td:
+        fin, fout = os.path.join(td, "in"), os.path.join(td, "out")
+        with open(fin, "wb") as f:
+            f.write(np.array([cap, ops.shape[0]], np.uint32).tobytes())
+            f.write(ops.tobytes())
+            f.write(np.ascontiguousarray(ids, np.uint32).tobytes())
+            f.write(np.ascontiguousarray(dists, np.float32).tobytes())
+        ref_run("queue", fin, fout)
+        raw = open(fout, "rb").read()
+    size, cur, npop = np.frombuffer(raw[:12], np.uint32)
+    o = 12
+    rid = np.frombuffer(raw[o:o + 4 * size], np.uint32); o += 4 * size
+    rd = np.frombuffer(raw[o:o + 4 * size], np.float32); o += 4 * size
+    rf = np.frombuffer(raw[o:o + size], np.uint8); o += size
+    pops = np.frombuffer(raw[o:o + 4 * npop], np.uint32)
+    return dict(size=int(size), cur=int(cur), ids=rid, dists=rd, flags=rf, pops=pops)
+
+
+def ref_search(base_fbin, index_path, query_fbin, metric, k, L, threads=1, repeat=1):
+    with tempfile.TemporaryDirectory() as td:
+        fout = os.path.join(td, "out")
+        r = ref_run("search", base_fbin, index_path, query_fbin, metric, k, L, threads, fout, repeat, check=False)
+        if r.returncode != 0:
+            raise RuntimeError((r.stdout + r.stderr).strip().splitlines()[-1])
+        raw = open(fout, "rb").read()
+    nq, kk = np.frombuffer(raw[:8], np.uint32)
+    o = 8
+    ids = np.frombuffer(raw[o:o + 4 * nq * kk], np.uint32).reshape(nq, kk); o += 4 * nq * kk
+    ds = np.frombuffer(raw[o:o + 4 * nq * kk], np.float32).reshape(nq, kk); o += 4 * nq * kk
+    cmps = np.frombuffer(raw[o:o + 4 * nq], np.uint32); o += 4 * nq
+    hops = np.frombuffer(raw[o:o + 4 * nq], np.uint32)
+    qps = None
+    for line in r.stdout.splitlines():
+        if line.startswith("QPS "):
+            qps = float(line.split()[1])
+    return ids, ds, cmps, hops, qps

@@ -1,0 +1,464 @@
+/*
+ * rg_oracle.c -- TEST INFRASTRUCTURE ONLY (see rg_oracle.h).
+ * Plain-C restatement of the RoarGraph hot path; citations are into /root/reference/.
+ */
+#define _GNU_SOURCE
+#include "rg_oracle.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------ errors */
+static __thread char g_err[512];
+const char *rgo_last_error(void) { return g_err; }
+static int fail(const char *msg) {
+    snprintf(g_err, sizeof g_err, "%s", msg);
+    return -1;
+}
+void rgo_free(void *p) { free(p); }
+
+/* ------------------------------------------------------------- a1/a2 scalar
+ * The reference accumulates 16 lanes with one FMA per element (GCC contracts
+ * _mm512_add_ps(_mm512_mul_ps) under its Release flags, CMakeLists.txt:28),
+ * folds 16->8 (distance.h:191-192 / 52-53), applies an 8-wide tail (194-201 /
+ * 55-63), folds 8->4 (203-204 / 65-66), 4-wide and masked tails (206-219 /
+ * 68-83), then two horizontal adds (221-222 / 85-86).
+ * Lane j of the accumulator therefore sees elements j, j+16, j+32 ... in
+ * increasing order, one fused multiply-add each.  fmaf() below is the single
+ * rounding FMA (the file is built with -mfma -ffp-contract=off so nothing
+ * else is fused or split). */
+static inline float fold_tail(float acc[16], const float *a, const float *b, unsigned rem, int l2) {
+    float s8[8], s4[4];
+    for (int j = 0; j < 8; ++j) s8[j] = acc[j + 8] + acc[j];
+    if (rem >= 8) {
+        for (int j = 0; j < 8; ++j) {
+            float x = a[j], y = b[j];
+            if (l2) { float t = x - y; s8[j] = fmaf(t, t, s8[j]); }
+            else s8[j] = fmaf(x, y, s8[j]);
+        }
+        a += 8; b += 8; rem -= 8;
+    }
+    for (int j = 0; j < 4; ++j) s4[j] = s8[j + 4] + s8[j];
+    if (rem >= 4) {
+        for (int j = 0; j < 4; ++j) {
+            float x = a[j], y = b[j];
+            if (l2) { float t = x - y; s4[j] = fmaf(t, t, s4[j]); }
+            else s4[j] = fmaf(x, y, s4[j]);
+        }
+        a += 4; b += 4; rem -= 4;
+    }
+    if (rem > 0) { /* masked_read pads with zeros (distance.h:94-106); the multiply-add still runs on all 4 lanes */
+        for (int j = 0; j < 4; ++j) {
+            float x = (unsigned)j < rem ? a[j] : 0.0f, y = (unsigned)j < rem ? b[j] : 0.0f;
+            if (l2) { float t = x - y; s4[j] = fmaf(t, t, s4[j]); }
+            else s4[j] = fmaf(x, y, s4[j]);
+        }
+    }
+    float h0 = s4[0] + s4[1], h1 = s4[2] + s4[3];
+    return h0 + h1;
+}
+
+static float compare_ip_scalar(const float *a, const float *b, unsigned d) {
+    float acc[16];
+    for (int j = 0; j < 16; ++j) acc[j] = 0.0f;
+    unsigned i = 0;
+    for (; d - i >= 16; i += 16)
+        for (int j = 0; j < 16; ++j) acc[j] = fmaf(a[i + j], b[i + j], acc[j]);
+    float r = fold_tail(acc, a + i, b + i, d - i, 0);
+    return -r; /* distance.h:223 */
+}
+
+static float compare_l2_scalar(const float *a, const float *b, unsigned d) {
+    float acc[16];
+    for (int j = 0; j < 16; ++j) acc[j] = 0.0f;
+    unsigned i = 0;
+    for (; d - i >= 16; i += 16)
+        for (int j = 0; j < 16; ++j) {
+            float t = a[i + j] - b[i + j];
+            acc[j] = fmaf(t, t, acc[j]);
+        }
+    return fold_tail(acc, a + i, b + i, d - i, 1); /* distance.h:87 */
+}
+
+/* ------------------------------------------------------------ a1/a2 AVX-512
+ * Same arithmetic held in zmm registers; only used to time a fair CPU
+ * baseline.  Tail handling drops to the scalar fold (bit-identical). */
+#if defined(__x86_64__)
+__attribute__((target("avx512f,fma"))) static float compare_ip_avx512(const float *a, const float *b, unsigned d) {
+    __m512 acc = _mm512_setzero_ps();
+    unsigned i = 0;
+    for (; d - i >= 16; i += 16) acc = _mm512_fmadd_ps(_mm512_loadu_ps(a + i), _mm512_loadu_ps(b + i), acc);
+    float lanes[16];
+    _mm512_storeu_ps(lanes, acc);
+    return -fold_tail(lanes, a + i, b + i, d - i, 0);
+}
+__attribute__((target("avx512f,fma"))) static float compare_l2_avx512(const float *a, const float *b, unsigned d) {
+    __m512 acc = _mm512_setzero_ps();
+    unsigned i = 0;
+    for (; d - i >= 16; i += 16) {
+        __m512 t = _mm512_sub_ps(_mm512_loadu_ps(a + i), _mm512_loadu_ps(b + i));
+        acc = _mm512_fmadd_ps(t, t, acc);
+    }
+    float lanes[16];
+    _mm512_storeu_ps(lanes, acc);
+    return fold_tail(lanes, a + i, b + i, d - i, 1);
+}
+#endif
+
+static int g_avx512 = 0;
+int rgo_have_avx512(void) {
+#if defined(__x86_64__)
+    return __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("fma");
+#else
+    return 0;
+#endif
+}
+void rgo_use_avx512(int on) { g_avx512 = on && rgo_have_avx512(); }
+
+float rgo_compare_ip(const float *a, const float *b, unsigned d) {
+#if defined(__x86_64__)
+    if (g_avx512) return compare_ip_avx512(a, b, d);
+#endif
+    return compare_ip_scalar(a, b, d);
+}
+float rgo_compare_l2(const float *a, const float *b, unsigned d) {
+#if defined(__x86_64__)
+    if (g_avx512) return compare_l2_avx512(a, b, d);
+#endif
+    return compare_l2_scalar(a, b, d);
+}
+/* a3: metric -> kernel selection, src/index.cpp:8-26 (COSINE uses the IP kernel on normalised data) */
+float rgo_compare(int metric, const float *a, const float *b, unsigned d) {
+    return metric == RGO_L2 ? rgo_compare_l2(a, b, d) : rgo_compare_ip(a, b, d);
+}
+
+void rgo_score_batch(const float *base, size_t stride, unsigned d, int metric, const float *query,
+                     const uint32_t *ids, size_t n, float *out) {
+    for (size_t i = 0; i < n; ++i) out[i] = rgo_compare(metric, base + (size_t)ids[i] * stride, query, d);
+}
+
+/* ------------------------------------------------------------------ a5 queue
+ * Sorted array of capacity cap ordered by (distance, id) (neighbor.h:29-31). */
+static inline int nb_less(uint32_t ida, float da, uint32_t idb, float db) {
+    return da < db || (da == db && ida < idb);
+}
+int rgo_queue_init(rgo_queue *q, size_t cap) {
+    q->size = 0; q->cap = cap; q->cur = 0;
+    q->data = (rgo_nb *)calloc(cap + 1, sizeof(rgo_nb));
+    return q->data ? 0 : -1;
+}
+void rgo_queue_free(rgo_queue *q) { free(q->data); q->data = NULL; }
+
+void rgo_queue_insert(rgo_queue *q, uint32_t id, float dist) {
+    /* full and not better than the worst kept entry: dropped (neighbor.h:151-153) */
+    if (q->size == q->cap) {
+        const rgo_nb *w = &q->data[q->size - 1];
+        if (nb_less(w->id, w->dist, id, dist)) return;
+    }
+    /* bisection; an equal id met on the probe path is dropped (neighbor.h:155-166) */
+    size_t lo = 0, hi = q->size;
+    while (lo < hi) {
+        size_t mid = (lo + hi) >> 1;
+        const rgo_nb *m = &q->data[mid];
+        if (nb_less(id, dist, m->id, m->dist)) hi = mid;
+        else if (m->id == id) return;
+        else lo = mid + 1;
+    }
+    /* open the gap; when full the tail entry falls into the slack slot and is forgotten (neighbor.h:168-170) */
+    if (lo < q->cap) memmove(&q->data[lo + 1], &q->data[lo], (q->size - lo) * sizeof(rgo_nb));
+    q->data[lo].id = id; q->data[lo].dist = dist; q->data[lo].flag = 0; /* :174 */
+    if (q->size < q->cap) q->size++;
+    if (lo < q->cur) q->cur = lo; /* :180-182 */
+}
+rgo_nb rgo_queue_pop(rgo_queue *q) {
+    q->data[q->cur].flag = 1;
+    size_t pre = q->cur;
+    while (q->cur < q->size && q->data[q->cur].flag) q->cur++;
+    return q->data[pre];
+}
+int rgo_queue_has_unexpanded(const rgo_queue *q) { return q->cur < q->size; }
+
+size_t rgo_queue_trace(size_t cap, const uint8_t *op, const uint32_t *ids, const float *dists, size_t nops,
+                       uint32_t *out_ids, float *out_dists, uint8_t *out_flags, uint32_t *pop_ids,
+                       size_t *out_cur) {
+    rgo_queue q;
+    rgo_queue_init(&q, cap);
+    size_t npop = 0;
+    for (size_t i = 0; i < nops; ++i) {
+        if (op[i] == 0) rgo_queue_insert(&q, ids[i], dists[i]);
+        else if (rgo_queue_has_unexpanded(&q)) pop_ids[npop++] = rgo_queue_pop(&q).id;
+    }
+    for (size_t i = 0; i < q.size; ++i) {
+        out_ids[i] = q.data[i].id; out_dists[i] = q.data[i].dist; out_flags[i] = q.data[i].flag;
+    }
+    *out_cur = q.cur;
+    size_t n = q.size;
+    rgo_queue_free(&q);
+    (void)npop;
+    return n;
+}
+
+/* --------------------------------------------------------------- a4 search
+ * One query of SearchRoarGraph (index_bipartite.cpp:2311-2420).  The visited
+ * set is the reference's epoch-tag array (visited_list_pool.h:8-29) reduced to
+ * its set semantics: tag[] holds the serial number of the last query that
+ * touched the node. */
+static int search_one(const float *base, size_t stride, unsigned d, int metric, const rgo_graph *g,
+                      const float *query, uint32_t k, uint32_t L, uint32_t *tag, uint32_t serial, rgo_queue *q,
+                      uint32_t *out_ids, float *out_dists, uint32_t *out_cmps, uint32_t *out_hops) {
+    q->size = 0; q->cur = 0;
+    /* entry point: scored and queued, NOT marked visited (:2338-2352, :2349 commented out) */
+    rgo_queue_insert(q, g->ep, rgo_compare(metric, base + (size_t)g->ep * stride, query, d));
+    uint32_t cmps = 0, hops = 0;
+    while (rgo_queue_has_unexpanded(q)) {                       /* :2356 */
+        uint32_t cur = rgo_queue_pop(q).id;                     /* :2358 */
+        ++hops;                                                 /* :2366, counted even for empty lists */
+        for (uint64_t e = g->offsets[cur]; e < g->offsets[cur + 1]; ++e) { /* :2368 */
+            uint32_t nbr = g->nbrs[e];
+            if (tag[nbr] == serial) continue;                   /* :2378 */
+            tag[nbr] = serial;                                  /* :2385 */
+            float dist = rgo_compare(metric, base + (size_t)nbr * stride, query, d); /* :2387 */
+            ++cmps;                                             /* :2397 */
+            rgo_queue_insert(q, nbr, dist);                     /* :2398 */
+        }
+    }
+    *out_cmps = cmps; *out_hops = hops;
+    if (q->size < k) return -1;                                 /* :2408-2412 */
+    for (uint32_t i = 0; i < k; ++i) { out_ids[i] = q->data[i].id; out_dists[i] = q->data[i].dist; } /* :2414-2418 */
+    return 0;
+}
+
+int rgo_search(const float *base, size_t stride, unsigned d, int metric, const rgo_graph *g,
+               const float *queries, size_t qstride, uint32_t nq, uint32_t k, uint32_t L, uint32_t *out_ids,
+               float *out_dists, uint32_t *out_cmps, uint32_t *out_hops, int nthreads, uint32_t *err_q) {
+    int bad = 0;
+    uint32_t badq = 0;
+    if (nthreads < 1) nthreads = 1;
+#ifdef _OPENMP
+#pragma omp parallel num_threads(nthreads)
+#endif
+    {
+        uint32_t *tag = (uint32_t *)calloc(g->nd, sizeof(uint32_t));
+        rgo_queue q;
+        rgo_queue_init(&q, L);
+        uint32_t serial = 0;
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 1) /* tests/test_search_roargraph.cpp:203 */
+#endif
+        for (uint32_t i = 0; i < nq; ++i) {
+            ++serial;
+            int rc = search_one(base, stride, d, metric, g, queries + (size_t)i * qstride, k, L, tag, serial, &q,
+                                out_ids + (size_t)i * k, out_dists + (size_t)i * k, &out_cmps[i], &out_hops[i]);
+            if (rc) {
+#ifdef _OPENMP
+#pragma omp critical
+#endif
+                { if (!bad || i < badq) badq = i; bad = 1; }
+            }
+        }
+        rgo_queue_free(&q);
+        free(tag);
+    }
+    if (bad) {
+        if (err_q) *err_q = badq;
+        snprintf(g_err, sizeof g_err, "not enough results (query %u), expected: %u", badq, k);
+        return -1;
+    }
+    return 0;
+}
+
+/* a9: recall = sum_q |{p in gt[q][:k] : p in res[q][:k]}| / (k*nq) (test_search_roargraph.cpp:23-36) */
+float rgo_recall(uint32_t nq, uint32_t k, uint32_t gt_dim, const uint32_t *res, const uint32_t *gt) {
+    uint32_t total = 0;
+    for (uint32_t i = 0; i < nq; ++i)
+        for (uint32_t a = 0; a < k; ++a) {
+            uint32_t p = gt[(size_t)i * gt_dim + a];
+            for (uint32_t b = 0; b < k; ++b)
+                if (res[(size_t)i * k + b] == p) { ++total; break; }
+        }
+    return (float)total / (float)(k * nq);
+}
+
+/* ----------------------------------------------------------------- formats */
+static long file_size(FILE *f) {
+    long cur = ftell(f);
+    fseek(f, 0, SEEK_END);
+    long n = ftell(f);
+    fseek(f, cur, SEEK_SET);
+    return n;
+}
+
+/* .fbin header + size rule: (filesize-8)/dim/4 must equal npts (util.h:106-127) */
+int rgo_fbin_meta(const char *path, uint32_t *npts, uint32_t *dim) {
+    FILE *f = fopen(path, "rb");
+    if (!f) return fail("open file error");
+    uint32_t h[2] = {0, 0};
+    if (fread(h, 4, 2, f) != 2 || h[1] == 0) { fclose(f); return fail("Data file size wrong!"); }
+    size_t fsize = (size_t)file_size(f);
+    fclose(f);
+    uint32_t contained = (uint32_t)((fsize - 8) / h[1] / 4);
+    if (h[0] != contained) return fail("Data file size wrong!");
+    *npts = h[0]; *dim = h[1];
+    return 0;
+}
+
+/* rows copied with stride ceil(d/8)*8 and zero padding (util.h:179-211, 37-75) */
+int rgo_fbin_load(const char *path, uint32_t *npts, uint32_t *dim, uint32_t *stride, float **data) {
+    if (rgo_fbin_meta(path, npts, dim)) return -1;
+    FILE *f = fopen(path, "rb");
+    if (!f) return fail("open file error");
+    fseek(f, 8, SEEK_SET);
+    size_t n = *npts, d = *dim, nd = (d + 7) / 8 * 8;
+    float *buf = (float *)aligned_alloc(64, ((n * nd * 4 + 63) / 64) * 64 + 64);
+    if (!buf) { fclose(f); return fail("out of memory"); }
+    for (size_t i = 0; i < n; ++i) {
+        if (fread(buf + i * nd, 4, d, f) != d) { free(buf); fclose(f); return fail("Data file size wrong!"); }
+        memset(buf + i * nd + d, 0, (nd - d) * 4);
+    }
+    fclose(f);
+    *stride = (uint32_t)nd; *data = buf;
+    return 0;
+}
+
+/* gt header: payload must hold 2*npts rows of K 4-byte values (util.h:84-105) */
+int rgo_gt_meta(const char *path, uint32_t *npts, uint32_t *k) {
+    FILE *f = fopen(path, "rb");
+    if (!f) return fail("open file error");
+    uint32_t h[2] = {0, 0};
+    if (fread(h, 4, 2, f) != 2 || h[1] == 0) { fclose(f); return fail("Data file size wrong!"); }
+    size_t fsize = (size_t)file_size(f);
+    fclose(f);
+    uint32_t contained = (uint32_t)((fsize - 8) / h[1] / 4);
+    if ((uint32_t)(h[0] * 2u) != contained) return fail("Data file size wrong!");
+    *npts = h[0]; *k = h[1];
+    return 0;
+}
+
+/* ids block then dists block (util.h:129-155) */
+int rgo_gt_load(const char *path, uint32_t *npts, uint32_t *k, uint32_t **ids, float **dists) {
+    if (rgo_gt_meta(path, npts, k)) return -1;
+    FILE *f = fopen(path, "rb");
+    if (!f) return fail("open file error");
+    fseek(f, 8, SEEK_SET);
+    size_t n = (size_t)*npts * *k;
+    uint32_t *i = (uint32_t *)malloc(n * 4 + 4);
+    float *dd = (float *)malloc(n * 4 + 4);
+    if (fread(i, 4, n, f) != n || fread(dd, 4, n, f) != n) { free(i); free(dd); fclose(f); return fail("Data file size wrong!"); }
+    fclose(f);
+    *ids = i; *dists = dd;
+    return 0;
+}
+
+/* train gt: header + ids only are read (index_bipartite.cpp:2622-2642) */
+int rgo_knn_ids_load(const char *path, uint32_t *npts, uint32_t *k, uint32_t **ids) {
+    FILE *f = fopen(path, "rb");
+    if (!f) { snprintf(g_err, sizeof g_err, "Could not open file %s", path); return -1; }
+    uint32_t h[2];
+    if (fread(h, 4, 2, f) != 2) { fclose(f); return fail("learn base knn file error"); }
+    size_t n = (size_t)h[0] * h[1];
+    uint32_t *i = (uint32_t *)malloc(n * 4 + 4);
+    if (fread(i, 4, n, f) != n) { free(i); fclose(f); return fail("learn base knn file error"); }
+    fclose(f);
+    *npts = h[0]; *k = h[1]; *ids = i;
+    return 0;
+}
+
+/* .index: u32 ep, u32 npts, then per node u32 deg + deg ids (index_bipartite.cpp:2097-2117) */
+int rgo_index_load(const char *path, rgo_graph *g) {
+    FILE *f = fopen(path, "rb");
+    if (!f) return fail("cannot open file");
+    long fsize = file_size(f);
+    uint32_t h[2];
+    if (fread(h, 4, 2, f) != 2) { fclose(f); return fail("index file truncated"); }
+    g->ep = h[0]; g->nd = h[1];
+    g->offsets = (uint64_t *)malloc(((size_t)g->nd + 1) * 8);
+    size_t cap = (size_t)(fsize - 8) / 4 + 1;
+    g->nbrs = (uint32_t *)malloc(cap * 4);
+    uint64_t off = 0;
+    for (uint32_t i = 0; i < g->nd; ++i) {
+        uint32_t deg;
+        if (fread(&deg, 4, 1, f) != 1 || off + deg > cap || fread(g->nbrs + off, 4, deg, f) != deg) {
+            fclose(f); rgo_graph_free(g); return fail("index file truncated");
+        }
+        g->offsets[i] = off;
+        off += deg;
+    }
+    g->offsets[g->nd] = off;
+    fclose(f);
+    return 0;
+}
+int rgo_index_save(const char *path, const rgo_graph *g) {
+    FILE *f = fopen(path, "wb");
+    if (!f) return fail("cannot open file");
+    fwrite(&g->ep, 4, 1, f);
+    fwrite(&g->nd, 4, 1, f);
+    for (uint32_t i = 0; i < g->nd; ++i) {
+        uint32_t deg = (uint32_t)(g->offsets[i + 1] - g->offsets[i]);
+        fwrite(&deg, 4, 1, f);
+        fwrite(g->nbrs + g->offsets[i], 4, deg, f);
+    }
+    fclose(f);
+    return 0;
+}
+void rgo_graph_free(rgo_graph *g) { free(g->offsets); free(g->nbrs); g->offsets = NULL; g->nbrs = NULL; }
+
+/* util.h:214-225: float sum of squares in index order, sqrt, divide */
+void rgo_normalize_rows(float *data, size_t n, size_t stride, unsigned d) {
+    for (size_t i = 0; i < n; ++i) {
+        float *r = data + i * stride;
+        float s = 0.0f;
+        for (unsigned j = 0; j < d; ++j) s += r[j] * r[j];
+        s = sqrtf(s);
+        for (unsigned j = 0; j < d; ++j) r[j] = r[j] / s;
+    }
+}
+
+/* ------------------------------------------------------------ a10 GT (fp64) */
+typedef struct { double s; uint32_t id; } gt_item;
+/* "a ranks before b": mips score desc / l2 dist asc, then id asc */
+static inline int gt_before(const gt_item *a, const gt_item *b, int l2) {
+    if (a->s != b->s) return l2 ? a->s < b->s : a->s > b->s;
+    return a->id < b->id;
+}
+int rgo_groundtruth_f64(const float *base, size_t bstride, uint32_t nb, const float *queries, size_t qstride,
+                        uint32_t nq, unsigned d, int metric, uint32_t K, uint32_t *out_ids, float *out_dists,
+                        double *out_scores64, int nthreads) {
+    if (K > nb) return fail("K larger than base size");
+    int l2 = metric == RGO_L2;
+    if (nthreads < 1) nthreads = 1;
+#ifdef _OPENMP
+#pragma omp parallel for schedule(dynamic, 4) num_threads(nthreads)
+#endif
+    for (uint32_t qi = 0; qi < nq; ++qi) {
+        const float *q = queries + (size_t)qi * qstride;
+        gt_item *top = (gt_item *)malloc((K + 1) * sizeof(gt_item));
+        uint32_t n = 0;
+        for (uint32_t bi = 0; bi < nb; ++bi) {
+            const float *b = base + (size_t)bi * bstride;
+            double s = 0.0;
+            if (l2) for (unsigned j = 0; j < d; ++j) { double t = (double)q[j] - (double)b[j]; s += t * t; }
+            else for (unsigned j = 0; j < d; ++j) s += (double)q[j] * (double)b[j];
+            gt_item it = {s, bi};
+            if (n == K && !gt_before(&it, &top[K - 1], l2)) continue;
+            uint32_t p = n < K ? n : K - 1;
+            while (p > 0 && gt_before(&it, &top[p - 1], l2)) { top[p] = top[p - 1]; --p; }
+            top[p] = it;
+            if (n < K) ++n;
+        }
+        for (uint32_t j = 0; j < K; ++j) {
+            out_ids[(size_t)qi * K + j] = top[j].id;
+            out_dists[(size_t)qi * K + j] = (float)top[j].s;
+            if (out_scores64) out_scores64[(size_t)qi * K + j] = top[j].s;
+        }
+        free(top);
+    }
+    return 0;
+}

@@ -1,0 +1,106 @@
+/*
+ * rg_oracle.h -- TEST INFRASTRUCTURE ONLY.
+ *
+ * CPU restatement (plain C) of the RoarGraph hot path: distance evaluation,
+ * the bounded sorted queue, the visited set, beam search, the file formats
+ * and the brute-force ground truth.  It is the checker the HIP path is
+ * compared against.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load it; the product (librg_hip.so) never does.
+ *
+ * Parity pin: every function here is checked bit-for-bit against
+ * oracle/_ref/rg_ref, a driver compiled from the reference's own headers
+ * (distance.h, neighbor.h, visited_list_pool.h, util.h) where they lie under
+ * /root/reference, and against the golden vectors that binary produced
+ * (tests/golden/, generator scripts/make_golden.py).  The reference's
+ * SearchRoarGraph translation unit itself (src/index_bipartite.cpp) needs
+ * Boost and tsl headers that are absent in this image, so the 110-line search
+ * loop is pinned through its genuine components plus this restatement, not
+ * through a build of that file.
+ *
+ * All file:line citations are into /root/reference/.
+ */
+#ifndef RG_ORACLE_H
+#define RG_ORACLE_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* metric codes follow include/efanna2e/distance.h:15 */
+enum { RGO_L2 = 0, RGO_IP = 1, RGO_COSINE = 4 };
+
+/* a1/a2: DistanceInnerProduct::compare (distance.h:180-223), DistanceL2::compare (distance.h:39-87) */
+float rgo_compare_ip(const float *a, const float *b, unsigned d);
+float rgo_compare_l2(const float *a, const float *b, unsigned d);
+float rgo_compare(int metric, const float *a, const float *b, unsigned d);
+/* same arithmetic with AVX-512 registers (used for the timed CPU baseline); falls back to scalar */
+int rgo_have_avx512(void);
+void rgo_use_avx512(int on);
+
+/* batched boundary form of a1/a2: out[i] = compare(base + ids[i]*stride, query, d) */
+void rgo_score_batch(const float *base, size_t stride, unsigned d, int metric, const float *query,
+                     const uint32_t *ids, size_t n, float *out);
+
+/* a5: NeighborPriorityQueue (neighbor.h:138-223) */
+typedef struct {
+    uint32_t id;
+    float dist;
+    uint8_t flag;
+} rgo_nb;
+typedef struct {
+    size_t size, cap, cur;
+    rgo_nb *data; /* cap + 1 entries (slack slot, neighbor.h:142) */
+} rgo_queue;
+int rgo_queue_init(rgo_queue *q, size_t cap);
+void rgo_queue_free(rgo_queue *q);
+void rgo_queue_insert(rgo_queue *q, uint32_t id, float dist);
+rgo_nb rgo_queue_pop(rgo_queue *q); /* closest_unexpanded, neighbor.h:185-192 */
+int rgo_queue_has_unexpanded(const rgo_queue *q);
+/* run a trace of operations; op[i] = 0 insert(ids[i],dists[i]), 1 pop. Dumps final state. For tests. */
+size_t rgo_queue_trace(size_t cap, const uint8_t *op, const uint32_t *ids, const float *dists, size_t nops,
+                       uint32_t *out_ids, float *out_dists, uint8_t *out_flags, uint32_t *pop_ids,
+                       size_t *out_cur);
+
+/* graph in CSR form (offsets has nd+1 entries) */
+typedef struct {
+    uint32_t nd;
+    uint32_t ep;
+    uint64_t *offsets;
+    uint32_t *nbrs;
+} rgo_graph;
+
+/* a4: IndexBipartite::SearchRoarGraph (src/index_bipartite.cpp:2311-2420).
+ * returns 0, or -1 when a query ends with fewer than k results (":2408-2412"); err_q receives that query. */
+int rgo_search(const float *base, size_t stride, unsigned d, int metric, const rgo_graph *g,
+               const float *queries, size_t qstride, uint32_t nq, uint32_t k, uint32_t L, uint32_t *out_ids,
+               float *out_dists, uint32_t *out_cmps, uint32_t *out_hops, int nthreads, uint32_t *err_q);
+
+/* a9: ComputeRecall (tests/test_search_roargraph.cpp:23-36) */
+float rgo_recall(uint32_t nq, uint32_t k, uint32_t gt_dim, const uint32_t *res, const uint32_t *gt);
+
+/* a7/a8 + Appendix A formats.  All return 0 on success, <0 with rgo_last_error() set. */
+const char *rgo_last_error(void);
+int rgo_fbin_meta(const char *path, uint32_t *npts, uint32_t *dim);          /* util.h:106-127 */
+int rgo_fbin_load(const char *path, uint32_t *npts, uint32_t *dim, uint32_t *stride, float **data); /* util.h:179-211 + 37-75 */
+int rgo_gt_meta(const char *path, uint32_t *npts, uint32_t *k);              /* util.h:84-105 */
+int rgo_gt_load(const char *path, uint32_t *npts, uint32_t *k, uint32_t **ids, float **dists); /* util.h:129-155 */
+int rgo_knn_ids_load(const char *path, uint32_t *npts, uint32_t *k, uint32_t **ids); /* index_bipartite.cpp:2622-2642 */
+int rgo_index_load(const char *path, rgo_graph *g);                          /* index_bipartite.cpp:2097-2117 */
+int rgo_index_save(const char *path, const rgo_graph *g);                    /* index_bipartite.cpp:2606-2619 */
+void rgo_graph_free(rgo_graph *g);
+void rgo_free(void *p);
+void rgo_normalize_rows(float *data, size_t n, size_t stride, unsigned d);   /* util.h:214-225 */
+
+/* a10: exact top-K ground truth (DiskANN compute_groundtruth; source absent, README.md:62-75).
+ * fp64 accumulation; order: mips = score desc then id asc, l2 = dist asc then id asc.
+ * dists written as +inner product for mips (test_search_bipartite.cpp:46-48), squared L2 for l2. */
+int rgo_groundtruth_f64(const float *base, size_t bstride, uint32_t nb, const float *queries, size_t qstride,
+                        uint32_t nq, unsigned d, int metric, uint32_t K, uint32_t *out_ids, float *out_dists,
+                        double *out_scores64, int nthreads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

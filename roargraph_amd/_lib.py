@@ -1,0 +1,55 @@
+"""ctypes binding of librg_hip.so (include/rg.h).
+
+The product has no CPU fallback: if the shared library is missing, or no GPU
+is visible when a compute entry point is called, this raises.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "librg_hip.so")
+
+RG_OK = 0
+RG_ERR_IO, RG_ERR_FORMAT, RG_ERR_ARG, RG_ERR_DEVICE, RG_ERR_NOT_ENOUGH, RG_ERR_OOM = -1, -2, -3, -4, -5, -6
+METRIC = {"l2": 0, "ip": 1, "mips": 1, "cosine": 4}
+
+# every symbol include/rg.h declares (tests/test_abi.py checks the header against this list and the .so)
+SYMBOLS = [
+    "rg_last_error", "rg_version", "rg_device_count", "rg_free",
+    "rg_fbin_meta", "rg_fbin_load", "rg_fbin_save", "rg_gt_meta", "rg_gt_load", "rg_gt_save", "rg_knn_ids_load",
+    "rg_graph_load", "rg_graph_save", "rg_recall", "rg_normalize_rows",
+    "rg_index_open", "rg_index_open_mem", "rg_index_open_dev", "rg_index_close", "rg_index_info", "rg_index_set",
+    "rg_score_batch", "rg_score_batch_dev", "rg_search", "rg_search_dev", "rg_search_wait",
+    "rg_gt_shard_dev", "rg_gt_merge_dev", "rg_groundtruth_mem", "rg_groundtruth",
+]
+
+
+class RgError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(msg)
+        self.code = code
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "librg_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` or "
+                "`make -C roargraph_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+        L = C.CDLL(LIB_PATH)
+        L.rg_last_error.restype = C.c_char_p
+        L.rg_version.restype = C.c_char_p
+        L.rg_recall.restype = C.c_float
+        L.rg_free.argtypes = [C.c_void_p]
+        L.rg_index_close.argtypes = [C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def check(rc):
+    if rc != RG_OK:
+        raise RgError(rc, lib().rg_last_error().decode(errors="replace"))

@@ -1,0 +1,122 @@
+// rg_device.h -- device-side building blocks of the gfx950 search path (wave64, LDS-DMA gather).
+//
+// Scoring layout ("one 16-lane group per candidate row"):
+//   A wave scores 4 candidate rows per sub-pass.  Lane l = 16*g + p belongs to group g (row g) and
+//   owns accumulator a = p of the reference's 16-lane AVX-512 register (include/efanna2e/distance.h:
+//   180-189 IP, 42-50 L2): it sees elements a, a+16, a+32, ... of the row in increasing order, one
+//   fused multiply-add each, then the 16->8->4->2->1 folds (distance.h:191-222 / 52-86) are wave
+//   shuffles with xor masks 8, 4, 1, 2.  IEEE addition is commutative, so the result is bit-identical
+//   to the AVX-512 path (and to oracle/rg_oracle.c).
+//
+// Gather: rows are fetched HBM -> LDS with global_load_lds_dwordx4 (LDS-DMA, no VGPR round trip).
+//   One instruction moves 4 rows x 256 B: lane l writes 16 B at stage + 16*l.  The 16-B slot of row
+//   block element group j that lane (g,p) fetches is j = (p - 4g) & 15, i.e. each row's 256-B block is
+//   rotated by 64*g bytes inside its LDS region, so that the later ds_read_b32 of element 16t+a by the
+//   two groups sharing a 32-lane LDS access land on disjoint banks.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace rg {
+
+constexpr uint32_t kFlagBit = 0x80000000u;  // "expanded" flag of a queue entry, kept in the id's top bit
+constexpr int kWave = 64;
+
+typedef __attribute__((address_space(3))) void lds_ptr_t;
+typedef const __attribute__((address_space(1))) void glb_ptr_t;
+
+__device__ __forceinline__ void wave_sync() {
+    // single-wave workgroups: make LDS traffic of all lanes visible to all lanes, keep the compiler from reordering
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+
+__device__ __forceinline__ float readlane_f(float v, int lane) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane));
+}
+__device__ __forceinline__ uint32_t readlane_u(uint32_t v, int lane) {
+    return (uint32_t)__builtin_amdgcn_readlane((int)v, lane);
+}
+
+// total order of the reference's Neighbor (include/efanna2e/neighbor.h:29-31)
+__device__ __forceinline__ bool nb_less(float da, uint32_t ia, float db, uint32_t ib) {
+    return da < db || (da == db && ia < ib);
+}
+
+// Issue the LDS-DMA loads of one sub-pass: row `row` (this lane's group), `dim` floats, into `stage`
+// (wave-uniform LDS address, ceil(dim/64) KiB).  Inactive groups issue nothing.
+__device__ __forceinline__ void gather_issue(const float *__restrict__ row, uint32_t dim, bool active,
+                                             float *stage, int lane) {
+    const int g = lane >> 4, p = lane & 15;
+    const int jsrc = (p - 4 * g) & 15;
+    const uint32_t nfull = dim >> 6, rem = dim & 63u;
+    const float *src = row + 4 * jsrc;
+    if (active) {
+        for (uint32_t b = 0; b < nfull; ++b)
+            __builtin_amdgcn_global_load_lds((glb_ptr_t *)(src + 64 * b), (lds_ptr_t *)(stage + 256 * b), 16, 0, 0);
+    }
+    if (rem) {
+        if (active && (uint32_t)(4 * jsrc) < rem)
+            __builtin_amdgcn_global_load_lds((glb_ptr_t *)(src + 64 * nfull), (lds_ptr_t *)(stage + 256 * nfull), 16, 0, 0);
+    }
+}
+
+__device__ __forceinline__ void gather_wait() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// Consume one staged sub-pass: returns the reference's compare() value of this lane's group row against qv
+// (valid in every lane of the group).  dim % 8 == 0.
+template <bool L2>
+__device__ __forceinline__ float gather_score(const float *stage, const float *qv, uint32_t dim, int lane) {
+    const int g = lane >> 4, a = lane & 15;
+    const uint32_t nfull = dim >> 6, rem = dim & 63u;
+    // float offset (inside a 256-float chunk) of element 16t+a of this group's row block: 64g + a + 16((t+g)&3)
+    const int o0 = 64 * g + a + 16 * ((0 + g) & 3);
+    const int o1 = 64 * g + a + 16 * ((1 + g) & 3);
+    const int o2 = 64 * g + a + 16 * ((2 + g) & 3);
+    const int o3 = 64 * g + a + 16 * ((3 + g) & 3);
+    float acc = 0.0f;
+#define RG_STEP(sp, off, qi)                               \
+    {                                                      \
+        float v = (sp)[(off)], q = qv[(qi)];               \
+        if (L2) { float t = v - q; acc = __builtin_fmaf(t, t, acc); } \
+        else acc = __builtin_fmaf(v, q, acc);              \
+    }
+    for (uint32_t b = 0; b < nfull; ++b) {
+        const float *s = stage + 256 * b;
+        const float *q = qv + 64 * b + a;
+        { float v0 = s[o0], v1 = s[o1], v2 = s[o2], v3 = s[o3];
+          float q0 = q[0], q1 = q[16], q2 = q[32], q3 = q[48];
+          if (L2) {
+              float t0 = v0 - q0, t1 = v1 - q1, t2 = v2 - q2, t3 = v3 - q3;
+              acc = __builtin_fmaf(t0, t0, acc); acc = __builtin_fmaf(t1, t1, acc);
+              acc = __builtin_fmaf(t2, t2, acc); acc = __builtin_fmaf(t3, t3, acc);
+          } else {
+              acc = __builtin_fmaf(v0, q0, acc); acc = __builtin_fmaf(v1, q1, acc);
+              acc = __builtin_fmaf(v2, q2, acc); acc = __builtin_fmaf(v3, q3, acc);
+          } }
+    }
+    const float *s = stage + 256 * nfull;
+    const uint32_t qb = 64 * nfull;
+    const uint32_t nt = rem >> 4;
+    if (nt > 0) RG_STEP(s, o0, qb + a);
+    if (nt > 1) RG_STEP(s, o1, qb + 16 + a);
+    if (nt > 2) RG_STEP(s, o2, qb + 32 + a);
+    // 16 -> 8 (distance.h:191-192): lanes a and a^8 now hold the same s8[a&7]
+    acc = acc + __shfl_xor(acc, 8, 64);
+    if (rem & 8u) {  // 8-wide tail (distance.h:194-201), element 16*nt + (a&7), applied to the folded sum
+        const int x = 16 * nt + (a & 7);
+        const int off = 64 * g + ((x + 16 * g) & 63);
+        RG_STEP(s, off, qb + x);
+    }
+#undef RG_STEP
+    acc = acc + __shfl_xor(acc, 4, 64);                  // 8 -> 4 (distance.h:203-204)
+    acc = acc + __shfl_xor(acc, 1, 64);                  // first hadd  (distance.h:221)
+    acc = acc + __shfl_xor(acc, 2, 64);                  // second hadd (distance.h:222)
+    return L2 ? acc : -acc;                              // IP returns -dot (distance.h:223)
+}
+
+}  // namespace rg

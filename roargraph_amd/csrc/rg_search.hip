@@ -1,0 +1,728 @@
+// rg_search.hip -- gfx950 kernels and C-ABI entry points of the search path.
+//
+//   K1  rg_search_kernel   persistent beam search, one wave64 per in-flight query
+//                          == IndexBipartite::SearchRoarGraph (src/index_bipartite.cpp:2311-2420)
+//   K1b rg_score_kernel    batched Distance::compare (include/efanna2e/distance.h:18)
+//
+// Per query (one wave, one single-wave workgroup, all state wave-private):
+//   LDS   : sorted beam of L_pq (dist, id|expanded) pairs  == NeighborPriorityQueue (neighbor.h:138-223)
+//           query vector, 64-entry candidate id/score scratch, LDS-DMA staging for the row gather
+//   HBM   : visited bitmap of nd bits per slot             == VisitedList (visited_list_pool.h:8-29), set semantics
+//           + a log of the ids touched, replayed to clear the bitmap after the query
+// Per hop (hop-synchronous, see SURVEY.md Appendix C-11 for why this reproduces the sequential inserts):
+//   pop closest unexpanded -> read its adjacency row -> atomicOr visited bits -> ballot-compact the unvisited ids
+//   -> gather + score them 4 rows per sub-pass -> rank-merge the survivors into the beam.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rg.h"
+#include "rg_device.h"
+#include "rg_internal.h"
+
+namespace rg {
+
+#define RG_HIP(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess)                                                                          \
+            return set_error(RG_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));        \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------------ device
+struct SearchParams {
+    const float *base;
+    uint32_t stride, dim, nd;
+    const uint32_t *ell;      // [nd][ell_stride]: word 0 = degree, then neighbour ids (null -> CSR)
+    uint32_t ell_stride;
+    const uint64_t *offsets;  // CSR
+    const uint32_t *nbrs;
+    uint32_t ep;
+    const float *queries;
+    uint32_t nq, qstride, k, L;
+    uint32_t *out_ids;
+    float *out_dists;
+    uint32_t *out_cmps, *out_hops;
+    uint32_t *visited;        // [slots][vwords]
+    uint32_t vwords;
+    uint32_t *vlog;           // [slots][logcap]
+    uint32_t logcap;
+    uint32_t *counter;        // work-queue head
+    unsigned long long *status;  // min over failing queries of (query << 32 | queue size); ~0 = none
+    uint32_t stage_floats;    // floats per sub-pass staging buffer (ceil(dim/64)*256)
+};
+
+struct Beam {
+    uint2 *ent;  // LDS: x = distance bits, y = id | kFlagBit
+    uint32_t size, cur, cap;
+};
+
+// closest_unexpanded (neighbor.h:185-192): flag the entry at cur, move cur to the next unflagged entry
+__device__ __forceinline__ uint32_t beam_pop(Beam &bm, int lane) {
+    uint2 e = bm.ent[bm.cur];
+    if (lane == 0) bm.ent[bm.cur].y = e.y | kFlagBit;
+    uint32_t c = bm.cur + 1;
+    for (;;) {
+        if (c >= bm.size) { c = bm.size; break; }
+        uint32_t idx = c + lane;
+        bool open = idx < bm.size && !(bm.ent[idx].y & kFlagBit);
+        unsigned long long m = __ballot(open);
+        if (m) { c += __ffsll((long long)m) - 1; break; }
+        c += kWave;
+    }
+    bm.cur = c;
+    wave_sync();
+    return e.y & ~kFlagBit;
+}
+
+// Insert the n (<= 64) scored candidates (lane i holds candidate i) -- the net effect of n calls of
+// NeighborPriorityQueue::insert (neighbor.h:150-183).  The beam is the top-cap of everything inserted so far
+// under the total order (distance, id); candidates are distinct unvisited nodes, the only possible repeat is the
+// entry point (never marked visited, index_bipartite.cpp:2349), whose second insert the reference drops.
+__device__ __forceinline__ void beam_merge(Beam &bm, float cd, uint32_t cid, uint32_t n, uint32_t ep, int lane) {
+    bool valid = (uint32_t)lane < n && cid != ep;
+    if (bm.size == bm.cap) {  // full: only candidates better than the current worst can enter (neighbor.h:151-153)
+        uint2 w = bm.ent[bm.cap - 1];
+        valid = valid && nb_less(cd, cid, __uint_as_float(w.x), w.y & ~kFlagBit);
+    }
+    const unsigned long long vmask = __ballot(valid);
+    if (!vmask) return;
+    const uint32_t nc = __popcll(vmask);
+    // rank among the candidates
+    uint32_t crank = 0;
+    for (unsigned long long m = vmask; m; m &= m - 1) {
+        const int s = __ffsll((long long)m) - 1;
+        const float od = readlane_f(cd, s);
+        const uint32_t oi = readlane_u(cid, s);
+        crank += nb_less(od, oi, cd, cid) ? 1u : 0u;
+    }
+    // rank among the beam entries (lower bound; no entry equals a candidate)
+    uint32_t lo = 0, hi = valid ? bm.size : 0;
+    while (__any(lo < hi)) {
+        if (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            const uint2 e = bm.ent[mid];
+            if (nb_less(__uint_as_float(e.x), e.y & ~kFlagBit, cd, cid)) lo = mid + 1;
+            else hi = mid;
+        }
+    }
+    const uint32_t qrank = valid ? lo : 0xffffffffu;
+    const uint32_t fpos = lo + crank;
+    const bool keep = valid && fpos < bm.cap;
+    // first beam index that moves
+    uint32_t minq = qrank;
+    for (int o = 32; o; o >>= 1) minq = min(minq, (uint32_t)__shfl_xor((int)minq, o, 64));
+    // new cursor: first unflagged entry after the merge
+    uint32_t ncur = 0xffffffffu;
+    if (bm.cur < bm.size) {
+        const uint32_t sh = __popcll(__ballot(valid && qrank <= bm.cur));
+        if (bm.cur + sh < bm.cap) ncur = bm.cur + sh;
+    }
+    uint32_t mp = keep ? fpos : 0xffffffffu;
+    for (int o = 32; o; o >>= 1) mp = min(mp, (uint32_t)__shfl_xor((int)mp, o, 64));
+    ncur = min(ncur, mp);
+    // shift entries [minq, size) right by the number of candidates ranked at or before them, top chunk first
+    for (int top = (int)bm.size - 1; top >= (int)minq; top -= kWave) {
+        const int i = top - lane;
+        const bool mv = i >= (int)minq;
+        uint2 e = make_uint2(0, 0);
+        if (mv) e = bm.ent[i];
+        uint32_t sh = 0;
+        for (unsigned long long m = vmask; m; m &= m - 1) {
+            const int s = __ffsll((long long)m) - 1;
+            sh += readlane_u(qrank, s) <= (uint32_t)i ? 1u : 0u;
+        }
+        wave_sync();
+        if (mv && (uint32_t)i + sh < bm.cap) bm.ent[(uint32_t)i + sh] = e;
+        wave_sync();
+    }
+    if (keep) bm.ent[fpos] = make_uint2(__float_as_uint(cd), cid);
+    bm.size = min(bm.cap, bm.size + nc);
+    bm.cur = ncur == 0xffffffffu ? bm.size : ncur;
+    wave_sync();
+}
+
+template <bool L2, bool ELL, int R>
+__global__ void __launch_bounds__(64) rg_search_kernel(SearchParams P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x;
+    const int g = lane >> 4;
+    // LDS carve (all offsets multiples of 16 B)
+    float *stage = reinterpret_cast<float *>(smem);                       // R * stage_floats
+    float *qv = stage + (size_t)R * P.stage_floats;                       // dim
+    uint32_t *cand_id = reinterpret_cast<uint32_t *>(qv + P.dim);         // 64
+    float *cand_d = reinterpret_cast<float *>(cand_id + kWave);           // 64
+    Beam bm;
+    bm.ent = reinterpret_cast<uint2 *>(cand_d + kWave);                   // L
+    bm.cap = P.L;
+
+    uint32_t *vmap = P.visited + (size_t)blockIdx.x * P.vwords;
+    uint32_t *vlog = P.vlog + (size_t)blockIdx.x * P.logcap;
+
+    for (;;) {
+        uint32_t qi = 0;
+        if (lane == 0) qi = atomicAdd(P.counter, 1u);
+        qi = readlane_u(qi, 0);
+        if (qi >= P.nq) break;
+        const float *query = P.queries + (size_t)qi * P.qstride;
+        for (uint32_t i = lane; i < P.dim; i += kWave) qv[i] = query[i];
+        wave_sync();
+
+        // entry point: scored and queued, not marked visited (index_bipartite.cpp:2338-2352)
+        gather_issue(P.base + (size_t)P.ep * P.stride, P.dim, g == 0, stage, lane);
+        gather_wait();
+        const float epd = gather_score<L2>(stage, qv, P.dim, lane);
+        if (lane == 0) bm.ent[0] = make_uint2(__float_as_uint(epd), P.ep);
+        bm.size = 1;
+        bm.cur = 0;
+        wave_sync();
+
+        uint32_t cmps = 0, hops = 0, logn = 0;
+        while (bm.cur < bm.size) {                                         // has_unexpanded_node, :2356
+            const uint32_t node = beam_pop(bm, lane);                      // :2358
+            ++hops;                                                        // :2366
+            // adjacency of `node`, 64 words at a time
+            uint32_t deg, first = 0;
+            const uint32_t *list;
+            if (ELL) {
+                const uint32_t *row = P.ell + (size_t)node * P.ell_stride;
+                first = (uint32_t)lane < P.ell_stride ? row[lane] : 0u;
+                deg = readlane_u(first, 0);
+                list = row + 1;
+            } else {
+                const uint64_t o0 = P.offsets[node], o1 = P.offsets[node + 1];
+                deg = (uint32_t)(o1 - o0);
+                list = P.nbrs + o0;
+            }
+            for (uint32_t c0 = 0; c0 < deg; c0 += kWave) {                 // neighbour loop, :2368
+                uint32_t id = 0;
+                bool have;
+                if (ELL && c0 == 0) {
+                    // words 1..63 of the row were fetched with the degree: neighbours 0..62
+                    id = (uint32_t)__shfl_down((int)first, 1, 64);
+                    have = (uint32_t)lane < min(deg, 63u);
+                    if (lane == 63 && deg > 63u) { id = list[63]; have = true; }
+                } else {
+                    have = c0 + lane < deg;
+                    if (have) id = list[c0 + lane];
+                }
+                // visited test-and-set (:2378, :2385); same-hop duplicates are resolved by the atomic's order
+                bool fresh = false;
+                if (have) {
+                    const uint32_t bit = 1u << (id & 31u);
+                    const uint32_t old = atomicOr(&vmap[id >> 5], bit);
+                    fresh = !(old & bit);
+                }
+                const unsigned long long fm = __ballot(fresh);
+                const uint32_t n = __popcll(fm);
+                if (n == 0) continue;
+                if (fresh) {
+                    const uint32_t slot = __popcll(fm & ((1ull << lane) - 1ull));
+                    cand_id[slot] = id;
+                    if (logn + slot < P.logcap) vlog[logn + slot] = id;
+                }
+                logn += n;
+                cmps += n;                                                 // :2397
+                wave_sync();
+                // gather + score, 4*R rows per pass (:2387)
+                for (uint32_t p0 = 0; p0 < n; p0 += 4 * R) {
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const uint32_t c = p0 + 4 * r + g;
+                        const bool act = c < n;
+                        const uint32_t rid = act ? cand_id[c] : 0u;
+                        gather_issue(P.base + (size_t)rid * P.stride, P.dim, act, stage + (size_t)r * P.stage_floats, lane);
+                    }
+                    gather_wait();
+#pragma unroll
+                    for (int r = 0; r < R; ++r) {
+                        const uint32_t c = p0 + 4 * r + g;
+                        const float d = gather_score<L2>(stage + (size_t)r * P.stage_floats, qv, P.dim, lane);
+                        if (c < n && (lane & 15) == 0) cand_d[c] = d;
+                    }
+                    wave_sync();
+                }
+                // queue inserts (:2398)
+                const float cd = (uint32_t)lane < n ? cand_d[lane] : 0.0f;
+                const uint32_t cid = (uint32_t)lane < n ? cand_id[lane] : 0u;
+                wave_sync();
+                beam_merge(bm, cd, cid, n, P.ep, lane);
+            }
+        }
+
+        // results (:2408-2418)
+        if (bm.size < P.k) {
+            if (lane == 0) atomicMin(P.status, ((unsigned long long)qi << 32) | bm.size);
+        } else {
+            for (uint32_t i = lane; i < P.k; i += kWave) {
+                const uint2 e = bm.ent[i];
+                P.out_ids[(size_t)qi * P.k + i] = e.y & ~kFlagBit;
+                P.out_dists[(size_t)qi * P.k + i] = __uint_as_float(e.x);
+            }
+        }
+        if (lane == 0) {
+            if (P.out_cmps) P.out_cmps[qi] = cmps;
+            if (P.out_hops) P.out_hops[qi] = hops;
+        }
+        // clear this slot's visited bits: replay the log, or wipe the bitmap if the log overflowed
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (logn <= P.logcap) {
+            for (uint32_t i = lane; i < logn; i += kWave) {
+                const uint32_t id = __hip_atomic_load(&vlog[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                vmap[id >> 5] = 0u;
+            }
+        } else {
+            for (uint32_t w = lane; w < P.vwords; w += kWave) vmap[w] = 0u;
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wave_sync();
+    }
+}
+
+// K1b: out[i] = compare(base[ids[i]], query) for n ids; one wave scores 4*R rows per pass
+template <bool L2, int R>
+__global__ void __launch_bounds__(64) rg_score_kernel(const float *__restrict__ base, uint32_t stride, uint32_t dim,
+                                                      const float *__restrict__ query, const uint32_t *__restrict__ ids,
+                                                      uint32_t n, float *__restrict__ out, uint32_t stage_floats) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x, g = lane >> 4;
+    float *stage = reinterpret_cast<float *>(smem);
+    float *qv = stage + (size_t)R * stage_floats;
+    for (uint32_t i = lane; i < dim; i += kWave) qv[i] = query[i];
+    wave_sync();
+    for (uint32_t p0 = blockIdx.x * 4 * R; p0 < n; p0 += gridDim.x * 4 * R) {
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t c = p0 + 4 * r + g;
+            const bool act = c < n;
+            const uint32_t rid = act ? ids[c] : 0u;
+            gather_issue(base + (size_t)rid * stride, dim, act, stage + (size_t)r * stage_floats, lane);
+        }
+        gather_wait();
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const uint32_t c = p0 + 4 * r + g;
+            const float d = gather_score<L2>(stage + (size_t)r * stage_floats, qv, dim, lane);
+            if (c < n && (lane & 15) == 0) out[c] = d;
+        }
+        wave_sync();
+    }
+}
+
+// CSR -> ELL ([deg, ids...] per node at a fixed stride), one wave per node
+__global__ void rg_csr_to_ell_kernel(const uint64_t *offsets, const uint32_t *nbrs, uint32_t nd, uint32_t *ell,
+                                     uint32_t ell_stride) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t wpb = blockDim.x / 64;
+    for (uint32_t node = blockIdx.x * wpb + threadIdx.x / 64; node < nd; node += gridDim.x * wpb) {
+        const uint64_t o0 = offsets[node];
+        const uint32_t deg = (uint32_t)(offsets[node + 1] - o0);
+        uint32_t *row = ell + (size_t)node * ell_stride;
+        if (lane == 0) row[0] = deg;
+        for (uint32_t j = lane; j < ell_stride - 1; j += 64) row[1 + j] = j < deg ? nbrs[o0 + j] : 0u;
+    }
+}
+
+// max degree, max neighbour id, edge count check
+__global__ void rg_graph_stats_kernel(const uint64_t *offsets, const uint32_t *nbrs, uint32_t nd, uint32_t *max_deg,
+                                      uint32_t *max_id) {
+    uint32_t md = 0, mi = 0;
+    const size_t tid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, nth = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = tid; i < nd; i += nth) md = max(md, (uint32_t)(offsets[i + 1] - offsets[i]));
+    const uint64_t ne = offsets[nd];
+    for (size_t e = tid; e < ne; e += nth) mi = max(mi, nbrs[e]);
+    for (int o = 32; o; o >>= 1) {
+        md = max(md, (uint32_t)__shfl_xor((int)md, o, 64));
+        mi = max(mi, (uint32_t)__shfl_xor((int)mi, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicMax(max_deg, md);
+        atomicMax(max_id, mi);
+    }
+}
+
+}  // namespace rg
+
+// -------------------------------------------------------------------------------------------------- host
+using rg::set_error;
+
+struct rg_index {
+    int device = 0;
+    int metric = RG_METRIC_IP;
+    uint32_t nd = 0, dim = 0, stride = 0, ep = 0;
+    float *d_base = nullptr;
+    bool own_base = false;
+    // graph
+    uint64_t *d_offsets = nullptr;
+    uint32_t *d_nbrs = nullptr;
+    uint32_t *d_ell = nullptr;
+    uint32_t ell_stride = 0;
+    uint64_t n_edges = 0;
+    uint32_t max_deg = 0;
+    // search scratch (lazily sized)
+    uint32_t *d_visited = nullptr;
+    uint32_t *d_vlog = nullptr;
+    uint32_t slots = 0, vwords = 0, logcap = 0;
+    uint32_t *d_counter = nullptr;
+    unsigned long long *d_status = nullptr;
+    unsigned long long *h_status = nullptr;  // pinned
+    // knobs
+    int waves_per_cu = 0;   // 0 = auto
+    int rows_per_pass = 8;  // 4*R
+    int force_csr = 0;
+    int num_cu = 256;
+    size_t lds_per_cu = 160 * 1024;
+};
+
+namespace rg {
+
+static rg_status pick_device(int device) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
+        return set_error(RG_ERR_DEVICE, "no HIP device visible: the gfx950 path cannot run (there is no CPU fallback)");
+    if (device < 0 || device >= n) return set_error(RG_ERR_ARG, "device index out of range");
+    RG_HIP(hipSetDevice(device));
+    return RG_OK;
+}
+
+static rg_status finish_graph(rg_index *ix, const uint64_t *d_off, const uint32_t *d_nb) {
+    // stats + validation
+    uint32_t *d_stat = nullptr;
+    RG_HIP(hipMalloc(&d_stat, 8));
+    RG_HIP(hipMemset(d_stat, 0, 8));
+    hipLaunchKernelGGL(rg_graph_stats_kernel, dim3(2048), dim3(256), 0, 0, d_off, d_nb, ix->nd, d_stat, d_stat + 1);
+    uint32_t st[2];
+    RG_HIP(hipMemcpy(st, d_stat, 8, hipMemcpyDeviceToHost));
+    RG_HIP(hipFree(d_stat));
+    uint64_t ne = 0;
+    RG_HIP(hipMemcpy(&ne, d_off + ix->nd, 8, hipMemcpyDeviceToHost));
+    ix->max_deg = st[0];
+    ix->n_edges = ne;
+    if (ne > 0 && st[1] >= ix->nd) return set_error(RG_ERR_FORMAT, "index file references a node id >= npts");
+    if (ix->ep >= ix->nd) return set_error(RG_ERR_FORMAT, "entry point >= npts");
+    if (ix->nd >= 0x80000000u) return set_error(RG_ERR_ARG, "more than 2^31-1 base points are not supported");
+    // ELL when it costs at most 2.5x the CSR bytes (real RoarGraph indexes: max degree <= 2*M_pjbp, avg ~ 0.6*max)
+    const uint32_t es = (ix->max_deg + 1 + 15) / 16 * 16;
+    const double ell_bytes = (double)ix->nd * es * 4.0, csr_bytes = (double)ne * 4.0 + (double)ix->nd * 8.0;
+    if (!ix->force_csr && ell_bytes <= 2.5 * csr_bytes + (64 << 20)) {
+        ix->ell_stride = es;
+        RG_HIP(hipMalloc(&ix->d_ell, (size_t)ix->nd * es * 4));
+        hipLaunchKernelGGL(rg_csr_to_ell_kernel, dim3(4096), dim3(256), 0, 0, d_off, d_nb, ix->nd, ix->d_ell, es);
+        RG_HIP(hipDeviceSynchronize());
+    } else {
+        RG_HIP(hipMalloc(&ix->d_offsets, ((size_t)ix->nd + 1) * 8));
+        RG_HIP(hipMalloc(&ix->d_nbrs, std::max<size_t>(ne * 4, 4)));
+        RG_HIP(hipMemcpy(ix->d_offsets, d_off, ((size_t)ix->nd + 1) * 8, hipMemcpyDeviceToDevice));
+        RG_HIP(hipMemcpy(ix->d_nbrs, d_nb, ne * 4, hipMemcpyDeviceToDevice));
+    }
+    RG_HIP(hipMalloc(&ix->d_counter, 64));
+    RG_HIP(hipMalloc(&ix->d_status, 64));
+    RG_HIP(hipHostMalloc(&ix->h_status, 64));
+    hipDeviceProp_t prop;
+    RG_HIP(hipGetDeviceProperties(&prop, ix->device));
+    ix->num_cu = prop.multiProcessorCount;
+    return RG_OK;
+}
+
+static size_t search_lds_bytes(const rg_index *ix, uint32_t L, int R) {
+    const size_t stage_floats = (size_t)((ix->dim + 63) / 64) * 256;
+    return (size_t)R * stage_floats * 4 + (size_t)ix->dim * 4 + 64 * 4 + 64 * 4 + (size_t)L * 8;
+}
+
+static rg_status ensure_scratch(rg_index *ix, uint32_t slots) {
+    const uint32_t vwords = (ix->nd + 31) / 32;
+    const uint32_t logcap = 1u << 16;
+    if (ix->slots >= slots && ix->vwords == vwords) return RG_OK;
+    if (ix->d_visited) (void)hipFree(ix->d_visited);
+    if (ix->d_vlog) (void)hipFree(ix->d_vlog);
+    ix->d_visited = nullptr;
+    ix->d_vlog = nullptr;
+    RG_HIP(hipMalloc(&ix->d_visited, (size_t)slots * vwords * 4));
+    RG_HIP(hipMemset(ix->d_visited, 0, (size_t)slots * vwords * 4));
+    RG_HIP(hipMalloc(&ix->d_vlog, (size_t)slots * logcap * 4));
+    ix->slots = slots;
+    ix->vwords = vwords;
+    ix->logcap = logcap;
+    return RG_OK;
+}
+
+template <bool L2, bool ELL, int R>
+static rg_status launch_search_t(rg_index *ix, const SearchParams &P, uint32_t grid, size_t lds, hipStream_t s) {
+    auto kern = rg_search_kernel<L2, ELL, R>;
+    RG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, s, P);
+    RG_HIP(hipGetLastError());
+    return RG_OK;
+}
+
+template <bool L2, bool ELL>
+static rg_status launch_search_r(rg_index *ix, const SearchParams &P, uint32_t grid, size_t lds, int R, hipStream_t s) {
+    switch (R) {
+        case 1: return launch_search_t<L2, ELL, 1>(ix, P, grid, lds, s);
+        case 2: return launch_search_t<L2, ELL, 2>(ix, P, grid, lds, s);
+        default: return launch_search_t<L2, ELL, 4>(ix, P, grid, lds, s);
+    }
+}
+
+static rg_status search_dev(rg_index *ix, const float *d_q, uint32_t nq, uint32_t qstride, uint32_t k, uint32_t L,
+                            uint32_t *d_ids, float *d_dists, uint32_t *d_cmps, uint32_t *d_hops, hipStream_t s) {
+    if (!ix) return set_error(RG_ERR_ARG, "null index");
+    if (k > L) return set_error(RG_ERR_ARG, "L_pq must greater or equal than k");  // test_search_roargraph.cpp:192-195
+    if (k == 0 || L == 0) return set_error(RG_ERR_ARG, "k and L_pq must be positive");
+    if (qstride < ix->dim) return set_error(RG_ERR_ARG, "query stride smaller than the index dimension");
+    if (nq == 0) return RG_OK;
+    RG_HIP(hipSetDevice(ix->device));
+    int R = std::max(1, std::min(4, ix->rows_per_pass / 4));
+    if (R == 3) R = 2;
+    size_t lds = search_lds_bytes(ix, L, R);
+    while (lds > ix->lds_per_cu && R > 1) { R >>= 1; lds = search_lds_bytes(ix, L, R); }
+    if (lds > ix->lds_per_cu) return set_error(RG_ERR_ARG, "L_pq too large for the 160 KiB LDS of one CU");
+    int wpc = (int)std::min<size_t>(ix->lds_per_cu / lds, 32);
+    if (ix->waves_per_cu > 0) wpc = std::min(wpc, ix->waves_per_cu);
+    else wpc = std::min(wpc, 16);
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(nq, (uint64_t)ix->num_cu * wpc);
+    rg_status st = ensure_scratch(ix, grid);
+    if (st != RG_OK) return st;
+    RG_HIP(hipMemsetAsync(ix->d_counter, 0, 4, s));
+    RG_HIP(hipMemsetAsync(ix->d_status, 0xff, 8, s));
+    SearchParams P;
+    P.base = ix->d_base; P.stride = ix->stride; P.dim = ix->dim; P.nd = ix->nd;
+    P.ell = ix->d_ell; P.ell_stride = ix->ell_stride; P.offsets = ix->d_offsets; P.nbrs = ix->d_nbrs;
+    P.ep = ix->ep; P.queries = d_q; P.nq = nq; P.qstride = qstride; P.k = k; P.L = L;
+    P.out_ids = d_ids; P.out_dists = d_dists; P.out_cmps = d_cmps; P.out_hops = d_hops;
+    P.visited = ix->d_visited; P.vwords = ix->vwords; P.vlog = ix->d_vlog; P.logcap = ix->logcap;
+    P.counter = ix->d_counter; P.status = ix->d_status;
+    P.stage_floats = ((ix->dim + 63) / 64) * 256;
+    const bool l2 = ix->metric == RG_METRIC_L2, ell = ix->d_ell != nullptr;
+    if (l2 && ell) return launch_search_r<true, true>(ix, P, grid, lds, R, s);
+    if (l2) return launch_search_r<true, false>(ix, P, grid, lds, R, s);
+    if (ell) return launch_search_r<false, true>(ix, P, grid, lds, R, s);
+    return launch_search_r<false, false>(ix, P, grid, lds, R, s);
+}
+
+static rg_status search_wait(rg_index *ix, hipStream_t s, uint32_t k) {
+    RG_HIP(hipMemcpyAsync(ix->h_status, ix->d_status, 8, hipMemcpyDeviceToHost, s));
+    RG_HIP(hipStreamSynchronize(s));
+    const unsigned long long v = *ix->h_status;
+    if (v != ~0ull) {
+        char buf[160];
+        if (k) snprintf(buf, sizeof buf, "not enough results: %u, expected: %u (query %u)", (unsigned)(v & 0xffffffffu), k, (unsigned)(v >> 32));
+        else snprintf(buf, sizeof buf, "not enough results: %u (query %u)", (unsigned)(v & 0xffffffffu), (unsigned)(v >> 32));
+        return set_error(RG_ERR_NOT_ENOUGH, buf);
+    }
+    return RG_OK;
+}
+
+static rg_status score_dev(rg_index *ix, const float *d_query, const uint32_t *d_ids, uint32_t n, float *d_out, hipStream_t s) {
+    if (!ix) return set_error(RG_ERR_ARG, "null index");
+    if (n == 0) return RG_OK;
+    RG_HIP(hipSetDevice(ix->device));
+    constexpr int R = 2;
+    const uint32_t stage_floats = ((ix->dim + 63) / 64) * 256;
+    const size_t lds = (size_t)R * stage_floats * 4 + (size_t)ix->dim * 4;
+    const uint32_t passes = (n + 4 * R - 1) / (4 * R);
+    const uint32_t grid = std::min<uint32_t>(passes, (uint32_t)ix->num_cu * 16u);
+    if (ix->metric == RG_METRIC_L2)
+        hipLaunchKernelGGL((rg_score_kernel<true, R>), dim3(grid), dim3(64), lds, s, ix->d_base, ix->stride, ix->dim, d_query, d_ids, n, d_out, stage_floats);
+    else
+        hipLaunchKernelGGL((rg_score_kernel<false, R>), dim3(grid), dim3(64), lds, s, ix->d_base, ix->stride, ix->dim, d_query, d_ids, n, d_out, stage_floats);
+    RG_HIP(hipGetLastError());
+    return RG_OK;
+}
+
+}  // namespace rg
+
+extern "C" {
+
+int rg_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+void rg_index_close(rg_index *ix) {
+    if (!ix) return;
+    (void)hipSetDevice(ix->device);
+    if (ix->own_base && ix->d_base) (void)hipFree(ix->d_base);
+    if (ix->d_offsets) (void)hipFree(ix->d_offsets);
+    if (ix->d_nbrs) (void)hipFree(ix->d_nbrs);
+    if (ix->d_ell) (void)hipFree(ix->d_ell);
+    if (ix->d_visited) (void)hipFree(ix->d_visited);
+    if (ix->d_vlog) (void)hipFree(ix->d_vlog);
+    if (ix->d_counter) (void)hipFree(ix->d_counter);
+    if (ix->d_status) (void)hipFree(ix->d_status);
+    if (ix->h_status) (void)hipHostFree(ix->h_status);
+    delete ix;
+}
+
+rg_status rg_index_open_dev(const float *d_base, uint32_t nd, uint32_t dim, uint32_t stride, const uint64_t *d_offsets,
+                            const uint32_t *d_nbrs, uint32_t ep, int metric, int device, rg_index **out) {
+    if (!out || !d_base || !d_offsets) return set_error(RG_ERR_ARG, "null argument");
+    if (metric != RG_METRIC_L2 && metric != RG_METRIC_IP && metric != RG_METRIC_COSINE)
+        return set_error(RG_ERR_ARG, "Unknown distance type");
+    if (dim == 0 || dim % 8 != 0 || stride < dim || stride % 4 != 0 || ((uintptr_t)d_base & 15))
+        return set_error(RG_ERR_ARG, "device base must be 16-byte aligned with dim % 8 == 0 and stride % 4 == 0");
+    rg_status st = rg::pick_device(device);
+    if (st != RG_OK) return st;
+    rg_index *ix = new rg_index();
+    ix->device = device; ix->metric = metric; ix->nd = nd; ix->dim = dim; ix->stride = stride; ix->ep = ep;
+    ix->d_base = const_cast<float *>(d_base);
+    ix->own_base = false;
+    if (const char *e = getenv("RG_FORCE_CSR")) ix->force_csr = atoi(e);
+    st = rg::finish_graph(ix, d_offsets, d_nbrs);
+    if (st != RG_OK) { rg_index_close(ix); return st; }
+    *out = ix;
+    return RG_OK;
+}
+
+rg_status rg_index_open_mem(const float *base, uint32_t nd, uint32_t dim, uint32_t stride, const uint64_t *offsets,
+                            const uint32_t *nbrs, uint32_t ep, int metric, int device, rg_index **out) {
+    if (!out || !base || !offsets) return set_error(RG_ERR_ARG, "null argument");
+    if (dim == 0 || stride < dim) return set_error(RG_ERR_ARG, "bad dim/stride");
+    rg_status st = rg::pick_device(device);
+    if (st != RG_OK) return st;
+    // device copy at the aligned stride, zero padded (data_align, util.h:37-75); cosine rows are normalised first
+    const uint32_t ad = rg::aligned_dim(dim);
+    float *d_base = nullptr;
+    RG_HIP(hipMalloc(&d_base, std::max<size_t>((size_t)nd * ad * 4, 16)));
+    if (metric == RG_METRIC_COSINE || ad != dim || ad != stride) {
+        std::vector<float> tmp((size_t)nd * ad, 0.0f);
+        for (size_t i = 0; i < nd; ++i) std::memcpy(tmp.data() + i * ad, base + i * (size_t)stride, (size_t)dim * 4);
+        if (metric == RG_METRIC_COSINE) rg_normalize_rows(tmp.data(), nd, ad, dim);
+        RG_HIP(hipMemcpy(d_base, tmp.data(), tmp.size() * 4, hipMemcpyHostToDevice));
+    } else {
+        RG_HIP(hipMemcpy(d_base, base, (size_t)nd * ad * 4, hipMemcpyHostToDevice));
+    }
+    const uint64_t ne = offsets[nd];
+    uint64_t *d_off = nullptr;
+    uint32_t *d_nb = nullptr;
+    RG_HIP(hipMalloc(&d_off, ((size_t)nd + 1) * 8));
+    RG_HIP(hipMalloc(&d_nb, std::max<size_t>(ne * 4, 4)));
+    RG_HIP(hipMemcpy(d_off, offsets, ((size_t)nd + 1) * 8, hipMemcpyHostToDevice));
+    RG_HIP(hipMemcpy(d_nb, nbrs, ne * 4, hipMemcpyHostToDevice));
+    rg_index *ix = nullptr;
+    st = rg_index_open_dev(d_base, nd, ad, ad, d_off, d_nb, ep, metric, device, &ix);
+    (void)hipFree(d_off);
+    (void)hipFree(d_nb);
+    if (st != RG_OK) { (void)hipFree(d_base); return st; }
+    ix->own_base = true;
+    *out = ix;
+    return RG_OK;
+}
+
+rg_status rg_index_open(const char *base_fbin, const char *index_path, int metric, int device, rg_index **out) {
+    if (!base_fbin || !index_path || !out) return set_error(RG_ERR_ARG, "null argument");
+    uint32_t nb = 0, dim = 0, stride = 0, nd = 0, ep = 0;
+    float *base = nullptr;
+    uint64_t *off = nullptr;
+    uint32_t *nbrs = nullptr;
+    rg_status st = rg_fbin_load(base_fbin, &nb, &dim, &stride, &base);
+    if (st != RG_OK) return st;
+    st = rg_graph_load(index_path, &nd, &ep, &off, &nbrs);
+    if (st != RG_OK) { rg_free(base); return st; }
+    if (nd != nb) {
+        rg_free(base); rg_free(off); rg_free(nbrs);
+        return set_error(RG_ERR_FORMAT, "index and base file disagree on the number of points");
+    }
+    st = rg_index_open_mem(base, nb, dim, stride, off, nbrs, ep, metric, device, out);
+    rg_free(base); rg_free(off); rg_free(nbrs);
+    return st;
+}
+
+rg_status rg_index_info(const rg_index *ix, uint32_t *nd, uint32_t *dim, uint32_t *stride, uint32_t *ep,
+                        float *avg_degree, uint32_t *max_degree, int *device) {
+    if (!ix) return set_error(RG_ERR_ARG, "null index");
+    if (nd) *nd = ix->nd;
+    if (dim) *dim = ix->dim;
+    if (stride) *stride = ix->stride;
+    if (ep) *ep = ix->ep;
+    if (avg_degree) *avg_degree = ix->nd ? (float)((double)ix->n_edges / ix->nd) : 0.0f;
+    if (max_degree) *max_degree = ix->max_deg;
+    if (device) *device = ix->device;
+    return RG_OK;
+}
+
+rg_status rg_index_set(rg_index *ix, const char *name, int value) {
+    if (!ix || !name) return set_error(RG_ERR_ARG, "null argument");
+    if (!strcmp(name, "waves_per_cu")) ix->waves_per_cu = value;
+    else if (!strcmp(name, "rows_per_pass")) ix->rows_per_pass = value;
+    else return set_error(RG_ERR_ARG, "unknown knob");
+    return RG_OK;
+}
+
+rg_status rg_search_dev(rg_index *ix, const float *d_queries, uint32_t nq, uint32_t qstride, uint32_t k, uint32_t L_pq,
+                        uint32_t *d_ids, float *d_dists, uint32_t *d_cmps, uint32_t *d_hops, void *stream) {
+    return rg::search_dev(ix, d_queries, nq, qstride, k, L_pq, d_ids, d_dists, d_cmps, d_hops, (hipStream_t)stream);
+}
+
+rg_status rg_search_wait(rg_index *ix, void *stream) {
+    if (!ix) return set_error(RG_ERR_ARG, "null index");
+    return rg::search_wait(ix, (hipStream_t)stream, 0);
+}
+
+rg_status rg_search(rg_index *ix, const float *queries, uint32_t nq, uint32_t qstride, uint32_t k, uint32_t L_pq,
+                    uint32_t *out_ids, float *out_dists, uint32_t *out_cmps, uint32_t *out_hops) {
+    if (!ix || !queries || !out_ids || !out_dists) return set_error(RG_ERR_ARG, "null argument");
+    if (k > L_pq) return set_error(RG_ERR_ARG, "L_pq must greater or equal than k");
+    if (nq == 0) return RG_OK;
+    RG_HIP(hipSetDevice(ix->device));
+    // queries -> device at the index stride, zero padded; cosine queries normalised (test_search_roargraph.cpp:167-172)
+    const uint32_t d = ix->dim;
+    const uint32_t use = std::min(qstride, d);
+    std::vector<float> hq((size_t)nq * d, 0.0f);
+    for (size_t i = 0; i < nq; ++i) std::memcpy(hq.data() + i * d, queries + i * (size_t)qstride, (size_t)use * 4);
+    if (ix->metric == RG_METRIC_COSINE) rg_normalize_rows(hq.data(), nq, d, d);
+    float *d_q = nullptr, *d_dist = nullptr;
+    uint32_t *d_ids = nullptr, *d_ch = nullptr;
+    RG_HIP(hipMalloc(&d_q, hq.size() * 4));
+    RG_HIP(hipMalloc(&d_ids, (size_t)nq * k * 4));
+    RG_HIP(hipMalloc(&d_dist, (size_t)nq * k * 4));
+    RG_HIP(hipMalloc(&d_ch, (size_t)nq * 8));
+    RG_HIP(hipMemcpy(d_q, hq.data(), hq.size() * 4, hipMemcpyHostToDevice));
+    RG_HIP(hipMemset(d_ids, 0, (size_t)nq * k * 4));
+    RG_HIP(hipMemset(d_dist, 0, (size_t)nq * k * 4));
+    rg_status st = rg::search_dev(ix, d_q, nq, d, k, L_pq, d_ids, d_dist, d_ch, d_ch + nq, nullptr);
+    if (st == RG_OK) st = rg::search_wait(ix, nullptr, k);
+    if (st == RG_OK || st == RG_ERR_NOT_ENOUGH) {
+        (void)hipMemcpy(out_ids, d_ids, (size_t)nq * k * 4, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(out_dists, d_dist, (size_t)nq * k * 4, hipMemcpyDeviceToHost);
+        if (out_cmps) (void)hipMemcpy(out_cmps, d_ch, (size_t)nq * 4, hipMemcpyDeviceToHost);
+        if (out_hops) (void)hipMemcpy(out_hops, d_ch + nq, (size_t)nq * 4, hipMemcpyDeviceToHost);
+    }
+    (void)hipFree(d_q); (void)hipFree(d_ids); (void)hipFree(d_dist); (void)hipFree(d_ch);
+    return st;
+}
+
+rg_status rg_score_batch_dev(rg_index *ix, const float *d_query, const uint32_t *d_ids, uint32_t n, float *d_out,
+                             void *stream) {
+    return rg::score_dev(ix, d_query, d_ids, n, d_out, (hipStream_t)stream);
+}
+
+rg_status rg_score_batch(rg_index *ix, const float *query, const uint32_t *ids, uint32_t n, float *out) {
+    if (!ix || !query || !ids || !out) return set_error(RG_ERR_ARG, "null argument");
+    if (n == 0) return RG_OK;
+    RG_HIP(hipSetDevice(ix->device));
+    for (uint32_t i = 0; i < n; ++i)
+        if (ids[i] >= ix->nd) return set_error(RG_ERR_ARG, "id out of range");
+    float *d_q = nullptr, *d_o = nullptr;
+    uint32_t *d_i = nullptr;
+    RG_HIP(hipMalloc(&d_q, (size_t)ix->dim * 4));
+    RG_HIP(hipMalloc(&d_o, (size_t)n * 4));
+    RG_HIP(hipMalloc(&d_i, (size_t)n * 4));
+    RG_HIP(hipMemcpy(d_q, query, (size_t)ix->dim * 4, hipMemcpyHostToDevice));
+    RG_HIP(hipMemcpy(d_i, ids, (size_t)n * 4, hipMemcpyHostToDevice));
+    rg_status st = rg::score_dev(ix, d_q, d_i, n, d_o, nullptr);
+    if (st == RG_OK) {
+        hipError_t e = hipMemcpy(out, d_o, (size_t)n * 4, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) st = set_error(RG_ERR_DEVICE, hipGetErrorString(e));
+    }
+    (void)hipFree(d_q); (void)hipFree(d_o); (void)hipFree(d_i);
+    return st;
+}
+
+}  // extern "C"

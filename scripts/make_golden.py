@@ -1,0 +1,141 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz from the reference's own code.
+
+Runs ONLY in the build container (needs /root/reference to build oracle/_ref/rg_ref, the driver around the
+reference's headers: distance.h, neighbor.h, visited_list_pool.h, util.h).  The outputs are data -- seeded inputs and
+the values the reference code returned for them -- and are committed so that the GPU box (which has no reference tree)
+can check both the oracle and the HIP path against them.
+
+  G1 dist_<metric>_<d>.npz    a[n,d], b[n,d], expect_bits[n]            DistanceInnerProduct/DistanceL2::compare
+  G2 queue_traces.npz         op/id/dist traces + final state            NeighborPriorityQueue insert / closest_unexpanded
+  G3 search_<name>.npz        base, queries, graph (CSR), ep and per (L,k): ids, dist bits, cmps, hops
+                              (genuine queue + visited pool + distance, loop restated -- see oracle/ref_driver.cpp)
+  G4 formats.npz              bytes of small .fbin / gt files (good and truncated) + what util.h's loaders said
+
+usage: python scripts/make_golden.py
+"""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import pyoracle as po  # noqa: E402
+from roargraph_amd import io, synth  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def g1():
+    rng = np.random.default_rng(20240501)
+    for metric in ("ip", "l2"):
+        for d, n in ((8, 128), (16, 128), (24, 128), (40, 128), (200, 128), (512, 96), (136, 64)):
+            a = rng.standard_normal((n, d)).astype(np.float32)
+            b = (0.3 + 0.5 * rng.standard_normal((n, d))).astype(np.float32)
+            # a few exact-cancellation / zero rows as edge cases
+            a[0] = 0.0
+            b[1] = a[1]
+            exp = po.ref_dist(metric, a, b)
+            np.savez_compressed(os.path.join(OUT, "dist_%s_%d.npz" % (metric, d)), a=a, b=b,
+                                expect_bits=exp.view(np.uint32))
+
+
+def g2():
+    rng = np.random.default_rng(7)
+    traces = {}
+    for t, (cap, nops, nid) in enumerate(((1, 40, 8), (4, 200, 20), (10, 600, 60), (50, 3000, 4000),
+                                           (100, 6000, 100000), (500, 8000, 100000))):
+        ops = (rng.random(nops) < 0.25).astype(np.uint8)
+        ids = rng.integers(0, nid, nops).astype(np.uint32)
+        # coarse distances so that ties (same distance, different id) and re-inserted ids are common
+        ds = (rng.integers(0, 64, nops) / 8.0).astype(np.float32)
+        r = po.ref_queue(cap, ops, ids, ds)
+        traces.update({"t%d_cap" % t: cap, "t%d_ops" % t: ops, "t%d_ids" % t: ids, "t%d_dists" % t: ds,
+                       "t%d_size" % t: r["size"], "t%d_cur" % t: r["cur"], "t%d_out_ids" % t: r["ids"],
+                       "t%d_out_dists" % t: r["dists"].view(np.uint32), "t%d_out_flags" % t: r["flags"],
+                       "t%d_pops" % t: r["pops"]})
+    traces["ntraces"] = 6
+    np.savez_compressed(os.path.join(OUT, "queue_traces.npz"), **traces)
+
+
+def g3():
+    sets = (("ip200", "ip", 2000, 200, 48), ("l2_512", "l2", 1000, 512, 32), ("ip24", "ip", 600, 24, 32))
+    with tempfile.TemporaryDirectory() as td:
+        for name, metric, nb, d, nq in sets:
+            base, q = synth.make_synth(1234, nb, nq, d)
+            tq = synth.make_synth(4321, nb, 500, d)[1]
+            lists, ep = synth.knn_graph(base, metric, M=10, train_queries=tq)
+            # format corner cases the file layout allows: an empty list, a list > 64 long, a duplicated id, a self loop
+            lists[5] = np.zeros(0, np.uint32)
+            lists[7] = np.arange(100, 100 + 150, dtype=np.uint32) % nb
+            lists[9] = np.concatenate([lists[9], lists[9][:3], [9]]).astype(np.uint32)
+            off, nbrs = io.lists_to_csr(lists)
+            bf, qf, gf = (os.path.join(td, x) for x in ("b.fbin", "q.fbin", "g.index"))
+            io.write_fbin(bf, base)
+            io.write_fbin(qf, q)
+            io.write_index(gf, off, nbrs, ep)
+            out = dict(base=base, queries=q, offsets=off, nbrs=nbrs, ep=ep, metric=metric)
+            cfgs = []
+            for L, k in ((10, 10), (50, 10), (100, 100), (500, 10), (1, 1), (64, 10), (65, 65)):
+                ids, ds, cmps, hops, _ = po.ref_search(bf, gf, qf, metric, k, L, threads=2)
+                tag = "L%d_k%d" % (L, k)
+                cfgs.append(tag)
+                out.update({tag + "_ids": ids, tag + "_dist_bits": ds.view(np.uint32), tag + "_cmps": cmps,
+                            tag + "_hops": hops})
+            out["configs"] = np.array(cfgs)
+            np.savez_compressed(os.path.join(OUT, "search_%s.npz" % name), **out)
+
+
+def g4():
+    out = {}
+    rng = np.random.default_rng(3)
+    with tempfile.TemporaryDirectory() as td:
+        def ask(kind, raw):
+            p = os.path.join(td, "f.bin")
+            open(p, "wb").write(raw)
+            r = po.ref_run("meta", kind, p, check=False)
+            lines = [l for l in r.stdout.splitlines() if l.startswith(("OK", "EXC"))]
+            return lines[-1] if lines else "EXIT %d" % r.returncode
+
+        data = rng.standard_normal((37, 24)).astype(np.float32)
+        good = np.array([37, 24], np.uint32).tobytes() + data.tobytes()
+        cases = {"fbin_good": good, "fbin_short_row": good[:-96], "fbin_short_bytes": good[:-5],
+                 "fbin_extra_bytes": good + b"\0" * 40, "fbin_extra_row": good + b"\0" * 96,
+                 "fbin_wrong_count": np.array([36, 24], np.uint32).tobytes() + data.tobytes()}
+        for k, raw in cases.items():
+            out[k] = np.frombuffer(raw, np.uint8)
+            out[k + "_says"] = ask("fbin", raw)
+        ids = rng.integers(0, 1000, (11, 5)).astype(np.uint32)
+        ds = rng.standard_normal((11, 5)).astype(np.float32)
+        ggood = np.array([11, 5], np.uint32).tobytes() + ids.tobytes() + ds.tobytes()
+        gcases = {"gt_good": ggood, "gt_ids_only": ggood[: 8 + 220], "gt_short": ggood[:-20],
+                  "gt_extra": ggood + b"\0" * 19}
+        for k, raw in gcases.items():
+            out[k] = np.frombuffer(raw, np.uint8)
+            out[k + "_says"] = ask("gt", raw)
+        # loaded content of the good files through the genuine loaders
+        p = os.path.join(td, "g.bin")
+        open(p, "wb").write(ggood)
+        po.ref_run("gtload", p, os.path.join(td, "o.bin"))
+        raw = np.fromfile(os.path.join(td, "o.bin"), np.uint32)
+        out["gt_good_ids"] = raw[:55].reshape(11, 5)
+        out["gt_good_dist_bits"] = raw[55:].reshape(11, 5)
+        open(p, "wb").write(good)
+        po.ref_run("fbinload", p, os.path.join(td, "o.bin"))
+        raw = np.fromfile(os.path.join(td, "o.bin"), np.uint32)
+        out["fbin_good_loaded_shape"] = raw[:2]
+        out["fbin_good_loaded_bits"] = raw[2:].reshape(int(raw[0]), int(raw[1]))
+    np.savez_compressed(os.path.join(OUT, "formats.npz"), **out)
+
+
+if __name__ == "__main__":
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
+    if not po.have_ref():
+        sys.exit("oracle/_ref/rg_ref is not available (needs /root/reference and an AVX-512 host)")
+    os.makedirs(OUT, exist_ok=True)
+    g1(); g2(); g3(); g4()
+    tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
+    print("golden fixtures written to", OUT, "(%.2f MB)" % (tot / 1e6))
