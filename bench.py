@@ -1,0 +1,235 @@
+#!/usr/bin/env python3
+"""bench.py -- QPS of the RoarGraph search hot path on MI355X (BASELINE.json metric #1).
+
+One "step" = one pass of the hot path over one batch: SearchRoarGraph for a batch of 10,000 queries
+(top-10, L_pq = 500) against a 10M x 200 inner-product base, the configuration of BASELINE.json configs[1]
+("t2i-10M d=200 IP ... 1xMI355X search kernel").  Inputs are synthetic (no dataset can be downloaded here):
+base ~ N(0,1), queries ~ N(0.3, 0.5^2), and -- because a real 10M-node roar.index cannot be built inside a
+bench run yet -- a random out-degree-40 graph, which drives the identical HBM access pattern (one random
+800-byte row per distance evaluation) but has no meaningful recall; recall is therefore reported as null.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Multi-GPU: the index is replicated, every rank searches its own batch of queries (independent units, no
+data-path collective); value = total queries / max-over-ranks time; scaling = weak.
+
+The JSON line also carries
+  roofline      achieved = algorithmic bytes (sum of distance evaluations x 4*dim) / kernel time (HIP events on
+                the launch stream), against the 8 TB/s HBM peak
+  cpu_baseline  the same workload on this box's host cores (rank 0, N=1 only), bounded sample:
+                kind "reference" = oracle/_ref/rg_ref (the reference's own distance/queue/visited code),
+                kind "port" = oracle/librg_oracle.so (AVX-512 restatement) when the former cannot run here.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--nb", type=int, default=10_000_000)
+    ap.add_argument("--dim", type=int, default=200)
+    ap.add_argument("--nq", type=int, default=10_000)
+    ap.add_argument("--k", type=int, default=10)
+    ap.add_argument("--L", type=int, default=500)
+    ap.add_argument("--deg", type=int, default=40)
+    ap.add_argument("--metric", default="ip")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall budget of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--waves-per-cu", type=int, default=0)
+    ap.add_argument("--rows-per-pass", type=int, default=0)
+    ap.add_argument("--sweep", default="", help="comma list of extra L_pq values to report (not part of the timed metric)")
+    return ap.parse_args()
+
+
+def _mem_available_gb():
+    try:
+        for line in open("/proc/meminfo"):
+            if line.startswith("MemAvailable"):
+                return int(line.split()[1]) / 1e6
+    except OSError:
+        pass
+    return 0.0
+
+
+def cpu_baseline(args, base_t, off_t, nbrs_t, ep, q_t, ids_gpu, budget_s):
+    """Time the CPU path on a bounded sample of the same workload; also re-checks parity on that sample."""
+    from oracle import pyoracle as po
+    from roargraph_amd import io
+    po.build() if not os.path.exists(po.LIB_PATH) else None
+    ncores = os.cpu_count() or 1
+    threads = min(16, ncores)  # README.md:110 evaluates with 16 threads
+    base = base_t.cpu().numpy()
+    off = off_t.cpu().numpy().view(np.uint64)
+    nbrs = nbrs_t.cpu().numpy().view(np.uint32)
+    q = q_t.cpu().numpy()
+    out = {"unit": "QPS", "cores": threads, "host_cores": ncores}
+    # pilot with the C port to size the sample
+    po.use_avx512(True)
+    pilot = min(args.nq, 2 * threads)
+    t0 = time.time()
+    r = po.search(base, args.metric, off, nbrs, ep, q[:pilot], args.k, args.L, nthreads=threads)
+    dt = max(time.time() - t0, 1e-6)
+    assert (r[0] == ids_gpu[:pilot]).all(), "CPU oracle and GPU disagree on the bench workload"
+    n = int(min(args.nq, max(pilot, budget_s * pilot / dt)))
+    n = max(threads, n - n % threads)
+    if po.have_ref() and _mem_available_gb() > 6.0 * base.nbytes / 1e9:
+        with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as td:
+            bf, qf, gf = (os.path.join(td, x) for x in ("b.fbin", "q.fbin", "g.index"))
+            io.write_fbin(bf, base)
+            io.write_fbin(qf, q[:n])
+            io.write_index(gf, off, nbrs, ep)
+            ids, _, cmps, _, qps = po.ref_search(bf, gf, qf, args.metric, args.k, args.L, threads=threads)
+        assert (ids == ids_gpu[:n]).all(), "reference-header driver and GPU disagree on the bench workload"
+        out.update(value=qps, kind="reference",
+                   sample="%d of %d queries, %d OpenMP threads, oracle/_ref/rg_ref (reference distance.h/neighbor.h/"
+                          "visited_list_pool.h, search loop restated)" % (n, args.nq, threads))
+    else:
+        t0 = time.time()
+        r = po.search(base, args.metric, off, nbrs, ep, q[:n], args.k, args.L, nthreads=threads)
+        dt = time.time() - t0
+        assert (r[0] == ids_gpu[:n]).all()
+        out.update(value=n / dt, kind="port",
+                   sample="%d of %d queries, %d OpenMP threads, oracle/librg_oracle.so (avx512=%s)"
+                          % (n, args.nq, threads, bool(po.have_avx512())))
+    out["mean_evals"] = float(np.mean(cmps if out["kind"] == "reference" else r[2]))
+    return out
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from roargraph_amd._lib import lib
+    from roargraph_amd.index import IndexBipartite
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if lib().rg_device_count() < 1:
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    # ---- synthetic t2i-10M-shaped inputs, resident in HBM before the timed region -------------------------------
+    g = torch.Generator(device=dev)
+    g.manual_seed(1234)  # same base + graph on every rank (replicated index)
+    base = torch.empty((args.nb, args.dim), dtype=torch.float32, device=dev)
+    chunk = 1 << 20
+    for s in range(0, args.nb, chunk):
+        base[s:s + chunk].normal_(generator=g)
+    nbrs = torch.randint(0, args.nb, (args.nb * args.deg,), dtype=torch.int32, device=dev, generator=g)
+    off = torch.arange(0, args.nb + 1, dtype=torch.int64, device=dev) * args.deg
+    ep = 0
+    g.manual_seed(99 + rank)  # each rank searches its own query batch
+    q = torch.empty((args.nq, args.dim), dtype=torch.float32, device=dev).normal_(generator=g) * 0.5 + 0.3
+    ids = torch.zeros((args.nq, args.k), dtype=torch.int32, device=dev)
+    dists = torch.zeros((args.nq, args.k), dtype=torch.float32, device=dev)
+    cmps = torch.zeros(args.nq, dtype=torch.int32, device=dev)
+    hops = torch.zeros(args.nq, dtype=torch.int32, device=dev)
+    index = IndexBipartite.from_device(base, off, nbrs, ep, metric=args.metric)
+    if args.waves_per_cu:
+        index.set("waves_per_cu", args.waves_per_cu)
+    if args.rows_per_pass:
+        index.set("rows_per_pass", args.rows_per_pass)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step(L):
+        index.search_dev(q, args.k, L, ids, dists, cmps, hops, stream=stream)
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(args.L)
+    index.search_wait(stream)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    sync_all()
+    t0 = time.perf_counter()
+    for a, b in evs:
+        a.record()
+        step(args.L)
+        b.record()
+    sync_all()
+    t1 = time.perf_counter()
+    index.search_wait(stream)
+    elapsed = t1 - t0
+    kernel_ms = [a.elapsed_time(b) for a, b in evs]
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    total_q = args.nq * args.steps * world
+    qps = total_q / elapsed
+    mean_cmps = float(cmps.float().mean().item())
+    mean_hops = float(hops.float().mean().item())
+    kavg = float(np.mean(kernel_ms)) / 1e3
+    alg_bytes = float(cmps.to(torch.int64).sum().item()) * 4.0 * args.dim
+    achieved = alg_bytes / kavg / 1e9
+
+    sweep = []
+    if args.sweep and rank == 0:
+        for L in [int(x) for x in args.sweep.split(",")]:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            step(L); torch.cuda.synchronize()
+            a.record(); step(L); b.record(); torch.cuda.synchronize()
+            ms = a.elapsed_time(b)
+            mc = float(cmps.float().mean().item())
+            sweep.append({"L_pq": L, "qps": args.nq / (ms / 1e3), "mean_evals": mc,
+                          "gbps": args.nq * mc * 4 * args.dim / (ms / 1e3) / 1e9})
+        step(args.L); torch.cuda.synchronize()
+
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_seconds > 0:
+        try:
+            cpu = cpu_baseline(args, base, off, nbrs, ep, q, ids.cpu().numpy().view(np.uint32), args.cpu_seconds)
+        except Exception as e:  # the baseline is a reported extra; never lose the GPU line over it
+            cpu = {"value": None, "unit": "QPS", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
+
+    if rank == 0:
+        line = {
+            "metric": "QPS @ recall@10, t2i-10M d=200 IP (search, top-%d, L_pq=%d)" % (args.k, args.L),
+            "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "t2i-10M-shaped: base %dx%d fp32 %s, %d queries/GPU/step, top-%d, L_pq=%d, "
+                                   "synthetic N(0,1) base, random out-degree-%d graph (replicated per GPU)"
+                                   % (args.nb, args.dim, args.metric, args.nq, args.k, args.L, args.deg),
+                       "parallelism": "query-sharded x%d, index replicated" % world,
+                       "recall_at_10": None,
+                       "recall_note": "random graph: same HBM access pattern as a real index, recall not meaningful",
+                       "mean_evals_per_query": mean_cmps, "mean_hops": mean_hops},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+                         "frac": achieved / 8000.0, "traffic": None,
+                         "kernel": "rg_search_kernel", "kernel_ms_avg": kavg * 1e3,
+                         "algorithmic_bytes_per_launch": alg_bytes,
+                         "frac_of_measured_stream_ceiling_6290": achieved / 6290.0},
+            "cpu_baseline": cpu,
+        }
+        if sweep:
+            line["L_pq_sweep"] = sweep
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
