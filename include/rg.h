@@ -129,8 +129,8 @@ rg_status rg_search_wait(rg_index *idx, void *stream);
  * (tests/test_search_bipartite.cpp:46-48) and squared L2 for l2.
  *
  * rg_gt_shard_dev: one GPU's part. Scores all nq queries against base rows [0, nb) of this shard and
- * writes the shard-local top-K (ids offset by id_base) sorted best first.  K <= 1024.
- * rg_gt_merge_dev: merges nlists sorted K-lists per query (layout [list][nq][K]) into one. */
+ * writes the shard-local top-K (ids offset by id_base) sorted best first.  K <= 896.
+ * rg_gt_merge_dev: merges nlists sorted K-lists per query (layout [list][nq][K]) into one; nlists*K <= 1024. */
 rg_status rg_gt_shard_dev(const float *d_base, uint32_t nb, uint32_t bstride, const float *d_queries, uint32_t nq,
                           uint32_t qstride, uint32_t dim, int metric, uint32_t K, uint32_t id_base, uint32_t *d_ids,
                           float *d_dists, int device, void *stream);

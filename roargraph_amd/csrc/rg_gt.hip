@@ -1,0 +1,591 @@
+// rg_gt.hip -- brute-force k-NN ground truth on gfx950 (replaces the external DiskANN compute_groundtruth that
+// RoarGraph's build consumes, README.md:62-75; consumer: LoadLearnBaseKNN, src/index_bipartite.cpp:2622-2642).
+//
+//   K2  rg_gt_kernel      fp32-input MFMA (v_mfma_f32_32x32x2_f32: exact fp32, k-ordered fma chain) scores of a block of
+//                         MQ queries against the whole base shard, streamed 128 rows at a time, with a fused
+//                         threshold filter + per-query candidate buffer + in-wave bitonic top-K
+//   K2b rg_gt_rescore     exact (q-b)^2 re-score of the K survivors for L2 (the MFMA ranks by q.b - |b|^2/2)
+//   K3  rg_gt_merge       merges per-shard sorted K-lists (multi-GPU: one list per rank) into the global top-K
+//
+// Work split: a workgroup (4 waves) OWNS a block of MQ queries for the whole pass, so the running thresholds and the
+// candidate counters are LDS-local and nothing is shared between workgroups.  The query block is staged once in LDS,
+// transposed to [k][query]; base rows stream through a double-buffered [k][row] LDS stage, prefetched through
+// registers one k-chunk ahead.  All co-resident workgroups walk the base shard in the same order, so the shard is
+// fetched from HBM about once per XCD per generation of workgroups and otherwise served by L2 / Infinity Cache.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "rg.h"
+#include "rg_internal.h"
+
+namespace rg {
+
+#define RG_HIP(expr)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (expr);                                                                        \
+        if (e_ != hipSuccess)                                                                          \
+            return set_error(RG_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));        \
+    } while (0)
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned long long u64;
+
+constexpr int kNB = 128;     // base rows per streamed tile
+constexpr int kBS = kNB + 4; // LDS row stride of the transposed base stage (bank spread)
+
+// order-preserving float -> uint (ascending)
+__device__ __forceinline__ uint32_t f2ord(float f) {
+    const uint32_t u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float ord2f(uint32_t o) {
+    const uint32_t u = (o & 0x80000000u) ? (o & 0x7fffffffu) : ~o;
+    return __uint_as_float(u);
+}
+// sort key, ascending = best first.  larger_first: score desc then id asc; else value asc then id asc.
+__device__ __forceinline__ u64 make_key(float s, uint32_t id, bool larger_first) {
+    const uint32_t o = f2ord(s + 0.0f);  // +0.0f folds -0 into +0
+    return ((u64)(larger_first ? ~o : o) << 32) | id;
+}
+__device__ __forceinline__ float key_value(u64 k, bool larger_first) {
+    const uint32_t hi = (uint32_t)(k >> 32);
+    return ord2f(larger_first ? ~hi : hi);
+}
+
+// ascending bitonic sort of 64*ITEMS keys held as key[it] in lane `lane` (element index = it*64 + lane)
+template <int ITEMS>
+__device__ __forceinline__ void wave_sort(u64 (&key)[ITEMS], int lane) {
+#pragma unroll
+    for (int k = 2; k <= 64 * ITEMS; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j >= 64) {
+                const int dj = j >> 6;
+#pragma unroll
+                for (int it = 0; it < ITEMS; ++it) {
+                    const int pt = it ^ dj;
+                    if (pt > it) {
+                        const bool up = ((it * 64) & k) == 0;
+                        const u64 a = key[it], b = key[pt];
+                        const bool sw = (a > b) == up;
+                        key[it] = sw ? b : a;
+                        key[pt] = sw ? a : b;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int it = 0; it < ITEMS; ++it) {
+                    const u64 mine = key[it];
+                    const u64 other = (u64)__shfl_xor((long long)mine, j, 64);
+                    const bool up = (((it * 64) + lane) & k) == 0;
+                    const bool lower = (lane & j) == 0;
+                    const u64 mn = mine < other ? mine : other, mx = mine < other ? other : mine;
+                    key[it] = (lower == up) ? mn : mx;
+                }
+            }
+        }
+    }
+}
+
+struct GtParams {
+    const float *base;
+    uint32_t nb, bstride;
+    const float *queries;
+    uint32_t nq, qstride, dim;
+    const float *bias;  // per base row added to q.b (null = 0): -|b|^2/2 for L2
+    uint32_t K, id_base;
+    uint32_t *out_ids;
+    float *out_vals;    // the ranking value t = q.b + bias, best (largest) first
+    u64 *cand;          // [grid][MQ][64*ITEMS]
+    uint32_t *counter;
+    uint32_t BK;
+};
+
+// keep the best K of the query's candidate buffer, publish the new threshold
+template <int ITEMS>
+__device__ __forceinline__ void gt_compact(u64 *buf, uint32_t *cnt, float *thr, uint32_t K, int lane) {
+    const uint32_t n = *cnt;
+    u64 key[ITEMS];
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+        const uint32_t e = it * 64 + lane;
+        key[it] = e < n ? buf[e] : ~0ull;
+    }
+    wave_sort<ITEMS>(key, lane);
+    const uint32_t keep = min(n, K);
+    u64 kth = 0;
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+        const uint32_t e = it * 64 + lane;
+        if (e < keep) buf[e] = key[it];
+        if ((uint32_t)it == (K - 1) / 64) kth = key[it];
+    }
+    kth = (u64)__shfl((long long)kth, (int)((K - 1) & 63), 64);
+    if (lane == 0) {
+        *cnt = keep;
+        *thr = n >= K ? key_value(kth, true) : -__builtin_inff();
+    }
+}
+
+template <int MQ, int ITEMS>
+__global__ void __launch_bounds__(256) rg_gt_kernel(GtParams P) {
+    constexpr int C = 64 * ITEMS;
+    constexpr int QS = MQ + 4;
+    constexpr int TN = MQ == 128 ? 2 : 1;    // 32-col tiles per wave along the base axis
+    constexpr int WN = 128 / (32 * TN);      // waves along the base axis (2 or 4)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int wn = w % WN, wm = w / WN;
+    const int qoff = 64 * wm, boff = 32 * TN * wn;
+    const uint32_t BK = P.BK, dim = P.dim;
+
+    float *Qt = reinterpret_cast<float *>(smem);                 // [dim][QS]
+    float *Bt = Qt + (size_t)dim * QS;                           // [2][BK][kBS]
+    float *thr = Bt + 2 * (size_t)BK * kBS;                      // [MQ]
+    uint32_t *cnt = reinterpret_cast<uint32_t *>(thr + MQ);      // [MQ]
+    uint32_t *flag = cnt + MQ;                                   // [4]
+    u64 *cand = P.cand + (size_t)blockIdx.x * MQ * C;
+
+    const uint32_t ntiles = (P.nb + kNB - 1) / kNB;
+    const uint32_t nkc = dim / BK;
+    const uint32_t f4_per_row = BK / 4;
+    const uint32_t nld = (kNB * BK / 4) / 256;  // float4 loads per thread per chunk (BK/8)
+
+    for (;;) {
+        if (tid == 0) flag[1] = atomicAdd(P.counter, 1u);
+        __syncthreads();
+        const uint32_t blk = flag[1];
+        __syncthreads();
+        if ((uint64_t)blk * MQ >= P.nq) break;
+        const uint32_t q0 = blk * MQ;
+        // stage the query block transposed: Qt[k][q]
+        for (uint32_t idx = tid; idx < (uint32_t)MQ * (dim / 4); idx += 256) {
+            const uint32_t row = idx / (dim / 4), f4 = idx % (dim / 4);
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (q0 + row < P.nq) v = *reinterpret_cast<const float4 *>(P.queries + (size_t)(q0 + row) * P.qstride + 4 * f4);
+            Qt[(4 * f4 + 0) * QS + row] = v.x;
+            Qt[(4 * f4 + 1) * QS + row] = v.y;
+            Qt[(4 * f4 + 2) * QS + row] = v.z;
+            Qt[(4 * f4 + 3) * QS + row] = v.w;
+        }
+        for (int i = tid; i < MQ; i += 256) { thr[i] = -__builtin_inff(); cnt[i] = 0; }
+        if (tid == 0) flag[0] = 0;
+
+        float4 pre[5];
+        auto load_chunk = [&](uint32_t c) {
+            const uint32_t tile = c / nkc, k0 = (c % nkc) * BK;
+#pragma unroll
+            for (uint32_t i = 0; i < 5; ++i) {
+                if (i < nld) {
+                    const uint32_t idx = tid + 256 * i;
+                    const uint32_t row = idx / f4_per_row, f4 = idx % f4_per_row;
+                    const uint32_t gr = tile * kNB + row;
+                    pre[i] = gr < P.nb ? *reinterpret_cast<const float4 *>(P.base + (size_t)gr * P.bstride + k0 + 4 * f4)
+                                       : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
+        };
+        auto store_chunk = [&](uint32_t buf) {
+            float *dst = Bt + (size_t)buf * BK * kBS;
+#pragma unroll
+            for (uint32_t i = 0; i < 5; ++i) {
+                if (i < nld) {
+                    const uint32_t idx = tid + 256 * i;
+                    const uint32_t row = idx / f4_per_row, f4 = idx % f4_per_row;
+                    dst[(4 * f4 + 0) * kBS + row] = pre[i].x;
+                    dst[(4 * f4 + 1) * kBS + row] = pre[i].y;
+                    dst[(4 * f4 + 2) * kBS + row] = pre[i].z;
+                    dst[(4 * f4 + 3) * kBS + row] = pre[i].w;
+                }
+            }
+        };
+
+        f32x16 acc[2][TN];
+        auto init_acc = [&](uint32_t tile) {
+#pragma unroll
+            for (int n = 0; n < TN; ++n) {
+                const uint32_t id = tile * kNB + boff + 32 * n + (lane & 31);
+                const float b = (P.bias && id < P.nb) ? P.bias[id] : 0.0f;
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[m][n][r] = b;
+            }
+        };
+
+        const uint32_t nchunks = ntiles * nkc;
+        load_chunk(0);
+        store_chunk(0);
+        init_acc(0);
+        __syncthreads();
+        for (uint32_t c = 0; c < nchunks; ++c) {
+            const uint32_t buf = c & 1u;
+            if (c + 1 < nchunks) load_chunk(c + 1);
+            // MFMA over this k-chunk
+            const float *bt = Bt + (size_t)buf * BK * kBS + boff + (lane & 31);
+            const float *qt = Qt + (size_t)((c % nkc) * BK) * QS + qoff + (lane & 31);
+            const int kh = lane >> 5;
+#pragma unroll 4
+            for (uint32_t kk = 0; kk < BK / 2; ++kk) {
+                const uint32_t kl = 2 * kk + kh;
+                float a[2], b[TN];
+                a[0] = qt[kl * QS];
+                a[1] = qt[kl * QS + 32];
+#pragma unroll
+                for (int n = 0; n < TN; ++n) b[n] = bt[kl * kBS + 32 * n];
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int n = 0; n < TN; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[n], acc[m][n], 0, 0, 0);
+            }
+            if (c + 1 < nchunks) store_chunk(buf ^ 1u);
+            if ((c + 1) % nkc == 0) {
+                // tile finished: threshold filter, survivors -> candidate buffers
+                const uint32_t tile = c / nkc;
+#pragma unroll
+                for (int n = 0; n < TN; ++n) {
+                    const uint32_t id = tile * kNB + boff + 32 * n + (lane & 31);
+                    if (id < P.nb) {
+#pragma unroll
+                        for (int m = 0; m < 2; ++m)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const int qi = qoff + 32 * m + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                                const float s = acc[m][n][r];
+                                if (s > thr[qi]) {
+                                    const uint32_t slot = atomicAdd(&cnt[qi], 1u);
+                                    cand[(size_t)qi * C + slot] = make_key(s, id, true);
+                                    if (slot + 1 + kNB > (uint32_t)C) flag[0] = 1;
+                                }
+                            }
+                    }
+                }
+                if (tile + 1 < ntiles) init_acc(tile + 1);
+                __syncthreads();
+                if (flag[0]) {
+                    for (int qi = w; qi < MQ; qi += 4)
+                        if (cnt[qi] + kNB > (uint32_t)C) gt_compact<ITEMS>(cand + (size_t)qi * C, &cnt[qi], &thr[qi], P.K, lane);
+                    __syncthreads();
+                    if (tid == 0) flag[0] = 0;
+                }
+            }
+            __syncthreads();
+        }
+        // final selection + output
+        for (int qi = w; qi < MQ; qi += 4) {
+            gt_compact<ITEMS>(cand + (size_t)qi * C, &cnt[qi], &thr[qi], P.K, lane);
+            const uint32_t q = q0 + qi;
+            if (q < P.nq) {
+                for (uint32_t e = lane; e < P.K; e += 64) {
+                    const u64 k = cand[(size_t)qi * C + e];
+                    P.out_ids[(size_t)q * P.K + e] = (uint32_t)k + P.id_base;
+                    P.out_vals[(size_t)q * P.K + e] = key_value(k, true);
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// bias[i] = -0.5 * |b_i|^2 (one 16-lane group per row)
+__global__ void rg_gt_bias_kernel(const float *base, uint32_t nb, uint32_t bstride, uint32_t dim, float *bias) {
+    const uint32_t gid = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, sub = threadIdx.x & 15;
+    if (gid >= nb) return;
+    const float *row = base + (size_t)gid * bstride;
+    float s = 0.f;
+    for (uint32_t j = sub; j < dim; j += 16) s = __builtin_fmaf(row[j], row[j], s);
+    for (int o = 8; o; o >>= 1) s += __shfl_xor(s, o, 64);
+    if (sub == 0) bias[gid] = -0.5f * s;
+}
+
+// L2 finalisation: exact squared distance of each selected pair, then re-sort the row by (dist, id).  One wave per query.
+template <int ITEMS>
+__global__ void __launch_bounds__(64) rg_gt_rescore_kernel(const float *base, uint32_t bstride, const float *queries,
+                                                           uint32_t qstride, uint32_t dim, uint32_t nq, uint32_t K,
+                                                           uint32_t id_base, uint32_t *ids, float *vals) {
+    const int lane = threadIdx.x;
+    for (uint32_t q = blockIdx.x; q < nq; q += gridDim.x) {
+        const float *qv = queries + (size_t)q * qstride;
+        u64 key[ITEMS];
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+            const uint32_t e = it * 64 + lane;
+            key[it] = ~0ull;
+            if (e < K) {
+                const uint32_t id = ids[(size_t)q * K + e];
+                const float *row = base + (size_t)(id - id_base) * bstride;
+                float s = 0.f;
+                for (uint32_t j = 0; j < dim; ++j) { const float t = qv[j] - row[j]; s = __builtin_fmaf(t, t, s); }
+                key[it] = make_key(s, id, false);
+            }
+        }
+        wave_sort<ITEMS>(key, lane);
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+            const uint32_t e = it * 64 + lane;
+            if (e < K) { ids[(size_t)q * K + e] = (uint32_t)key[it]; vals[(size_t)q * K + e] = key_value(key[it], false); }
+        }
+    }
+}
+
+// K3: merge nlists sorted K-lists per query; one wave per query
+template <int ITEMS>
+__global__ void __launch_bounds__(64) rg_gt_merge_kernel(const uint32_t *ids_in, const float *vals_in, uint32_t nlists,
+                                                         uint32_t nq, uint32_t K, int larger_first, uint32_t *ids,
+                                                         float *vals) {
+    const int lane = threadIdx.x;
+    for (uint32_t q = blockIdx.x; q < nq; q += gridDim.x) {
+        u64 key[ITEMS];
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+            const uint32_t e = it * 64 + lane;
+            key[it] = ~0ull;
+            if (e < nlists * K) {
+                const uint32_t l = e / K, j = e % K;
+                const size_t src = ((size_t)l * nq + q) * K + j;
+                key[it] = make_key(vals_in[src], ids_in[src], larger_first != 0);
+            }
+        }
+        wave_sort<ITEMS>(key, lane);
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+            const uint32_t e = it * 64 + lane;
+            if (e < K) { ids[(size_t)q * K + e] = (uint32_t)key[it]; vals[(size_t)q * K + e] = key_value(key[it], larger_first != 0); }
+        }
+    }
+}
+
+static size_t gt_lds(uint32_t dim, uint32_t mq, uint32_t bk) {
+    return ((size_t)dim * (mq + 4) + 2 * (size_t)bk * kBS + 2 * mq + 8) * 4;
+}
+
+template <int MQ, int ITEMS>
+static rg_status launch_gt(const GtParams &P, uint32_t grid, size_t lds, hipStream_t s) {
+    auto kern = rg_gt_kernel<MQ, ITEMS>;
+    RG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, P);
+    RG_HIP(hipGetLastError());
+    return RG_OK;
+}
+template <int MQ>
+static rg_status launch_gt_items(int items, const GtParams &P, uint32_t grid, size_t lds, hipStream_t s) {
+    switch (items) {
+        case 4: return launch_gt<MQ, 4>(P, grid, lds, s);
+        case 8: return launch_gt<MQ, 8>(P, grid, lds, s);
+        default: return launch_gt<MQ, 16>(P, grid, lds, s);
+    }
+}
+static int items_for(uint32_t n) {  // smallest ITEMS in {4,8,16} with 64*ITEMS >= n
+    int it = 4;
+    while ((uint32_t)(64 * it) < n && it < 16) it <<= 1;
+    return it;
+}
+
+}  // namespace rg
+
+using rg::set_error;
+
+extern "C" {
+
+rg_status rg_gt_shard_dev(const float *d_base, uint32_t nb, uint32_t bstride, const float *d_queries, uint32_t nq,
+                          uint32_t qstride, uint32_t dim, int metric, uint32_t K, uint32_t id_base, uint32_t *d_ids,
+                          float *d_dists, int device, void *stream) {
+    using namespace rg;
+    hipStream_t s = (hipStream_t)stream;
+    if (!d_base || !d_queries || !d_ids || !d_dists) return set_error(RG_ERR_ARG, "null argument");
+    if (metric != RG_METRIC_L2 && metric != RG_METRIC_IP && metric != RG_METRIC_COSINE)
+        return set_error(RG_ERR_ARG, "Unknown distance type");
+    if (dim == 0 || dim % 8 || bstride % 4 || qstride % 4 || bstride < dim || qstride < dim ||
+        ((uintptr_t)d_base & 15) || ((uintptr_t)d_queries & 15))
+        return set_error(RG_ERR_ARG, "ground truth needs dim % 8 == 0, strides % 4 == 0 and 16-byte aligned buffers");
+    if (K == 0 || K > nb) return set_error(RG_ERR_ARG, "K must be in [1, number of base rows in the shard]");
+    if (K + kNB > 1024) return set_error(RG_ERR_ARG, "K larger than 896 is not supported");
+    if (nq == 0) return RG_OK;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return set_error(RG_ERR_DEVICE, "no HIP device visible: the gfx950 path cannot run (there is no CPU fallback)");
+    RG_HIP(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    RG_HIP(hipGetDeviceProperties(&prop, device));
+    const size_t lds_max = 160 * 1024;
+    uint32_t bk = 0, mq = 0;
+    for (uint32_t cand_mq : {128u, 64u}) {
+        for (uint32_t m = 5; m >= 1 && !bk; --m)
+            if ((dim / 8) % m == 0 && gt_lds(dim, cand_mq, 8 * m) <= lds_max) { bk = 8 * m; mq = cand_mq; }
+        if (bk) break;
+    }
+    if (!bk) return set_error(RG_ERR_ARG, "dimension too large for the LDS-resident query block");
+    const size_t lds = gt_lds(dim, mq, bk);
+    const int items = items_for(K + kNB);
+    const uint32_t nblocks = (nq + mq - 1) / mq;
+    const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(2, lds_max / lds));
+    const uint32_t grid = std::min<uint32_t>(nblocks, (uint32_t)prop.multiProcessorCount * per_cu);
+    float *bias = nullptr;
+    u64 *cand = nullptr;
+    uint32_t *counter = nullptr;
+    float *vals = d_dists;
+    if (metric == RG_METRIC_L2) {
+        RG_HIP(hipMallocAsync((void **)&bias, (size_t)nb * 4, s));
+        hipLaunchKernelGGL(rg_gt_bias_kernel, dim3((nb * 16 + 255) / 256), dim3(256), 0, s, d_base, nb, bstride, dim, bias);
+    }
+    RG_HIP(hipMallocAsync((void **)&cand, (size_t)grid * mq * 64 * items * 8, s));
+    RG_HIP(hipMallocAsync((void **)&counter, 64, s));
+    RG_HIP(hipMemsetAsync(counter, 0, 4, s));
+    GtParams P;
+    P.base = d_base; P.nb = nb; P.bstride = bstride; P.queries = d_queries; P.nq = nq; P.qstride = qstride; P.dim = dim;
+    P.bias = bias; P.K = K; P.id_base = id_base; P.out_ids = d_ids; P.out_vals = vals; P.cand = cand;
+    P.counter = counter; P.BK = bk;
+    rg_status st = mq == 128 ? launch_gt_items<128>(items, P, grid, lds, s) : launch_gt_items<64>(items, P, grid, lds, s);
+    if (st == RG_OK && metric == RG_METRIC_L2) {
+        const uint32_t g2 = std::min<uint32_t>(nq, (uint32_t)prop.multiProcessorCount * 16u);
+        const int it2 = items_for(K);
+        switch (it2) {
+            case 4: hipLaunchKernelGGL((rg_gt_rescore_kernel<4>), dim3(g2), dim3(64), 0, s, d_base, bstride, d_queries, qstride, dim, nq, K, id_base, d_ids, d_dists); break;
+            case 8: hipLaunchKernelGGL((rg_gt_rescore_kernel<8>), dim3(g2), dim3(64), 0, s, d_base, bstride, d_queries, qstride, dim, nq, K, id_base, d_ids, d_dists); break;
+            default: hipLaunchKernelGGL((rg_gt_rescore_kernel<16>), dim3(g2), dim3(64), 0, s, d_base, bstride, d_queries, qstride, dim, nq, K, id_base, d_ids, d_dists); break;
+        }
+    }
+    if (bias) (void)hipFreeAsync(bias, s);
+    (void)hipFreeAsync(cand, s);
+    (void)hipFreeAsync(counter, s);
+    if (st != RG_OK) return st;
+    RG_HIP(hipGetLastError());
+    return RG_OK;
+}
+
+rg_status rg_gt_merge_dev(const uint32_t *d_ids_in, const float *d_dists_in, uint32_t nlists, uint32_t nq, uint32_t K,
+                          int metric, uint32_t *d_ids, float *d_dists, int device, void *stream) {
+    using namespace rg;
+    hipStream_t s = (hipStream_t)stream;
+    if (!d_ids_in || !d_dists_in || !d_ids || !d_dists) return set_error(RG_ERR_ARG, "null argument");
+    if (nlists == 0 || K == 0) return set_error(RG_ERR_ARG, "nlists and K must be positive");
+    if ((uint64_t)nlists * K > 1024) return set_error(RG_ERR_ARG, "nlists * K larger than 1024 is not supported");
+    if (nq == 0) return RG_OK;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return set_error(RG_ERR_DEVICE, "no HIP device visible: the gfx950 path cannot run (there is no CPU fallback)");
+    RG_HIP(hipSetDevice(device));
+    const int lf = metric == RG_METRIC_L2 ? 0 : 1;
+    const uint32_t grid = std::min<uint32_t>(nq, 256u * 16u);
+    switch (items_for(nlists * K)) {
+        case 4: hipLaunchKernelGGL((rg_gt_merge_kernel<4>), dim3(grid), dim3(64), 0, s, d_ids_in, d_dists_in, nlists, nq, K, lf, d_ids, d_dists); break;
+        case 8: hipLaunchKernelGGL((rg_gt_merge_kernel<8>), dim3(grid), dim3(64), 0, s, d_ids_in, d_dists_in, nlists, nq, K, lf, d_ids, d_dists); break;
+        default: hipLaunchKernelGGL((rg_gt_merge_kernel<16>), dim3(grid), dim3(64), 0, s, d_ids_in, d_dists_in, nlists, nq, K, lf, d_ids, d_dists); break;
+    }
+    RG_HIP(hipGetLastError());
+    return RG_OK;
+}
+
+rg_status rg_groundtruth_mem(const float *base, uint32_t nb, uint32_t bstride, const float *queries, uint32_t nq,
+                             uint32_t qstride, uint32_t dim, int metric, uint32_t K, uint32_t *out_ids,
+                             float *out_dists, const int *devices, int ndev) {
+    using namespace rg;
+    if (!base || !queries || !out_ids || !out_dists) return set_error(RG_ERR_ARG, "null argument");
+    if (K == 0 || K > nb) return set_error(RG_ERR_ARG, "K must be in [1, number of base rows]");
+    int visible = 0;
+    if (hipGetDeviceCount(&visible) != hipSuccess || visible <= 0)
+        return set_error(RG_ERR_DEVICE, "no HIP device visible: the gfx950 path cannot run (there is no CPU fallback)");
+    std::vector<int> devs;
+    if (devices && ndev > 0) devs.assign(devices, devices + ndev);
+    else devs.push_back(0);
+    while (devs.size() > 1 && nb / devs.size() < K) devs.pop_back();
+    const uint32_t nd = (uint32_t)devs.size();
+    const uint32_t ad = aligned_dim(dim);
+    // host staging at the aligned stride (zero padded), cosine rows normalised (compute_groundtruth's cosine mode)
+    auto stage = [&](const float *src, uint32_t n, uint32_t stride, std::vector<float> &dst) {
+        dst.assign((size_t)n * ad, 0.0f);
+        for (size_t i = 0; i < n; ++i) std::memcpy(dst.data() + i * ad, src + i * (size_t)stride, (size_t)dim * 4);
+        if (metric == RG_METRIC_COSINE) rg_normalize_rows(dst.data(), n, ad, dim);
+    };
+    std::vector<float> hq, hb;
+    stage(queries, nq, qstride, hq);
+    stage(base, nb, bstride, hb);
+    const int m = metric == RG_METRIC_COSINE ? RG_METRIC_IP : metric;
+    std::vector<uint32_t> all_ids((size_t)nd * nq * K);
+    std::vector<float> all_vals((size_t)nd * nq * K);
+    struct Dev { float *b = nullptr, *q = nullptr, *v = nullptr; uint32_t *i = nullptr; hipStream_t s = nullptr; };
+    std::vector<Dev> D(nd);
+    rg_status st = RG_OK;
+    const uint32_t per = (nb + nd - 1) / nd;
+    for (uint32_t r = 0; r < nd && st == RG_OK; ++r) {
+        const uint32_t lo = std::min(nb, r * per), hi = std::min(nb, lo + per);
+        RG_HIP(hipSetDevice(devs[r]));
+        RG_HIP(hipStreamCreate(&D[r].s));
+        RG_HIP(hipMalloc(&D[r].b, std::max<size_t>((size_t)(hi - lo) * ad * 4, 16)));
+        RG_HIP(hipMalloc(&D[r].q, (size_t)nq * ad * 4));
+        RG_HIP(hipMalloc(&D[r].i, (size_t)nq * K * 4));
+        RG_HIP(hipMalloc(&D[r].v, (size_t)nq * K * 4));
+        RG_HIP(hipMemcpyAsync(D[r].b, hb.data() + (size_t)lo * ad, (size_t)(hi - lo) * ad * 4, hipMemcpyHostToDevice, D[r].s));
+        RG_HIP(hipMemcpyAsync(D[r].q, hq.data(), (size_t)nq * ad * 4, hipMemcpyHostToDevice, D[r].s));
+        st = rg_gt_shard_dev(D[r].b, hi - lo, ad, D[r].q, nq, ad, ad, m, K, lo, D[r].i, D[r].v, devs[r], D[r].s);
+        if (st == RG_OK) {
+            RG_HIP(hipMemcpyAsync(all_ids.data() + (size_t)r * nq * K, D[r].i, (size_t)nq * K * 4, hipMemcpyDeviceToHost, D[r].s));
+            RG_HIP(hipMemcpyAsync(all_vals.data() + (size_t)r * nq * K, D[r].v, (size_t)nq * K * 4, hipMemcpyDeviceToHost, D[r].s));
+        }
+    }
+    for (uint32_t r = 0; r < nd; ++r) {
+        if (!D[r].s) continue;
+        (void)hipSetDevice(devs[r]);
+        hipError_t e = hipStreamSynchronize(D[r].s);
+        if (e != hipSuccess && st == RG_OK) st = set_error(RG_ERR_DEVICE, hipGetErrorString(e));
+    }
+    if (st == RG_OK) {
+        if (nd == 1) {
+            std::memcpy(out_ids, all_ids.data(), (size_t)nq * K * 4);
+            std::memcpy(out_dists, all_vals.data(), (size_t)nq * K * 4);
+        } else {
+            // K3 on device 0 (single-process form; the one-process-per-GPU form exchanges these lists over RCCL)
+            (void)hipSetDevice(devs[0]);
+            uint32_t *di = nullptr, *doi = nullptr;
+            float *dv = nullptr, *dov = nullptr;
+            RG_HIP(hipMalloc(&di, all_ids.size() * 4));
+            RG_HIP(hipMalloc(&dv, all_vals.size() * 4));
+            RG_HIP(hipMalloc(&doi, (size_t)nq * K * 4));
+            RG_HIP(hipMalloc(&dov, (size_t)nq * K * 4));
+            RG_HIP(hipMemcpy(di, all_ids.data(), all_ids.size() * 4, hipMemcpyHostToDevice));
+            RG_HIP(hipMemcpy(dv, all_vals.data(), all_vals.size() * 4, hipMemcpyHostToDevice));
+            st = rg_gt_merge_dev(di, dv, nd, nq, K, m, doi, dov, devs[0], nullptr);
+            if (st == RG_OK) {
+                RG_HIP(hipMemcpy(out_ids, doi, (size_t)nq * K * 4, hipMemcpyDeviceToHost));
+                RG_HIP(hipMemcpy(out_dists, dov, (size_t)nq * K * 4, hipMemcpyDeviceToHost));
+            }
+            (void)hipFree(di); (void)hipFree(dv); (void)hipFree(doi); (void)hipFree(dov);
+        }
+    }
+    for (uint32_t r = 0; r < nd; ++r) {
+        (void)hipSetDevice(devs[r]);
+        if (D[r].b) (void)hipFree(D[r].b);
+        if (D[r].q) (void)hipFree(D[r].q);
+        if (D[r].i) (void)hipFree(D[r].i);
+        if (D[r].v) (void)hipFree(D[r].v);
+        if (D[r].s) (void)hipStreamDestroy(D[r].s);
+    }
+    return st;
+}
+
+rg_status rg_groundtruth(const char *base_fbin, const char *query_fbin, const char *gt_out, int metric, uint32_t K,
+                         const int *devices, int ndev) {
+    if (!base_fbin || !query_fbin || !gt_out) return set_error(RG_ERR_ARG, "null argument");
+    uint32_t nb = 0, bd = 0, bs = 0, nq = 0, qd = 0, qs = 0;
+    float *base = nullptr, *q = nullptr;
+    rg_status st = rg_fbin_load(base_fbin, &nb, &bd, &bs, &base);
+    if (st != RG_OK) return st;
+    st = rg_fbin_load(query_fbin, &nq, &qd, &qs, &q);
+    if (st != RG_OK) { rg_free(base); return st; }
+    if (bd != qd) { rg_free(base); rg_free(q); return set_error(RG_ERR_ARG, "base and query dimension mismatch"); }
+    std::vector<uint32_t> ids((size_t)nq * K);
+    std::vector<float> ds((size_t)nq * K);
+    st = rg_groundtruth_mem(base, nb, bs, q, nq, qs, bd, metric, K, ids.data(), ds.data(), devices, ndev);
+    rg_free(base);
+    rg_free(q);
+    if (st != RG_OK) return st;
+    return rg_gt_save(gt_out, ids.data(), ds.data(), nq, K);
+}
+
+}  // extern "C"
