@@ -40,6 +40,13 @@ def lib():
             raise RuntimeError(
                 "librg_hip.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` or "
                 "`make -C roargraph_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+        # One HIP/HSA runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7.  If librg_hip.so were
+        # loaded first it would pull in /opt/rocm's copy and torch would then fail to see the GPU, so when torch is
+        # installed load it first and let librg_hip.so bind to the runtime that is already resident.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         L.rg_last_error.restype = C.c_char_p
         L.rg_version.restype = C.c_char_p

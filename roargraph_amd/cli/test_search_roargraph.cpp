@@ -1,0 +1,132 @@
+// test_search_roargraph -- drop-in twin of the reference's search driver (tests/test_search_roargraph.cpp:64-250)
+// running the search on an MI355X through the C ABI (include/rg.h).  Same flags (including the required-but-ignored
+// --data_type), same stdout table and CSV row: L_pq, QPS, avg_visited, mean_latency, recall@k, avg_hops.
+//
+// Differences, all additive:
+//   --device N          GPU to use (default 0); -T/--num_threads is accepted and ignored (the OpenMP loop of
+//                       test_search_roargraph.cpp:203-209 runs inside the kernel, one wave per in-flight query)
+//   timing              QPS uses a nanosecond clock around the device-resident batch (queries already in HBM); the
+//                       reference's integer-millisecond clock (:210-213) cannot resolve a 10k-query batch on a GPU
+//   warm-up             min(100, q_pts) queries, as :198-200
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <string>
+#include <vector>
+
+#include "argparse_lite.h"
+#include "rg.h"
+
+#define CK(x)                                                                  \
+    do {                                                                       \
+        rg_status s_ = (x);                                                    \
+        if (s_ != RG_OK) { std::cerr << rg_last_error() << std::endl; return -1; } \
+    } while (0)
+#define HK(x)                                                                                        \
+    do {                                                                                             \
+        hipError_t e_ = (x);                                                                         \
+        if (e_ != hipSuccess) { std::cerr << #x << ": " << hipGetErrorString(e_) << std::endl; return -1; } \
+    } while (0)
+
+int main(int argc, char **argv) {
+    Args a;
+    a.add("data_type", true, "data type <int8/uint8/float>");
+    a.add("dist", true, "distance function <l2/ip>");
+    a.add("base_data_path", true, "Input data file in bin format");
+    a.add("query_path", true, "Query file in bin format");
+    a.add("gt_path", true, "Groundtruth file in bin format");
+    a.add("projection_index_save_path", true, "Path prefix for saving projetion index file components");
+    a.add("L_pq", true, "Priority queue length for searching");
+    a.add("k", false, "k nearest neighbors", "1");
+    a.add("evaluation_save_path", false, "Path prefix for saving evaluation results", "");
+    a.add("num_threads", false, "accepted for compatibility (ignored on the GPU path)", "0", "T");
+    a.add("device", false, "HIP device index", "0");
+    if (!a.parse(argc, argv)) return -1;
+    if (a.help()) { a.usage(std::cout); return 0; }
+
+    const std::string dist = a.str("dist");
+    int metric = RG_METRIC_IP;
+    if (dist == "l2") { metric = RG_METRIC_L2; std::cout << "Using l2 as distance metric" << std::endl; }
+    else if (dist == "ip") { metric = RG_METRIC_IP; std::cout << "Using inner product as distance metric" << std::endl; }
+    else if (dist == "cosine") { metric = RG_METRIC_COSINE; std::cout << "Using cosine as distance metric" << std::endl; }
+    else { std::cout << "Unknown distance type: " << dist << std::endl; return -1; }
+
+    uint32_t base_num = 0, base_dim = 0;
+    CK(rg_fbin_meta(a.str("base_data_path").c_str(), &base_num, &base_dim));
+    uint32_t q_pts = 0, q_dim = 0, q_stride = 0;
+    float *query = nullptr;
+    CK(rg_fbin_load(a.str("query_path").c_str(), &q_pts, &q_dim, &q_stride, &query));
+    uint32_t gt_pts = 0, gt_dim = 0, *gt_ids = nullptr;
+    float *gt_dists = nullptr;
+    CK(rg_gt_load(a.str("gt_path").c_str(), &gt_pts, &gt_dim, &gt_ids, &gt_dists));
+    {
+        std::ifstream probe(a.str("projection_index_save_path"));
+        if (!probe.good()) { std::cout << "projection index file does not exist." << std::endl; return -1; }
+    }
+    const int device = (int)a.u("device");
+    rg_index *index = nullptr;
+    std::cout << "Load graph index: " << a.str("projection_index_save_path") << std::endl;
+    CK(rg_index_open(a.str("base_data_path").c_str(), a.str("projection_index_save_path").c_str(), metric, device, &index));
+    uint32_t nd, dim, stride, ep, maxdeg;
+    float avgdeg;
+    CK(rg_index_info(index, &nd, &dim, &stride, &ep, &avgdeg, &maxdeg, nullptr));
+    std::cout << "Projection graph, ep: " << ep << std::endl;
+    std::cout << "Projection graph, avg_degree: " << avgdeg << std::endl;
+    if (q_stride != dim) { std::cerr << "base and query dimension mismatch" << std::endl; return -1; }
+    if (metric == RG_METRIC_COSINE) {
+        std::cout << "Normalizing query data" << std::endl;
+        rg_normalize_rows(query, q_pts, q_stride, q_stride);
+    }
+    const uint32_t k = (uint32_t)a.u("k");
+    std::cout << "k: " << k << std::endl;
+
+    HK(hipSetDevice(device));
+    float *d_q = nullptr, *d_dist = nullptr;
+    uint32_t *d_ids = nullptr, *d_cmps = nullptr, *d_hops = nullptr;
+    HK(hipMalloc(&d_q, (size_t)q_pts * q_stride * 4));
+    HK(hipMalloc(&d_ids, (size_t)q_pts * k * 4));
+    HK(hipMalloc(&d_dist, (size_t)q_pts * k * 4));
+    HK(hipMalloc(&d_cmps, (size_t)q_pts * 4));
+    HK(hipMalloc(&d_hops, (size_t)q_pts * 4));
+    HK(hipMemcpy(d_q, query, (size_t)q_pts * q_stride * 4, hipMemcpyHostToDevice));
+    std::vector<uint32_t> res((size_t)q_pts * k), cmps(q_pts), hops(q_pts);
+
+    std::ofstream evaluation_out;
+    if (!a.str("evaluation_save_path").empty()) evaluation_out.open(a.str("evaluation_save_path"), std::ios::out);
+    std::cout << "Using thread: " << a.u("num_threads") << " (GPU path: one wave per in-flight query)" << std::endl;
+    std::cout << "L_pq" << "\t\tQPS" << "\t\t\tavg_visited" << "\tmean_latency" << "\trecall@" << k << "\tavg_hops" << std::endl;
+    for (const std::string &ls : a.list("L_pq")) {
+        const uint32_t L_pq = (uint32_t)std::strtoul(ls.c_str(), nullptr, 10);
+        if (k > L_pq) { std::cout << "L_pq must greater or equal than k" << std::endl; return 1; }
+        const uint32_t warm = q_pts < 100 ? q_pts : 100;
+        CK(rg_search_dev(index, d_q, warm, q_stride, k, L_pq, d_ids, d_dist, d_cmps, d_hops, nullptr));
+        CK(rg_search_wait(index, nullptr));
+        auto t0 = std::chrono::high_resolution_clock::now();
+        CK(rg_search_dev(index, d_q, q_pts, q_stride, k, L_pq, d_ids, d_dist, d_cmps, d_hops, nullptr));
+        CK(rg_search_wait(index, nullptr));
+        auto t1 = std::chrono::high_resolution_clock::now();
+        const double ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+        HK(hipMemcpy(res.data(), d_ids, res.size() * 4, hipMemcpyDeviceToHost));
+        HK(hipMemcpy(cmps.data(), d_cmps, cmps.size() * 4, hipMemcpyDeviceToHost));
+        HK(hipMemcpy(hops.data(), d_hops, hops.size() * 4, hipMemcpyDeviceToHost));
+        const float qps = (float)q_pts / ((float)ms / 1000.0f);
+        const float recall = rg_recall(q_pts, k, gt_dim, res.data(), gt_ids);
+        float avg_cmps = 0.0f, avg_hops = 0.0f;
+        for (uint32_t i = 0; i < q_pts; ++i) { avg_cmps += cmps[i]; avg_hops += hops[i]; }
+        avg_cmps /= q_pts;
+        avg_hops /= (float)q_pts;
+        std::cout << L_pq << "\t\t" << qps << "\t\t" << avg_cmps << "\t\t" << ((float)ms / q_pts) << "\t\t" << recall
+                  << "\t\t" << avg_hops << std::endl;
+        if (evaluation_out.is_open())
+            evaluation_out << L_pq << "," << qps << "," << avg_cmps << "," << ((float)ms / q_pts) << "," << recall << ","
+                           << avg_hops << std::endl;
+    }
+    if (evaluation_out.is_open()) evaluation_out.close();
+    rg_index_close(index);
+    rg_free(query); rg_free(gt_ids); rg_free(gt_dists);
+    (void)hipFree(d_q); (void)hipFree(d_ids); (void)hipFree(d_dist); (void)hipFree(d_cmps); (void)hipFree(d_hops);
+    return 0;
+}

@@ -6,7 +6,7 @@
 //   180-189 IP, 42-50 L2): it sees elements a, a+16, a+32, ... of the row in increasing order, one
 //   fused multiply-add each, then the 16->8->4->2->1 folds (distance.h:191-222 / 52-86) are wave
 //   shuffles with xor masks 8, 4, 1, 2.  IEEE addition is commutative, so the result is bit-identical
-//   to the AVX-512 path (and to oracle/rg_oracle.c).
+//   to the AVX-512 path.
 //
 // Gather: rows are fetched HBM -> LDS with global_load_lds_dwordx4 (LDS-DMA, no VGPR round trip).
 //   One instruction moves 4 rows x 256 B: lane l writes 16 B at stage + 16*l.  The 16-B slot of row

@@ -1,0 +1,112 @@
+"""Brute-force k-NN ground truth (the `compute_groundtruth` step of the RoarGraph pipeline, README.md:62-75).
+
+Thin host layer over the C ABI (rg_gt_shard_dev / rg_gt_merge_dev / rg_groundtruth_mem).  The multi-GPU form is one
+process per GPU: every rank holds a contiguous ROW SHARD of the base, scores ALL queries against it (K2), then the
+per-shard top-K lists are exchanged with one all-to-all (each rank receives the lists of the query range it owns)
+and merged (K3).  The exchange goes through torch.distributed -- backend "nccl" is RCCL over xGMI on the GPU box,
+"gloo" in the CPU tests.
+"""
+import ctypes as C
+
+import numpy as np
+
+from ._lib import METRIC, check, lib
+
+
+def _vp(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def compute_groundtruth(base, queries, metric, K, devices=None):
+    """Host buffers in, (ids[nq,K] u32, dists[nq,K] f32) out; dists = +inner product (mips) or squared L2."""
+    base = np.ascontiguousarray(base, np.float32)
+    queries = np.ascontiguousarray(queries, np.float32)
+    nq = queries.shape[0]
+    ids = np.zeros((nq, K), np.uint32)
+    dists = np.zeros((nq, K), np.float32)
+    devs = (C.c_int * len(devices))(*devices) if devices else None
+    check(lib().rg_groundtruth_mem(_vp(base), C.c_uint32(base.shape[0]), C.c_uint32(base.shape[1]), _vp(queries),
+                                   C.c_uint32(nq), C.c_uint32(queries.shape[1]), C.c_uint32(base.shape[1]),
+                                   METRIC[metric], C.c_uint32(K), _vp(ids), _vp(dists), devs,
+                                   len(devices) if devices else 0))
+    return ids, dists
+
+
+def compute_groundtruth_files(base_fbin, query_fbin, gt_out, metric, K, devices=None):
+    devs = (C.c_int * len(devices))(*devices) if devices else None
+    check(lib().rg_groundtruth(base_fbin.encode(), query_fbin.encode(), gt_out.encode(), METRIC[metric], C.c_uint32(K),
+                               devs, len(devices) if devices else 0))
+
+
+def gt_shard_dev(base_t, queries_t, metric, K, id_base, ids_t, dists_t, dim=None, stream=0):
+    """K2 on torch CUDA tensors (row-major fp32, strides % 4 == 0); async on `stream`."""
+    check(lib().rg_gt_shard_dev(C.c_void_p(base_t.data_ptr()), C.c_uint32(base_t.shape[0]), C.c_uint32(base_t.stride(0)),
+                                C.c_void_p(queries_t.data_ptr()), C.c_uint32(queries_t.shape[0]),
+                                C.c_uint32(queries_t.stride(0)), C.c_uint32(dim or base_t.shape[1]), METRIC[metric],
+                                C.c_uint32(K), C.c_uint32(id_base), C.c_void_p(ids_t.data_ptr()),
+                                C.c_void_p(dists_t.data_ptr()), base_t.device.index or 0, C.c_void_p(stream)))
+
+
+def gt_merge_dev(ids_in_t, dists_in_t, nlists, nq, K, metric, ids_t, dists_t, stream=0):
+    """K3: [nlists][nq][K] sorted lists -> [nq][K]."""
+    check(lib().rg_gt_merge_dev(C.c_void_p(ids_in_t.data_ptr()), C.c_void_p(dists_in_t.data_ptr()), C.c_uint32(nlists),
+                                C.c_uint32(nq), C.c_uint32(K), METRIC[metric], C.c_void_p(ids_t.data_ptr()),
+                                C.c_void_p(dists_t.data_ptr()), ids_in_t.device.index or 0, C.c_void_p(stream)))
+
+
+def query_ranges(nq, world):
+    """Contiguous query ranges owned by each rank for the merge step."""
+    per = (nq + world - 1) // world
+    return [(min(nq, r * per), min(nq, (r + 1) * per)) for r in range(world)]
+
+
+def shard_rows(nb, world):
+    per = (nb + world - 1) // world
+    return [(min(nb, r * per), min(nb, (r + 1) * per)) for r in range(world)]
+
+
+def groundtruth_distributed(base_shard, id_base, queries, metric, K, group=None, shard_fn=None, merge_fn=None):
+    """One process per GPU.  base_shard: this rank's rows (torch tensor), id_base: global id of its first row,
+    queries: ALL queries (same on every rank).  Returns (ids, dists) for the query range this rank owns
+    (query_ranges(nq, world)[rank]); torch tensors on base_shard's device.
+
+    shard_fn / merge_fn default to the HIP kernels; the CPU (gloo) tests pass numpy stand-ins to exercise the
+    partitioning + exchange logic without a GPU.
+    """
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    rank = dist.get_rank(group) if dist.is_initialized() else 0
+    dev = base_shard.device
+    nq = queries.shape[0]
+    ids = torch.zeros((nq, K), dtype=torch.int32, device=dev)
+    vals = torch.zeros((nq, K), dtype=torch.float32, device=dev)
+    if shard_fn is None:
+        gt_shard_dev(base_shard, queries, metric, K, id_base, ids, vals,
+                     stream=torch.cuda.current_stream().cuda_stream)
+    else:
+        shard_fn(base_shard, queries, metric, K, id_base, ids, vals)
+    if world == 1:
+        return ids, vals
+    # all-to-all: send rank j the rows of the query range j owns; pad ranges to a common length
+    ranges = query_ranges(nq, world)
+    per = max(hi - lo for lo, hi in ranges)
+    send_i = torch.zeros((world, per, K), dtype=torch.int32, device=dev)
+    send_v = torch.zeros((world, per, K), dtype=torch.float32, device=dev)
+    for j, (lo, hi) in enumerate(ranges):
+        send_i[j, : hi - lo] = ids[lo:hi]
+        send_v[j, : hi - lo] = vals[lo:hi]
+    recv_i = torch.empty_like(send_i)
+    recv_v = torch.empty_like(send_v)
+    dist.all_to_all_single(recv_i, send_i, group=group)
+    dist.all_to_all_single(recv_v, send_v, group=group)
+    lo, hi = ranges[rank]
+    n_own = hi - lo
+    out_i = torch.zeros((per, K), dtype=torch.int32, device=dev)
+    out_v = torch.zeros((per, K), dtype=torch.float32, device=dev)
+    if merge_fn is None:
+        gt_merge_dev(recv_i, recv_v, world, per, K, metric, out_i, out_v,
+                     stream=torch.cuda.current_stream().cuda_stream)
+    else:
+        merge_fn(recv_i, recv_v, world, per, K, metric, out_i, out_v)
+    return out_i[:n_own], out_v[:n_own]

@@ -1,0 +1,161 @@
+"""CPU: the C-ABI library loads, exports every symbol include/rg.h declares, its host-side format logic matches the
+goldens / oracle, and compute entry points FAIL LOUDLY without a GPU (no CPU fallback exists)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from helpers import bits
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture(scope="module")
+def rg():
+    if not os.path.exists(os.path.join(ROOT, "roargraph_amd", "librg_hip.so")):
+        import __graft_entry__
+        __graft_entry__.build()
+    from roargraph_amd import index
+    return index
+
+
+def header_symbols():
+    src = open(os.path.join(ROOT, "include", "rg.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(rg_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_exports_every_declared_symbol(rg):
+    from roargraph_amd._lib import SYMBOLS, lib
+    names = header_symbols()
+    assert len(names) >= 25
+    assert sorted(SYMBOLS) == names, "roargraph_amd/_lib.py SYMBOLS out of sync with include/rg.h"
+    L = lib()
+    for n in names:
+        assert hasattr(L, n), "librg_hip.so does not export %s" % n
+    assert b"gfx950" in L.rg_version()
+
+
+def test_header_cites_reference_lines():
+    src = open(os.path.join(ROOT, "include", "rg.h")).read()
+    for needle in ("distance.h:18", "index_bipartite.h:100-101", "util.h:106-127", "index_bipartite.cpp:2097-2117",
+                   "README.md:62-75", "test_search_roargraph.cpp:23-36"):
+        assert needle in src
+
+
+def test_format_rules_match_reference_goldens(rg, tmp_path):
+    from roargraph_amd._lib import RgError
+    z = np.load(os.path.join(GOLD, "formats.npz"))
+    p = str(tmp_path / "f.bin")
+    for key in z.files:
+        if not key.endswith("_says"):
+            continue
+        case = key[:-5]
+        open(p, "wb").write(z[case].tobytes())
+        said = str(z[key])
+        fn = rg.gt_meta if case.startswith("gt_") else rg.fbin_meta
+        if said.startswith("OK"):
+            assert list(fn(p)) == [int(x) for x in said.split()[1:]], case
+        else:
+            with pytest.raises(RgError, match="Data file size wrong!"):
+                fn(p)
+    open(p, "wb").write(z["gt_good"].tobytes())
+    ids, ds = rg.gt_load(p)
+    assert (ids == z["gt_good_ids"]).all() and (bits(ds) == z["gt_good_dist_bits"]).all()
+    assert (rg.knn_ids_load(p) == ids).all()
+    open(p, "wb").write(z["fbin_good"].tobytes())
+    arr, d = rg.fbin_load(p)
+    assert d == 24 and (bits(arr) == z["fbin_good_loaded_bits"]).all()
+    with pytest.raises(RgError, match="open file error"):
+        rg.fbin_meta(str(tmp_path / "missing.fbin"))
+
+
+def test_fbin_padding_to_multiple_of_8(rg, oracle, tmp_path):
+    from roargraph_amd import io
+    data = np.random.default_rng(0).standard_normal((9, 13)).astype(np.float32)
+    p = str(tmp_path / "odd.fbin")
+    io.write_fbin(p, data)
+    arr, d = rg.fbin_load(p)
+    assert d == 13 and arr.shape == (9, 16)
+    assert (arr[:, :13] == data).all() and (arr[:, 13:] == 0).all()
+    o, od = oracle.fbin_load(p)
+    assert od == 13 and (bits(o) == bits(arr)).all()
+
+
+def test_graph_and_gt_roundtrip(rg, oracle, tmp_path):
+    from roargraph_amd import io
+    rng = np.random.default_rng(1)
+    lists = [rng.integers(0, 40, rng.integers(0, 9)).astype(np.uint32) for _ in range(40)]
+    lists[3] = np.zeros(0, np.uint32)
+    off, nbrs = io.lists_to_csr(lists)
+    p = str(tmp_path / "g.index")
+    rg.graph_save(p, off, nbrs, 17)
+    for loader in (rg.graph_load, oracle.index_load, io.read_index):
+        o2, n2, ep = loader(p)
+        assert ep == 17 and (np.asarray(o2) == off).all() and (np.asarray(n2) == nbrs).all()
+    q = str(tmp_path / "g2.index")
+    oracle.index_save(q, off, nbrs, 17)
+    assert open(p, "rb").read() == open(q, "rb").read()
+    io.write_index(q, off, nbrs, 17)
+    assert open(p, "rb").read() == open(q, "rb").read()
+    # truncated index
+    open(q, "wb").write(open(p, "rb").read()[:-6])
+    from roargraph_amd._lib import RgError
+    with pytest.raises(RgError, match="truncated"):
+        rg.graph_load(q)
+    ids = rng.integers(0, 99, (6, 4)).astype(np.uint32)
+    ds = rng.standard_normal((6, 4)).astype(np.float32)
+    g = str(tmp_path / "gt.bin")
+    rg.gt_save(g, ids, ds)
+    assert oracle.gt_meta(g) == (6, 4)
+    i2, d2 = oracle.gt_load(g)
+    assert (i2 == ids).all() and (bits(d2) == bits(ds)).all()
+
+
+def test_recall_matches_oracle(rg, oracle):
+    rng = np.random.default_rng(2)
+    res = rng.integers(0, 50, (30, 10)).astype(np.uint32)
+    gt = rng.integers(0, 50, (30, 25)).astype(np.uint32)
+    assert rg.recall(res, gt, 10) == oracle.recall(res, gt, 10)
+
+
+def test_normalize_matches_oracle(rg, oracle):
+    from roargraph_amd._lib import lib
+    a = np.random.default_rng(3).standard_normal((20, 24)).astype(np.float32)
+    b = a.copy()
+    lib().rg_normalize_rows(a.ctypes.data_as(C.c_void_p), C.c_size_t(20), C.c_size_t(24), C.c_uint32(24))
+    oracle.lib().rgo_normalize_rows(b.ctypes.data_as(C.c_void_p), C.c_size_t(20), C.c_size_t(24), C.c_uint(24))
+    assert (bits(a) == bits(b)).all()
+
+
+def test_compute_fails_loudly_without_gpu(rg):
+    """On a CPU-only host every compute entry point must return RG_ERR_DEVICE -- never silently compute elsewhere."""
+    from roargraph_amd._lib import RG_ERR_DEVICE, RgError, lib
+    if lib().rg_device_count() > 0:
+        pytest.skip("a GPU is visible here")
+    base = np.zeros((10, 8), np.float32)
+    with pytest.raises(RgError) as e:
+        rg.IndexBipartite.from_arrays(base, np.zeros(11, np.uint64), np.zeros(0, np.uint32), 0)
+    assert e.value.code == RG_ERR_DEVICE and "no CPU fallback" in str(e.value)
+    from roargraph_amd import groundtruth
+    with pytest.raises(RgError) as e:
+        groundtruth.compute_groundtruth(base, base, "ip", 2)
+    assert e.value.code == RG_ERR_DEVICE
+
+
+def test_product_never_touches_the_oracle():
+    """The shipped path (roargraph_amd/, bench hot path aside) must not import, link or name anything under oracle/."""
+    pkg = os.path.join(ROOT, "roargraph_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", "Makefile")):
+                txt = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "pyoracle" not in txt and "rg_oracle" not in txt and "librg_oracle" not in txt, f
+    import subprocess
+    so = os.path.join(pkg, "librg_hip.so")
+    if os.path.exists(so):
+        out = subprocess.run(["ldd", so], capture_output=True, text=True).stdout
+        assert "oracle" not in out

@@ -1,0 +1,99 @@
+"""-m gpu: K2/K3 (fp32 MFMA brute-force top-K) against the fp64 oracle.
+
+The MFMA sums in a different order than any CPU GEMM, so ids are compared with a tie band:
+every returned id must be a legitimate member of the top-K up to 1e-5 relative in the fp64 score, the returned order
+must follow the fp64 scores up to that band, and the stored distances must be within 1e-4 relative of fp64.
+"""
+import numpy as np
+import pytest
+
+from roargraph_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def fp64_scores(base, q, ids, metric):
+    b = base.astype(np.float64)[ids.astype(np.int64)]          # [nq, K, d]
+    qq = q.astype(np.float64)[:, None, :]
+    if metric == "l2":
+        return ((qq - b) ** 2).sum(-1)
+    return (qq * b).sum(-1)
+
+
+def check_gt(base, q, metric, K, ids, dists, ref_ids, ref_s64, tol=1e-5):
+    nq = q.shape[0]
+    s = fp64_scores(base, q, ids, metric)
+    scale = np.abs(ref_s64).max(axis=1, keepdims=True) + 1e-30
+    for i in range(nq):
+        assert len(set(ids[i].tolist())) == K, "duplicate ids in row %d" % i
+    if metric == "l2":
+        assert (s <= ref_s64[:, -1:] + tol * scale).all(), "an id outside the true top-K was returned"
+        assert (np.diff(s, axis=1) >= -tol * scale).all(), "rows not sorted best-first"
+    else:
+        assert (s >= ref_s64[:, -1:] - tol * scale).all(), "an id outside the true top-K was returned"
+        assert (np.diff(s, axis=1) <= tol * scale).all(), "rows not sorted best-first"
+    # rank-by-rank: same id, or a tie-band neighbour
+    same = ids == ref_ids
+    assert (np.abs(s - ref_s64)[~same] <= tol * np.broadcast_to(scale, s.shape)[~same]).all()
+    assert same.mean() > 0.999
+    assert (np.abs(dists.astype(np.float64) - s) <= 1e-4 * np.abs(s) + 1e-4 * scale * 1e-2).all(), "stored distances off"
+
+
+@pytest.mark.parametrize("metric,d,nb,nq,K", [("ip", 200, 20000, 300, 100), ("l2", 512, 6000, 130, 100),
+                                              ("ip", 200, 1000, 5, 10), ("l2", 24, 3000, 257, 1),
+                                              ("ip", 104, 5000, 64, 100), ("ip", 200, 130, 128, 128),
+                                              ("l2", 200, 4000, 100, 300)])
+def test_groundtruth_vs_fp64(oracle, metric, d, nb, nq, K):
+    from roargraph_amd import groundtruth
+    base, q = synth.make_synth(77, nb, nq, d)
+    ids, dists = groundtruth.compute_groundtruth(base, q, metric, K)
+    ref_ids, _, ref_s = oracle.groundtruth_f64(base, q, metric, K, nthreads=16)
+    check_gt(base, q, metric, K, ids, dists, ref_ids, ref_s)
+
+
+def test_groundtruth_exact_ties_by_id(oracle):
+    """Duplicated base rows give exactly equal scores: order must fall back to id ascending."""
+    from roargraph_amd import groundtruth
+    base, q = synth.make_synth(5, 2000, 50, 200)
+    base[1000:2000] = base[0:1000]
+    ids, dists = groundtruth.compute_groundtruth(base, q, "ip", 20)
+    ref_ids, _, ref_s = oracle.groundtruth_f64(base, q, "ip", 20, nthreads=8)
+    assert (ids[:, 0::2] + 1000 == ids[:, 1::2]).all(), "equal scores must be ordered by id"
+    check_gt(base, q, "ip", 20, ids, dists, ref_ids, ref_s)
+
+
+def test_shard_merge_equals_single(oracle):
+    """Base split in 3 row shards (K2 with id_base) + K3 merge == one-shot result, bit for bit."""
+    import torch
+    from roargraph_amd import groundtruth
+    base, q = synth.make_synth(9, 9000, 200, 200)
+    K = 100
+    dev = torch.device("cuda", 0)
+    bt, qt = torch.from_numpy(base).to(dev), torch.from_numpy(q).to(dev)
+    one_i = torch.zeros((200, K), dtype=torch.int32, device=dev)
+    one_v = torch.zeros((200, K), dtype=torch.float32, device=dev)
+    groundtruth.gt_shard_dev(bt, qt, "ip", K, 0, one_i, one_v)
+    parts_i = torch.zeros((3, 200, K), dtype=torch.int32, device=dev)
+    parts_v = torch.zeros((3, 200, K), dtype=torch.float32, device=dev)
+    for r, (lo, hi) in enumerate(groundtruth.shard_rows(9000, 3)):
+        groundtruth.gt_shard_dev(bt[lo:hi], qt, "ip", K, lo, parts_i[r], parts_v[r])
+    mi = torch.zeros_like(one_i)
+    mv = torch.zeros_like(one_v)
+    groundtruth.gt_merge_dev(parts_i, parts_v, 3, 200, K, "ip", mi, mv)
+    torch.cuda.synchronize()
+    assert torch.equal(mi, one_i)
+    assert torch.equal(mv.view(torch.int32), one_v.view(torch.int32))
+
+
+def test_gt_file_roundtrip(tmp_path, oracle):
+    """CLI-body form: .fbin in, gt file out, readable by the reference's loader rules (ids block + dists block)."""
+    from roargraph_amd import groundtruth, index, io
+    base, q = synth.make_synth(3, 3000, 40, 200)
+    io.write_fbin(str(tmp_path / "b.fbin"), base)
+    io.write_fbin(str(tmp_path / "q.fbin"), q)
+    groundtruth.compute_groundtruth_files(str(tmp_path / "b.fbin"), str(tmp_path / "q.fbin"), str(tmp_path / "gt.bin"), "ip", 100)
+    assert oracle.gt_meta(str(tmp_path / "gt.bin")) == (40, 100)
+    ids, ds = index.gt_load(str(tmp_path / "gt.bin"))
+    ref_ids, _, ref_s = oracle.groundtruth_f64(base, q, "ip", 100, nthreads=8)
+    check_gt(base, q, "ip", 100, ids, ds, ref_ids, ref_s)
+    assert (index.knn_ids_load(str(tmp_path / "gt.bin")) == ids).all()
