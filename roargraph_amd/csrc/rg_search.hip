@@ -7,8 +7,9 @@
 // Per query (one wave, one single-wave workgroup, all state wave-private):
 //   LDS   : sorted beam of L_pq (dist, id|expanded) pairs  == NeighborPriorityQueue (neighbor.h:138-223)
 //           query vector, 64-entry candidate id/score scratch, LDS-DMA staging for the row gather
-//   HBM   : visited bitmap of nd bits per slot             == VisitedList (visited_list_pool.h:8-29), set semantics
-//           + a log of the ids touched, replayed to clear the bitmap after the query
+//   HBM   : epoch-tagged visited words per slot             == VisitedList (visited_list_pool.h:8-29): like the
+//           reference's curV tag array, a word is "set for this query" only if its 16-bit epoch equals the query's,
+//           so nothing is ever cleared between queries (a wipe happens once per 65,535 queries of a slot)
 // Per hop (hop-synchronous, see SURVEY.md Appendix C-11 for why this reproduces the sequential inserts):
 //   pop closest unexpanded -> read its adjacency row -> atomicOr visited bits -> ballot-compact the unvisited ids
 //   -> gather + score them 4 rows per sub-pass -> rank-merge the survivors into the beam.
@@ -48,10 +49,9 @@ struct SearchParams {
     uint32_t *out_ids;
     float *out_dists;
     uint32_t *out_cmps, *out_hops;
-    uint32_t *visited;        // [slots][vwords]
+    uint32_t *visited;        // [slots][vwords]; word = epoch16 << 16 | 16 visited bits (nodes 16w .. 16w+15)
     uint32_t vwords;
-    uint32_t *vlog;           // [slots][logcap]
-    uint32_t logcap;
+    uint32_t *slot_epoch;     // [slots] last epoch used by the slot (persists across launches)
     uint32_t *counter;        // work-queue head
     unsigned long long *status;  // min over failing queries of (query << 32 | queue size); ~0 = none
     uint32_t stage_floats;    // floats per sub-pass staging buffer (ceil(dim/64)*256)
@@ -162,7 +162,7 @@ __global__ void __launch_bounds__(64) rg_search_kernel(SearchParams P) {
     bm.cap = P.L;
 
     uint32_t *vmap = P.visited + (size_t)blockIdx.x * P.vwords;
-    uint32_t *vlog = P.vlog + (size_t)blockIdx.x * P.logcap;
+    uint32_t epoch = P.slot_epoch[blockIdx.x];
 
     for (;;) {
         uint32_t qi = 0;
@@ -171,6 +171,13 @@ __global__ void __launch_bounds__(64) rg_search_kernel(SearchParams P) {
         if (qi >= P.nq) break;
         const float *query = P.queries + (size_t)qi * P.qstride;
         for (uint32_t i = lane; i < P.dim; i += kWave) qv[i] = query[i];
+        // new visited epoch (VisitedList::reset, visited_list_pool.h:20-26: ++curV, wipe on wrap)
+        if (++epoch == 0x10000u) {
+            for (uint32_t w = lane; w < P.vwords; w += kWave) vmap[w] = 0u;
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            epoch = 1;
+        }
+        const uint32_t etag = epoch << 16;
         wave_sync();
 
         // entry point: scored and queued, not marked visited (index_bipartite.cpp:2338-2352)
@@ -182,7 +189,7 @@ __global__ void __launch_bounds__(64) rg_search_kernel(SearchParams P) {
         bm.cur = 0;
         wave_sync();
 
-        uint32_t cmps = 0, hops = 0, logn = 0;
+        uint32_t cmps = 0, hops = 0;
         while (bm.cur < bm.size) {                                         // has_unexpanded_node, :2356
             const uint32_t node = beam_pop(bm, lane);                      // :2358
             ++hops;                                                        // :2366
@@ -214,8 +221,10 @@ __global__ void __launch_bounds__(64) rg_search_kernel(SearchParams P) {
                 // visited test-and-set (:2378, :2385); same-hop duplicates are resolved by the atomic's order
                 bool fresh = false;
                 if (have) {
-                    const uint32_t bit = 1u << (id & 31u);
-                    const uint32_t old = atomicOr(&vmap[id >> 5], bit);
+                    uint32_t *w = &vmap[id >> 4];
+                    const uint32_t bit = 1u << (id & 15u);
+                    atomicMax(w, etag);                    // stale epoch -> word becomes (epoch, no bits)
+                    const uint32_t old = atomicOr(w, bit); // same address, same lane: ordered behind the max
                     fresh = !(old & bit);
                 }
                 const unsigned long long fm = __ballot(fresh);
@@ -224,9 +233,7 @@ __global__ void __launch_bounds__(64) rg_search_kernel(SearchParams P) {
                 if (fresh) {
                     const uint32_t slot = __popcll(fm & ((1ull << lane) - 1ull));
                     cand_id[slot] = id;
-                    if (logn + slot < P.logcap) vlog[logn + slot] = id;
                 }
-                logn += n;
                 cmps += n;                                                 // :2397
                 wave_sync();
                 // gather + score, 4*R rows per pass (:2387)
@@ -269,19 +276,9 @@ __global__ void __launch_bounds__(64) rg_search_kernel(SearchParams P) {
             if (P.out_cmps) P.out_cmps[qi] = cmps;
             if (P.out_hops) P.out_hops[qi] = hops;
         }
-        // clear this slot's visited bits: replay the log, or wipe the bitmap if the log overflowed
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (logn <= P.logcap) {
-            for (uint32_t i = lane; i < logn; i += kWave) {
-                const uint32_t id = __hip_atomic_load(&vlog[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                vmap[id >> 5] = 0u;
-            }
-        } else {
-            for (uint32_t w = lane; w < P.vwords; w += kWave) vmap[w] = 0u;
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         wave_sync();
     }
+    if (lane == 0) P.slot_epoch[blockIdx.x] = epoch;
 }
 
 // K1b: out[i] = compare(base[ids[i]], query) for n ids; one wave scores 4*R rows per pass
@@ -366,8 +363,8 @@ struct rg_index {
     uint32_t max_deg = 0;
     // search scratch (lazily sized)
     uint32_t *d_visited = nullptr;
-    uint32_t *d_vlog = nullptr;
-    uint32_t slots = 0, vwords = 0, logcap = 0;
+    uint32_t *d_epoch = nullptr;
+    uint32_t slots = 0, vwords = 0;
     uint32_t *d_counter = nullptr;
     unsigned long long *d_status = nullptr;
     unsigned long long *h_status = nullptr;  // pinned
@@ -435,19 +432,19 @@ static size_t search_lds_bytes(const rg_index *ix, uint32_t L, int R) {
 }
 
 static rg_status ensure_scratch(rg_index *ix, uint32_t slots) {
-    const uint32_t vwords = (ix->nd + 31) / 32;
-    const uint32_t logcap = 1u << 16;
+    const uint32_t vwords = (ix->nd + 15) / 16;
     if (ix->slots >= slots && ix->vwords == vwords) return RG_OK;
     if (ix->d_visited) (void)hipFree(ix->d_visited);
-    if (ix->d_vlog) (void)hipFree(ix->d_vlog);
+    if (ix->d_epoch) (void)hipFree(ix->d_epoch);
     ix->d_visited = nullptr;
-    ix->d_vlog = nullptr;
+    ix->d_epoch = nullptr;
+    ix->slots = 0;
     RG_HIP(hipMalloc(&ix->d_visited, (size_t)slots * vwords * 4));
     RG_HIP(hipMemset(ix->d_visited, 0, (size_t)slots * vwords * 4));
-    RG_HIP(hipMalloc(&ix->d_vlog, (size_t)slots * logcap * 4));
+    RG_HIP(hipMalloc(&ix->d_epoch, (size_t)slots * 4));
+    RG_HIP(hipMemset(ix->d_epoch, 0, (size_t)slots * 4));
     ix->slots = slots;
     ix->vwords = vwords;
-    ix->logcap = logcap;
     return RG_OK;
 }
 
@@ -495,7 +492,7 @@ static rg_status search_dev(rg_index *ix, const float *d_q, uint32_t nq, uint32_
     P.ell = ix->d_ell; P.ell_stride = ix->ell_stride; P.offsets = ix->d_offsets; P.nbrs = ix->d_nbrs;
     P.ep = ix->ep; P.queries = d_q; P.nq = nq; P.qstride = qstride; P.k = k; P.L = L;
     P.out_ids = d_ids; P.out_dists = d_dists; P.out_cmps = d_cmps; P.out_hops = d_hops;
-    P.visited = ix->d_visited; P.vwords = ix->vwords; P.vlog = ix->d_vlog; P.logcap = ix->logcap;
+    P.visited = ix->d_visited; P.vwords = ix->vwords; P.slot_epoch = ix->d_epoch;
     P.counter = ix->d_counter; P.status = ix->d_status;
     P.stage_floats = ((ix->dim + 63) / 64) * 256;
     const bool l2 = ix->metric == RG_METRIC_L2, ell = ix->d_ell != nullptr;
@@ -553,7 +550,7 @@ void rg_index_close(rg_index *ix) {
     if (ix->d_nbrs) (void)hipFree(ix->d_nbrs);
     if (ix->d_ell) (void)hipFree(ix->d_ell);
     if (ix->d_visited) (void)hipFree(ix->d_visited);
-    if (ix->d_vlog) (void)hipFree(ix->d_vlog);
+    if (ix->d_epoch) (void)hipFree(ix->d_epoch);
     if (ix->d_counter) (void)hipFree(ix->d_counter);
     if (ix->d_status) (void)hipFree(ix->d_status);
     if (ix->h_status) (void)hipHostFree(ix->h_status);
