@@ -38,8 +38,8 @@ sys.path.insert(0, ROOT)
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--nb", type=int, default=10_000_000)
     ap.add_argument("--dim", type=int, default=200)
     ap.add_argument("--nq", type=int, default=10_000)
@@ -48,6 +48,10 @@ def parse():
     ap.add_argument("--deg", type=int, default=40)
     ap.add_argument("--metric", default="ip")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall budget of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--visited", type=int, default=1,
+                    help="1 = LDS exact-match visited filter (ids/dists/hops bit-exact, evals = work performed); "
+                         "0 = exact HBM visited words (cmps bit-exact too)")
+    ap.add_argument("--filter-log2", type=int, default=10)
     ap.add_argument("--waves-per-cu", type=int, default=0)
     ap.add_argument("--rows-per-pass", type=int, default=0)
     ap.add_argument("--sweep", default="", help="comma list of extra L_pq values to report (not part of the timed metric)")
@@ -147,6 +151,14 @@ def main():
     if args.rows_per_pass:
         index.set("rows_per_pass", args.rows_per_pass)
     stream = torch.cuda.current_stream().cuda_stream
+    index.set("filter_log2", args.filter_log2)
+
+    # reference-equivalent evaluation counts (exact visited mode), and a parity check between the two modes
+    index.set("visited", 0)
+    index.search_dev(q, args.k, args.L, ids, dists, cmps, hops, stream=stream)
+    index.search_wait(stream)
+    ref_ids, ref_dists, ref_cmps, ref_hops = ids.clone(), dists.clone(), cmps.clone(), hops.clone()
+    index.set("visited", args.visited)
 
     def step(L):
         index.search_dev(q, args.k, L, ids, dists, cmps, hops, stream=stream)
@@ -178,11 +190,29 @@ def main():
         elapsed = float(t.item())
     total_q = args.nq * args.steps * world
     qps = total_q / elapsed
-    mean_cmps = float(cmps.float().mean().item())
+    assert torch.equal(ids, ref_ids) and torch.equal(hops, ref_hops), "visited modes disagree on ids/hops"
+    assert torch.equal(dists.view(torch.int32), ref_dists.view(torch.int32)), "visited modes disagree on distances"
+    assert bool((cmps >= ref_cmps).all())
+    mean_cmps = float(ref_cmps.float().mean().item())      # the reference's avg_visited (distinct nodes scored)
+    mean_done = float(cmps.float().mean().item())           # evaluations this mode actually performed
     mean_hops = float(hops.float().mean().item())
     kavg = float(np.mean(kernel_ms)) / 1e3
-    alg_bytes = float(cmps.to(torch.int64).sum().item()) * 4.0 * args.dim
+    # algorithmic bytes: the REFERENCE's evaluation count x 4*dim (re-scored repeats of the filter mode are not credited)
+    alg_bytes = float(ref_cmps.to(torch.int64).sum().item()) * 4.0 * args.dim
     achieved = alg_bytes / kavg / 1e9
+
+    other = None
+    if rank == 0:
+        om = 1 - args.visited
+        index.set("visited", om)
+        step(args.L); torch.cuda.synchronize()
+        oe = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(min(3, args.steps))]
+        for a, b in oe:
+            a.record(); step(args.L); b.record()
+        torch.cuda.synchronize()
+        oms = float(np.mean([a.elapsed_time(b) for a, b in oe]))
+        other = {"visited": om, "qps": args.nq / (oms / 1e3), "kernel_ms_avg": oms, "achieved_GBps": alg_bytes / (oms / 1e3) / 1e9}
+        index.set("visited", args.visited)
 
     sweep = []
     if args.sweep and rank == 0:
@@ -215,13 +245,16 @@ def main():
                        "parallelism": "query-sharded x%d, index replicated" % world,
                        "recall_at_10": None,
                        "recall_note": "random graph: same HBM access pattern as a real index, recall not meaningful",
-                       "mean_evals_per_query": mean_cmps, "mean_hops": mean_hops},
+                       "visited": ("lds-filter 2^%d (ids/dists/hops bit-exact vs exact mode, checked in this run)" % args.filter_log2)
+                                  if args.visited else "exact (HBM epoch words; cmps bit-exact too)",
+                       "mean_evals_per_query": mean_cmps, "mean_evals_performed": mean_done, "mean_hops": mean_hops},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": None,
                          "kernel": "rg_search_kernel", "kernel_ms_avg": kavg * 1e3,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "frac_of_measured_stream_ceiling_6290": achieved / 6290.0},
             "cpu_baseline": cpu,
+            "other_visited_mode": other,
         }
         if sweep:
             line["L_pq_sweep"] = sweep

@@ -62,10 +62,27 @@ __device__ __forceinline__ void gather_issue(const float *__restrict__ row, uint
     }
 }
 
-__device__ __forceinline__ void gather_wait() {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+// Wait until at most `n` of this wave's vector-memory loads are still outstanding (loads retire in issue order), then
+// fence the compiler.  n is wave-uniform; the immediate form of s_waitcnt needs a literal, hence the switch.
+__device__ __forceinline__ void gather_wait(uint32_t n) {
+#define RG_W(i) case i: asm volatile("s_waitcnt vmcnt(" #i ")" ::: "memory"); break;
+    switch (n) {
+        RG_W(1) RG_W(2) RG_W(3) RG_W(4) RG_W(5) RG_W(6) RG_W(7) RG_W(8) RG_W(9) RG_W(10) RG_W(11) RG_W(12)
+        RG_W(13) RG_W(14) RG_W(15) RG_W(16) RG_W(17) RG_W(18) RG_W(19) RG_W(20) RG_W(21) RG_W(22) RG_W(23) RG_W(24)
+        RG_W(25) RG_W(26) RG_W(27) RG_W(28) RG_W(29) RG_W(30) RG_W(31) RG_W(32) RG_W(33) RG_W(34) RG_W(35) RG_W(36)
+        RG_W(37) RG_W(38) RG_W(39) RG_W(40) RG_W(41) RG_W(42) RG_W(43) RG_W(44) RG_W(45) RG_W(46) RG_W(47) RG_W(48)
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+#undef RG_W
     __builtin_amdgcn_wave_barrier();
 }
+// LDS-only ordering point inside a wave (does not drain the vector-memory queue, unlike wave_sync)
+__device__ __forceinline__ void lds_sync() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+}
+// loads one pass (4 rows) issues: used to count outstanding loads per pass
+__device__ __forceinline__ uint32_t loads_per_pass(uint32_t dim) { return (dim >> 6) + ((dim & 63u) ? 1u : 0u); }
 
 // Consume one staged sub-pass: returns the reference's compare() value of this lane's group row against qv
 // (valid in every lane of the group).  dim % 8 == 0.

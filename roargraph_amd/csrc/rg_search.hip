@@ -55,6 +55,9 @@ struct SearchParams {
     uint32_t *counter;        // work-queue head
     unsigned long long *status;  // min over failing queries of (query << 32 | queue size); ~0 = none
     uint32_t stage_floats;    // floats per sub-pass staging buffer (ceil(dim/64)*256)
+    uint32_t diag;            // diagnostics only (breaks parity): bit0 = skip the visited test
+    uint32_t vf_slots_log2;   // VIS=1: log2 of the LDS visited-filter size (16-bit entries)
+    uint32_t id_bits;         // VIS=1: ceil(log2(nd))
 };
 
 struct Beam {
@@ -84,11 +87,36 @@ __device__ __forceinline__ uint32_t beam_pop(Beam &bm, int lane) {
 // NeighborPriorityQueue::insert (neighbor.h:150-183).  The beam is the top-cap of everything inserted so far
 // under the total order (distance, id); candidates are distinct unvisited nodes, the only possible repeat is the
 // entry point (never marked visited, index_bipartite.cpp:2349), whose second insert the reference drops.
+template <bool DEDUP>
 __device__ __forceinline__ void beam_merge(Beam &bm, float cd, uint32_t cid, uint32_t n, uint32_t ep, int lane) {
     bool valid = (uint32_t)lane < n && cid != ep;
     if (bm.size == bm.cap) {  // full: only candidates better than the current worst can enter (neighbor.h:151-153)
         uint2 w = bm.ent[bm.cap - 1];
         valid = valid && nb_less(cd, cid, __uint_as_float(w.x), w.y & ~kFlagBit);
+    }
+    if (!__any(valid)) return;
+    // rank among the beam entries: lower bound under (distance, id)
+    uint32_t lo = 0, hi = valid ? bm.size : 0;
+    while (__any(lo < hi)) {
+        if (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            const uint2 e = bm.ent[mid];
+            if (nb_less(__uint_as_float(e.x), e.y & ~kFlagBit, cd, cid)) lo = mid + 1;
+            else hi = mid;
+        }
+    }
+    if (DEDUP) {
+        // With the lossy visited filter a node can be scored again.  Its distance bits are the same, so the lower bound
+        // lands exactly on its beam entry if it is still there: drop it (the reference's equal-id rule, neighbor.h:161);
+        // if it was evicted the tail test above already rejected it.  Same id twice in one hop: keep the lowest lane.
+        if (valid && lo < bm.size && (bm.ent[lo].y & ~kFlagBit) == cid) valid = false;
+        const unsigned long long m0 = __ballot(valid);
+        bool dup = false;
+        for (unsigned long long m = m0; m; m &= m - 1) {
+            const int s = __ffsll((long long)m) - 1;
+            dup = dup || (readlane_u(cid, s) == cid && s < lane);
+        }
+        valid = valid && !dup;
     }
     const unsigned long long vmask = __ballot(valid);
     if (!vmask) return;
@@ -100,16 +128,6 @@ __device__ __forceinline__ void beam_merge(Beam &bm, float cd, uint32_t cid, uin
         const float od = readlane_f(cd, s);
         const uint32_t oi = readlane_u(cid, s);
         crank += nb_less(od, oi, cd, cid) ? 1u : 0u;
-    }
-    // rank among the beam entries (lower bound; no entry equals a candidate)
-    uint32_t lo = 0, hi = valid ? bm.size : 0;
-    while (__any(lo < hi)) {
-        if (lo < hi) {
-            const uint32_t mid = (lo + hi) >> 1;
-            const uint2 e = bm.ent[mid];
-            if (nb_less(__uint_as_float(e.x), e.y & ~kFlagBit, cd, cid)) lo = mid + 1;
-            else hi = mid;
-        }
     }
     const uint32_t qrank = valid ? lo : 0xffffffffu;
     const uint32_t fpos = lo + crank;
@@ -147,7 +165,7 @@ __device__ __forceinline__ void beam_merge(Beam &bm, float cd, uint32_t cid, uin
     wave_sync();
 }
 
-template <bool L2, bool ELL, int R>
+template <bool L2, bool ELL, int R, int VIS>
 __global__ void __launch_bounds__(64) rg_search_kernel(SearchParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
@@ -160,9 +178,13 @@ __global__ void __launch_bounds__(64) rg_search_kernel(SearchParams P) {
     Beam bm;
     bm.ent = reinterpret_cast<uint2 *>(cand_d + kWave);                   // L
     bm.cap = P.L;
+    // VIS=1: lossy exact-match visited filter (direct mapped, 16-bit remainders of a bijective id hash)
+    uint16_t *vtab = reinterpret_cast<uint16_t *>(bm.ent + P.L);
+    const uint32_t vf_rem_bits = P.id_bits > P.vf_slots_log2 ? P.id_bits - P.vf_slots_log2 : 0u;
+    const uint32_t vf_id_mask = P.id_bits >= 32u ? 0xffffffffu : ((1u << P.id_bits) - 1u);
 
     uint32_t *vmap = P.visited + (size_t)blockIdx.x * P.vwords;
-    uint32_t epoch = P.slot_epoch[blockIdx.x];
+    uint32_t epoch = VIS == 0 ? P.slot_epoch[blockIdx.x] : 0u;
 
     for (;;) {
         uint32_t qi = 0;
@@ -172,17 +194,23 @@ __global__ void __launch_bounds__(64) rg_search_kernel(SearchParams P) {
         const float *query = P.queries + (size_t)qi * P.qstride;
         for (uint32_t i = lane; i < P.dim; i += kWave) qv[i] = query[i];
         // new visited epoch (VisitedList::reset, visited_list_pool.h:20-26: ++curV, wipe on wrap)
-        if (++epoch == 0x10000u) {
-            for (uint32_t w = lane; w < P.vwords; w += kWave) vmap[w] = 0u;
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            epoch = 1;
+        uint32_t etag = 0;
+        if (VIS == 0) {
+            if (++epoch == 0x10000u) {
+                for (uint32_t w = lane; w < P.vwords; w += kWave) vmap[w] = 0u;
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                epoch = 1;
+            }
+            etag = epoch << 16;
+        } else {
+            uint32_t *vt32 = reinterpret_cast<uint32_t *>(vtab);
+            for (uint32_t i = lane; i < (1u << P.vf_slots_log2) / 2u; i += kWave) vt32[i] = 0xffffffffu;
         }
-        const uint32_t etag = epoch << 16;
         wave_sync();
 
         // entry point: scored and queued, not marked visited (index_bipartite.cpp:2338-2352)
         gather_issue(P.base + (size_t)P.ep * P.stride, P.dim, g == 0, stage, lane);
-        gather_wait();
+        gather_wait(0);
         const float epd = gather_score<L2>(stage, qv, P.dim, lane);
         if (lane == 0) bm.ent[0] = make_uint2(__float_as_uint(epd), P.ep);
         bm.size = 1;
@@ -220,7 +248,23 @@ __global__ void __launch_bounds__(64) rg_search_kernel(SearchParams P) {
                 }
                 // visited test-and-set (:2378, :2385); same-hop duplicates are resolved by the atomic's order
                 bool fresh = false;
-                if (have) {
+                if (VIS == 1) {
+                    // exact-match lookup: a hit proves "visited"; a miss is treated as fresh (may re-score a node whose
+                    // entry was overwritten -- harmless for the beam, see beam_merge<true>)
+                    if (have) {
+                        const uint32_t x = (id * 0x9E3779B1u) & vf_id_mask;   // odd multiplier: bijection on id_bits bits
+                        const uint32_t slot = x >> vf_rem_bits;
+                        const uint16_t rem = (uint16_t)(x & ((1u << vf_rem_bits) - 1u));
+                        fresh = vtab[slot] != rem;
+                        if (fresh) vtab[slot] = rem;
+                    }
+                } else if (have && (P.diag & 1u)) fresh = true;
+                else if (have && (P.diag & 2u)) {  // traffic without the dependency: fire-and-forget atomics
+                    uint32_t *w = &vmap[id >> 4];
+                    atomicMax(w, etag);
+                    __hip_atomic_fetch_or(w, 1u << (id & 15u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    fresh = true;
+                } else if (have) {
                     uint32_t *w = &vmap[id >> 4];
                     const uint32_t bit = 1u << (id & 15u);
                     atomicMax(w, etag);                    // stale epoch -> word becomes (epoch, no bits)
@@ -236,29 +280,35 @@ __global__ void __launch_bounds__(64) rg_search_kernel(SearchParams P) {
                 }
                 cmps += n;                                                 // :2397
                 wave_sync();
-                // gather + score, 4*R rows per pass (:2387)
-                for (uint32_t p0 = 0; p0 < n; p0 += 4 * R) {
-#pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        const uint32_t c = p0 + 4 * r + g;
-                        const bool act = c < n;
-                        const uint32_t rid = act ? cand_id[c] : 0u;
-                        gather_issue(P.base + (size_t)rid * P.stride, P.dim, act, stage + (size_t)r * P.stage_floats, lane);
+                // gather + score (:2387): 4 rows per pass, a ring of R staging buffers keeps up to R passes in flight;
+                // pass p is consumed once only the loads of the passes issued after it are still outstanding
+                {
+                    const uint32_t npass = (n + 3u) >> 2, lpp = loads_per_pass(P.dim);
+                    for (uint32_t p = 0; p < (uint32_t)R && p < npass; ++p) {
+                        const uint32_t c = 4 * p + g;
+                        const uint32_t rid = c < n ? cand_id[c] : 0u;
+                        gather_issue(P.base + (size_t)rid * P.stride, P.dim, c < n, stage + (size_t)p * P.stage_floats, lane);
                     }
-                    gather_wait();
-#pragma unroll
-                    for (int r = 0; r < R; ++r) {
-                        const uint32_t c = p0 + 4 * r + g;
-                        const float d = gather_score<L2>(stage + (size_t)r * P.stage_floats, qv, P.dim, lane);
+                    for (uint32_t p = 0; p < npass; ++p) {
+                        const uint32_t last = min(npass, p + (uint32_t)R) - 1u;
+                        gather_wait((last - p) * lpp);
+                        float *buf = stage + (size_t)(p & (R - 1)) * P.stage_floats;
+                        const uint32_t c = 4 * p + g;
+                        const float d = gather_score<L2>(buf, qv, P.dim, lane);
                         if (c < n && (lane & 15) == 0) cand_d[c] = d;
+                        lds_sync();
+                        if (p + R < npass) {
+                            const uint32_t c2 = 4 * (p + R) + g;
+                            const uint32_t rid = c2 < n ? cand_id[c2] : 0u;
+                            gather_issue(P.base + (size_t)rid * P.stride, P.dim, c2 < n, buf, lane);
+                        }
                     }
-                    wave_sync();
                 }
                 // queue inserts (:2398)
                 const float cd = (uint32_t)lane < n ? cand_d[lane] : 0.0f;
                 const uint32_t cid = (uint32_t)lane < n ? cand_id[lane] : 0u;
                 wave_sync();
-                beam_merge(bm, cd, cid, n, P.ep, lane);
+                beam_merge<VIS == 1>(bm, cd, cid, n, P.ep, lane);
             }
         }
 
@@ -278,7 +328,7 @@ __global__ void __launch_bounds__(64) rg_search_kernel(SearchParams P) {
         }
         wave_sync();
     }
-    if (lane == 0) P.slot_epoch[blockIdx.x] = epoch;
+    if (VIS == 0 && lane == 0) P.slot_epoch[blockIdx.x] = epoch;
 }
 
 // K1b: out[i] = compare(base[ids[i]], query) for n ids; one wave scores 4*R rows per pass
@@ -292,22 +342,28 @@ __global__ void __launch_bounds__(64) rg_score_kernel(const float *__restrict__ 
     float *qv = stage + (size_t)R * stage_floats;
     for (uint32_t i = lane; i < dim; i += kWave) qv[i] = query[i];
     wave_sync();
-    for (uint32_t p0 = blockIdx.x * 4 * R; p0 < n; p0 += gridDim.x * 4 * R) {
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const uint32_t c = p0 + 4 * r + g;
-            const bool act = c < n;
-            const uint32_t rid = act ? ids[c] : 0u;
-            gather_issue(base + (size_t)rid * stride, dim, act, stage + (size_t)r * stage_floats, lane);
-        }
-        gather_wait();
-#pragma unroll
-        for (int r = 0; r < R; ++r) {
-            const uint32_t c = p0 + 4 * r + g;
-            const float d = gather_score<L2>(stage + (size_t)r * stage_floats, qv, dim, lane);
-            if (c < n && (lane & 15) == 0) out[c] = d;
-        }
-        wave_sync();
+    // each wave owns a contiguous run of passes (4 ids each) and streams them through a ring of R staging buffers
+    const uint32_t npass_all = (n + 3u) >> 2;
+    const uint32_t per = (npass_all + gridDim.x - 1) / gridDim.x;
+    const uint32_t p_lo = min(npass_all, blockIdx.x * per), p_hi = min(npass_all, p_lo + per);
+    const uint32_t npass = p_hi - p_lo, lpp = loads_per_pass(dim);
+    auto issue = [&](uint32_t p, float *buf) {
+        const uint32_t c = 4 * (p_lo + p) + g;
+        const bool act = c < n;
+        uint32_t rid = 0;
+        if (act) rid = ids[c];
+        gather_issue(base + (size_t)rid * stride, dim, act, buf, lane);
+    };
+    for (uint32_t p = 0; p < (uint32_t)R && p < npass; ++p) issue(p, stage + (size_t)p * stage_floats);
+    for (uint32_t p = 0; p < npass; ++p) {
+        const uint32_t last = min(npass, p + (uint32_t)R) - 1u;
+        gather_wait((last - p) * lpp);
+        float *buf = stage + (size_t)(p & (R - 1)) * stage_floats;
+        const uint32_t c = 4 * (p_lo + p) + g;
+        const float d = gather_score<L2>(buf, qv, dim, lane);
+        if (c < n && (lane & 15) == 0) out[c] = d;
+        lds_sync();
+        if (p + R < npass) issue(p + R, buf);
     }
 }
 
@@ -372,6 +428,9 @@ struct rg_index {
     int waves_per_cu = 0;   // 0 = auto
     int rows_per_pass = 8;  // 4*R
     int force_csr = 0;
+    int diag = 0;
+    int visited_mode = 0;   // 0 = exact (HBM epoch words), 1 = LDS exact-match filter (ids/dists/hops exact, cmps = work done)
+    int filter_log2 = 11;   // VIS=1: 2^11 16-bit entries = 4 KiB
     int num_cu = 256;
     size_t lds_per_cu = 160 * 1024;
 };
@@ -426,9 +485,22 @@ static rg_status finish_graph(rg_index *ix, const uint64_t *d_off, const uint32_
     return RG_OK;
 }
 
+static uint32_t id_bits_of(uint32_t nd) {
+    uint32_t b = 1;
+    while (b < 32 && (1ull << b) < nd) ++b;
+    return b;
+}
+static uint32_t filter_log2_of(const rg_index *ix) {  // remainder must fit 15 bits
+    const uint32_t bits = id_bits_of(ix->nd);
+    uint32_t t = (uint32_t)std::max(4, std::min(14, ix->filter_log2));
+    if (bits > t + 15) t = bits - 15;
+    return std::min(t, bits);
+}
 static size_t search_lds_bytes(const rg_index *ix, uint32_t L, int R) {
     const size_t stage_floats = (size_t)((ix->dim + 63) / 64) * 256;
-    return (size_t)R * stage_floats * 4 + (size_t)ix->dim * 4 + 64 * 4 + 64 * 4 + (size_t)L * 8;
+    size_t b = (size_t)R * stage_floats * 4 + (size_t)ix->dim * 4 + 64 * 4 + 64 * 4 + (size_t)L * 8;
+    if (ix->visited_mode == 1) b += std::max<size_t>(4, (size_t)2 << filter_log2_of(ix));
+    return (b + 15) / 16 * 16;
 }
 
 static rg_status ensure_scratch(rg_index *ix, uint32_t slots) {
@@ -448,13 +520,19 @@ static rg_status ensure_scratch(rg_index *ix, uint32_t slots) {
     return RG_OK;
 }
 
-template <bool L2, bool ELL, int R>
-static rg_status launch_search_t(rg_index *ix, const SearchParams &P, uint32_t grid, size_t lds, hipStream_t s) {
-    auto kern = rg_search_kernel<L2, ELL, R>;
+template <bool L2, bool ELL, int R, int VIS>
+static rg_status launch_search_v(rg_index *ix, const SearchParams &P, uint32_t grid, size_t lds, hipStream_t s) {
+    auto kern = rg_search_kernel<L2, ELL, R, VIS>;
     RG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, s, P);
     RG_HIP(hipGetLastError());
     return RG_OK;
+}
+
+template <bool L2, bool ELL, int R>
+static rg_status launch_search_t(rg_index *ix, const SearchParams &P, uint32_t grid, size_t lds, hipStream_t s) {
+    return ix->visited_mode == 1 ? launch_search_v<L2, ELL, R, 1>(ix, P, grid, lds, s)
+                                 : launch_search_v<L2, ELL, R, 0>(ix, P, grid, lds, s);
 }
 
 template <bool L2, bool ELL>
@@ -483,8 +561,10 @@ static rg_status search_dev(rg_index *ix, const float *d_q, uint32_t nq, uint32_
     if (ix->waves_per_cu > 0) wpc = std::min(wpc, ix->waves_per_cu);
     else wpc = std::min(wpc, 16);
     const uint32_t grid = (uint32_t)std::min<uint64_t>(nq, (uint64_t)ix->num_cu * wpc);
-    rg_status st = ensure_scratch(ix, grid);
-    if (st != RG_OK) return st;
+    if (ix->visited_mode == 0) {
+        rg_status st = ensure_scratch(ix, grid);
+        if (st != RG_OK) return st;
+    }
     RG_HIP(hipMemsetAsync(ix->d_counter, 0, 4, s));
     RG_HIP(hipMemsetAsync(ix->d_status, 0xff, 8, s));
     SearchParams P;
@@ -495,6 +575,9 @@ static rg_status search_dev(rg_index *ix, const float *d_q, uint32_t nq, uint32_
     P.visited = ix->d_visited; P.vwords = ix->vwords; P.slot_epoch = ix->d_epoch;
     P.counter = ix->d_counter; P.status = ix->d_status;
     P.stage_floats = ((ix->dim + 63) / 64) * 256;
+    P.diag = (uint32_t)ix->diag;
+    P.vf_slots_log2 = filter_log2_of(ix);
+    P.id_bits = id_bits_of(ix->nd);
     const bool l2 = ix->metric == RG_METRIC_L2, ell = ix->d_ell != nullptr;
     if (l2 && ell) return launch_search_r<true, true>(ix, P, grid, lds, R, s);
     if (l2) return launch_search_r<true, false>(ix, P, grid, lds, R, s);
@@ -519,10 +602,10 @@ static rg_status score_dev(rg_index *ix, const float *d_query, const uint32_t *d
     if (!ix) return set_error(RG_ERR_ARG, "null index");
     if (n == 0) return RG_OK;
     RG_HIP(hipSetDevice(ix->device));
-    constexpr int R = 2;
+    constexpr int R = 4;
     const uint32_t stage_floats = ((ix->dim + 63) / 64) * 256;
     const size_t lds = (size_t)R * stage_floats * 4 + (size_t)ix->dim * 4;
-    const uint32_t passes = (n + 4 * R - 1) / (4 * R);
+    const uint32_t passes = (n + 3) / 4;
     const uint32_t grid = std::min<uint32_t>(passes, (uint32_t)ix->num_cu * 16u);
     if (ix->metric == RG_METRIC_L2)
         hipLaunchKernelGGL((rg_score_kernel<true, R>), dim3(grid), dim3(64), lds, s, ix->d_base, ix->stride, ix->dim, d_query, d_ids, n, d_out, stage_floats);
@@ -648,6 +731,9 @@ rg_status rg_index_set(rg_index *ix, const char *name, int value) {
     if (!ix || !name) return set_error(RG_ERR_ARG, "null argument");
     if (!strcmp(name, "waves_per_cu")) ix->waves_per_cu = value;
     else if (!strcmp(name, "rows_per_pass")) ix->rows_per_pass = value;
+    else if (!strcmp(name, "diag")) ix->diag = value;
+    else if (!strcmp(name, "visited")) ix->visited_mode = value ? 1 : 0;
+    else if (!strcmp(name, "filter_log2")) ix->filter_log2 = value;
     else return set_error(RG_ERR_ARG, "unknown knob");
     return RG_OK;
 }

@@ -17,6 +17,9 @@ ap.add_argument("--rpp", default="8")
 ap.add_argument("--metric", default="ip")
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--stride", type=int, default=0)
+ap.add_argument("--diag", type=int, default=0)
+ap.add_argument("--visited", default="0")
+ap.add_argument("--filter", default="11")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 g = torch.Generator(device=dev); g.manual_seed(1234)
@@ -30,13 +33,17 @@ g.manual_seed(99)
 q = torch.empty((a.nq, a.dim), device=dev).normal_(generator=g) * 0.5 + 0.3
 ix = IndexBipartite.from_device(base, off, nbrs, 0, metric=a.metric, dim=a.dim)
 k = 10
+ix.set('diag', a.diag)
 ids = torch.zeros((a.nq, k), dtype=torch.int32, device=dev); ds = torch.zeros((a.nq, k), device=dev)
 cm = torch.zeros(a.nq, dtype=torch.int32, device=dev); hp = torch.zeros(a.nq, dtype=torch.int32, device=dev)
 st = torch.cuda.current_stream().cuda_stream
 for L in [int(x) for x in a.L.split(",")]:
     for wpc in [int(x) for x in a.wpc.split(",")]:
         for rpp in [int(x) for x in a.rpp.split(",")]:
-            ix.set("waves_per_cu", wpc); ix.set("rows_per_pass", rpp)
+          for vis in [int(x) for x in a.visited.split(",")]:
+           for fl in ([int(x) for x in a.filter.split(",")] if vis else [0]):
+            ix.set("waves_per_cu", wpc); ix.set("rows_per_pass", rpp); ix.set("visited", vis)
+            if vis: ix.set("filter_log2", fl)
             ix.search_dev(q, k, L, ids, ds, cm, hp, stream=st); torch.cuda.synchronize()
             best = 1e9
             for _ in range(a.reps):
@@ -44,5 +51,5 @@ for L in [int(x) for x in a.L.split(",")]:
                 e0.record(); ix.search_dev(q, k, L, ids, ds, cm, hp, stream=st); e1.record(); torch.cuda.synchronize()
                 best = min(best, e0.elapsed_time(e1))
             mc = cm.float().mean().item()
-            print(json.dumps({"L": L, "wpc": wpc, "rpp": rpp, "ms": round(best, 3), "qps": round(a.nq / best * 1e3),
+            print(json.dumps({"L": L, "wpc": wpc, "rpp": rpp, "vis": vis, "flt": fl, "ms": round(best, 3), "qps": round(a.nq / best * 1e3),
                               "evals": round(mc, 1), "GBps": round(a.nq * mc * 4 * a.dim / best / 1e6, 1)}), flush=True)

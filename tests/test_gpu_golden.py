@@ -44,6 +44,11 @@ def test_search_goldens_on_gpu(name, layout, monkeypatch):
         L, k = (int(x[1:]) for x in str(tag).split("_"))
         for rpp in (4, 8, 16):
             ix.set("rows_per_pass", rpp)
+            ix.set("visited", 1)    # LDS filter mode: everything but cmps must still match the reference
+            ids, ds, cmps, hops = ix.SearchRoarGraph(z["queries"], k, L)
+            assert (hops == z[tag + "_hops"]).all() and (ids == z[tag + "_ids"]).all(), (tag, rpp, "filter")
+            assert (bits(ds) == z[tag + "_dist_bits"]).all() and (cmps >= z[tag + "_cmps"]).all(), (tag, rpp, "filter")
+            ix.set("visited", 0)
             ids, ds, cmps, hops = ix.SearchRoarGraph(z["queries"], k, L)
             assert (cmps == z[tag + "_cmps"]).all() and (hops == z[tag + "_hops"]).all(), (tag, rpp)
             assert (ids == z[tag + "_ids"]).all(), (tag, rpp)

@@ -47,3 +47,23 @@ def test_search_bit_exact(rg, oracle, metric, d, nb, L, k):
     assert (got[0] == want[0]).all(), "neighbour ids differ"
     assert (bits(got[1]) == bits(want[1])).all(), "distance bits differ"
     ix.close()
+
+
+@pytest.mark.parametrize("metric,d,nb", [("ip", 200, 4000), ("l2", 512, 2000)])
+@pytest.mark.parametrize("L,k", [(10, 10), (100, 100), (500, 10)])
+@pytest.mark.parametrize("flt", [4, 9, 11])
+def test_search_lds_filter_mode(rg, oracle, metric, d, nb, L, k, flt):
+    """visited=1: the LDS exact-match filter may forget a node and score it again, which cannot change the beam
+    (same distance bits -> dropped as a repeat or rejected by the tail).  ids, distances and hops stay bit-exact;
+    cmps counts the evaluations actually performed (>= the reference's)."""
+    base, q, off, nbrs, ep = small_set(metric, nb, d)
+    ix = rg.IndexBipartite.from_arrays(base, off, nbrs, ep, metric=metric)
+    ix.set("visited", 1)
+    ix.set("filter_log2", flt)
+    got = ix.SearchRoarGraph(q, k, L)
+    want = oracle.search(base, metric, off, nbrs, ep, q, k, L, nthreads=4)
+    assert (got[3] == want[3]).all(), "hops differ"
+    assert (got[0] == want[0]).all(), "neighbour ids differ"
+    assert (bits(got[1]) == bits(want[1])).all(), "distance bits differ"
+    assert (got[2] >= want[2]).all(), "fewer evaluations than the reference is impossible"
+    ix.close()
