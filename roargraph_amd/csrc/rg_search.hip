@@ -559,7 +559,7 @@ static rg_status search_dev(rg_index *ix, const float *d_q, uint32_t nq, uint32_
     if (lds > ix->lds_per_cu) return set_error(RG_ERR_ARG, "L_pq too large for the 160 KiB LDS of one CU");
     int wpc = (int)std::min<size_t>(ix->lds_per_cu / lds, 32);
     if (ix->waves_per_cu > 0) wpc = std::min(wpc, ix->waves_per_cu);
-    else wpc = std::min(wpc, 16);
+    else wpc = std::min(wpc, 24);
     const uint32_t grid = (uint32_t)std::min<uint64_t>(nq, (uint64_t)ix->num_cu * wpc);
     if (ix->visited_mode == 0) {
         rg_status st = ensure_scratch(ix, grid);
@@ -602,7 +602,7 @@ static rg_status score_dev(rg_index *ix, const float *d_query, const uint32_t *d
     if (!ix) return set_error(RG_ERR_ARG, "null index");
     if (n == 0) return RG_OK;
     RG_HIP(hipSetDevice(ix->device));
-    constexpr int R = 4;
+    constexpr int R = 2;
     const uint32_t stage_floats = ((ix->dim + 63) / 64) * 256;
     const size_t lds = (size_t)R * stage_floats * 4 + (size_t)ix->dim * 4;
     const uint32_t passes = (n + 3) / 4;

@@ -1,0 +1,66 @@
+"""-m gpu: the C++ CLI twins (roargraph_amd/bin) against the oracle: same flags, same table/CSV columns as
+tests/test_search_roargraph.cpp:190,231-236, same gt file layout as compute_groundtruth (README.md:70-74)."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from helpers import small_set
+from roargraph_amd import io
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "roargraph_amd", "bin")
+
+
+@pytest.fixture(scope="module")
+def bins():
+    if not os.path.exists(os.path.join(BIN, "test_search_roargraph")):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "roargraph_amd", "cli")])
+    return BIN
+
+
+def test_compute_groundtruth_then_search_cli(bins, oracle, tmp_path):
+    metric, d, nb = "ip", 200, 3000
+    base, q, off, nbrs, ep = small_set(metric, nb, d, nq=120)
+    bf, qf, gf, gtf, csv = (str(tmp_path / x) for x in ("b.fbin", "q.fbin", "g.index", "gt.bin", "eval.csv"))
+    io.write_fbin(bf, base); io.write_fbin(qf, q); io.write_index(gf, off, nbrs, ep)
+    # ground truth through the CLI twin
+    r = subprocess.run([os.path.join(bins, "compute_groundtruth"), "--data_type", "float", "--dist_fn", "mips",
+                        "--base_file", bf, "--query_file", qf, "--gt_file", gtf, "--K", "100"],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    gt_ids, gt_d = oracle.gt_load(gtf)                       # layout accepted by the reference's size rule
+    ref_ids, _, ref_s = oracle.groundtruth_f64(base, q, metric, 100, nthreads=8)
+    assert (gt_ids == ref_ids).mean() > 0.999
+    assert np.allclose(gt_d, ref_s, rtol=1e-4, atol=1e-4)
+    # search through the CLI twin, two L_pq values as a multitoken option
+    r = subprocess.run([os.path.join(bins, "test_search_roargraph"), "--data_type", "float", "--dist", "ip",
+                        "--base_data_path", bf, "--query_path", qf, "--gt_path", gtf,
+                        "--projection_index_save_path", gf, "--L_pq", "20", "100", "--k", "10", "-T", "16",
+                        "--evaluation_save_path", csv], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "L_pq\t\tQPS\t\t\tavg_visited\tmean_latency\trecall@10\tavg_hops" in r.stdout
+    rows = [l.split(",") for l in open(csv).read().strip().splitlines()]
+    assert [int(x[0]) for x in rows] == [20, 100] and all(len(x) == 6 for x in rows)
+    for row in rows:
+        L = int(row[0])
+        ids, _, cmps, hops = oracle.search(base, metric, off, nbrs, ep, q, 10, L, nthreads=4)
+        assert float(row[2]) == pytest.approx(float(np.float32(cmps.astype(np.float32).sum() / 120)), rel=1e-5)
+        assert float(row[5]) == pytest.approx(float(hops.mean()), rel=1e-5)
+        assert float(row[4]) == pytest.approx(oracle.recall(ids, gt_ids, 10), abs=1e-6)
+        assert float(row[1]) > 0
+
+
+def test_cli_errors(bins, tmp_path):
+    r = subprocess.run([os.path.join(bins, "test_search_roargraph"), "--data_type", "float"], capture_output=True, text=True)
+    assert r.returncode != 0 and "is required but missing" in r.stderr
+    base = np.zeros((10, 8), np.float32)
+    bf = str(tmp_path / "b.fbin")
+    io.write_fbin(bf, base)
+    open(bf, "ab").write(b"\0" * 40)          # one extra row worth of bytes -> the reference's size check fires
+    r = subprocess.run([os.path.join(bins, "compute_groundtruth"), "--data_type", "float", "--dist_fn", "l2",
+                        "--base_file", bf, "--query_file", bf, "--gt_file", str(tmp_path / "o"), "--K", "2"],
+                       capture_output=True, text=True)
+    assert r.returncode != 0 and "Data file size wrong!" in (r.stdout + r.stderr)
