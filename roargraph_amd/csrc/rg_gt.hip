@@ -36,7 +36,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned long long u64;
 
 constexpr int kNB = 128;     // base rows per streamed tile
-constexpr int kBS = kNB + 4; // LDS row stride of the transposed base stage (bank spread)
+constexpr int kBS = kNB + 1; // LDS row stride of the transposed base stage (bank spread for reads and transposed writes)
 
 // order-preserving float -> uint (ascending)
 __device__ __forceinline__ uint32_t f2ord(float f) {
@@ -133,15 +133,15 @@ __device__ __forceinline__ void gt_compact(u64 *buf, uint32_t *cnt, float *thr, 
 }
 
 template <int MQ, int ITEMS>
-__global__ void __launch_bounds__(256) rg_gt_kernel(GtParams P) {
+__global__ void __launch_bounds__(512) rg_gt_kernel(GtParams P) {
     constexpr int C = 64 * ITEMS;
-    constexpr int QS = MQ + 4;
-    constexpr int TN = MQ == 128 ? 2 : 1;    // 32-col tiles per wave along the base axis
-    constexpr int WN = 128 / (32 * TN);      // waves along the base axis (2 or 4)
+    constexpr int QS = MQ + 1;               // +1: fragment reads and transposed writes both spread over the banks
+    constexpr int TM = MQ / 64;              // 32-row query tiles per wave (2 for MQ=128, 1 for MQ=64)
+    constexpr int NW = 8;                    // waves per workgroup: 2 (query axis) x 4 (base axis), two per SIMD
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int wn = w % WN, wm = w / WN;
-    const int qoff = 64 * wm, boff = 32 * TN * wn;
+    const int wn = w & 3, wm = w >> 2;
+    const int qoff = 32 * TM * wm, boff = 32 * wn;
     const uint32_t BK = P.BK, dim = P.dim;
 
     float *Qt = reinterpret_cast<float *>(smem);                 // [dim][QS]
@@ -154,7 +154,7 @@ __global__ void __launch_bounds__(256) rg_gt_kernel(GtParams P) {
     const uint32_t ntiles = (P.nb + kNB - 1) / kNB;
     const uint32_t nkc = dim / BK;
     const uint32_t f4_per_row = BK / 4;
-    const uint32_t nld = (kNB * BK / 4) / 256;  // float4 loads per thread per chunk (BK/8)
+    const uint32_t nf4 = kNB * f4_per_row;      // float4 loads per chunk, spread over 512 threads (<= 3 each)
 
     for (;;) {
         if (tid == 0) flag[1] = atomicAdd(P.counter, 1u);
@@ -164,7 +164,7 @@ __global__ void __launch_bounds__(256) rg_gt_kernel(GtParams P) {
         if ((uint64_t)blk * MQ >= P.nq) break;
         const uint32_t q0 = blk * MQ;
         // stage the query block transposed: Qt[k][q]
-        for (uint32_t idx = tid; idx < (uint32_t)MQ * (dim / 4); idx += 256) {
+        for (uint32_t idx = tid; idx < (uint32_t)MQ * (dim / 4); idx += 512) {
             const uint32_t row = idx / (dim / 4), f4 = idx % (dim / 4);
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (q0 + row < P.nq) v = *reinterpret_cast<const float4 *>(P.queries + (size_t)(q0 + row) * P.qstride + 4 * f4);
@@ -173,16 +173,16 @@ __global__ void __launch_bounds__(256) rg_gt_kernel(GtParams P) {
             Qt[(4 * f4 + 2) * QS + row] = v.z;
             Qt[(4 * f4 + 3) * QS + row] = v.w;
         }
-        for (int i = tid; i < MQ; i += 256) { thr[i] = -__builtin_inff(); cnt[i] = 0; }
+        for (int i = tid; i < MQ; i += 512) { thr[i] = -__builtin_inff(); cnt[i] = 0; }
         if (tid == 0) flag[0] = 0;
 
-        float4 pre[5];
+        float4 pre[3];
         auto load_chunk = [&](uint32_t c) {
             const uint32_t tile = c / nkc, k0 = (c % nkc) * BK;
 #pragma unroll
-            for (uint32_t i = 0; i < 5; ++i) {
-                if (i < nld) {
-                    const uint32_t idx = tid + 256 * i;
+            for (uint32_t i = 0; i < 3; ++i) {
+                const uint32_t idx = tid + 512 * i;
+                if (idx < nf4) {
                     const uint32_t row = idx / f4_per_row, f4 = idx % f4_per_row;
                     const uint32_t gr = tile * kNB + row;
                     pre[i] = gr < P.nb ? *reinterpret_cast<const float4 *>(P.base + (size_t)gr * P.bstride + k0 + 4 * f4)
@@ -193,9 +193,9 @@ __global__ void __launch_bounds__(256) rg_gt_kernel(GtParams P) {
         auto store_chunk = [&](uint32_t buf) {
             float *dst = Bt + (size_t)buf * BK * kBS;
 #pragma unroll
-            for (uint32_t i = 0; i < 5; ++i) {
-                if (i < nld) {
-                    const uint32_t idx = tid + 256 * i;
+            for (uint32_t i = 0; i < 3; ++i) {
+                const uint32_t idx = tid + 512 * i;
+                if (idx < nf4) {
                     const uint32_t row = idx / f4_per_row, f4 = idx % f4_per_row;
                     dst[(4 * f4 + 0) * kBS + row] = pre[i].x;
                     dst[(4 * f4 + 1) * kBS + row] = pre[i].y;
@@ -205,17 +205,14 @@ __global__ void __launch_bounds__(256) rg_gt_kernel(GtParams P) {
             }
         };
 
-        f32x16 acc[2][TN];
+        f32x16 acc[TM];
         auto init_acc = [&](uint32_t tile) {
+            const uint32_t id = tile * kNB + boff + (lane & 31);
+            const float b = (P.bias && id < P.nb) ? P.bias[id] : 0.0f;
 #pragma unroll
-            for (int n = 0; n < TN; ++n) {
-                const uint32_t id = tile * kNB + boff + 32 * n + (lane & 31);
-                const float b = (P.bias && id < P.nb) ? P.bias[id] : 0.0f;
+            for (int m = 0; m < TM; ++m)
 #pragma unroll
-                for (int m = 0; m < 2; ++m)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[m][n][r] = b;
-            }
+                for (int r = 0; r < 16; ++r) acc[m][r] = b;
         };
 
         const uint32_t nchunks = ntiles * nkc;
@@ -223,53 +220,70 @@ __global__ void __launch_bounds__(256) rg_gt_kernel(GtParams P) {
         store_chunk(0);
         init_acc(0);
         __syncthreads();
+        const int kh = lane >> 5;
         for (uint32_t c = 0; c < nchunks; ++c) {
             const uint32_t buf = c & 1u;
             if (c + 1 < nchunks) load_chunk(c + 1);
-            // MFMA over this k-chunk
-            const float *bt = Bt + (size_t)buf * BK * kBS + boff + (lane & 31);
-            const float *qt = Qt + (size_t)((c % nkc) * BK) * QS + qoff + (lane & 31);
-            const int kh = lane >> 5;
-#pragma unroll 4
-            for (uint32_t kk = 0; kk < BK / 2; ++kk) {
-                const uint32_t kl = 2 * kk + kh;
-                float a[2], b[TN];
-                a[0] = qt[kl * QS];
-                a[1] = qt[kl * QS + 32];
+            // MFMA over this k-chunk, 4 k-pairs per step, operands of the next step fetched from LDS ahead of the MFMAs
+            const float *bt = Bt + (size_t)buf * BK * kBS + boff + (lane & 31) + kh * kBS;
+            const float *qt = Qt + (size_t)((c % nkc) * BK + kh) * QS + qoff + (lane & 31);
+            float a0[4][TM], b0[4], a1[4][TM], b1[4];
+            auto fetch = [&](uint32_t kk, float (&a)[4][TM], float (&b)[4]) {
 #pragma unroll
-                for (int n = 0; n < TN; ++n) b[n] = bt[kl * kBS + 32 * n];
+                for (int u = 0; u < 4; ++u) {
+                    const uint32_t kl = 2 * (kk + u);
+                    b[u] = bt[kl * kBS];
 #pragma unroll
-                for (int m = 0; m < 2; ++m)
+                    for (int m = 0; m < TM; ++m) a[u][m] = qt[kl * QS + 32 * m];
+                }
+            };
+            auto mfma4 = [&](float (&a)[4][TM], float (&b)[4]) {
 #pragma unroll
-                    for (int n = 0; n < TN; ++n)
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], b[n], acc[m][n], 0, 0, 0);
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int m = 0; m < TM; ++m)
+                        acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][m], b[u], acc[m], 0, 0, 0);
+            };
+            // two operand sets alternate: the LDS reads of one are issued while the MFMAs of the other run
+            const uint32_t nk = BK / 2;
+            fetch(0, a0, b0);
+            for (uint32_t kk = 0; kk < nk; kk += 8) {
+                if (kk + 4 < nk) fetch(kk + 4, a1, b1);
+                mfma4(a0, b0);
+                if (kk + 8 < nk) fetch(kk + 8, a0, b0);
+                if (kk + 4 < nk) mfma4(a1, b1);
             }
             if (c + 1 < nchunks) store_chunk(buf ^ 1u);
             if ((c + 1) % nkc == 0) {
                 // tile finished: threshold filter, survivors -> candidate buffers
                 const uint32_t tile = c / nkc;
+                const uint32_t id = tile * kNB + boff + (lane & 31);
+                // all threshold reads first (independent LDS loads), then the rare survivors one by one
+                uint32_t win = 0;
 #pragma unroll
-                for (int n = 0; n < TN; ++n) {
-                    const uint32_t id = tile * kNB + boff + 32 * n + (lane & 31);
-                    if (id < P.nb) {
+                for (int m = 0; m < TM; ++m)
 #pragma unroll
-                        for (int m = 0; m < 2; ++m)
-#pragma unroll
-                            for (int r = 0; r < 16; ++r) {
-                                const int qi = qoff + 32 * m + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                                const float s = acc[m][n][r];
-                                if (s > thr[qi]) {
-                                    const uint32_t slot = atomicAdd(&cnt[qi], 1u);
-                                    cand[(size_t)qi * C + slot] = make_key(s, id, true);
-                                    if (slot + 1 + kNB > (uint32_t)C) flag[0] = 1;
-                                }
-                            }
+                    for (int r = 0; r < 16; ++r) {
+                        const int qi = qoff + 32 * m + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                        win |= (acc[m][r] > thr[qi] ? 1u : 0u) << (16 * m + r);
                     }
+                if (id >= P.nb) win = 0;
+                if (win) {
+#pragma unroll
+                    for (int m = 0; m < TM; ++m)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r)
+                            if (win & (1u << (16 * m + r))) {
+                                const int qi = qoff + 32 * m + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                                const uint32_t slot = atomicAdd(&cnt[qi], 1u);
+                                cand[(size_t)qi * C + slot] = make_key(acc[m][r], id, true);
+                                if (slot + 1 + kNB > (uint32_t)C) flag[0] = 1;
+                            }
                 }
                 if (tile + 1 < ntiles) init_acc(tile + 1);
                 __syncthreads();
                 if (flag[0]) {
-                    for (int qi = w; qi < MQ; qi += 4)
+                    for (int qi = w; qi < MQ; qi += NW)
                         if (cnt[qi] + kNB > (uint32_t)C) gt_compact<ITEMS>(cand + (size_t)qi * C, &cnt[qi], &thr[qi], P.K, lane);
                     __syncthreads();
                     if (tid == 0) flag[0] = 0;
@@ -278,7 +292,7 @@ __global__ void __launch_bounds__(256) rg_gt_kernel(GtParams P) {
             __syncthreads();
         }
         // final selection + output
-        for (int qi = w; qi < MQ; qi += 4) {
+        for (int qi = w; qi < MQ; qi += NW) {
             gt_compact<ITEMS>(cand + (size_t)qi * C, &cnt[qi], &thr[qi], P.K, lane);
             const uint32_t q = q0 + qi;
             if (q < P.nq) {
@@ -362,14 +376,14 @@ __global__ void __launch_bounds__(64) rg_gt_merge_kernel(const uint32_t *ids_in,
 }
 
 static size_t gt_lds(uint32_t dim, uint32_t mq, uint32_t bk) {
-    return ((size_t)dim * (mq + 4) + 2 * (size_t)bk * kBS + 2 * mq + 8) * 4;
+    return ((size_t)dim * (mq + 1) + 2 * (size_t)bk * kBS + 2 * mq + 8) * 4;
 }
 
 template <int MQ, int ITEMS>
 static rg_status launch_gt(const GtParams &P, uint32_t grid, size_t lds, hipStream_t s) {
     auto kern = rg_gt_kernel<MQ, ITEMS>;
     RG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, s, P);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, s, P);
     RG_HIP(hipGetLastError());
     return RG_OK;
 }
@@ -424,7 +438,7 @@ rg_status rg_gt_shard_dev(const float *d_base, uint32_t nb, uint32_t bstride, co
     const size_t lds = gt_lds(dim, mq, bk);
     const int items = items_for(K + kNB);
     const uint32_t nblocks = (nq + mq - 1) / mq;
-    const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(2, lds_max / lds));
+    const uint32_t per_cu = 1;  // 8 waves (two per SIMD) per workgroup, one workgroup per CU
     const uint32_t grid = std::min<uint32_t>(nblocks, (uint32_t)prop.multiProcessorCount * per_cu);
     float *bias = nullptr;
     u64 *cand = nullptr;

@@ -57,6 +57,10 @@ struct SearchParams {
     uint32_t stage_floats;    // floats per sub-pass staging buffer (ceil(dim/64)*256)
     uint32_t diag;            // diagnostics only (breaks parity): bit0 = skip the visited test
     uint32_t vf_slots_log2;   // VIS=1: log2 of the LDS visited-filter size (16-bit entries)
+    uint32_t *qlog;           // VIS=1, optional: [nq][logcap] ids scored by each query (input of the exact distinct count)
+    uint32_t logcap;
+    uint32_t *qlog_n;         // [nq] number of ids scored (may exceed logcap: overflow)
+    const uint32_t *qlist;    // optional: work item i is query qlist[i] (fallback pass), results other than cmps untouched
     uint32_t id_bits;         // VIS=1: ceil(log2(nd))
 };
 
@@ -179,7 +183,10 @@ __global__ void __launch_bounds__(64) rg_search_kernel(SearchParams P) {
     bm.ent = reinterpret_cast<uint2 *>(cand_d + kWave);                   // L
     bm.cap = P.L;
     // VIS=1: lossy exact-match visited filter (direct mapped, 16-bit remainders of a bijective id hash)
-    uint16_t *vtab = reinterpret_cast<uint16_t *>(bm.ent + P.L);
+    // id-log staging: ids are appended here and flushed to HBM 64 at a time (256-B aligned full-line stores; small
+    // unaligned appends would turn into read-modify-writes at the memory side once the line has left L2)
+    uint32_t *logbuf = reinterpret_cast<uint32_t *>(bm.ent + P.L);        // 128
+    uint16_t *vtab = reinterpret_cast<uint16_t *>(logbuf + 128);
     const uint32_t vf_rem_bits = P.id_bits > P.vf_slots_log2 ? P.id_bits - P.vf_slots_log2 : 0u;
     const uint32_t vf_id_mask = P.id_bits >= 32u ? 0xffffffffu : ((1u << P.id_bits) - 1u);
 
@@ -191,7 +198,11 @@ __global__ void __launch_bounds__(64) rg_search_kernel(SearchParams P) {
         if (lane == 0) qi = atomicAdd(P.counter, 1u);
         qi = readlane_u(qi, 0);
         if (qi >= P.nq) break;
+        const bool cmps_only = P.qlist != nullptr;
+        if (cmps_only) qi = P.qlist[qi];
         const float *query = P.queries + (size_t)qi * P.qstride;
+        uint32_t *qlog = (VIS == 1 && P.qlog) ? P.qlog + (size_t)qi * P.logcap : nullptr;
+        uint32_t logn = 0, lbn = 0;   // ids scored so far / ids waiting in logbuf
         for (uint32_t i = lane; i < P.dim; i += kWave) qv[i] = query[i];
         // new visited epoch (VisitedList::reset, visited_list_pool.h:20-26: ++curV, wipe on wrap)
         uint32_t etag = 0;
@@ -277,7 +288,21 @@ __global__ void __launch_bounds__(64) rg_search_kernel(SearchParams P) {
                 if (fresh) {
                     const uint32_t slot = __popcll(fm & ((1ull << lane) - 1ull));
                     cand_id[slot] = id;
+                    if (VIS == 1 && qlog) logbuf[lbn + slot] = id;
                 }
+                if (VIS == 1 && qlog) {
+                    lbn += n;
+                    if (lbn >= (uint32_t)kWave) {
+                        lds_sync();
+                        const uint32_t pos = logn - (lbn - n);          // ids already flushed (multiple of 64)
+                        const uint32_t v = logbuf[lane], rest = logbuf[kWave + lane];
+                        if (pos + lane < P.logcap) qlog[pos + lane] = v;
+                        lds_sync();
+                        lbn -= kWave;
+                        if ((uint32_t)lane < lbn) logbuf[lane] = rest;
+                    }
+                }
+                logn += n;
                 cmps += n;                                                 // :2397
                 wave_sync();
                 // gather + score (:2387): 4 rows per pass, a ring of R staging buffers keeps up to R passes in flight;
@@ -313,7 +338,8 @@ __global__ void __launch_bounds__(64) rg_search_kernel(SearchParams P) {
         }
 
         // results (:2408-2418)
-        if (bm.size < P.k) {
+        if (cmps_only) {
+        } else if (bm.size < P.k) {
             if (lane == 0) atomicMin(P.status, ((unsigned long long)qi << 32) | bm.size);
         } else {
             for (uint32_t i = lane; i < P.k; i += kWave) {
@@ -322,13 +348,81 @@ __global__ void __launch_bounds__(64) rg_search_kernel(SearchParams P) {
                 P.out_dists[(size_t)qi * P.k + i] = __uint_as_float(e.x);
             }
         }
+        if (VIS == 1 && qlog && lbn) {   // tail of the id log
+            lds_sync();
+            const uint32_t pos = logn - lbn;
+            if ((uint32_t)lane < lbn && pos + lane < P.logcap) qlog[pos + lane] = logbuf[lane];
+        }
         if (lane == 0) {
             if (P.out_cmps) P.out_cmps[qi] = cmps;
-            if (P.out_hops) P.out_hops[qi] = hops;
+            if (P.out_hops && !cmps_only) P.out_hops[qi] = hops;
+            if (VIS == 1 && P.qlog_n) P.qlog_n[qi] = logn;
         }
         wave_sync();
     }
     if (VIS == 0 && lane == 0) P.slot_epoch[blockIdx.x] = epoch;
+}
+
+// K4: exact number of DISTINCT ids a query scored == the reference's cmps (every unvisited neighbour is scored exactly
+// once there, index_bipartite.cpp:2378-2397).  The LDS visited filter of K1 may score a node twice; this pass counts the
+// distinct ids of the query's log with an exact hash set held in LDS (one workgroup per query, table of 2^tbits ids;
+// logs larger than the table are processed in hash partitions).  Queries whose log overflowed are listed for the
+// exact fallback pass.
+__global__ void __launch_bounds__(512) rg_distinct_kernel(const uint32_t *qlog, uint32_t logcap, const uint32_t *qlog_n,
+                                                          uint32_t nq, uint32_t *out_cmps, uint32_t *ovf_list,
+                                                          uint32_t *ovf_count, uint32_t tbits) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    uint32_t *tab = reinterpret_cast<uint32_t *>(smem);
+    __shared__ uint32_t s_cnt, s_fail;
+    const uint32_t T = 1u << tbits, cap = (T / 4u) * 3u;
+    const int tid = threadIdx.x;
+    for (uint32_t q = blockIdx.x; q < nq; q += gridDim.x) {
+        const uint32_t n = qlog_n[q];
+        if (tid == 0) { s_cnt = 0; s_fail = n > logcap ? 1u : 0u; }
+        __syncthreads();
+        if (n <= logcap && n > 0) {
+            const uint32_t *log = qlog + (size_t)q * logcap;
+            const uint32_t parts = (n + cap - 1) / cap;
+            uint32_t mine = 0;
+            for (uint32_t p = 0; p < parts; ++p) {
+                for (uint32_t i = tid; i < T; i += blockDim.x) tab[i] = 0xffffffffu;
+                __syncthreads();
+                // 8 independent loads per thread in flight, then the LDS inserts (a load-insert-load chain is latency bound)
+                for (uint32_t i0 = tid; i0 < n; i0 += blockDim.x * 8u) {
+                    uint32_t v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const uint32_t i = i0 + (uint32_t)u * blockDim.x;
+                        v[u] = i < n ? log[i] : 0xffffffffu;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const uint32_t id = v[u];
+                        if (id == 0xffffffffu) continue;
+                        if (parts > 1 && ((id * 0x85EBCA6Bu) >> 16) % parts != p) continue;
+                        uint32_t slot = (id * 0x9E3779B1u) >> (32u - tbits);
+                        uint32_t probes = 0;
+                        for (;;) {
+                            const uint32_t old = atomicCAS(&tab[slot], 0xffffffffu, id);
+                            if (old == 0xffffffffu) { ++mine; break; }
+                            if (old == id) break;
+                            slot = (slot + 1u) & (T - 1u);
+                            if (++probes >= T) { s_fail = 1; break; }
+                        }
+                    }
+                }
+                __syncthreads();
+            }
+            for (int o = 32; o; o >>= 1) mine += (uint32_t)__shfl_xor((int)mine, o, 64);
+            if ((tid & 63) == 0) atomicAdd(&s_cnt, mine);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            if (s_fail) ovf_list[atomicAdd(ovf_count, 1u)] = q;
+            else out_cmps[q] = s_cnt;
+        }
+        __syncthreads();
+    }
 }
 
 // K1b: out[i] = compare(base[ids[i]], query) for n ids; one wave scores 4*R rows per pass
@@ -429,7 +523,15 @@ struct rg_index {
     int rows_per_pass = 8;  // 4*R
     int force_csr = 0;
     int diag = 0;
-    int visited_mode = 0;   // 0 = exact (HBM epoch words), 1 = LDS exact-match filter (ids/dists/hops exact, cmps = work done)
+    // 0 = exact visited words in HBM; 1 = LDS exact-match filter only (cmps = evaluations performed);
+    // 2 = LDS filter + id log + exact distinct count (K4): everything bit-exact incl. cmps (default)
+    int visited_mode = 2;
+    uint32_t *d_qlog = nullptr, *d_qlog_n = nullptr, *d_ovf = nullptr;
+    size_t qlog_cap_total = 0;
+    uint32_t qlog_nq = 0, logcap = 0;
+    int log_cap_knob = 0;       // 0 = auto; tests force small logs to exercise the exact fallback
+    int count_table_log2 = 15;  // K4 LDS table: 2^15 ids = 128 KiB
+    struct Pending { bool active = false; const float *q = nullptr; uint32_t nq = 0, qstride = 0, k = 0, L = 0; uint32_t *ids = nullptr; float *dists = nullptr; uint32_t *cmps = nullptr, *hops = nullptr; } pending;
     int filter_log2 = 11;   // VIS=1: 2^11 16-bit entries = 4 KiB
     int num_cu = 256;
     size_t lds_per_cu = 160 * 1024;
@@ -499,7 +601,7 @@ static uint32_t filter_log2_of(const rg_index *ix) {  // remainder must fit 15 b
 static size_t search_lds_bytes(const rg_index *ix, uint32_t L, int R) {
     const size_t stage_floats = (size_t)((ix->dim + 63) / 64) * 256;
     size_t b = (size_t)R * stage_floats * 4 + (size_t)ix->dim * 4 + 64 * 4 + 64 * 4 + (size_t)L * 8;
-    if (ix->visited_mode == 1) b += std::max<size_t>(4, (size_t)2 << filter_log2_of(ix));
+    if (ix->visited_mode != 0) b += 128 * 4 + std::max<size_t>(4, (size_t)2 << filter_log2_of(ix));
     return (b + 15) / 16 * 16;
 }
 
@@ -531,7 +633,7 @@ static rg_status launch_search_v(rg_index *ix, const SearchParams &P, uint32_t g
 
 template <bool L2, bool ELL, int R>
 static rg_status launch_search_t(rg_index *ix, const SearchParams &P, uint32_t grid, size_t lds, hipStream_t s) {
-    return ix->visited_mode == 1 ? launch_search_v<L2, ELL, R, 1>(ix, P, grid, lds, s)
+    return P.visited == nullptr ? launch_search_v<L2, ELL, R, 1>(ix, P, grid, lds, s)
                                  : launch_search_v<L2, ELL, R, 0>(ix, P, grid, lds, s);
 }
 
@@ -544,6 +646,67 @@ static rg_status launch_search_r(rg_index *ix, const SearchParams &P, uint32_t g
     }
 }
 
+// one K1 launch.  mode: 0 exact HBM visited words, 1 LDS filter (optionally logging the scored ids).
+static rg_status launch_k1(rg_index *ix, int mode, const float *d_q, uint32_t nq, uint32_t qstride, uint32_t k,
+                           uint32_t L, uint32_t *d_ids, float *d_dists, uint32_t *d_cmps, uint32_t *d_hops,
+                           const uint32_t *qlist, bool with_log, hipStream_t s) {
+    int R = std::max(1, std::min(4, ix->rows_per_pass / 4));
+    if (R == 3) R = 2;
+    const int saved_mode = ix->visited_mode;
+    ix->visited_mode = mode;  // search_lds_bytes() looks at it
+    size_t lds = search_lds_bytes(ix, L, R);
+    while (lds > ix->lds_per_cu && R > 1) { R >>= 1; lds = search_lds_bytes(ix, L, R); }
+    ix->visited_mode = saved_mode;
+    if (lds > ix->lds_per_cu) return set_error(RG_ERR_ARG, "L_pq too large for the 160 KiB LDS of one CU");
+    int wpc = (int)std::min<size_t>(ix->lds_per_cu / lds, 32);
+    if (ix->waves_per_cu > 0) wpc = std::min(wpc, ix->waves_per_cu);
+    else wpc = std::min(wpc, 24);
+    const uint32_t grid = (uint32_t)std::min<uint64_t>(nq, (uint64_t)ix->num_cu * wpc);
+    if (mode == 0) {
+        rg_status st = ensure_scratch(ix, grid);
+        if (st != RG_OK) return st;
+    }
+    RG_HIP(hipMemsetAsync(ix->d_counter, 0, 4, s));
+    SearchParams P;
+    P.base = ix->d_base; P.stride = ix->stride; P.dim = ix->dim; P.nd = ix->nd;
+    P.ell = ix->d_ell; P.ell_stride = ix->ell_stride; P.offsets = ix->d_offsets; P.nbrs = ix->d_nbrs;
+    P.ep = ix->ep; P.queries = d_q; P.nq = nq; P.qstride = qstride; P.k = k; P.L = L;
+    P.out_ids = d_ids; P.out_dists = d_dists; P.out_cmps = d_cmps; P.out_hops = d_hops;
+    P.visited = mode == 0 ? ix->d_visited : nullptr; P.vwords = ix->vwords; P.slot_epoch = ix->d_epoch;
+    P.counter = ix->d_counter; P.status = ix->d_status;
+    P.stage_floats = ((ix->dim + 63) / 64) * 256;
+    P.diag = (uint32_t)ix->diag;
+    P.vf_slots_log2 = filter_log2_of(ix);
+    P.id_bits = id_bits_of(ix->nd);
+    P.qlog = with_log ? ix->d_qlog : nullptr; P.logcap = ix->logcap; P.qlog_n = with_log ? ix->d_qlog_n : nullptr;
+    P.qlist = qlist;
+    const bool l2 = ix->metric == RG_METRIC_L2, ell = ix->d_ell != nullptr;
+    if (l2 && ell) return launch_search_r<true, true>(ix, P, grid, lds, R, s);
+    if (l2) return launch_search_r<true, false>(ix, P, grid, lds, R, s);
+    if (ell) return launch_search_r<false, true>(ix, P, grid, lds, R, s);
+    return launch_search_r<false, false>(ix, P, grid, lds, R, s);
+}
+
+static rg_status ensure_qlog(rg_index *ix, uint32_t nq) {
+    // per-query id log: up to 64K ids (256 KiB) each, within a 6 GiB budget; longer logs take the exact fallback pass
+    uint32_t cap = 1u << 16;
+    const size_t budget = (size_t)6 << 30;
+    while (cap > 4096 && (size_t)nq * cap * 4 > budget) cap >>= 1;
+    if (ix->log_cap_knob > 0) cap = (uint32_t)ix->log_cap_knob;
+    if (ix->d_qlog && ix->qlog_nq >= nq && ix->logcap == cap) return RG_OK;
+    if (ix->d_qlog) (void)hipFree(ix->d_qlog);
+    if (ix->d_qlog_n) (void)hipFree(ix->d_qlog_n);
+    if (ix->d_ovf) (void)hipFree(ix->d_ovf);
+    ix->d_qlog = ix->d_qlog_n = ix->d_ovf = nullptr;
+    ix->qlog_nq = 0;
+    RG_HIP(hipMalloc(&ix->d_qlog, (size_t)nq * cap * 4));
+    RG_HIP(hipMalloc(&ix->d_qlog_n, (size_t)nq * 4));
+    RG_HIP(hipMalloc(&ix->d_ovf, ((size_t)nq + 1) * 4));   // [0] = count, then the list
+    ix->qlog_nq = nq;
+    ix->logcap = cap;
+    return RG_OK;
+}
+
 static rg_status search_dev(rg_index *ix, const float *d_q, uint32_t nq, uint32_t qstride, uint32_t k, uint32_t L,
                             uint32_t *d_ids, float *d_dists, uint32_t *d_cmps, uint32_t *d_hops, hipStream_t s) {
     if (!ix) return set_error(RG_ERR_ARG, "null index");
@@ -552,43 +715,46 @@ static rg_status search_dev(rg_index *ix, const float *d_q, uint32_t nq, uint32_
     if (qstride < ix->dim) return set_error(RG_ERR_ARG, "query stride smaller than the index dimension");
     if (nq == 0) return RG_OK;
     RG_HIP(hipSetDevice(ix->device));
-    int R = std::max(1, std::min(4, ix->rows_per_pass / 4));
-    if (R == 3) R = 2;
-    size_t lds = search_lds_bytes(ix, L, R);
-    while (lds > ix->lds_per_cu && R > 1) { R >>= 1; lds = search_lds_bytes(ix, L, R); }
-    if (lds > ix->lds_per_cu) return set_error(RG_ERR_ARG, "L_pq too large for the 160 KiB LDS of one CU");
-    int wpc = (int)std::min<size_t>(ix->lds_per_cu / lds, 32);
-    if (ix->waves_per_cu > 0) wpc = std::min(wpc, ix->waves_per_cu);
-    else wpc = std::min(wpc, 24);
-    const uint32_t grid = (uint32_t)std::min<uint64_t>(nq, (uint64_t)ix->num_cu * wpc);
-    if (ix->visited_mode == 0) {
-        rg_status st = ensure_scratch(ix, grid);
-        if (st != RG_OK) return st;
-    }
-    RG_HIP(hipMemsetAsync(ix->d_counter, 0, 4, s));
     RG_HIP(hipMemsetAsync(ix->d_status, 0xff, 8, s));
-    SearchParams P;
-    P.base = ix->d_base; P.stride = ix->stride; P.dim = ix->dim; P.nd = ix->nd;
-    P.ell = ix->d_ell; P.ell_stride = ix->ell_stride; P.offsets = ix->d_offsets; P.nbrs = ix->d_nbrs;
-    P.ep = ix->ep; P.queries = d_q; P.nq = nq; P.qstride = qstride; P.k = k; P.L = L;
-    P.out_ids = d_ids; P.out_dists = d_dists; P.out_cmps = d_cmps; P.out_hops = d_hops;
-    P.visited = ix->d_visited; P.vwords = ix->vwords; P.slot_epoch = ix->d_epoch;
-    P.counter = ix->d_counter; P.status = ix->d_status;
-    P.stage_floats = ((ix->dim + 63) / 64) * 256;
-    P.diag = (uint32_t)ix->diag;
-    P.vf_slots_log2 = filter_log2_of(ix);
-    P.id_bits = id_bits_of(ix->nd);
-    const bool l2 = ix->metric == RG_METRIC_L2, ell = ix->d_ell != nullptr;
-    if (l2 && ell) return launch_search_r<true, true>(ix, P, grid, lds, R, s);
-    if (l2) return launch_search_r<true, false>(ix, P, grid, lds, R, s);
-    if (ell) return launch_search_r<false, true>(ix, P, grid, lds, R, s);
-    return launch_search_r<false, false>(ix, P, grid, lds, R, s);
+    ix->pending.active = false;
+    const bool exact_count = ix->visited_mode == 2 && d_cmps != nullptr;
+    if (!exact_count)
+        return launch_k1(ix, ix->visited_mode == 0 ? 0 : 1, d_q, nq, qstride, k, L, d_ids, d_dists, d_cmps, d_hops, nullptr, false, s);
+    // mode 2: LDS-filter search with id log, then the exact distinct count (K4); overflowed logs are re-counted by an
+    // exact pass inside rg_search_wait
+    rg_status st = ensure_qlog(ix, nq);
+    if (st != RG_OK) return st;
+    RG_HIP(hipMemsetAsync(ix->d_ovf, 0, 4, s));
+    st = launch_k1(ix, 1, d_q, nq, qstride, k, L, d_ids, d_dists, d_cmps, d_hops, nullptr, true, s);
+    if (st != RG_OK) return st;
+    const uint32_t tbits = (uint32_t)std::max(6, std::min(15, ix->count_table_log2));  // default 32768 ids = 128 KiB of LDS
+    auto kern = rg_distinct_kernel;
+    RG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 4 << tbits));
+    hipLaunchKernelGGL(kern, dim3(std::min<uint32_t>(nq, (uint32_t)ix->num_cu)), dim3(512), (size_t)4 << tbits, s, ix->d_qlog,
+                       ix->logcap, ix->d_qlog_n, nq, d_cmps, ix->d_ovf + 1, ix->d_ovf, tbits);
+    RG_HIP(hipGetLastError());
+    ix->pending.active = true;
+    ix->pending.q = d_q; ix->pending.nq = nq; ix->pending.qstride = qstride; ix->pending.k = k; ix->pending.L = L;
+    ix->pending.ids = d_ids; ix->pending.dists = d_dists; ix->pending.cmps = d_cmps; ix->pending.hops = d_hops;
+    return RG_OK;
 }
 
 static rg_status search_wait(rg_index *ix, hipStream_t s, uint32_t k) {
     RG_HIP(hipMemcpyAsync(ix->h_status, ix->d_status, 8, hipMemcpyDeviceToHost, s));
+    if (ix->pending.active) RG_HIP(hipMemcpyAsync(ix->h_status + 1, ix->d_ovf, 4, hipMemcpyDeviceToHost, s));
     RG_HIP(hipStreamSynchronize(s));
     const unsigned long long v = *ix->h_status;
+    if (ix->pending.active) {
+        ix->pending.active = false;
+        const uint32_t novf = (uint32_t)(ix->h_status[1] & 0xffffffffu);
+        if (novf > 0 && v == ~0ull) {
+            // logs that did not fit: recount those queries with the exact HBM visited words (only cmps is rewritten)
+            const auto &pd = ix->pending;
+            rg_status st = launch_k1(ix, 0, pd.q, novf, pd.qstride, pd.k, pd.L, pd.ids, pd.dists, pd.cmps, pd.hops, ix->d_ovf + 1, false, s);
+            if (st != RG_OK) return st;
+            RG_HIP(hipStreamSynchronize(s));
+        }
+    }
     if (v != ~0ull) {
         char buf[160];
         if (k) snprintf(buf, sizeof buf, "not enough results: %u, expected: %u (query %u)", (unsigned)(v & 0xffffffffu), k, (unsigned)(v >> 32));
@@ -634,6 +800,9 @@ void rg_index_close(rg_index *ix) {
     if (ix->d_ell) (void)hipFree(ix->d_ell);
     if (ix->d_visited) (void)hipFree(ix->d_visited);
     if (ix->d_epoch) (void)hipFree(ix->d_epoch);
+    if (ix->d_qlog) (void)hipFree(ix->d_qlog);
+    if (ix->d_qlog_n) (void)hipFree(ix->d_qlog_n);
+    if (ix->d_ovf) (void)hipFree(ix->d_ovf);
     if (ix->d_counter) (void)hipFree(ix->d_counter);
     if (ix->d_status) (void)hipFree(ix->d_status);
     if (ix->h_status) (void)hipHostFree(ix->h_status);
@@ -732,8 +901,10 @@ rg_status rg_index_set(rg_index *ix, const char *name, int value) {
     if (!strcmp(name, "waves_per_cu")) ix->waves_per_cu = value;
     else if (!strcmp(name, "rows_per_pass")) ix->rows_per_pass = value;
     else if (!strcmp(name, "diag")) ix->diag = value;
-    else if (!strcmp(name, "visited")) ix->visited_mode = value ? 1 : 0;
+    else if (!strcmp(name, "visited")) ix->visited_mode = value < 0 || value > 2 ? 2 : value;
     else if (!strcmp(name, "filter_log2")) ix->filter_log2 = value;
+    else if (!strcmp(name, "log_cap")) ix->log_cap_knob = value;
+    else if (!strcmp(name, "count_table_log2")) ix->count_table_log2 = value;
     else return set_error(RG_ERR_ARG, "unknown knob");
     return RG_OK;
 }

@@ -67,3 +67,20 @@ def test_search_lds_filter_mode(rg, oracle, metric, d, nb, L, k, flt):
     assert (bits(got[1]) == bits(want[1])).all(), "distance bits differ"
     assert (got[2] >= want[2]).all(), "fewer evaluations than the reference is impossible"
     ix.close()
+
+
+@pytest.mark.parametrize("log_cap,table", [(0, 15), (64, 15), (100000, 7), (700, 8)])
+def test_default_mode_exact_cmps_paths(rg, oracle, log_cap, table):
+    """visited=2 (default): LDS filter + id log + exact distinct count.  Forced corner paths: logs that overflow
+    (exact fallback pass re-counts those queries) and a tiny K4 table (multi-partition counting)."""
+    base, q, off, nbrs, ep = small_set("ip", 4000, 200)
+    ix = rg.IndexBipartite.from_arrays(base, off, nbrs, ep, metric="ip")
+    ix.set("filter_log2", 6)            # forgetful filter -> plenty of re-scored nodes to de-duplicate
+    ix.set("log_cap", log_cap)
+    ix.set("count_table_log2", table)
+    for L, k in ((10, 10), (200, 10)):
+        got = ix.SearchRoarGraph(q, k, L)
+        want = oracle.search(base, "ip", off, nbrs, ep, q, k, L, nthreads=4)
+        assert (got[2] == want[2]).all(), "cmps differ"
+        assert (got[3] == want[3]).all() and (got[0] == want[0]).all() and (bits(got[1]) == bits(want[1])).all()
+    ix.close()
