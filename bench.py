@@ -48,13 +48,15 @@ def parse():
     ap.add_argument("--deg", type=int, default=40)
     ap.add_argument("--metric", default="ip")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall budget of the CPU baseline sample (0 = skip)")
-    ap.add_argument("--visited", type=int, default=1,
-                    help="1 = LDS exact-match visited filter (ids/dists/hops bit-exact, evals = work performed); "
-                         "0 = exact HBM visited words (cmps bit-exact too)")
-    ap.add_argument("--filter-log2", type=int, default=10)
+    ap.add_argument("--visited", type=int, default=2,
+                    help="2 = LDS visited filter + id log + exact distinct count (library default; ids, dists, hops and "
+                         "cmps bit-exact); 1 = LDS filter only (cmps = evaluations performed); 0 = visited words in HBM")
+    ap.add_argument("--filter-log2", type=int, default=9)
     ap.add_argument("--waves-per-cu", type=int, default=0)
     ap.add_argument("--rows-per-pass", type=int, default=0)
     ap.add_argument("--sweep", default="", help="comma list of extra L_pq values to report (not part of the timed metric)")
+    ap.add_argument("--gt-nq", type=int, default=65536, help="queries of the ground-truth (K2) leg; 0 = skip")
+    ap.add_argument("--gt-K", type=int, default=100)
     return ap.parse_args()
 
 
@@ -193,6 +195,8 @@ def main():
     assert torch.equal(ids, ref_ids) and torch.equal(hops, ref_hops), "visited modes disagree on ids/hops"
     assert torch.equal(dists.view(torch.int32), ref_dists.view(torch.int32)), "visited modes disagree on distances"
     assert bool((cmps >= ref_cmps).all())
+    if args.visited != 1:
+        assert torch.equal(cmps, ref_cmps), "cmps differ from the exact visited mode"
     mean_cmps = float(ref_cmps.float().mean().item())      # the reference's avg_visited (distinct nodes scored)
     mean_done = float(cmps.float().mean().item())           # evaluations this mode actually performed
     mean_hops = float(hops.float().mean().item())
@@ -203,15 +207,18 @@ def main():
 
     other = None
     if rank == 0:
-        om = 1 - args.visited
-        index.set("visited", om)
-        step(args.L); torch.cuda.synchronize()
-        oe = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(min(3, args.steps))]
-        for a, b in oe:
-            a.record(); step(args.L); b.record()
-        torch.cuda.synchronize()
-        oms = float(np.mean([a.elapsed_time(b) for a, b in oe]))
-        other = {"visited": om, "qps": args.nq / (oms / 1e3), "kernel_ms_avg": oms, "achieved_GBps": alg_bytes / (oms / 1e3) / 1e9}
+        other = []
+        for om in (0, 1, 2):
+            if om == args.visited:
+                continue
+            index.set("visited", om)
+            step(args.L); torch.cuda.synchronize()
+            oe = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(min(3, args.steps))]
+            for a, b in oe:
+                a.record(); step(args.L); b.record()
+            torch.cuda.synchronize()
+            oms = float(np.mean([a.elapsed_time(b) for a, b in oe]))
+            other.append({"visited": om, "qps": args.nq / (oms / 1e3), "ms_avg": oms, "achieved_GBps": alg_bytes / (oms / 1e3) / 1e9})
         index.set("visited", args.visited)
 
     sweep = []
@@ -225,6 +232,32 @@ def main():
             sweep.append({"L_pq": L, "qps": args.nq / (ms / 1e3), "mean_evals": mc,
                           "gbps": args.nq * mc * 4 * args.dim / (ms / 1e3) / 1e9})
         step(args.L); torch.cuda.synchronize()
+
+    # ---- second BASELINE metric: ground-truth build, distances/s.  Base rows sharded over the ranks (each rank scores
+    # ALL gt queries against its rows), per-shard top-K exchanged with one all-to-all over RCCL, merged by K3.
+    gt = None
+    if args.gt_nq > 0:
+        from roargraph_amd import groundtruth
+        lo, hi = groundtruth.shard_rows(args.nb, world)[rank]
+        g.manual_seed(4242)
+        gq = torch.empty((args.gt_nq, args.dim), dtype=torch.float32, device=dev).normal_(generator=g) * 0.5 + 0.3
+        shard = base[lo:hi]
+        groundtruth.groundtruth_distributed(shard[: min(hi - lo, 65536)], lo, gq[:2048], args.metric, args.gt_K)  # warm-up
+        sync_all()
+        tg0 = time.perf_counter()
+        gi, gv = groundtruth.groundtruth_distributed(shard, lo, gq, args.metric, args.gt_K)
+        sync_all()
+        tg = time.perf_counter() - tg0
+        if world > 1:
+            t = torch.tensor([tg], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            tg = float(t.item())
+        dps = float(args.gt_nq) * float(args.nb) / tg
+        gt = {"metric": "GT-build distances/sec (K=%d, %d queries x %d base rows, base sharded x%d)" % (args.gt_K, args.gt_nq, args.nb, world),
+              "value": dps, "seconds": tg, "TFLOPs_fp32_mfma": 2.0 * args.dim * dps / 1e12,
+              "roofline": {"bound": "mfma", "achieved": 2.0 * args.dim * dps / 1e12, "peak": 157.3 * world, "unit": "TFLOP/s",
+                           "frac": 2.0 * args.dim * dps / 1e12 / (157.3 * world)}}
+        del gi, gv, gq
 
     cpu = None
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
@@ -245,16 +278,19 @@ def main():
                        "parallelism": "query-sharded x%d, index replicated" % world,
                        "recall_at_10": None,
                        "recall_note": "random graph: same HBM access pattern as a real index, recall not meaningful",
-                       "visited": ("lds-filter 2^%d (ids/dists/hops bit-exact vs exact mode, checked in this run)" % args.filter_log2)
-                                  if args.visited else "exact (HBM epoch words; cmps bit-exact too)",
+                       "visited": {2: "lds-filter 2^%d + id log + exact distinct count (ids/dists/hops/cmps bit-exact vs the "
+                                      "HBM-visited mode, checked in this run)" % args.filter_log2,
+                                   1: "lds-filter 2^%d only (ids/dists/hops bit-exact; cmps = evaluations performed)" % args.filter_log2,
+                                   0: "exact visited words in HBM"}[args.visited],
                        "mean_evals_per_query": mean_cmps, "mean_evals_performed": mean_done, "mean_hops": mean_hops},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": None,
-                         "kernel": "rg_search_kernel", "kernel_ms_avg": kavg * 1e3,
+                         "kernel": "rg_search_kernel (+ rg_distinct_kernel in visited mode 2)", "kernel_ms_avg": kavg * 1e3,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "frac_of_measured_stream_ceiling_6290": achieved / 6290.0},
             "cpu_baseline": cpu,
-            "other_visited_mode": other,
+            "other_visited_modes": other,
+            "gt_build": gt,
         }
         if sweep:
             line["L_pq_sweep"] = sweep
