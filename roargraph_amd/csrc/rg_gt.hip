@@ -16,6 +16,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -104,6 +105,7 @@ struct GtParams {
     u64 *cand;          // [grid][MQ][64*ITEMS]
     uint32_t *counter;
     uint32_t BK;
+    uint32_t diag;  // ablation switches for profiling only (wrong results): 1 no base streaming, 2 no epilogue, 4 no per-chunk barrier
 };
 
 // keep the best K of the query's candidate buffer, publish the new threshold
@@ -176,32 +178,35 @@ __global__ void __launch_bounds__(512) rg_gt_kernel(GtParams P) {
         for (int i = tid; i < MQ; i += 512) { thr[i] = -__builtin_inff(); cnt[i] = 0; }
         if (tid == 0) flag[0] = 0;
 
-        float4 pre[3];
-        auto load_chunk = [&](uint32_t c) {
+        // this thread's share of a base chunk (fixed for the whole pass): up to 3 float4 pieces, piece i covers
+        // row pr[i], floats 4*pf[i].. of the chunk
+        float4 preA[3], preB[3];   // two register sets: base chunks are fetched two chunks ahead of their use
+        uint32_t pr[3], pf[3];
+#pragma unroll
+        for (uint32_t i = 0; i < 3; ++i) {
+            // no per-lane conditions around the loads (hipcc would serialise them with vmcnt(0) waits): surplus threads
+            // re-load the last piece, rows past the end of the shard are clamped (their scores are never looked at)
+            const uint32_t idx = min(tid + 512u * i, nf4 - 1u);
+            pr[i] = idx / f4_per_row;
+            pf[i] = idx % f4_per_row;
+        }
+        auto load_chunk = [&](uint32_t c, float4 (&pre)[3]) {
             const uint32_t tile = c / nkc, k0 = (c % nkc) * BK;
 #pragma unroll
             for (uint32_t i = 0; i < 3; ++i) {
-                const uint32_t idx = tid + 512 * i;
-                if (idx < nf4) {
-                    const uint32_t row = idx / f4_per_row, f4 = idx % f4_per_row;
-                    const uint32_t gr = tile * kNB + row;
-                    pre[i] = gr < P.nb ? *reinterpret_cast<const float4 *>(P.base + (size_t)gr * P.bstride + k0 + 4 * f4)
-                                       : make_float4(0.f, 0.f, 0.f, 0.f);
-                }
+                const uint32_t gr = min(tile * kNB + pr[i], P.nb - 1u);
+                pre[i] = *reinterpret_cast<const float4 *>(P.base + (size_t)gr * P.bstride + k0 + 4 * pf[i]);
             }
         };
-        auto store_chunk = [&](uint32_t buf) {
+        auto store_chunk = [&](uint32_t buf, float4 (&pre)[3]) {
             float *dst = Bt + (size_t)buf * BK * kBS;
 #pragma unroll
             for (uint32_t i = 0; i < 3; ++i) {
-                const uint32_t idx = tid + 512 * i;
-                if (idx < nf4) {
-                    const uint32_t row = idx / f4_per_row, f4 = idx % f4_per_row;
-                    dst[(4 * f4 + 0) * kBS + row] = pre[i].x;
-                    dst[(4 * f4 + 1) * kBS + row] = pre[i].y;
-                    dst[(4 * f4 + 2) * kBS + row] = pre[i].z;
-                    dst[(4 * f4 + 3) * kBS + row] = pre[i].w;
-                }
+                float *d0 = dst + (4 * pf[i]) * kBS + pr[i];
+                d0[0] = pre[i].x;
+                d0[kBS] = pre[i].y;
+                d0[2 * kBS] = pre[i].z;
+                d0[3 * kBS] = pre[i].w;
             }
         };
 
@@ -216,14 +221,17 @@ __global__ void __launch_bounds__(512) rg_gt_kernel(GtParams P) {
         };
 
         const uint32_t nchunks = ntiles * nkc;
-        load_chunk(0);
-        store_chunk(0);
+        load_chunk(0, preA);
+        store_chunk(0, preA);
+        if (nchunks > 1) load_chunk(1, preB);
         init_acc(0);
         __syncthreads();
         const int kh = lane >> 5;
-        for (uint32_t c = 0; c < nchunks; ++c) {
+        // chunk c is computed from LDS buffer c&1; `ps` holds chunk c+1 (stored to the other buffer during this chunk),
+        // `pl` receives chunk c+2 (global loads issued now, consumed two chunks later)
+        auto chunk_body = [&](uint32_t c, float4 (&ps)[3], float4 (&pl)[3]) {
             const uint32_t buf = c & 1u;
-            if (c + 1 < nchunks) load_chunk(c + 1);
+            if (c + 2 < nchunks && !(P.diag & 1u)) load_chunk(c + 2, pl);
             // MFMA over this k-chunk, 4 k-pairs per step, operands of the next step fetched from LDS ahead of the MFMAs
             const float *bt = Bt + (size_t)buf * BK * kBS + boff + (lane & 31) + kh * kBS;
             const float *qt = Qt + (size_t)((c % nkc) * BK + kh) * QS + qoff + (lane & 31);
@@ -247,14 +255,18 @@ __global__ void __launch_bounds__(512) rg_gt_kernel(GtParams P) {
             // two operand sets alternate: the LDS reads of one are issued while the MFMAs of the other run
             const uint32_t nk = BK / 2;
             fetch(0, a0, b0);
+            const bool more = c + 1 < nchunks;
             for (uint32_t kk = 0; kk < nk; kk += 8) {
                 if (kk + 4 < nk) fetch(kk + 4, a1, b1);
                 mfma4(a0, b0);
                 if (kk + 8 < nk) fetch(kk + 8, a0, b0);
                 if (kk + 4 < nk) mfma4(a1, b1);
+                // the next chunk's rows (prefetched into registers at the top) go to the other LDS buffer while the
+                // rest of this chunk's MFMAs are still queued, so the transposed writes are off the critical path
+                if (kk == 0 && more && nk > 8 && !(P.diag & 1u)) store_chunk(buf ^ 1u, ps);
             }
-            if (c + 1 < nchunks) store_chunk(buf ^ 1u);
-            if ((c + 1) % nkc == 0) {
+            if (more && nk <= 8 && !(P.diag & 1u)) store_chunk(buf ^ 1u, ps);
+            if ((c + 1) % nkc == 0 && !(P.diag & 2u)) {
                 // tile finished: threshold filter, survivors -> candidate buffers
                 const uint32_t tile = c / nkc;
                 const uint32_t id = tile * kNB + boff + (lane & 31);
@@ -289,7 +301,11 @@ __global__ void __launch_bounds__(512) rg_gt_kernel(GtParams P) {
                     if (tid == 0) flag[0] = 0;
                 }
             }
-            __syncthreads();
+            if (!(P.diag & 4u)) __syncthreads();
+        };
+        for (uint32_t c = 0; c < nchunks; c += 2) {
+            chunk_body(c, preB, preA);
+            if (c + 1 < nchunks) chunk_body(c + 1, preA, preB);
         }
         // final selection + output
         for (int qi = w; qi < MQ; qi += NW) {
@@ -455,6 +471,7 @@ rg_status rg_gt_shard_dev(const float *d_base, uint32_t nb, uint32_t bstride, co
     P.base = d_base; P.nb = nb; P.bstride = bstride; P.queries = d_queries; P.nq = nq; P.qstride = qstride; P.dim = dim;
     P.bias = bias; P.K = K; P.id_base = id_base; P.out_ids = d_ids; P.out_vals = vals; P.cand = cand;
     P.counter = counter; P.BK = bk;
+    P.diag = getenv("RG_GT_DIAG") ? (uint32_t)atoi(getenv("RG_GT_DIAG")) : 0u;
     rg_status st = mq == 128 ? launch_gt_items<128>(items, P, grid, lds, s) : launch_gt_items<64>(items, P, grid, lds, s);
     if (st == RG_OK && metric == RG_METRIC_L2) {
         const uint32_t g2 = std::min<uint32_t>(nq, (uint32_t)prop.multiProcessorCount * 16u);
