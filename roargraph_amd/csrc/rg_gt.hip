@@ -134,29 +134,39 @@ __device__ __forceinline__ void gt_compact(u64 *buf, uint32_t *cnt, float *thr, 
     }
 }
 
+typedef __attribute__((address_space(3))) void lds_ptr_t;
+typedef const __attribute__((address_space(1))) void glb_ptr_t;
+
+// LDS layout of both operands: k-quads, [k/4][row][4 floats] -- one 16-byte slot per (k-quad, row).
+//  * the base chunk arrives by LDS-DMA (global_load_lds_dwordx4): a wave instruction fills 64 consecutive slots
+//    (64 rows of one k-quad), no VGPR staging and no transposing ds_write pass;
+//  * an MFMA operand fetch is one conflict-free ds_read_b128 per lane (rows are consecutive slots) that serves TWO
+//    v_mfma_f32_32x32x2_f32: lanes 0-31 use elements 0 and 2, lanes 32-63 elements 1 and 3 (operand lane l holds
+//    k = l >> 5 of the pair).
 template <int MQ, int ITEMS>
 __global__ void __launch_bounds__(512) rg_gt_kernel(GtParams P) {
     constexpr int C = 64 * ITEMS;
-    constexpr int QS = MQ + 1;               // +1: fragment reads and transposed writes both spread over the banks
     constexpr int TM = MQ / 64;              // 32-row query tiles per wave (2 for MQ=128, 1 for MQ=64)
     constexpr int NW = 8;                    // waves per workgroup: 2 (query axis) x 4 (base axis), two per SIMD
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = w & 3, wm = w >> 2;
     const int qoff = 32 * TM * wm, boff = 32 * wn;
     const uint32_t BK = P.BK, dim = P.dim;
+    const uint32_t kq_chunk = BK / 4;                               // k-quads per chunk
 
-    float *Qt = reinterpret_cast<float *>(smem);                 // [dim][QS]
-    float *Bt = Qt + (size_t)dim * QS;                           // [2][BK][kBS]
-    float *thr = Bt + 2 * (size_t)BK * kBS;                      // [MQ]
-    uint32_t *cnt = reinterpret_cast<uint32_t *>(thr + MQ);      // [MQ]
-    uint32_t *flag = cnt + MQ;                                   // [4]
+    float4 *Qq = reinterpret_cast<float4 *>(smem);                  // [dim/4][MQ]
+    float4 *Bq = Qq + (size_t)(dim / 4) * MQ;                       // [2][BK/4][128]
+    float *thr = reinterpret_cast<float *>(Bq + 2 * (size_t)kq_chunk * kNB);   // [MQ]
+    uint32_t *cnt = reinterpret_cast<uint32_t *>(thr + MQ);         // [MQ]
+    uint32_t *flag = cnt + MQ;                                      // [4]
     u64 *cand = P.cand + (size_t)blockIdx.x * MQ * C;
 
     const uint32_t ntiles = (P.nb + kNB - 1) / kNB;
     const uint32_t nkc = dim / BK;
-    const uint32_t f4_per_row = BK / 4;
-    const uint32_t nf4 = kNB * f4_per_row;      // float4 loads per chunk, spread over 512 threads (<= 3 each)
+    const uint32_t ninstr = kq_chunk * (kNB / 64);                  // LDS-DMA wave instructions per chunk (2 per k-quad)
+    const bool hi = lane >= 32;
 
     for (;;) {
         if (tid == 0) flag[1] = atomicAdd(P.counter, 1u);
@@ -165,48 +175,30 @@ __global__ void __launch_bounds__(512) rg_gt_kernel(GtParams P) {
         __syncthreads();
         if ((uint64_t)blk * MQ >= P.nq) break;
         const uint32_t q0 = blk * MQ;
-        // stage the query block transposed: Qt[k][q]
+        // stage the query block: Qq[k/4][q] (16-byte stores, consecutive rows -> consecutive slots)
         for (uint32_t idx = tid; idx < (uint32_t)MQ * (dim / 4); idx += 512) {
-            const uint32_t row = idx / (dim / 4), f4 = idx % (dim / 4);
+            const uint32_t row = idx % MQ, f4 = idx / MQ;
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (q0 + row < P.nq) v = *reinterpret_cast<const float4 *>(P.queries + (size_t)(q0 + row) * P.qstride + 4 * f4);
-            Qt[(4 * f4 + 0) * QS + row] = v.x;
-            Qt[(4 * f4 + 1) * QS + row] = v.y;
-            Qt[(4 * f4 + 2) * QS + row] = v.z;
-            Qt[(4 * f4 + 3) * QS + row] = v.w;
+            Qq[(size_t)f4 * MQ + row] = v;
         }
         for (int i = tid; i < MQ; i += 512) { thr[i] = -__builtin_inff(); cnt[i] = 0; }
         if (tid == 0) flag[0] = 0;
 
-        // this thread's share of a base chunk (fixed for the whole pass): up to 3 float4 pieces, piece i covers
-        // row pr[i], floats 4*pf[i].. of the chunk
-        float4 preA[3], preB[3];   // two register sets: base chunks are fetched two chunks ahead of their use
-        uint32_t pr[3], pf[3];
-#pragma unroll
-        for (uint32_t i = 0; i < 3; ++i) {
-            // no per-lane conditions around the loads (hipcc would serialise them with vmcnt(0) waits): surplus threads
-            // re-load the last piece, rows past the end of the shard are clamped (their scores are never looked at)
-            const uint32_t idx = min(tid + 512u * i, nf4 - 1u);
-            pr[i] = idx / f4_per_row;
-            pf[i] = idx % f4_per_row;
-        }
-        auto load_chunk = [&](uint32_t c, float4 (&pre)[3]) {
+        // LDS-DMA of base chunk c into buffer `buf`: instruction j covers k-quad j/2, rows 64*(j&1) .. +63
+        auto stream_chunk = [&](uint32_t c, uint32_t buf) {
             const uint32_t tile = c / nkc, k0 = (c % nkc) * BK;
-#pragma unroll
-            for (uint32_t i = 0; i < 3; ++i) {
-                const uint32_t gr = min(tile * kNB + pr[i], P.nb - 1u);
-                pre[i] = *reinterpret_cast<const float4 *>(P.base + (size_t)gr * P.bstride + k0 + 4 * pf[i]);
-            }
-        };
-        auto store_chunk = [&](uint32_t buf, float4 (&pre)[3]) {
-            float *dst = Bt + (size_t)buf * BK * kBS;
-#pragma unroll
-            for (uint32_t i = 0; i < 3; ++i) {
-                float *d0 = dst + (4 * pf[i]) * kBS + pr[i];
-                d0[0] = pre[i].x;
-                d0[kBS] = pre[i].y;
-                d0[2 * kBS] = pre[i].z;
-                d0[3 * kBS] = pre[i].w;
+            float4 *dst = Bq + (size_t)buf * kq_chunk * kNB;
+            for (uint32_t j = (uint32_t)w; j < ninstr; j += NW) {
+                const uint32_t kq = j >> 1, row = 64u * (j & 1u) + (uint32_t)lane;
+                const uint32_t gr = min(tile * kNB + row, P.nb - 1u);   // clamp: scores of rows past the end are ignored
+                const float *src = P.base + (size_t)gr * P.bstride + k0 + 4 * kq;
+                // issued through inline asm on purpose: hipcc treats the builtin as an LDS write it cannot disambiguate
+                // and parks an s_waitcnt vmcnt(0) in front of the very next ds_read (of the OTHER buffer), which would
+                // serialise the stream with the MFMAs.  The DMA is waited for explicitly before the chunk's barrier.
+                const uint32_t lds_addr = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(lds_ptr_t *)(dst + (size_t)j * 64));
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
+                             :: "s"(lds_addr), "v"(src) : "memory");
             }
         };
 
@@ -221,51 +213,42 @@ __global__ void __launch_bounds__(512) rg_gt_kernel(GtParams P) {
         };
 
         const uint32_t nchunks = ntiles * nkc;
-        load_chunk(0, preA);
-        store_chunk(0, preA);
-        if (nchunks > 1) load_chunk(1, preB);
+        stream_chunk(0, 0);
         init_acc(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        const int kh = lane >> 5;
-        // chunk c is computed from LDS buffer c&1; `ps` holds chunk c+1 (stored to the other buffer during this chunk),
-        // `pl` receives chunk c+2 (global loads issued now, consumed two chunks later)
-        auto chunk_body = [&](uint32_t c, float4 (&ps)[3], float4 (&pl)[3]) {
+        for (uint32_t c = 0; c < nchunks; ++c) {
             const uint32_t buf = c & 1u;
-            if (c + 2 < nchunks && !(P.diag & 1u)) load_chunk(c + 2, pl);
-            // MFMA over this k-chunk, 4 k-pairs per step, operands of the next step fetched from LDS ahead of the MFMAs
-            const float *bt = Bt + (size_t)buf * BK * kBS + boff + (lane & 31) + kh * kBS;
-            const float *qt = Qt + (size_t)((c % nkc) * BK + kh) * QS + qoff + (lane & 31);
-            float a0[4][TM], b0[4], a1[4][TM], b1[4];
-            auto fetch = [&](uint32_t kk, float (&a)[4][TM], float (&b)[4]) {
+            if (c + 1 < nchunks && !(P.diag & 1u)) stream_chunk(c + 1, buf ^ 1u);
+            const float4 *bq = Bq + (size_t)buf * kq_chunk * kNB + boff + (lane & 31);
+            const float4 *qq = Qq + (size_t)((c % nkc) * kq_chunk) * MQ + qoff + (lane & 31);
+            // two k-quads per step: operands of step s+1 are read from LDS while the 4*TM MFMAs of step s issue
+            float4 a0[TM], b0, a1[TM], b1;
+            auto fetch = [&](uint32_t kq, float4 (&a)[TM], float4 &b) {
+                b = bq[(size_t)kq * kNB];
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    const uint32_t kl = 2 * (kk + u);
-                    b[u] = bt[kl * kBS];
+                for (int m = 0; m < TM; ++m) a[m] = qq[(size_t)kq * MQ + 32 * m];
+            };
+            auto mfma_quad = [&](const float4 (&a)[TM], const float4 &b) {
+                const float bl = hi ? b.y : b.x, bh = hi ? b.w : b.z;
 #pragma unroll
-                    for (int m = 0; m < TM; ++m) a[u][m] = qt[kl * QS + 32 * m];
+                for (int m = 0; m < TM; ++m) {
+                    const float al = hi ? a[m].y : a[m].x;
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(al, bl, acc[m], 0, 0, 0);
+                }
+#pragma unroll
+                for (int m = 0; m < TM; ++m) {
+                    const float ah = hi ? a[m].w : a[m].z;
+                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(ah, bh, acc[m], 0, 0, 0);
                 }
             };
-            auto mfma4 = [&](float (&a)[4][TM], float (&b)[4]) {
-#pragma unroll
-                for (int u = 0; u < 4; ++u)
-#pragma unroll
-                    for (int m = 0; m < TM; ++m)
-                        acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][m], b[u], acc[m], 0, 0, 0);
-            };
-            // two operand sets alternate: the LDS reads of one are issued while the MFMAs of the other run
-            const uint32_t nk = BK / 2;
             fetch(0, a0, b0);
-            const bool more = c + 1 < nchunks;
-            for (uint32_t kk = 0; kk < nk; kk += 8) {
-                if (kk + 4 < nk) fetch(kk + 4, a1, b1);
-                mfma4(a0, b0);
-                if (kk + 8 < nk) fetch(kk + 8, a0, b0);
-                if (kk + 4 < nk) mfma4(a1, b1);
-                // the next chunk's rows (prefetched into registers at the top) go to the other LDS buffer while the
-                // rest of this chunk's MFMAs are still queued, so the transposed writes are off the critical path
-                if (kk == 0 && more && nk > 8 && !(P.diag & 1u)) store_chunk(buf ^ 1u, ps);
+            for (uint32_t kq = 0; kq < kq_chunk; kq += 2) {
+                if (kq + 1 < kq_chunk) fetch(kq + 1, a1, b1);
+                mfma_quad(a0, b0);
+                if (kq + 2 < kq_chunk) fetch(kq + 2, a0, b0);
+                if (kq + 1 < kq_chunk) mfma_quad(a1, b1);
             }
-            if (more && nk <= 8 && !(P.diag & 1u)) store_chunk(buf ^ 1u, ps);
             if ((c + 1) % nkc == 0 && !(P.diag & 2u)) {
                 // tile finished: threshold filter, survivors -> candidate buffers
                 const uint32_t tile = c / nkc;
@@ -301,11 +284,8 @@ __global__ void __launch_bounds__(512) rg_gt_kernel(GtParams P) {
                     if (tid == 0) flag[0] = 0;
                 }
             }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next chunk's DMA has landed
             if (!(P.diag & 4u)) __syncthreads();
-        };
-        for (uint32_t c = 0; c < nchunks; c += 2) {
-            chunk_body(c, preB, preA);
-            if (c + 1 < nchunks) chunk_body(c + 1, preA, preB);
         }
         // final selection + output
         for (int qi = w; qi < MQ; qi += NW) {
@@ -392,7 +372,7 @@ __global__ void __launch_bounds__(64) rg_gt_merge_kernel(const uint32_t *ids_in,
 }
 
 static size_t gt_lds(uint32_t dim, uint32_t mq, uint32_t bk) {
-    return ((size_t)dim * (mq + 1) + 2 * (size_t)bk * kBS + 2 * mq + 8) * 4;
+    return ((size_t)dim * mq + 2 * (size_t)bk * kNB + 2 * mq + 8) * 4;
 }
 
 template <int MQ, int ITEMS>
