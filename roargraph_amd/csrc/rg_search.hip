@@ -688,8 +688,8 @@ static rg_status launch_k1(rg_index *ix, int mode, const float *d_q, uint32_t nq
 }
 
 static rg_status ensure_qlog(rg_index *ix, uint32_t nq) {
-    // per-query id log: up to 64K ids (256 KiB) each, within a 6 GiB budget; longer logs take the exact fallback pass
-    uint32_t cap = 1u << 16;
+    // per-query id log: up to 128K ids (512 KiB) each, within a 6 GiB budget; longer logs take the exact fallback pass
+    uint32_t cap = 1u << 17;
     const size_t budget = (size_t)6 << 30;
     while (cap > 4096 && (size_t)nq * cap * 4 > budget) cap >>= 1;
     if (ix->log_cap_knob > 0) cap = (uint32_t)ix->log_cap_knob;
