@@ -39,6 +39,28 @@ __device__ __forceinline__ uint32_t readlane_u(uint32_t v, int lane) {
     return (uint32_t)__builtin_amdgcn_readlane((int)v, lane);
 }
 
+// cross-lane moves inside a 16-lane row as DPP modifiers (a VALU move, no LDS-crossbar round trip like ds_bpermute):
+//   row_ror:8 == lane ^ 8, row_ror:4 == lane +- 4 (== ^4 for data of period 8), quad_perm [1,0,3,2] == ^1, [2,3,0,1] == ^2
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+
+template <int CTRL>
+__device__ __forceinline__ uint32_t dpp_u(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xf, 0xf, true);
+}
+// wave-wide minimum (uniform result): 4 DPP steps inside each 16-lane row, then the 4 row results through SGPRs
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v) {
+    v = min(v, dpp_u<0xB1>(v));
+    v = min(v, dpp_u<0x4E>(v));
+    v = min(v, dpp_u<0x124>(v));
+    v = min(v, dpp_u<0x128>(v));
+    const uint32_t a = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), b = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
+    const uint32_t c = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), d = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+    return min(min(a, b), min(c, d));
+}
+
 // total order of the reference's Neighbor (include/efanna2e/neighbor.h:29-31)
 __device__ __forceinline__ bool nb_less(float da, uint32_t ia, float db, uint32_t ib) {
     return da < db || (da == db && ia < ib);
@@ -123,16 +145,16 @@ __device__ __forceinline__ float gather_score(const float *stage, const float *q
     if (nt > 1) RG_STEP(s, o1, qb + 16 + a);
     if (nt > 2) RG_STEP(s, o2, qb + 32 + a);
     // 16 -> 8 (distance.h:191-192): lanes a and a^8 now hold the same s8[a&7]
-    acc = acc + __shfl_xor(acc, 8, 64);
+    acc = acc + dpp_f<0x128>(acc);
     if (rem & 8u) {  // 8-wide tail (distance.h:194-201), element 16*nt + (a&7), applied to the folded sum
         const int x = 16 * nt + (a & 7);
         const int off = 64 * g + ((x + 16 * g) & 63);
         RG_STEP(s, off, qb + x);
     }
 #undef RG_STEP
-    acc = acc + __shfl_xor(acc, 4, 64);                  // 8 -> 4 (distance.h:203-204)
-    acc = acc + __shfl_xor(acc, 1, 64);                  // first hadd  (distance.h:221)
-    acc = acc + __shfl_xor(acc, 2, 64);                  // second hadd (distance.h:222)
+    acc = acc + dpp_f<0x124>(acc);                       // 8 -> 4 (distance.h:203-204)
+    acc = acc + dpp_f<0xB1>(acc);                        // first hadd  (distance.h:221)
+    acc = acc + dpp_f<0x4E>(acc);                        // second hadd (distance.h:222)
     return L2 ? acc : -acc;                              // IP returns -dot (distance.h:223)
 }
 

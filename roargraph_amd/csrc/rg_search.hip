@@ -137,30 +137,39 @@ __device__ __forceinline__ void beam_merge(Beam &bm, float cd, uint32_t cid, uin
     const uint32_t fpos = lo + crank;
     const bool keep = valid && fpos < bm.cap;
     // first beam index that moves
-    uint32_t minq = qrank;
-    for (int o = 32; o; o >>= 1) minq = min(minq, (uint32_t)__shfl_xor((int)minq, o, 64));
+    const uint32_t minq = wave_min_u32(qrank);
     // new cursor: first unflagged entry after the merge
     uint32_t ncur = 0xffffffffu;
     if (bm.cur < bm.size) {
         const uint32_t sh = __popcll(__ballot(valid && qrank <= bm.cur));
         if (bm.cur + sh < bm.cap) ncur = bm.cur + sh;
     }
-    uint32_t mp = keep ? fpos : 0xffffffffu;
-    for (int o = 32; o; o >>= 1) mp = min(mp, (uint32_t)__shfl_xor((int)mp, o, 64));
-    ncur = min(ncur, mp);
-    // shift entries [minq, size) right by the number of candidates ranked at or before them, top chunk first
-    for (int top = (int)bm.size - 1; top >= (int)minq; top -= kWave) {
-        const int i = top - lane;
-        const bool mv = i >= (int)minq;
-        uint2 e = make_uint2(0, 0);
-        if (mv) e = bm.ent[i];
-        uint32_t sh = 0;
+    ncur = min(ncur, wave_min_u32(keep ? fpos : 0xffffffffu));
+    // shift entries [minq, size) right by the number of candidates ranked at or before them.  Done in place, top group
+    // first; a group is up to 8 chunks of 64 entries held in registers, so its reads all complete before its writes
+    // (which only land on indices >= the ones read, i.e. inside the group or in groups already moved).
+    constexpr int G = 8;
+    for (int top = (int)bm.size - 1; top >= (int)minq; top -= kWave * G) {
+        uint2 e[G];
+        uint32_t sh[G];
+#pragma unroll
+        for (int g2 = 0; g2 < G; ++g2) {
+            const int i = top - kWave * g2 - lane;
+            e[g2] = i >= (int)minq ? bm.ent[i] : make_uint2(0, 0);
+            sh[g2] = 0;
+        }
         for (unsigned long long m = vmask; m; m &= m - 1) {
             const int s = __ffsll((long long)m) - 1;
-            sh += readlane_u(qrank, s) <= (uint32_t)i ? 1u : 0u;
+            const int q = (int)readlane_u(qrank, s);
+#pragma unroll
+            for (int g2 = 0; g2 < G; ++g2) sh[g2] += q <= top - kWave * g2 - lane ? 1u : 0u;
         }
         wave_sync();
-        if (mv && (uint32_t)i + sh < bm.cap) bm.ent[(uint32_t)i + sh] = e;
+#pragma unroll
+        for (int g2 = 0; g2 < G; ++g2) {
+            const int i = top - kWave * g2 - lane;
+            if (i >= (int)minq && (uint32_t)i + sh[g2] < bm.cap) bm.ent[(uint32_t)i + sh[g2]] = e[g2];
+        }
         wave_sync();
     }
     if (keep) bm.ent[fpos] = make_uint2(__float_as_uint(cd), cid);
@@ -520,7 +529,7 @@ struct rg_index {
     unsigned long long *h_status = nullptr;  // pinned
     // knobs
     int waves_per_cu = 0;   // 0 = auto
-    int rows_per_pass = 8;  // 4*R
+    int rows_per_pass = 4;  // 4*R (R = staging ring depth)
     int force_csr = 0;
     int diag = 0;
     // 0 = exact visited words in HBM; 1 = LDS exact-match filter only (cmps = evaluations performed);
