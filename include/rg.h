@@ -148,6 +148,16 @@ rg_status rg_groundtruth_mem(const float *base, uint32_t nb, uint32_t bstride, c
 rg_status rg_groundtruth(const char *base_fbin, const char *query_fbin, const char *gt_out, int metric, uint32_t K,
                          const int *devices, int ndev);
 
+/* --------------------------------------------------------- graph construction
+ * Replaces: IndexBipartite::BuildRoarGraph(n_sq, nullptr, n_bp, base, params{M_sq, M_pjbp, L_pjpq, num_threads})
+ * after LoadLearnBaseKNN (tests/test_build_roargraph.cpp:117-136; src/index_bipartite.cpp:143-233, 1043-1277).
+ * CPU code, as in the reference.  knn_ids = the train-query ground truth ids (nq x knn_k,
+ * best first); the result is the projection graph in CSR form (release with rg_free) and its entry point.
+ * One thread gives the reference's deterministic T=1 construction; more threads are scheduling dependent, as there. */
+rg_status rg_build_roargraph(const float *base, uint32_t nb, uint32_t dim, uint32_t stride, const uint32_t *knn_ids,
+                             uint32_t nq, uint32_t knn_k, int metric, uint32_t M_sq, uint32_t M_pjbp, uint32_t L_pjpq,
+                             uint32_t num_threads, uint32_t *out_ep, uint64_t **out_offsets, uint32_t **out_nbrs);
+
 #ifdef __cplusplus
 }
 #endif

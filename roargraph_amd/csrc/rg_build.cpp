@@ -1,0 +1,455 @@
+// rg_build.cpp -- CPU restatement of RoarGraph's graph construction (a "next" row; the
+// reference keeps construction on the CPU and so does this).  It consumes the ground truth produced by K2 and emits
+// the .index the search path loads, which closes the pipeline  GT (GPU) -> build (CPU) -> search (GPU).
+//
+// Follows IndexBipartite::BuildRoarGraph (src/index_bipartite.cpp:143-233):
+//   CalculateProjectionep                       :2004-2041   entry point = base row nearest to the centroid
+//   LinkProjection                              :1043-1277   phases 1-5 below
+//   PruneBiSearchBaseGetBase                    :1612-1694
+//   ProjectionAddReverse / PruneProjectionReverseCandidates             :1391-1432 / :1526-1610
+//   SearchProjectionGraphInternal               :1279-1350
+//   PruneProjectionBaseSearchCandidates         :1846-1940
+//   SupplyAddReverse / PruneProjectionInternalReverseCandidates         :1352-1389 / :1434-1524
+//
+// PARITY STATUS: unpinned.  The reference translation unit cannot be compiled in this image (Boost / tsl headers are
+// absent), so there is no reference-built .index to compare with; the code below is a line-by-line behavioural
+// restatement, including the reference's quirks that shape the output (e.g. the zero-initialised phantom entries of
+// PruneProjectionInternalReverseCandidates, :1438), and is validated by properties (degree bounds, determinism at one
+// thread, recall of the search over the built index).  Out-of-range accesses the reference would perform on empty
+// candidate pools are guarded instead of replicated.
+//
+// Threads: one thread reproduces the reference's T=1 result deterministically; with more threads the same per-node
+// mutex scheme is used and, exactly like the reference, the result depends on scheduling.
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <functional>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+#if defined(__x86_64__)
+#include <immintrin.h>
+#endif
+
+#include "rg.h"
+#include "rg_internal.h"
+
+namespace rg {
+namespace {
+
+// ---- distance on the host, same value as the reference's AVX-512 kernels (distance.h:39-87, 180-223) ----------------
+// lane j of a 16-wide accumulator takes elements j, j+16, ... with one FMA each; folds 16->8 (+8-wide tail) ->4 -> 2 hadds.
+__attribute__((target("fma"))) float fold16(const float (&acc)[16], const float *a, const float *b, unsigned rem, bool l2) {
+    float s8[8], s4[4];
+    for (int j = 0; j < 8; ++j) s8[j] = acc[j + 8] + acc[j];
+    if (rem >= 8) {
+        for (int j = 0; j < 8; ++j) {
+            if (l2) { const float t = a[j] - b[j]; s8[j] = __builtin_fmaf(t, t, s8[j]); }
+            else s8[j] = __builtin_fmaf(a[j], b[j], s8[j]);
+        }
+    }
+    for (int j = 0; j < 4; ++j) s4[j] = s8[j + 4] + s8[j];
+    return (s4[0] + s4[1]) + (s4[2] + s4[3]);
+}
+__attribute__((target("fma"))) float dist_scalar(const float *a, const float *b, unsigned d, bool l2) {
+    float acc[16] = {0};
+    unsigned i = 0;
+    for (; d - i >= 16; i += 16)
+        for (int j = 0; j < 16; ++j) {
+            if (l2) { const float t = a[i + j] - b[i + j]; acc[j] = __builtin_fmaf(t, t, acc[j]); }
+            else acc[j] = __builtin_fmaf(a[i + j], b[i + j], acc[j]);
+        }
+    const float r = fold16(acc, a + i, b + i, d - i, l2);
+    return l2 ? r : -r;
+}
+#if defined(__x86_64__)
+__attribute__((target("avx512f,fma"))) float dist_avx512(const float *a, const float *b, unsigned d, bool l2) {
+    __m512 acc = _mm512_setzero_ps();
+    unsigned i = 0;
+    if (l2) {
+        for (; d - i >= 16; i += 16) {
+            const __m512 t = _mm512_sub_ps(_mm512_loadu_ps(a + i), _mm512_loadu_ps(b + i));
+            acc = _mm512_fmadd_ps(t, t, acc);
+        }
+    } else {
+        for (; d - i >= 16; i += 16) acc = _mm512_fmadd_ps(_mm512_loadu_ps(a + i), _mm512_loadu_ps(b + i), acc);
+    }
+    float lanes[16];
+    _mm512_storeu_ps(lanes, acc);
+    const float r = fold16(lanes, a + i, b + i, d - i, l2);
+    return l2 ? r : -r;
+}
+#endif
+
+struct Nb {
+    uint32_t id;
+    float dist;
+    bool operator<(const Nb &o) const { return dist < o.dist || (dist == o.dist && id < o.id); }  // neighbor.h:29-31
+};
+
+// bounded sorted queue with the reference's insert / closest_unexpanded rules (neighbor.h:150-192)
+struct Beam {
+    struct E { uint32_t id; float dist; bool done; };
+    std::vector<E> e;
+    size_t size = 0, cap = 0, cur = 0;
+    void reset(size_t c) { cap = c; e.resize(c + 1); size = 0; cur = 0; }
+    static bool less(uint32_t ia, float da, uint32_t ib, float db) { return da < db || (da == db && ia < ib); }
+    void insert(uint32_t id, float d) {
+        if (size == cap && less(e[size - 1].id, e[size - 1].dist, id, d)) return;
+        size_t lo = 0, hi = size;
+        while (lo < hi) {
+            const size_t mid = (lo + hi) >> 1;
+            if (less(id, d, e[mid].id, e[mid].dist)) hi = mid;
+            else if (e[mid].id == id) return;
+            else lo = mid + 1;
+        }
+        if (lo < cap) std::memmove(&e[lo + 1], &e[lo], (size - lo) * sizeof(E));
+        e[lo] = {id, d, false};
+        if (size < cap) ++size;
+        if (lo < cur) cur = lo;
+    }
+    bool has_open() const { return cur < size; }
+    E pop() {
+        e[cur].done = true;
+        const size_t pre = cur;
+        while (cur < size && e[cur].done) ++cur;
+        return e[pre];
+    }
+};
+
+struct Builder {
+    const float *base;
+    size_t stride;
+    unsigned dim;
+    uint32_t nd;
+    bool l2, avx512;
+    uint32_t M, L, Nq;  // M_pjbp, L_pjpq, M_sq
+    uint32_t ep = 0;
+    std::vector<std::vector<uint32_t>> proj, supply;
+    std::vector<std::mutex> locks;
+    int threads = 1;
+
+    float cmp(uint32_t a, uint32_t b) const {
+        const float *pa = base + (size_t)a * stride, *pb = base + (size_t)b * stride;
+#if defined(__x86_64__)
+        if (avx512) return dist_avx512(pa, pb, dim, l2);
+#endif
+        return dist_scalar(pa, pb, dim, l2);
+    }
+    static bool has(const std::vector<uint32_t> &v, uint32_t x) { return std::find(v.begin(), v.end(), x) != v.end(); }
+
+    // static-chunk (phases 1, 2) or dynamic-chunk (phases 3-5) loops, as the reference's omp schedules
+    void parallel_for(uint32_t n, uint32_t chunk, const std::function<void(uint32_t, int)> &fn) {
+        if (threads <= 1) { for (uint32_t i = 0; i < n; ++i) fn(i, 0); return; }
+        std::atomic<uint32_t> next(0);
+        std::vector<std::thread> pool;
+        for (int t = 0; t < threads; ++t)
+            pool.emplace_back([&, t] {
+                for (;;) {
+                    const uint32_t lo = next.fetch_add(chunk);
+                    if (lo >= n) break;
+                    const uint32_t hi = std::min(n, lo + chunk);
+                    for (uint32_t i = lo; i < hi; ++i) fn(i, t);
+                }
+            });
+        for (auto &th : pool) th.join();
+    }
+
+    // occlusion scan shared by all prune routines: p survives if it is not yet chosen and no chosen r is closer to it
+    // than p is to the pivot
+    bool occluded(const Nb &p, const std::vector<uint32_t> &result) const {
+        for (uint32_t r : result) {
+            if (p.id == r) return true;
+            if (cmp(p.id, r) < p.dist) return true;
+        }
+        return false;
+    }
+
+    // :1612-1694
+    void prune_get_base(std::vector<Nb> &pool, uint32_t tgt, std::vector<uint32_t> &out) const {
+        std::vector<Nb> bp;
+        std::vector<uint32_t> ids;
+        for (const Nb &b : pool)
+            if (!has(ids, b.id)) {
+                if (b.id == tgt) continue;
+                bp.push_back(b);
+                ids.push_back(b.id);
+            }
+        std::vector<uint32_t> result;
+        if (bp.empty()) { out = result; return; }
+        std::sort(bp.begin(), bp.end());
+        result.reserve(2 * M);
+        uint32_t start = 0;
+        result.push_back(bp[0].id);
+        while (result.size() < M && (++start) < bp.size()) {
+            const Nb &p = bp[start];
+            if (!occluded(p, result) && p.id != tgt) result.push_back(p.id);
+        }
+        start = 0;
+        while (result.size() < M && (++start) < pool.size()) {   // second sweep walks the UNSORTED pool (:1662)
+            const Nb &p = pool[start];
+            if (has(result, p.id)) continue;
+            if (!occluded(p, result) && p.id != tgt && !has(result, p.id)) result.push_back(p.id);
+        }
+        for (size_t i = 1; i < bp.size() && result.size() < M; ++i)
+            if (!has(result, bp[i].id) && bp[i].id != tgt) result.push_back(bp[i].id);
+        out = result;
+    }
+
+    // :1526-1610 (phantoms = false) and :1434-1524 (phantoms = true: the queue starts with list.size() zero entries)
+    void prune_reverse(uint32_t src, std::vector<uint32_t> &list, bool phantoms) const {
+        std::vector<Nb> pq;
+        if (phantoms) pq.assign(list.size(), Nb{0u, 0.0f});
+        for (uint32_t id : list) {
+            const float d = cmp(src, id);
+            bool seen = false;
+            for (const Nb &x : pq) if (x.id == id) { seen = true; break; }
+            if (!seen) pq.push_back(Nb{id, d});
+        }
+        std::vector<uint32_t> result;
+        if (pq.empty()) { list = result; return; }
+        std::sort(pq.begin(), pq.end());
+        result.reserve(2 * M);
+        uint32_t start = 0;
+        if (pq[start].id == src) ++start;
+        if (start >= pq.size()) { list = result; return; }
+        result.push_back(pq[start].id);
+        while (result.size() < M && (++start) < pq.size()) {
+            const Nb &p = pq[start];
+            if (!occluded(p, result) && p.id != src) result.push_back(p.id);
+        }
+        start = 0;
+        while (result.size() < M && (++start) < pq.size()) {
+            const Nb &p = pq[start];
+            if (!occluded(p, result) && p.id != src && !has(result, p.id)) result.push_back(p.id);
+        }
+        if (!phantoms)   // :1594-1598 top-up in the original list order
+            for (size_t i = 0; i < list.size() && result.size() < M; ++i)
+                if (!has(result, list[i])) result.push_back(list[i]);
+        list = result;
+    }
+
+    // :1391-1432 (on proj, limit M, plain prune) and :1352-1389 (on supply, limit 2M, phantom prune)
+    void add_reverse(std::vector<std::vector<uint32_t>> &g, uint32_t src, uint32_t limit, bool phantoms) {
+        std::vector<uint32_t> nbrs;
+        {   // snapshot (identical to iterating the live list at one thread: pruning `des` never rewrites g[src])
+            std::lock_guard<std::mutex> guard(locks[src]);
+            nbrs = g[src];
+        }
+        for (size_t i = 0; i < nbrs.size(); ++i) {
+            const uint32_t des = nbrs[i];
+            std::vector<uint32_t> copy;
+            bool need = false;
+            {
+                std::lock_guard<std::mutex> guard(locks[des]);
+                std::vector<uint32_t> &dn = g[des];
+                if (has(dn, src)) continue;
+                if (dn.size() < limit) dn.push_back(src);
+                else { need = true; copy = dn; }
+            }
+            if (need) {
+                copy.push_back(src);
+                prune_reverse(des, copy, phantoms);
+                std::lock_guard<std::mutex> guard(locks[des]);
+                g[des] = copy;
+            }
+        }
+    }
+
+    // :1846-1940
+    void prune_search(std::vector<Nb> &pool, uint32_t node, std::vector<uint32_t> &out) const {
+        std::vector<uint32_t> result;
+        if (pool.empty()) { out = result; return; }
+        std::sort(pool.begin(), pool.end());
+        result.reserve(2 * M);
+        uint32_t start = 0;
+        if (pool[start].id == node) ++start;
+        const std::vector<uint32_t> &have = proj[node];
+        while (start < pool.size() && has(have, pool[start].id)) ++start;
+        if (start >= pool.size()) { out = result; return; }
+        result.push_back(pool[start].id);
+        while (result.size() < M && (++start) < pool.size()) {
+            const Nb &p = pool[start];
+            if (!occluded(p, result) && p.id != node) result.push_back(p.id);
+        }
+        start = 0;
+        while (result.size() < M && (++start) < pool.size()) {
+            const Nb &p = pool[start];
+            if (!occluded(p, result) && p.id != node && !has(result, p.id)) result.push_back(p.id);
+        }
+        out = result;
+    }
+
+    // node's current list -> (id, distance to node) without repeated ids (:1112-1121, :1229-1238)
+    void scored_unique(const std::vector<uint32_t> &lst, uint32_t node, std::vector<Nb> &out) const {
+        out.clear();
+        std::vector<uint32_t> seen;
+        for (uint32_t id : lst) {
+            if (has(seen, id)) continue;
+            seen.push_back(id);
+            out.push_back(Nb{id, cmp(id, node)});
+        }
+    }
+
+    void run(const uint32_t *knn, uint32_t nq, uint32_t kdim) {
+        proj.assign(nd, {});
+        supply.assign(nd, {});
+        locks = std::vector<std::mutex>(nd);
+        // ---- entry point (:2004-2041): float sums in index order, plain (unfused) arithmetic
+        {
+            std::vector<float> center(dim, 0.0f);
+            for (size_t i = 0; i < nd; ++i)
+                for (unsigned d = 0; d < dim; ++d) center[d] += base[i * stride + d];
+            for (unsigned d = 0; d < dim; ++d) center[d] /= (float)nd;
+            uint32_t best = 0;
+            float bestd = 0.0f;
+            for (size_t i = 0; i < nd; ++i) {
+                float diff = 0.0f;
+                for (unsigned j = 0; j < dim; ++j) {
+                    const float t = center[j] - base[i * stride + j];
+                    diff += t * t;
+                }
+                if (i == 0 || diff < bestd) { best = (uint32_t)i; bestd = diff; }
+            }
+            ep = best;
+        }
+        // ---- phase 1 (:1059-1097): every training query links its nearest base point to its other neighbours
+        parallel_for(nq, 100, [&](uint32_t sq, int) {
+            const uint32_t n = std::min(kdim, Nq);
+            if (n == 0) return;
+            const uint32_t *nn = knn + (size_t)sq * kdim;
+            const uint32_t tgt = nn[0];
+            std::vector<Nb> full;
+            for (uint32_t i = 0; i < n; ++i)
+                if (nn[i] != tgt) full.push_back(Nb{nn[i], cmp(nn[i], tgt)});
+            std::vector<uint32_t> pruned;
+            prune_get_base(full, tgt, pruned);
+            {
+                std::lock_guard<std::mutex> guard(locks[tgt]);
+                proj[tgt] = pruned;
+            }
+            add_reverse(proj, tgt, M, false);
+        });
+        // ---- phase 2 (:1100-1136)
+        parallel_for(nd, 100, [&](uint32_t node, int) { add_reverse(proj, node, M, false); });
+        parallel_for(nd, 2048, [&](uint32_t node, int) {
+            if (proj[node].size() <= M) return;
+            std::vector<Nb> full;
+            scored_unique(proj[node], node, full);
+            full.erase(std::remove_if(full.begin(), full.end(), [&](const Nb &x) { return x.id == node; }), full.end());
+            std::vector<uint32_t> pruned;
+            prune_get_base(full, node, pruned);
+            std::lock_guard<std::mutex> guard(locks[node]);
+            proj[node] = pruned;
+        });
+        for (uint32_t i = 0; i < nd; ++i) supply[i] = proj[i];   // :1183-1188
+        // ---- phase 3 (:1192-1220): connectivity enhancement -- beam search from the entry point towards every node
+        std::vector<std::vector<uint32_t>> stamp(std::max(1, threads));
+        std::vector<uint32_t> serial(std::max(1, threads), 0);
+        parallel_for(nd, 2048, [&](uint32_t node, int t) {
+            std::vector<uint32_t> &seen = stamp[t];
+            if (seen.empty()) seen.assign(nd, 0u);
+            const uint32_t tag = ++serial[t];
+            Beam beam;
+            beam.reset(L);
+            std::vector<Nb> expanded;
+            expanded.reserve(L);
+            beam.insert(ep, cmp(ep, node));
+            seen[ep] = tag;
+            while (beam.has_open()) {
+                const Beam::E cur = beam.pop();
+                expanded.push_back(Nb{cur.id, cur.dist});
+                std::vector<uint32_t> nbrs;
+                {   // the reference iterates supply_nbrs_[cur] unlocked; take a snapshot so a concurrent writer cannot tear it
+                    std::lock_guard<std::mutex> guard(locks[cur.id]);
+                    nbrs = supply[cur.id];
+                }
+                for (uint32_t nb : nbrs) {
+                    if (seen[nb] == tag || nb == node) continue;
+                    seen[nb] = tag;
+                    beam.insert(nb, cmp(nb, node));
+                }
+            }
+            expanded.erase(std::remove_if(expanded.begin(), expanded.end(), [&](const Nb &x) { return x.id == node; }), expanded.end());
+            std::vector<uint32_t> pruned;
+            prune_search(expanded, node, pruned);
+            {
+                std::lock_guard<std::mutex> guard(locks[node]);
+                supply[node] = pruned;
+            }
+            add_reverse(supply, node, 2 * M, true);
+        });
+        // ---- phase 4 (:1224-1248)
+        parallel_for(nd, 2048, [&](uint32_t node, int) {
+            if (supply[node].size() <= M) return;
+            std::vector<Nb> full;
+            scored_unique(supply[node], node, full);
+            std::vector<uint32_t> pruned;
+            prune_search(full, node, pruned);
+            std::lock_guard<std::mutex> guard(locks[node]);
+            supply[node] = pruned;
+        });
+        // ---- phase 5 (:1251-1264): append up to 2*M supply edges that the projection list lacks
+        parallel_for(nd, 100, [&](uint32_t i, int) {
+            std::vector<uint32_t> ok;
+            for (uint32_t s : supply[i]) {
+                if (ok.size() >= 2 * M) break;
+                if (!has(proj[i], s)) ok.push_back(s);
+            }
+            proj[i].insert(proj[i].end(), ok.begin(), ok.end());
+        });
+    }
+};
+
+}  // namespace
+}  // namespace rg
+
+extern "C" rg_status rg_build_roargraph(const float *base, uint32_t nb, uint32_t dim, uint32_t stride,
+                                        const uint32_t *knn_ids, uint32_t nq, uint32_t knn_k, int metric, uint32_t M_sq,
+                                        uint32_t M_pjbp, uint32_t L_pjpq, uint32_t num_threads, uint32_t *out_ep,
+                                        uint64_t **out_offsets, uint32_t **out_nbrs) {
+    using rg::set_error;
+    if (!base || !knn_ids || !out_ep || !out_offsets || !out_nbrs) return set_error(RG_ERR_ARG, "null argument");
+    if (nb == 0 || dim == 0 || stride < dim || M_pjbp == 0 || L_pjpq == 0 || knn_k == 0)
+        return set_error(RG_ERR_ARG, "bad build parameters");
+    if (metric != RG_METRIC_L2 && metric != RG_METRIC_IP && metric != RG_METRIC_COSINE)
+        return set_error(RG_ERR_ARG, "Unknown distance type");
+    for (size_t i = 0; i < (size_t)nq * knn_k; ++i)
+        if (knn_ids[i] >= nb) return set_error(RG_ERR_FORMAT, "learn base knn file references a base id >= npts");
+    std::vector<float> normed;
+    if (metric == RG_METRIC_COSINE) {   // BuildRoarGraph normalises the base in place (:175-181)
+        normed.assign(base, base + (size_t)nb * stride);
+        rg_normalize_rows(normed.data(), nb, stride, dim);
+        base = normed.data();
+    }
+    rg::Builder b;
+    b.base = base; b.stride = stride; b.dim = dim; b.nd = nb;
+    b.l2 = metric == RG_METRIC_L2;
+#if defined(__x86_64__)
+    b.avx512 = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("fma");
+#else
+    b.avx512 = false;
+#endif
+    b.M = M_pjbp; b.L = L_pjpq; b.Nq = M_sq;
+    b.threads = (int)std::max<uint32_t>(1, num_threads);
+    b.run(knn_ids, nq, knn_k);
+    size_t edges = 0;
+    for (auto &l : b.proj) edges += l.size();
+    uint64_t *off = (uint64_t *)std::malloc(((size_t)nb + 1) * 8);
+    uint32_t *nbr = (uint32_t *)std::malloc(std::max<size_t>(edges * 4, 4));
+    if (!off || !nbr) { std::free(off); std::free(nbr); return set_error(RG_ERR_OOM, "out of host memory"); }
+    size_t pos = 0;
+    for (uint32_t i = 0; i < nb; ++i) {
+        off[i] = pos;
+        std::memcpy(nbr + pos, b.proj[i].data(), b.proj[i].size() * 4);
+        pos += b.proj[i].size();
+    }
+    off[nb] = pos;
+    *out_ep = b.ep;
+    *out_offsets = off;
+    *out_nbrs = nbr;
+    return RG_OK;
+}

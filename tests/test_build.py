@@ -1,0 +1,109 @@
+"""CPU: graph construction (rg_build_roargraph, the restated BuildRoarGraph) -- a 'next' row.
+
+Parity status: UNPINNED.  The reference's build translation unit cannot be compiled under this round's rules (Boost /
+tsl headers absent, stand-ins not allowed), so these tests check properties, determinism, and one regression value.
+"""
+import hashlib
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from roargraph_amd import io
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def rgb():
+    from roargraph_amd import build
+    return build
+
+
+def gen(seed, nb, nt, nq, d):
+    """the survey's probe generator: one rng, base then train then query"""
+    rng = np.random.default_rng(seed)
+    base = rng.standard_normal((nb, d)).astype(np.float32)
+    train = (rng.standard_normal((nt, d)) * 0.5 + 0.3).astype(np.float32)
+    query = (rng.standard_normal((nq, d)) * 0.5 + 0.3).astype(np.float32)
+    return base, train, query
+
+
+def np_gt(q, b, K):
+    s = q.astype(np.float64) @ b.T.astype(np.float64)
+    return np.argsort(-s, axis=1, kind="stable")[:, :K].astype(np.uint32)
+
+
+def test_small_build_properties_and_recall(rgb, oracle):
+    base, train, query = gen(5, 4000, 1500, 100, 64)
+    knn = np_gt(train, base, 100)
+    M = 20
+    off, nbrs, ep = rgb.build_roargraph(base, knn, "ip", M_sq=100, M_pjbp=M, L_pjpq=200, num_threads=1)
+    off2, nbrs2, ep2 = rgb.build_roargraph(base, knn, "ip", M_sq=100, M_pjbp=M, L_pjpq=200, num_threads=1)
+    assert ep == ep2 and (off == off2).all() and (nbrs == nbrs2).all(), "one-thread build must be deterministic"
+    deg = np.diff(off.astype(np.int64))
+    assert deg.max() <= 2 * M and nbrs.max() < 4000
+    for i in range(0, 4000, 97):
+        lst = nbrs[int(off[i]):int(off[i + 1])]
+        assert i not in lst and len(set(lst.tolist())) == len(lst), "self loop or repeated neighbour"
+    c = base.astype(np.float64).mean(0)
+    assert abs(((base[ep] - c) ** 2).sum() - ((base - c) ** 2).sum(1).min()) < 1e-3
+    gt = np_gt(query, base, 100)
+    ids, _, _, _ = oracle.search(base, "ip", off, nbrs, ep, query, 10, 200, nthreads=4)
+    assert oracle.recall(ids, gt, 10) > 0.95
+    # multi-threaded build: scheduling dependent like the reference, but the same quality
+    off8, nbrs8, ep8 = rgb.build_roargraph(base, knn, "ip", M_sq=100, M_pjbp=M, L_pjpq=200, num_threads=8)
+    ids8, _, _, _ = oracle.search(base, "ip", off8, nbrs8, ep8, query, 10, 200, nthreads=4)
+    assert ep8 == ep and np.diff(off8.astype(np.int64)).max() <= 2 * M and oracle.recall(ids8, gt, 10) > 0.95
+
+
+def test_l2_build(rgb, oracle):
+    base, train, query = gen(9, 3000, 1000, 80, 32)
+    s = ((train.astype(np.float64)[:, None, :] - base.astype(np.float64)[None, :, :]) ** 2).sum(-1)
+    knn = np.argsort(s, axis=1, kind="stable")[:, :50].astype(np.uint32)
+    off, nbrs, ep = rgb.build_roargraph(base, knn, "l2", M_sq=50, M_pjbp=16, L_pjpq=100, num_threads=4)
+    sq = ((query.astype(np.float64)[:, None, :] - base.astype(np.float64)[None, :, :]) ** 2).sum(-1)
+    gt = np.argsort(sq, axis=1, kind="stable")[:, :100].astype(np.uint32)
+    ids, _, _, _ = oracle.search(base, "l2", off, nbrs, ep, query, 10, 100, nthreads=4)
+    assert np.diff(off.astype(np.int64)).max() <= 32 and oracle.recall(ids, gt, 10) > 0.9
+
+
+def test_survey_probe_regression(rgb, oracle):
+    """20k x 200 IP, 5k train queries, M_sq=100 M_pjbp=35 L_pjpq=500, ONE thread -- the survey's probe set.
+    SURVEY.md Appendix D records for the reference's T=1 index: avg degree 41.9, max 70, recall@10 0.995 at L_pq=500,
+    mean cmps 11,764.  The md5 below is the value this implementation produces; it equals the md5 of the T=1 index the
+    survey's probe build wrote (a build that cannot be re-created under this round's no-stand-in rule, hence a
+    regression value and an informal observation, not a parity pin)."""
+    base, train, query = gen(1234, 20000, 5000, 200, 200)
+    knn = np_gt(train, base, 100)
+    off, nbrs, ep = rgb.build_roargraph(base, knn, "ip", M_sq=100, M_pjbp=35, L_pjpq=500, num_threads=1)
+    deg = np.diff(off.astype(np.int64))
+    assert abs(deg.mean() - 41.9) < 0.05 and deg.max() == 70
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        p = os.path.join(td, "t1.index")
+        io.write_index(p, off, nbrs, ep)
+        assert hashlib.md5(open(p, "rb").read()).hexdigest() == "f109604b40df5c87a1e52649b2de91bc"
+    gt = np_gt(query, base, 100)
+    ids, _, cmps, hops = oracle.search(base, "ip", off, nbrs, ep, query, 10, 500, nthreads=8)
+    assert abs(oracle.recall(ids, gt, 10) - 0.995) < 0.003 and abs(cmps.mean() - 11764) < 5 and abs(hops.mean() - 501.2) < 0.1
+
+
+def test_build_cli_twin(tmp_path, oracle):
+    exe = os.path.join(ROOT, "roargraph_amd", "bin", "test_build_roargraph")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "roargraph_amd", "cli")])
+    base, train, _ = gen(3, 1500, 400, 10, 24)
+    knn = np_gt(train, base, 40)
+    bf, tf, kf, out = (str(tmp_path / x) for x in ("b.fbin", "t.fbin", "knn.bin", "g.index"))
+    io.write_fbin(bf, base); io.write_fbin(tf, train); io.write_gt(kf, knn)   # ids only, as LoadLearnBaseKNN accepts
+    r = subprocess.run([exe, "--data_type", "float", "--dist", "ip", "--base_data_path", bf, "--sampled_query_data_path", tf,
+                        "--projection_index_save_path", out, "--learn_base_nn_path", kf, "--M_sq", "40", "--M_pjbp", "12",
+                        "--L_pjpq", "60", "-T", "1"], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "Using inner product as distance metric" in r.stdout and "Save index to" in r.stdout
+    off, nbrs, ep = oracle.index_load(out)
+    from roargraph_amd import build
+    o2, n2, e2 = build.build_roargraph(base, knn, "ip", 40, 12, 60, 1)
+    assert ep == e2 and (off == o2).all() and (nbrs == n2).all()
