@@ -64,3 +64,28 @@ def test_cli_errors(bins, tmp_path):
                         "--base_file", bf, "--query_file", bf, "--gt_file", str(tmp_path / "o"), "--K", "2"],
                        capture_output=True, text=True)
     assert r.returncode != 0 and "Data file size wrong!" in (r.stdout + r.stderr)
+
+
+def test_end_to_end_pipeline_gt_build_search(oracle):
+    """BASELINE config 5 in miniature: K2 ground truth of the training queries -> CPU graph build -> K1 search.
+    The GPU search over the freshly built index must equal the oracle's search over the same index, and reach the
+    recall the same pipeline reaches on the CPU."""
+    from roargraph_amd import build, groundtruth, synth
+    from roargraph_amd.index import IndexBipartite
+    rng = np.random.default_rng(21)
+    base = rng.standard_normal((6000, 200)).astype(np.float32)
+    train = (rng.standard_normal((3000, 200)) * 0.5 + 0.3).astype(np.float32)
+    q = (rng.standard_normal((200, 200)) * 0.5 + 0.3).astype(np.float32)
+    knn, _ = groundtruth.compute_groundtruth(base, train, "ip", 100)
+    ref_knn, _, _ = oracle.groundtruth_f64(base, train, "ip", 100, nthreads=16)
+    assert (knn == ref_knn).mean() > 0.999
+    off, nbrs, ep = build.build_roargraph(base, knn, "ip", 100, 35, 500, num_threads=1)
+    ix = IndexBipartite.from_arrays(base, off, nbrs, ep, metric="ip")
+    gt, _ = groundtruth.compute_groundtruth(base, q, "ip", 100)
+    for L in (20, 200):
+        got = ix.SearchRoarGraph(q, 10, L)
+        want = oracle.search(base, "ip", off, nbrs, ep, q, 10, L, nthreads=8)
+        assert all((a == b).all() for a, b in zip((got[0], got[2], got[3]), (want[0], want[2], want[3])))
+        assert (got[1].view(np.uint32) == want[1].view(np.uint32)).all()
+    assert oracle.recall(got[0], gt, 10) > 0.97
+    ix.close()
