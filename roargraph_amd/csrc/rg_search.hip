@@ -35,6 +35,18 @@ namespace rg {
             return set_error(RG_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));        \
     } while (0)
 
+// device allocation released on every exit path of a host wrapper
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    hipError_t alloc(size_t n) { return hipMalloc(&p, std::max<size_t>(n * sizeof(T), 16)); }
+    ~DevBuf() { if (p) (void)hipFree(p); }
+    T *release() { T *r = p; p = nullptr; return r; }
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;
+    DevBuf &operator=(const DevBuf &) = delete;
+};
+
 // ------------------------------------------------------------------------------------------------ device
 struct SearchParams {
     const float *base;
@@ -846,29 +858,28 @@ rg_status rg_index_open_mem(const float *base, uint32_t nd, uint32_t dim, uint32
     if (st != RG_OK) return st;
     // device copy at the aligned stride, zero padded (data_align, util.h:37-75); cosine rows are normalised first
     const uint32_t ad = rg::aligned_dim(dim);
-    float *d_base = nullptr;
-    RG_HIP(hipMalloc(&d_base, std::max<size_t>((size_t)nd * ad * 4, 16)));
+    rg::DevBuf<float> d_base;
+    RG_HIP(d_base.alloc((size_t)nd * ad));
     if (metric == RG_METRIC_COSINE || ad != dim || ad != stride) {
         std::vector<float> tmp((size_t)nd * ad, 0.0f);
         for (size_t i = 0; i < nd; ++i) std::memcpy(tmp.data() + i * ad, base + i * (size_t)stride, (size_t)dim * 4);
         if (metric == RG_METRIC_COSINE) rg_normalize_rows(tmp.data(), nd, ad, dim);
-        RG_HIP(hipMemcpy(d_base, tmp.data(), tmp.size() * 4, hipMemcpyHostToDevice));
+        RG_HIP(hipMemcpy(d_base.p, tmp.data(), tmp.size() * 4, hipMemcpyHostToDevice));
     } else {
-        RG_HIP(hipMemcpy(d_base, base, (size_t)nd * ad * 4, hipMemcpyHostToDevice));
+        RG_HIP(hipMemcpy(d_base.p, base, (size_t)nd * ad * 4, hipMemcpyHostToDevice));
     }
     const uint64_t ne = offsets[nd];
-    uint64_t *d_off = nullptr;
-    uint32_t *d_nb = nullptr;
-    RG_HIP(hipMalloc(&d_off, ((size_t)nd + 1) * 8));
-    RG_HIP(hipMalloc(&d_nb, std::max<size_t>(ne * 4, 4)));
-    RG_HIP(hipMemcpy(d_off, offsets, ((size_t)nd + 1) * 8, hipMemcpyHostToDevice));
-    RG_HIP(hipMemcpy(d_nb, nbrs, ne * 4, hipMemcpyHostToDevice));
+    rg::DevBuf<uint64_t> d_off;
+    rg::DevBuf<uint32_t> d_nb;
+    RG_HIP(d_off.alloc((size_t)nd + 1));
+    RG_HIP(d_nb.alloc(ne));
+    RG_HIP(hipMemcpy(d_off.p, offsets, ((size_t)nd + 1) * 8, hipMemcpyHostToDevice));
+    RG_HIP(hipMemcpy(d_nb.p, nbrs, ne * 4, hipMemcpyHostToDevice));
     rg_index *ix = nullptr;
-    st = rg_index_open_dev(d_base, nd, ad, ad, d_off, d_nb, ep, metric, device, &ix);
-    (void)hipFree(d_off);
-    (void)hipFree(d_nb);
-    if (st != RG_OK) { (void)hipFree(d_base); return st; }
+    st = rg_index_open_dev(d_base.p, nd, ad, ad, d_off.p, d_nb.p, ep, metric, device, &ix);
+    if (st != RG_OK) return st;
     ix->own_base = true;
+    (void)d_base.release();   // now owned by the index
     *out = ix;
     return RG_OK;
 }
@@ -940,24 +951,23 @@ rg_status rg_search(rg_index *ix, const float *queries, uint32_t nq, uint32_t qs
     std::vector<float> hq((size_t)nq * d, 0.0f);
     for (size_t i = 0; i < nq; ++i) std::memcpy(hq.data() + i * d, queries + i * (size_t)qstride, (size_t)use * 4);
     if (ix->metric == RG_METRIC_COSINE) rg_normalize_rows(hq.data(), nq, d, d);
-    float *d_q = nullptr, *d_dist = nullptr;
-    uint32_t *d_ids = nullptr, *d_ch = nullptr;
-    RG_HIP(hipMalloc(&d_q, hq.size() * 4));
-    RG_HIP(hipMalloc(&d_ids, (size_t)nq * k * 4));
-    RG_HIP(hipMalloc(&d_dist, (size_t)nq * k * 4));
-    RG_HIP(hipMalloc(&d_ch, (size_t)nq * 8));
-    RG_HIP(hipMemcpy(d_q, hq.data(), hq.size() * 4, hipMemcpyHostToDevice));
-    RG_HIP(hipMemset(d_ids, 0, (size_t)nq * k * 4));
-    RG_HIP(hipMemset(d_dist, 0, (size_t)nq * k * 4));
-    rg_status st = rg::search_dev(ix, d_q, nq, d, k, L_pq, d_ids, d_dist, d_ch, d_ch + nq, nullptr);
+    rg::DevBuf<float> d_q, d_dist;
+    rg::DevBuf<uint32_t> d_ids, d_ch;
+    RG_HIP(d_q.alloc(hq.size()));
+    RG_HIP(d_ids.alloc((size_t)nq * k));
+    RG_HIP(d_dist.alloc((size_t)nq * k));
+    RG_HIP(d_ch.alloc((size_t)nq * 2));
+    RG_HIP(hipMemcpy(d_q.p, hq.data(), hq.size() * 4, hipMemcpyHostToDevice));
+    RG_HIP(hipMemset(d_ids.p, 0, (size_t)nq * k * 4));
+    RG_HIP(hipMemset(d_dist.p, 0, (size_t)nq * k * 4));
+    rg_status st = rg::search_dev(ix, d_q.p, nq, d, k, L_pq, d_ids.p, d_dist.p, d_ch.p, d_ch.p + nq, nullptr);
     if (st == RG_OK) st = rg::search_wait(ix, nullptr, k);
     if (st == RG_OK || st == RG_ERR_NOT_ENOUGH) {
-        (void)hipMemcpy(out_ids, d_ids, (size_t)nq * k * 4, hipMemcpyDeviceToHost);
-        (void)hipMemcpy(out_dists, d_dist, (size_t)nq * k * 4, hipMemcpyDeviceToHost);
-        if (out_cmps) (void)hipMemcpy(out_cmps, d_ch, (size_t)nq * 4, hipMemcpyDeviceToHost);
-        if (out_hops) (void)hipMemcpy(out_hops, d_ch + nq, (size_t)nq * 4, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(out_ids, d_ids.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(out_dists, d_dist.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost);
+        if (out_cmps) (void)hipMemcpy(out_cmps, d_ch.p, (size_t)nq * 4, hipMemcpyDeviceToHost);
+        if (out_hops) (void)hipMemcpy(out_hops, d_ch.p + nq, (size_t)nq * 4, hipMemcpyDeviceToHost);
     }
-    (void)hipFree(d_q); (void)hipFree(d_ids); (void)hipFree(d_dist); (void)hipFree(d_ch);
     return st;
 }
 
@@ -972,19 +982,18 @@ rg_status rg_score_batch(rg_index *ix, const float *query, const uint32_t *ids, 
     RG_HIP(hipSetDevice(ix->device));
     for (uint32_t i = 0; i < n; ++i)
         if (ids[i] >= ix->nd) return set_error(RG_ERR_ARG, "id out of range");
-    float *d_q = nullptr, *d_o = nullptr;
-    uint32_t *d_i = nullptr;
-    RG_HIP(hipMalloc(&d_q, (size_t)ix->dim * 4));
-    RG_HIP(hipMalloc(&d_o, (size_t)n * 4));
-    RG_HIP(hipMalloc(&d_i, (size_t)n * 4));
-    RG_HIP(hipMemcpy(d_q, query, (size_t)ix->dim * 4, hipMemcpyHostToDevice));
-    RG_HIP(hipMemcpy(d_i, ids, (size_t)n * 4, hipMemcpyHostToDevice));
-    rg_status st = rg::score_dev(ix, d_q, d_i, n, d_o, nullptr);
+    rg::DevBuf<float> d_q, d_o;
+    rg::DevBuf<uint32_t> d_i;
+    RG_HIP(d_q.alloc(ix->dim));
+    RG_HIP(d_o.alloc(n));
+    RG_HIP(d_i.alloc(n));
+    RG_HIP(hipMemcpy(d_q.p, query, (size_t)ix->dim * 4, hipMemcpyHostToDevice));
+    RG_HIP(hipMemcpy(d_i.p, ids, (size_t)n * 4, hipMemcpyHostToDevice));
+    rg_status st = rg::score_dev(ix, d_q.p, d_i.p, n, d_o.p, nullptr);
     if (st == RG_OK) {
-        hipError_t e = hipMemcpy(out, d_o, (size_t)n * 4, hipMemcpyDeviceToHost);
+        hipError_t e = hipMemcpy(out, d_o.p, (size_t)n * 4, hipMemcpyDeviceToHost);
         if (e != hipSuccess) st = set_error(RG_ERR_DEVICE, hipGetErrorString(e));
     }
-    (void)hipFree(d_q); (void)hipFree(d_o); (void)hipFree(d_i);
     return st;
 }
 
