@@ -19,6 +19,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "rg.h"
@@ -303,6 +304,195 @@ __global__ void __launch_bounds__(512) rg_gt_kernel(GtParams P) {
     }
 }
 
+// K2-RS: "queries stationary in registers" form of K2 for the dimensions of the BASELINE configs (200, 512).
+// A wave keeps the MFMA A-operands of its 32*TMW queries for ALL k in VGPRs (DIM/2 registers per 32-query tile: lane l
+// holds Q[q = l&31][k = 2*kk + (l>>5)]), owns all four 32-column tiles of the streamed base tile, and therefore issues
+// 8*TMW MFMAs per k-pair with only the B fragments coming from LDS.  One wave per SIMD (4 waves = one workgroup per CU,
+// 128*TMW queries); LDS holds just the double-buffered base chunk, barriers are BK/2 * 8*TMW MFMAs apart (10k cycles at
+// d=200) and the base stream is shared by twice as many queries as in the LDS-resident form.  Everything in k is
+// unrolled at compile time (register arrays need static indices), hence the DIM template parameter.
+template <int DIM, int BK, int TMW, int ITEMS, int WPS>
+__global__ void __launch_bounds__(256, WPS) rg_gt_rs_kernel(GtParams P) {
+    constexpr int C = 64 * ITEMS;
+    constexpr int MQB = 128 * TMW;            // queries per workgroup
+    constexpr int NKC = DIM / BK;             // k-chunks per base tile
+    constexpr int KQC = BK / 4;               // k-quads per chunk
+    constexpr int NINSTR = KQC * 2;           // LDS-DMA wave instructions per chunk (64 rows of one k-quad each)
+    static_assert(DIM % BK == 0 && BK % 4 == 0, "chunking");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int qoff = 32 * TMW * w;
+    const bool hi = lane >= 32;
+
+    float4 *Bq = reinterpret_cast<float4 *>(smem);                               // [2][KQC][128]
+    float *thr = reinterpret_cast<float *>(Bq + 2 * (size_t)KQC * kNB);          // [MQB]
+    uint32_t *cnt = reinterpret_cast<uint32_t *>(thr + MQB);                     // [MQB]
+    uint32_t *flag = cnt + MQB;                                                  // [4]
+    u64 *cand = P.cand + (size_t)blockIdx.x * MQB * C;
+    const uint32_t ntiles = (P.nb + kNB - 1) / kNB;
+
+    for (;;) {
+        if (tid == 0) flag[1] = atomicAdd(P.counter, 1u);
+        __syncthreads();
+        const uint32_t blk = flag[1];
+        __syncthreads();
+        if ((uint64_t)blk * MQB >= P.nq) break;
+        const uint32_t q0 = blk * MQB;
+        // A operands of this wave's queries, all k, into registers
+        float areg[DIM / 2][TMW];
+#pragma unroll
+        for (int m = 0; m < TMW; ++m) {
+            const uint32_t q = q0 + qoff + 32 * m + (lane & 31);
+            const float *qrow = P.queries + (size_t)min(q, P.nq - 1u) * P.qstride + (hi ? 1 : 0);
+            const float scale = q < P.nq ? 1.0f : 0.0f;
+#pragma unroll
+            for (int kk = 0; kk < DIM / 2; ++kk) areg[kk][m] = qrow[2 * kk] * scale;
+        }
+        for (int i = tid; i < MQB; i += 256) { thr[i] = -__builtin_inff(); cnt[i] = 0; }
+        if (tid == 0) flag[0] = 0;
+        // thresholds of this lane's query rows: kept in registers when the budget allows (TMW == 1), else read from LDS
+        constexpr bool kThrRegs = TMW == 1;
+        float thr_r[kThrRegs ? TMW : 1][16];
+        if (kThrRegs) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) thr_r[0][r] = -__builtin_inff();
+        }
+
+        auto stream_chunk = [&](uint32_t tile, uint32_t c, uint32_t buf) {
+            float4 *dst = Bq + (size_t)buf * KQC * kNB;
+            for (uint32_t j = (uint32_t)w; j < (uint32_t)NINSTR; j += 4) {
+                const uint32_t kq = j >> 1, row = 64u * (j & 1u) + (uint32_t)lane;
+                const uint32_t gr = min(tile * kNB + row, P.nb - 1u);
+                const float *src = P.base + (size_t)gr * P.bstride + c * BK + 4 * kq;
+                const uint32_t lds_addr = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(lds_ptr_t *)(dst + (size_t)j * 64));
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(lds_addr), "v"(src) : "memory");
+            }
+        };
+
+        f32x16 acc[TMW][4];
+        uint32_t step = 0;   // running chunk counter: LDS buffer = step & 1
+        stream_chunk(0, 0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        for (uint32_t tile = 0; tile < ntiles; ++tile) {
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                const uint32_t id = tile * kNB + 32 * n + (lane & 31);
+                const float b = (P.bias && id < P.nb) ? P.bias[id] : 0.0f;
+#pragma unroll
+                for (int m = 0; m < TMW; ++m)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[m][n][r] = b;
+            }
+            // one instantiation per chunk index (a generic lambda over integral_constant): the register array of A
+            // operands needs compile-time indices, and hipcc declines to unroll a loop body of this size
+            auto chunk = [&](auto cc) __attribute__((always_inline)) {
+                constexpr int c = decltype(cc)::value;
+                const uint32_t buf = step & 1u;
+                // next chunk (of this tile or the first of the next tile) streams while this one is multiplied
+                if (c + 1 < NKC) stream_chunk(tile, c + 1, buf ^ 1u);
+                else if (tile + 1 < ntiles) stream_chunk(tile + 1, 0, buf ^ 1u);
+                const float4 *bq = Bq + (size_t)buf * KQC * kNB + (lane & 31);
+                float4 b0[4], b1[4];
+#pragma unroll
+                for (int n = 0; n < 4; ++n) b0[n] = bq[32 * n];
+#pragma unroll
+                for (int kq = 0; kq < KQC; ++kq) {
+                    float4 (&bc)[4] = (kq & 1) ? b1 : b0;
+                    float4 (&bn)[4] = (kq & 1) ? b0 : b1;
+                    if (kq + 1 < KQC) {
+#pragma unroll
+                        for (int n = 0; n < 4; ++n) bn[n] = bq[(size_t)(kq + 1) * kNB + 32 * n];
+                    }
+                    const int kk = 2 * (c * KQC + kq);   // first k-pair of this quad
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) {
+                        const float bl = hi ? bc[n].y : bc[n].x;
+#pragma unroll
+                        for (int m = 0; m < TMW; ++m)
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[kk][m], bl, acc[m][n], 0, 0, 0);
+                    }
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) {
+                        const float bh = hi ? bc[n].w : bc[n].z;
+#pragma unroll
+                        for (int m = 0; m < TMW; ++m)
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[kk + 1][m], bh, acc[m][n], 0, 0, 0);
+                    }
+                }
+                ++step;
+                if (c + 1 == NKC) {
+                    // tile finished: threshold filter (register thresholds), survivors -> candidate buffers
+                    bool any_win = false;
+#pragma unroll
+                    for (int n = 0; n < 4; ++n) {
+                        const uint32_t id = tile * kNB + 32 * n + (lane & 31);
+#pragma unroll
+                        for (int m = 0; m < TMW; ++m) {
+                            uint32_t win = 0;
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) {
+                                const float t = kThrRegs ? thr_r[kThrRegs ? m : 0][r]
+                                                         : thr[qoff + 32 * m + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)];
+                                win |= (acc[m][n][r] > t ? 1u : 0u) << r;
+                            }
+                            if (id >= P.nb) win = 0;
+                            if (win) {
+                                any_win = true;
+#pragma unroll
+                                for (int r = 0; r < 16; ++r)
+                                    if (win & (1u << r)) {
+                                        const int qi = qoff + 32 * m + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                                        const uint32_t slot = atomicAdd(&cnt[qi], 1u);
+                                        cand[(size_t)qi * C + slot] = make_key(acc[m][n][r], id, true);
+                                        if (slot + 1 + kNB > (uint32_t)C) flag[0] = 1;
+                                    }
+                            }
+                        }
+                    }
+                    (void)any_win;
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next chunk's DMA (and any candidate stores) landed
+                __syncthreads();
+                if (c + 1 == NKC && flag[0]) {
+                    for (int qi = w; qi < MQB; qi += 4)
+                        if (cnt[qi] + kNB > (uint32_t)C) gt_compact<ITEMS>(cand + (size_t)qi * C, &cnt[qi], &thr[qi], P.K, lane);
+                    __syncthreads();
+                    if (tid == 0) flag[0] = 0;
+                    if (kThrRegs) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) thr_r[0][r] = thr[qoff + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)];
+                    }
+                    __syncthreads();
+                }
+            };
+            if constexpr (0 < NKC) chunk(std::integral_constant<int, 0>{});
+            if constexpr (1 < NKC) chunk(std::integral_constant<int, 1>{});
+            if constexpr (2 < NKC) chunk(std::integral_constant<int, 2>{});
+            if constexpr (3 < NKC) chunk(std::integral_constant<int, 3>{});
+            if constexpr (4 < NKC) chunk(std::integral_constant<int, 4>{});
+            if constexpr (5 < NKC) chunk(std::integral_constant<int, 5>{});
+            if constexpr (6 < NKC) chunk(std::integral_constant<int, 6>{});
+            if constexpr (7 < NKC) chunk(std::integral_constant<int, 7>{});
+            static_assert(NKC <= 8, "add chunk calls");
+        }
+        // final selection + output
+        for (int qi = w; qi < MQB; qi += 4) {
+            gt_compact<ITEMS>(cand + (size_t)qi * C, &cnt[qi], &thr[qi], P.K, lane);
+            const uint32_t q = q0 + qi;
+            if (q < P.nq) {
+                for (uint32_t e = lane; e < P.K; e += 64) {
+                    const u64 k = cand[(size_t)qi * C + e];
+                    P.out_ids[(size_t)q * P.K + e] = (uint32_t)k + P.id_base;
+                    P.out_vals[(size_t)q * P.K + e] = key_value(k, true);
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // bias[i] = -0.5 * |b_i|^2 (one 16-lane group per row)
 __global__ void rg_gt_bias_kernel(const float *base, uint32_t nb, uint32_t bstride, uint32_t dim, float *bias) {
     const uint32_t gid = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, sub = threadIdx.x & 15;
@@ -433,8 +623,16 @@ rg_status rg_gt_shard_dev(const float *d_base, uint32_t nb, uint32_t bstride, co
     if (!bk) return set_error(RG_ERR_ARG, "dimension too large for the LDS-resident query block");
     const size_t lds = gt_lds(dim, mq, bk);
     const int items = items_for(K + kNB);
+    // register-stationary kernel for the BASELINE dimensions when the sort fits ITEMS=4 (K <= 128)
+    uint32_t rs_tmw = 0, rs_bk = 0, rs_mqb = 0;
+    if (items == 4 && !getenv("RG_GT_GENERIC")) {
+        if (dim == 200) { rs_tmw = getenv("RG_GT_RS_TMW2") ? 2 : 1; rs_bk = 40;   // default: 32 queries per wave, two workgroups per CU }
+        else if (dim == 512) { rs_tmw = 1; rs_bk = 64; }
+        rs_mqb = 128 * rs_tmw;
+    }
+    if (rs_tmw) mq = rs_mqb;
     const uint32_t nblocks = (nq + mq - 1) / mq;
-    const uint32_t per_cu = 1;  // 8 waves (two per SIMD) per workgroup, one workgroup per CU
+    const uint32_t per_cu = (rs_tmw == 1 && dim == 200) ? 2 : 1;
     const uint32_t grid = std::min<uint32_t>(nblocks, (uint32_t)prop.multiProcessorCount * per_cu);
     float *bias = nullptr;
     u64 *cand = nullptr;
@@ -452,7 +650,26 @@ rg_status rg_gt_shard_dev(const float *d_base, uint32_t nb, uint32_t bstride, co
     P.bias = bias; P.K = K; P.id_base = id_base; P.out_ids = d_ids; P.out_vals = vals; P.cand = cand;
     P.counter = counter; P.BK = bk;
     P.diag = getenv("RG_GT_DIAG") ? (uint32_t)atoi(getenv("RG_GT_DIAG")) : 0u;
-    rg_status st = mq == 128 ? launch_gt_items<128>(items, P, grid, lds, s) : launch_gt_items<64>(items, P, grid, lds, s);
+    rg_status st;
+    if (rs_tmw) {
+        const size_t lds_rs = ((size_t)2 * rs_bk * kNB + 2 * rs_mqb + 8) * 4;
+        if (dim == 200 && rs_tmw == 1) {
+            auto kern = rg_gt_rs_kernel<200, 40, 1, 4, 2>;
+            RG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rs));
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_rs, s, P);
+        } else if (dim == 200) {
+            auto kern = rg_gt_rs_kernel<200, 40, 2, 4, 1>;
+            RG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rs));
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_rs, s, P);
+        } else {
+            auto kern = rg_gt_rs_kernel<512, 64, 1, 4, 1>;
+            RG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rs));
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_rs, s, P);
+        }
+        st = hipGetLastError() == hipSuccess ? RG_OK : set_error(RG_ERR_DEVICE, "K2-RS launch failed");
+    } else {
+        st = mq == 128 ? launch_gt_items<128>(items, P, grid, lds, s) : launch_gt_items<64>(items, P, grid, lds, s);
+    }
     if (st == RG_OK && metric == RG_METRIC_L2) {
         const uint32_t g2 = std::min<uint32_t>(nq, (uint32_t)prop.multiProcessorCount * 16u);
         const int it2 = items_for(K);
