@@ -626,7 +626,7 @@ rg_status rg_gt_shard_dev(const float *d_base, uint32_t nb, uint32_t bstride, co
     // register-stationary kernel for the BASELINE dimensions when the sort fits ITEMS=4 (K <= 128)
     uint32_t rs_tmw = 0, rs_bk = 0, rs_mqb = 0;
     if (items == 4 && !getenv("RG_GT_GENERIC")) {
-        if (dim == 200) { rs_tmw = getenv("RG_GT_RS_TMW2") ? 2 : 1; rs_bk = 40;   // default: 32 queries per wave, two workgroups per CU }
+        if (dim == 200) { rs_tmw = getenv("RG_GT_RS_TMW2") ? 2 : 1; rs_bk = 40; }   // default: 32 queries per wave, two workgroups per CU
         else if (dim == 512) { rs_tmw = 1; rs_bk = 64; }
         rs_mqb = 128 * rs_tmw;
     }
