@@ -12,6 +12,7 @@ ap.add_argument("--dim", type=int, default=200)
 ap.add_argument("--K", type=int, default=100)
 ap.add_argument("--metric", default="ip")
 ap.add_argument("--reps", type=int, default=2)
+ap.add_argument("--no-warmup", action="store_true", help="single launch (for rocprofv3 kernel-trace averages)")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 g = torch.Generator(device=dev); g.manual_seed(1)
@@ -22,7 +23,8 @@ q = torch.empty((a.nq, a.dim), device=dev).normal_(generator=g) * 0.5 + 0.3
 ids = torch.zeros((a.nq, a.K), dtype=torch.int32, device=dev)
 vals = torch.zeros((a.nq, a.K), device=dev)
 st = torch.cuda.current_stream().cuda_stream
-groundtruth.gt_shard_dev(base[: 1 << 16], q[:1024], a.metric, a.K, 0, ids[:1024], vals[:1024], stream=st); torch.cuda.synchronize()
+if not a.no_warmup:
+    groundtruth.gt_shard_dev(base[: 1 << 16], q[:1024], a.metric, a.K, 0, ids[:1024], vals[:1024], stream=st); torch.cuda.synchronize()
 best = 1e18
 for _ in range(a.reps):
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -27,7 +27,7 @@ if [ "$WHAT" = "search" ] || [ "$WHAT" = "all" ]; then
   done
 fi
 if [ "$WHAT" = "gt" ] || [ "$WHAT" = "all" ]; then
-  G="python $R/scripts/bench_gt.py --nq 16384 --reps 1"
+  G="python $R/scripts/bench_gt.py --nq 65536 --reps 1 --no-warmup"
   run gt_trace --kernel-trace --stats -d /tmp/rp_gt_trace -o s -- $G
   run gt_pmc1 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY -d /tmp/rp_gt_pmc1 -o s -- $G
   run gt_pmc2 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS -d /tmp/rp_gt_pmc2 -o s -- $G
