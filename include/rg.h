@@ -157,6 +157,15 @@ rg_status rg_groundtruth(const char *base_fbin, const char *query_fbin, const ch
 rg_status rg_build_roargraph(const float *base, uint32_t nb, uint32_t dim, uint32_t stride, const uint32_t *knn_ids,
                              uint32_t nq, uint32_t knn_k, int metric, uint32_t M_sq, uint32_t M_pjbp, uint32_t L_pjpq,
                              uint32_t num_threads, uint32_t *out_ep, uint64_t **out_offsets, uint32_t **out_nbrs);
+/* Same construction with phase 3 -- the n beam searches of the connectivity enhancement (index_bipartite.cpp:1192-1220,
+ * 1279-1350), 85-93 % of the build time -- on the GPU (K1 in build mode), `batch` nodes at a time (0 = auto); pruning
+ * and reverse-edge insertion stay on the host threads.  Nodes of a batch search the graph as it stood when the batch
+ * started, i.e. a valid scheduling of the reference's (already scheduling dependent) multi-threaded build, not its
+ * one-thread result.  Needs dim % 8 == 0 and stride % 4 == 0. */
+rg_status rg_build_roargraph_gpu(const float *base, uint32_t nb, uint32_t dim, uint32_t stride, const uint32_t *knn_ids,
+                                 uint32_t nq, uint32_t knn_k, int metric, uint32_t M_sq, uint32_t M_pjbp,
+                                 uint32_t L_pjpq, uint32_t num_threads, int device, uint32_t batch, uint32_t *out_ep,
+                                 uint64_t **out_offsets, uint32_t **out_nbrs);
 
 #ifdef __cplusplus
 }

@@ -6,18 +6,23 @@ import numpy as np
 from ._lib import METRIC, check, lib
 
 
-def build_roargraph(base, knn_ids, metric, M_sq=100, M_pjbp=35, L_pjpq=500, num_threads=1, dim=None):
+def build_roargraph(base, knn_ids, metric, M_sq=100, M_pjbp=35, L_pjpq=500, num_threads=1, dim=None, device=None,
+                    batch=0):
     """base [nb, stride] fp32, knn_ids [nq, K] (train-query ground truth, best first).
-    Returns (offsets u64[nb+1], nbrs u32[], ep).  Defaults are the paper's parameters (README.md:92-97)."""
+    Returns (offsets u64[nb+1], nbrs u32[], ep).  Defaults are the paper's parameters (README.md:92-97).
+    device=None: all on the CPU (one thread = the reference's T=1 result); device=N: phase 3 searches on GPU N."""
     base = np.ascontiguousarray(base, np.float32)
     knn_ids = np.ascontiguousarray(knn_ids, np.uint32)
     nb, stride = base.shape
     ep = C.c_uint32()
     po, pn = C.c_void_p(), C.c_void_p()
-    check(lib().rg_build_roargraph(base.ctypes.data_as(C.c_void_p), C.c_uint32(nb), C.c_uint32(dim or stride),
-                                   C.c_uint32(stride), knn_ids.ctypes.data_as(C.c_void_p), C.c_uint32(knn_ids.shape[0]),
-                                   C.c_uint32(knn_ids.shape[1]), METRIC[metric], C.c_uint32(M_sq), C.c_uint32(M_pjbp),
-                                   C.c_uint32(L_pjpq), C.c_uint32(num_threads), C.byref(ep), C.byref(po), C.byref(pn)))
+    common = (base.ctypes.data_as(C.c_void_p), C.c_uint32(nb), C.c_uint32(dim or stride), C.c_uint32(stride),
+              knn_ids.ctypes.data_as(C.c_void_p), C.c_uint32(knn_ids.shape[0]), C.c_uint32(knn_ids.shape[1]), METRIC[metric],
+              C.c_uint32(M_sq), C.c_uint32(M_pjbp), C.c_uint32(L_pjpq), C.c_uint32(num_threads))
+    if device is None:
+        check(lib().rg_build_roargraph(*common, C.byref(ep), C.byref(po), C.byref(pn)))
+    else:
+        check(lib().rg_build_roargraph_gpu(*common, C.c_int(device), C.c_uint32(batch), C.byref(ep), C.byref(po), C.byref(pn)))
     off = np.ctypeslib.as_array(C.cast(po, C.POINTER(C.c_uint64)), shape=(nb + 1,)).copy()
     ne = int(off[-1])
     nbrs = np.ctypeslib.as_array(C.cast(pn, C.POINTER(C.c_uint32)), shape=(max(ne, 1),)).copy()[:ne]

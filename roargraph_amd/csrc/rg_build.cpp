@@ -34,7 +34,10 @@
 #include <immintrin.h>
 #endif
 
+#include <hip/hip_runtime.h>
+
 #include "rg.h"
+#include "rg_index_struct.h"
 #include "rg_internal.h"
 
 namespace rg {
@@ -294,7 +297,141 @@ struct Builder {
         }
     }
 
-    void run(const uint32_t *knn, uint32_t nq, uint32_t kdim) {
+    // SearchProjectionGraphInternal (:1279-1350) over the live supply graph; returns the expanded nodes in pop order
+    void search_live(uint32_t node, std::vector<uint32_t> &seen, uint32_t &serial, std::vector<Nb> &expanded) {
+        if (seen.empty()) seen.assign(nd, 0u);
+        const uint32_t tag = ++serial;
+        Beam beam;
+        beam.reset(L);
+        expanded.clear();
+        expanded.reserve(L);
+        beam.insert(ep, cmp(ep, node));
+        seen[ep] = tag;
+        while (beam.has_open()) {
+            const Beam::E cur = beam.pop();
+            expanded.push_back(Nb{cur.id, cur.dist});
+            std::vector<uint32_t> nbrs;
+            {   // the reference iterates supply_nbrs_[cur] unlocked; take a snapshot so a concurrent writer cannot tear it
+                std::lock_guard<std::mutex> guard(locks[cur.id]);
+                nbrs = supply[cur.id];
+            }
+            for (uint32_t nb : nbrs) {
+                if (seen[nb] == tag || nb == node) continue;
+                seen[nb] = tag;
+                beam.insert(nb, cmp(nb, node));
+            }
+        }
+    }
+    // the same search over a frozen ELL snapshot (verification of the GPU batches)
+    void search_snapshot(uint32_t node, const uint32_t *ell, uint32_t S, std::vector<uint32_t> &seen, uint32_t &serial,
+                         std::vector<Nb> &expanded) const {
+        if (seen.empty()) seen.assign(nd, 0u);
+        const uint32_t tag = ++serial;
+        Beam beam;
+        beam.reset(L);
+        expanded.clear();
+        beam.insert(ep, cmp(ep, node));
+        seen[ep] = tag;
+        while (beam.has_open()) {
+            const Beam::E cur = beam.pop();
+            expanded.push_back(Nb{cur.id, cur.dist});
+            const uint32_t *row = ell + (size_t)cur.id * S;
+            for (uint32_t j = 0; j < row[0]; ++j) {
+                const uint32_t nb = row[1 + j];
+                if (seen[nb] == tag || nb == node) continue;
+                seen[nb] = tag;
+                beam.insert(nb, cmp(nb, node));
+            }
+        }
+    }
+    // rest of the per-node work of phase 3 (:1203-1215)
+    void link_from_search(uint32_t node, std::vector<Nb> &expanded) {
+        expanded.erase(std::remove_if(expanded.begin(), expanded.end(), [&](const Nb &x) { return x.id == node; }), expanded.end());
+        std::vector<uint32_t> pruned;
+        prune_search(expanded, node, pruned);
+        {
+            std::lock_guard<std::mutex> guard(locks[node]);
+            supply[node] = pruned;
+        }
+        add_reverse(supply, node, 2 * M, true);
+    }
+
+    // Phase 3 with the n beam searches on the GPU (K1 in build mode), in batches: every node of a batch searches the
+    // supply graph as it stood when the batch started (the reference's multi-threaded build sees a similarly racy
+    // graph; at one thread it sees every earlier node's links -- so this variant is NOT the T=1 result, it is a valid
+    // scheduling of the same algorithm).  Pruning and reverse-edge insertion stay on the host threads.
+    int gpu_device = -1;
+    uint32_t gpu_batch = 0;
+    bool gpu_verify = false;
+    std::string gpu_error;
+    bool phase3_gpu() {
+        auto fail = [&](const std::string &m) { gpu_error = m; return false; };
+        const uint32_t S = (2 * M + 1 + 15) / 16 * 16;
+        const uint32_t cap = (2 * L + 63) / 64 * 64;
+        const uint32_t B = gpu_batch ? gpu_batch : std::max<uint32_t>(8192, std::min<uint32_t>(131072, nd / 24));
+        if (hipSetDevice(gpu_device) != hipSuccess) return fail("cannot select the build GPU");
+        float *d_base = nullptr;
+        uint2_pod *d_exp = nullptr;
+        uint32_t *d_nexp = nullptr;
+        rg_index *ix = nullptr;
+        std::vector<uint32_t> h_ell((size_t)nd * S);
+        std::vector<uint2_pod> h_exp((size_t)B * cap);
+        std::vector<uint32_t> h_nexp(B);
+        bool ok = hipMalloc(&d_base, (size_t)nd * stride * 4) == hipSuccess &&
+                  hipMemcpy(d_base, base, (size_t)nd * stride * 4, hipMemcpyHostToDevice) == hipSuccess &&
+                  hipMalloc(&d_exp, (size_t)B * cap * 8) == hipSuccess && hipMalloc(&d_nexp, (size_t)B * 4) == hipSuccess;
+        if (ok) ok = build_index_create(d_base, nd, dim, (uint32_t)stride, ep, l2 ? RG_METRIC_L2 : RG_METRIC_IP, gpu_device, S, &ix) == RG_OK;
+        std::atomic<uint32_t> mismatches(0);
+        std::vector<std::vector<uint32_t>> stamp(std::max(1, threads));
+        std::vector<uint32_t> serial(std::max(1, threads), 0);
+        for (uint32_t b0 = 0; ok && b0 < nd; b0 += B) {
+            const uint32_t n = std::min(B, nd - b0);
+            parallel_for(nd, 4096, [&](uint32_t i, int) {
+                uint32_t *row = h_ell.data() + (size_t)i * S;
+                const std::vector<uint32_t> &l = supply[i];
+                row[0] = (uint32_t)l.size();
+                std::memcpy(row + 1, l.data(), l.size() * 4);
+            });
+            ok = build_index_set_ell(ix, h_ell.data(), nullptr) == RG_OK &&
+                 build_search_dev(ix, b0, n, L, d_exp, cap, d_nexp, nullptr) == RG_OK &&
+                 hipMemcpy(h_nexp.data(), d_nexp, (size_t)n * 4, hipMemcpyDeviceToHost) == hipSuccess &&
+                 hipMemcpy(h_exp.data(), d_exp, (size_t)n * cap * 8, hipMemcpyDeviceToHost) == hipSuccess;
+            if (!ok) break;
+            parallel_for(n, 64, [&](uint32_t i, int t) {
+                const uint32_t node = b0 + i;
+                std::vector<Nb> expanded;
+                if (h_nexp[i] > cap) {
+                    search_snapshot(node, h_ell.data(), S, stamp[t], serial[t], expanded);   // expansion list did not fit
+                } else {
+                    expanded.resize(h_nexp[i]);
+                    const uint2_pod *e = h_exp.data() + (size_t)i * cap;
+                    for (uint32_t j = 0; j < h_nexp[i]; ++j) {
+                        float d;
+                        std::memcpy(&d, &e[j].x, 4);
+                        expanded[j] = Nb{e[j].y, d};
+                    }
+                    if (gpu_verify) {
+                        std::vector<Nb> ref;
+                        search_snapshot(node, h_ell.data(), S, stamp[t], serial[t], ref);
+                        bool same = ref.size() == expanded.size();
+                        for (size_t j = 0; same && j < ref.size(); ++j)
+                            same = ref[j].id == expanded[j].id && std::memcmp(&ref[j].dist, &expanded[j].dist, 4) == 0;
+                        if (!same) mismatches.fetch_add(1);
+                    }
+                }
+                link_from_search(node, expanded);
+            });
+        }
+        if (ix) rg_index_close(ix);
+        if (d_base) (void)hipFree(d_base);
+        if (d_exp) (void)hipFree(d_exp);
+        if (d_nexp) (void)hipFree(d_nexp);
+        if (!ok) return fail(std::string("GPU phase 3 failed: ") + rg_last_error());
+        if (mismatches.load()) return fail("GPU phase 3: " + std::to_string(mismatches.load()) + " expansion lists differ from the host search");
+        return true;
+    }
+
+    bool run(const uint32_t *knn, uint32_t nq, uint32_t kdim) {
         proj.assign(nd, {});
         supply.assign(nd, {});
         locks = std::vector<std::mutex>(nd);
@@ -347,41 +484,17 @@ struct Builder {
         });
         for (uint32_t i = 0; i < nd; ++i) supply[i] = proj[i];   // :1183-1188
         // ---- phase 3 (:1192-1220): connectivity enhancement -- beam search from the entry point towards every node
-        std::vector<std::vector<uint32_t>> stamp(std::max(1, threads));
-        std::vector<uint32_t> serial(std::max(1, threads), 0);
-        parallel_for(nd, 2048, [&](uint32_t node, int t) {
-            std::vector<uint32_t> &seen = stamp[t];
-            if (seen.empty()) seen.assign(nd, 0u);
-            const uint32_t tag = ++serial[t];
-            Beam beam;
-            beam.reset(L);
-            std::vector<Nb> expanded;
-            expanded.reserve(L);
-            beam.insert(ep, cmp(ep, node));
-            seen[ep] = tag;
-            while (beam.has_open()) {
-                const Beam::E cur = beam.pop();
-                expanded.push_back(Nb{cur.id, cur.dist});
-                std::vector<uint32_t> nbrs;
-                {   // the reference iterates supply_nbrs_[cur] unlocked; take a snapshot so a concurrent writer cannot tear it
-                    std::lock_guard<std::mutex> guard(locks[cur.id]);
-                    nbrs = supply[cur.id];
-                }
-                for (uint32_t nb : nbrs) {
-                    if (seen[nb] == tag || nb == node) continue;
-                    seen[nb] = tag;
-                    beam.insert(nb, cmp(nb, node));
-                }
-            }
-            expanded.erase(std::remove_if(expanded.begin(), expanded.end(), [&](const Nb &x) { return x.id == node; }), expanded.end());
-            std::vector<uint32_t> pruned;
-            prune_search(expanded, node, pruned);
-            {
-                std::lock_guard<std::mutex> guard(locks[node]);
-                supply[node] = pruned;
-            }
-            add_reverse(supply, node, 2 * M, true);
-        });
+        if (gpu_device >= 0) {
+            if (!phase3_gpu()) return false;
+        } else {
+            std::vector<std::vector<uint32_t>> stamp(std::max(1, threads));
+            std::vector<uint32_t> serial(std::max(1, threads), 0);
+            parallel_for(nd, 2048, [&](uint32_t node, int t) {
+                std::vector<Nb> expanded;
+                search_live(node, stamp[t], serial[t], expanded);
+                link_from_search(node, expanded);
+            });
+        }
         // ---- phase 4 (:1224-1248)
         parallel_for(nd, 2048, [&](uint32_t node, int) {
             if (supply[node].size() <= M) return;
@@ -401,22 +514,25 @@ struct Builder {
             }
             proj[i].insert(proj[i].end(), ok.begin(), ok.end());
         });
+        return true;
     }
 };
 
 }  // namespace
 }  // namespace rg
 
-extern "C" rg_status rg_build_roargraph(const float *base, uint32_t nb, uint32_t dim, uint32_t stride,
-                                        const uint32_t *knn_ids, uint32_t nq, uint32_t knn_k, int metric, uint32_t M_sq,
-                                        uint32_t M_pjbp, uint32_t L_pjpq, uint32_t num_threads, uint32_t *out_ep,
-                                        uint64_t **out_offsets, uint32_t **out_nbrs) {
+static rg_status build_impl(const float *base, uint32_t nb, uint32_t dim, uint32_t stride, const uint32_t *knn_ids,
+                            uint32_t nq, uint32_t knn_k, int metric, uint32_t M_sq, uint32_t M_pjbp, uint32_t L_pjpq,
+                            uint32_t num_threads, int device, uint32_t batch, uint32_t *out_ep, uint64_t **out_offsets,
+                            uint32_t **out_nbrs) {
     using rg::set_error;
     if (!base || !knn_ids || !out_ep || !out_offsets || !out_nbrs) return set_error(RG_ERR_ARG, "null argument");
     if (nb == 0 || dim == 0 || stride < dim || M_pjbp == 0 || L_pjpq == 0 || knn_k == 0)
         return set_error(RG_ERR_ARG, "bad build parameters");
     if (metric != RG_METRIC_L2 && metric != RG_METRIC_IP && metric != RG_METRIC_COSINE)
         return set_error(RG_ERR_ARG, "Unknown distance type");
+    if (device >= 0 && (dim % 8 || stride % 4))
+        return set_error(RG_ERR_ARG, "GPU-assisted build needs dim % 8 == 0 and stride % 4 == 0 (load the base with rg_fbin_load)");
     for (size_t i = 0; i < (size_t)nq * knn_k; ++i)
         if (knn_ids[i] >= nb) return set_error(RG_ERR_FORMAT, "learn base knn file references a base id >= npts");
     std::vector<float> normed;
@@ -435,7 +551,10 @@ extern "C" rg_status rg_build_roargraph(const float *base, uint32_t nb, uint32_t
 #endif
     b.M = M_pjbp; b.L = L_pjpq; b.Nq = M_sq;
     b.threads = (int)std::max<uint32_t>(1, num_threads);
-    b.run(knn_ids, nq, knn_k);
+    b.gpu_device = device;
+    b.gpu_batch = batch;
+    b.gpu_verify = getenv("RG_BUILD_VERIFY") != nullptr;
+    if (!b.run(knn_ids, nq, knn_k)) return set_error(RG_ERR_DEVICE, b.gpu_error);
     size_t edges = 0;
     for (auto &l : b.proj) edges += l.size();
     uint64_t *off = (uint64_t *)std::malloc(((size_t)nb + 1) * 8);
@@ -452,4 +571,24 @@ extern "C" rg_status rg_build_roargraph(const float *base, uint32_t nb, uint32_t
     *out_offsets = off;
     *out_nbrs = nbr;
     return RG_OK;
+}
+
+extern "C" rg_status rg_build_roargraph(const float *base, uint32_t nb, uint32_t dim, uint32_t stride,
+                                        const uint32_t *knn_ids, uint32_t nq, uint32_t knn_k, int metric, uint32_t M_sq,
+                                        uint32_t M_pjbp, uint32_t L_pjpq, uint32_t num_threads, uint32_t *out_ep,
+                                        uint64_t **out_offsets, uint32_t **out_nbrs) {
+    return build_impl(base, nb, dim, stride, knn_ids, nq, knn_k, metric, M_sq, M_pjbp, L_pjpq, num_threads, -1, 0, out_ep,
+                      out_offsets, out_nbrs);
+}
+
+extern "C" rg_status rg_build_roargraph_gpu(const float *base, uint32_t nb, uint32_t dim, uint32_t stride,
+                                            const uint32_t *knn_ids, uint32_t nq, uint32_t knn_k, int metric,
+                                            uint32_t M_sq, uint32_t M_pjbp, uint32_t L_pjpq, uint32_t num_threads,
+                                            int device, uint32_t batch, uint32_t *out_ep, uint64_t **out_offsets,
+                                            uint32_t **out_nbrs) {
+    int ndev = 0;
+    if (device < 0 || hipGetDeviceCount(&ndev) != hipSuccess || device >= ndev)
+        return rg::set_error(RG_ERR_DEVICE, "no HIP device visible: the gfx950 path cannot run (there is no CPU fallback)");
+    return build_impl(base, nb, dim, stride, knn_ids, nq, knn_k, metric, M_sq, M_pjbp, L_pjpq, num_threads, device, batch,
+                      out_ep, out_offsets, out_nbrs);
 }

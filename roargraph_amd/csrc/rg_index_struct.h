@@ -1,0 +1,57 @@
+// rg_index_struct.h -- the opaque rg_index of include/rg.h (shared by rg_search.hip and the GPU-assisted build)
+#pragma once
+#include <cstddef>
+#include <cstdint>
+
+#include "rg.h"
+
+struct rg_index {
+    int device = 0;
+    int metric = RG_METRIC_IP;
+    uint32_t nd = 0, dim = 0, stride = 0, ep = 0;
+    float *d_base = nullptr;
+    bool own_base = false;
+    // graph
+    uint64_t *d_offsets = nullptr;
+    uint32_t *d_nbrs = nullptr;
+    uint32_t *d_ell = nullptr;
+    uint32_t ell_stride = 0;
+    uint64_t n_edges = 0;
+    uint32_t max_deg = 0;
+    // search scratch (lazily sized)
+    uint32_t *d_visited = nullptr;
+    uint32_t *d_epoch = nullptr;
+    uint32_t slots = 0, vwords = 0;
+    uint32_t *d_counter = nullptr;
+    unsigned long long *d_status = nullptr;
+    unsigned long long *h_status = nullptr;  // pinned
+    // knobs
+    int waves_per_cu = 0;   // 0 = auto
+    int rows_per_pass = 4;  // 4*R (R = staging ring depth)
+    int force_csr = 0;
+    int diag = 0;
+    // 0 = exact visited words in HBM; 1 = LDS exact-match filter only (cmps = evaluations performed);
+    // 2 = LDS filter + id log + exact distinct count (K4): everything bit-exact incl. cmps (default)
+    int visited_mode = 2;
+    uint32_t *d_qlog = nullptr, *d_qlog_n = nullptr, *d_ovf = nullptr;
+    size_t qlog_cap_total = 0;
+    uint32_t qlog_nq = 0, logcap = 0;
+    int log_cap_knob = 0;       // 0 = auto; tests force small logs to exercise the exact fallback
+    int count_table_log2 = 15;  // K4 LDS table: 2^15 ids = 128 KiB
+    struct Pending { bool active = false; const float *q = nullptr; uint32_t nq = 0, qstride = 0, k = 0, L = 0; uint32_t *ids = nullptr; float *dists = nullptr; uint32_t *cmps = nullptr, *hops = nullptr; } pending;
+    int filter_log2 = 11;   // VIS=1: 2^11 16-bit entries = 4 KiB
+    int num_cu = 256;
+    size_t lds_per_cu = 160 * 1024;
+};
+
+namespace rg {
+struct uint2_pod { uint32_t x, y; };   // (distance bits, id) pairs of the build-mode expansion list
+// K1 in build mode (SearchProjectionGraphInternal, src/index_bipartite.cpp:1279-1350): query i is base row node0+i, the
+// node itself is never scored, and the output is the sequence of expanded (popped) nodes instead of the top-k.
+rg_status build_search_dev(rg_index *ix, uint32_t node0, uint32_t n, uint32_t L, uint2_pod *d_exp, uint32_t exp_cap,
+                           uint32_t *d_nexp, void *stream);
+// an index over a caller-owned device base whose ELL adjacency (fixed stride) is overwritten between batches
+rg_status build_index_create(const float *d_base, uint32_t nd, uint32_t dim, uint32_t stride, uint32_t ep, int metric,
+                             int device, uint32_t ell_stride, rg_index **out);
+rg_status build_index_set_ell(rg_index *ix, const uint32_t *h_ell, void *stream);
+}  // namespace rg

@@ -73,6 +73,9 @@ struct SearchParams {
     uint32_t logcap;
     uint32_t *qlog_n;         // [nq] number of ids scored (may exceed logcap: overflow)
     const uint32_t *qlist;    // optional: work item i is query qlist[i] (fallback pass), results other than cmps untouched
+    uint2 *out_exp;           // build mode (graph construction phase 3): [nq][exp_cap] expanded (dist bits, id) in pop order
+    uint32_t exp_cap, tgt_base;
+    uint32_t *out_nexp;       // [nq] number of expansions
     uint32_t id_bits;         // VIS=1: ceil(log2(nd))
 };
 
@@ -82,7 +85,7 @@ struct Beam {
 };
 
 // closest_unexpanded (neighbor.h:185-192): flag the entry at cur, move cur to the next unflagged entry
-__device__ __forceinline__ uint32_t beam_pop(Beam &bm, int lane) {
+__device__ __forceinline__ uint2 beam_pop(Beam &bm, int lane) {
     uint2 e = bm.ent[bm.cur];
     if (lane == 0) bm.ent[bm.cur].y = e.y | kFlagBit;
     uint32_t c = bm.cur + 1;
@@ -96,7 +99,7 @@ __device__ __forceinline__ uint32_t beam_pop(Beam &bm, int lane) {
     }
     bm.cur = c;
     wave_sync();
-    return e.y & ~kFlagBit;
+    return make_uint2(e.x, e.y & ~kFlagBit);
 }
 
 // Insert the n (<= 64) scored candidates (lane i holds candidate i) -- the net effect of n calls of
@@ -220,6 +223,8 @@ __global__ void __launch_bounds__(64) rg_search_kernel(SearchParams P) {
         qi = readlane_u(qi, 0);
         if (qi >= P.nq) break;
         const bool cmps_only = P.qlist != nullptr;
+        const bool build = P.out_exp != nullptr;
+        const uint32_t tgt = P.tgt_base + qi;   // build mode: the node being linked is never scored (:1327)
         if (cmps_only) qi = P.qlist[qi];
         const float *query = P.queries + (size_t)qi * P.qstride;
         uint32_t *qlog = (VIS == 1 && P.qlog) ? P.qlog + (size_t)qi * P.logcap : nullptr;
@@ -251,7 +256,9 @@ __global__ void __launch_bounds__(64) rg_search_kernel(SearchParams P) {
 
         uint32_t cmps = 0, hops = 0;
         while (bm.cur < bm.size) {                                         // has_unexpanded_node, :2356
-            const uint32_t node = beam_pop(bm, lane);                      // :2358
+            const uint2 popped = beam_pop(bm, lane);                       // :2358
+            const uint32_t node = popped.y;
+            if (build && lane == 0 && hops < P.exp_cap) P.out_exp[(size_t)qi * P.exp_cap + hops] = popped;   // full_retset, :1319
             ++hops;                                                        // :2366
             // adjacency of `node`, 64 words at a time
             uint32_t deg, first = 0;
@@ -278,6 +285,7 @@ __global__ void __launch_bounds__(64) rg_search_kernel(SearchParams P) {
                     have = c0 + lane < deg;
                     if (have) id = list[c0 + lane];
                 }
+                if (build && id == tgt) have = false;
                 // visited test-and-set (:2378, :2385); same-hop duplicates are resolved by the atomic's order
                 bool fresh = false;
                 if (VIS == 1) {
@@ -359,7 +367,8 @@ __global__ void __launch_bounds__(64) rg_search_kernel(SearchParams P) {
         }
 
         // results (:2408-2418)
-        if (cmps_only) {
+        if (cmps_only || build) {
+            if (build && lane == 0) P.out_nexp[qi] = hops;
         } else if (bm.size < P.k) {
             if (lane == 0) atomicMin(P.status, ((unsigned long long)qi << 32) | bm.size);
         } else {
@@ -519,44 +528,7 @@ __global__ void rg_graph_stats_kernel(const uint64_t *offsets, const uint32_t *n
 // -------------------------------------------------------------------------------------------------- host
 using rg::set_error;
 
-struct rg_index {
-    int device = 0;
-    int metric = RG_METRIC_IP;
-    uint32_t nd = 0, dim = 0, stride = 0, ep = 0;
-    float *d_base = nullptr;
-    bool own_base = false;
-    // graph
-    uint64_t *d_offsets = nullptr;
-    uint32_t *d_nbrs = nullptr;
-    uint32_t *d_ell = nullptr;
-    uint32_t ell_stride = 0;
-    uint64_t n_edges = 0;
-    uint32_t max_deg = 0;
-    // search scratch (lazily sized)
-    uint32_t *d_visited = nullptr;
-    uint32_t *d_epoch = nullptr;
-    uint32_t slots = 0, vwords = 0;
-    uint32_t *d_counter = nullptr;
-    unsigned long long *d_status = nullptr;
-    unsigned long long *h_status = nullptr;  // pinned
-    // knobs
-    int waves_per_cu = 0;   // 0 = auto
-    int rows_per_pass = 4;  // 4*R (R = staging ring depth)
-    int force_csr = 0;
-    int diag = 0;
-    // 0 = exact visited words in HBM; 1 = LDS exact-match filter only (cmps = evaluations performed);
-    // 2 = LDS filter + id log + exact distinct count (K4): everything bit-exact incl. cmps (default)
-    int visited_mode = 2;
-    uint32_t *d_qlog = nullptr, *d_qlog_n = nullptr, *d_ovf = nullptr;
-    size_t qlog_cap_total = 0;
-    uint32_t qlog_nq = 0, logcap = 0;
-    int log_cap_knob = 0;       // 0 = auto; tests force small logs to exercise the exact fallback
-    int count_table_log2 = 15;  // K4 LDS table: 2^15 ids = 128 KiB
-    struct Pending { bool active = false; const float *q = nullptr; uint32_t nq = 0, qstride = 0, k = 0, L = 0; uint32_t *ids = nullptr; float *dists = nullptr; uint32_t *cmps = nullptr, *hops = nullptr; } pending;
-    int filter_log2 = 11;   // VIS=1: 2^11 16-bit entries = 4 KiB
-    int num_cu = 256;
-    size_t lds_per_cu = 160 * 1024;
-};
+#include "rg_index_struct.h"
 
 namespace rg {
 
@@ -667,10 +639,12 @@ static rg_status launch_search_r(rg_index *ix, const SearchParams &P, uint32_t g
     }
 }
 
+struct BuildOut { uint2_pod *exp; uint32_t exp_cap, node0; uint32_t *nexp; };
+
 // one K1 launch.  mode: 0 exact HBM visited words, 1 LDS filter (optionally logging the scored ids).
 static rg_status launch_k1(rg_index *ix, int mode, const float *d_q, uint32_t nq, uint32_t qstride, uint32_t k,
                            uint32_t L, uint32_t *d_ids, float *d_dists, uint32_t *d_cmps, uint32_t *d_hops,
-                           const uint32_t *qlist, bool with_log, hipStream_t s) {
+                           const uint32_t *qlist, bool with_log, hipStream_t s, const BuildOut *bp = nullptr) {
     int R = std::max(1, std::min(4, ix->rows_per_pass / 4));
     if (R == 3) R = 2;
     const int saved_mode = ix->visited_mode;
@@ -701,6 +675,8 @@ static rg_status launch_k1(rg_index *ix, int mode, const float *d_q, uint32_t nq
     P.id_bits = id_bits_of(ix->nd);
     P.qlog = with_log ? ix->d_qlog : nullptr; P.logcap = ix->logcap; P.qlog_n = with_log ? ix->d_qlog_n : nullptr;
     P.qlist = qlist;
+    P.out_exp = nullptr; P.exp_cap = 0; P.tgt_base = 0; P.out_nexp = nullptr;
+    if (bp) { P.out_exp = reinterpret_cast<uint2 *>(bp->exp); P.exp_cap = bp->exp_cap; P.tgt_base = bp->node0; P.out_nexp = bp->nexp; }
     const bool l2 = ix->metric == RG_METRIC_L2, ell = ix->d_ell != nullptr;
     if (l2 && ell) return launch_search_r<true, true>(ix, P, grid, lds, R, s);
     if (l2) return launch_search_r<true, false>(ix, P, grid, lds, R, s);
@@ -799,6 +775,49 @@ static rg_status score_dev(rg_index *ix, const float *d_query, const uint32_t *d
     else
         hipLaunchKernelGGL((rg_score_kernel<false, R>), dim3(grid), dim3(64), lds, s, ix->d_base, ix->stride, ix->dim, d_query, d_ids, n, d_out, stage_floats);
     RG_HIP(hipGetLastError());
+    return RG_OK;
+}
+
+rg_status build_search_dev(rg_index *ix, uint32_t node0, uint32_t n, uint32_t L, uint2_pod *d_exp, uint32_t exp_cap,
+                           uint32_t *d_nexp, void *stream) {
+    if (!ix || !d_exp || !d_nexp) return set_error(RG_ERR_ARG, "null argument");
+    if (n == 0) return RG_OK;
+    if ((uint64_t)node0 + n > ix->nd) return set_error(RG_ERR_ARG, "node range out of bounds");
+    RG_HIP(hipSetDevice(ix->device));
+    RG_HIP(hipMemsetAsync(ix->d_status, 0xff, 8, (hipStream_t)stream));
+    BuildOut bo{d_exp, exp_cap, node0, d_nexp};
+    // queries are the base rows themselves; k = 1 (no top-k is written in build mode)
+    return launch_k1(ix, 1, ix->d_base + (size_t)node0 * ix->stride, n, ix->stride, 1, L, nullptr, nullptr, nullptr, nullptr,
+                     nullptr, false, (hipStream_t)stream, &bo);
+}
+
+rg_status build_index_create(const float *d_base, uint32_t nd, uint32_t dim, uint32_t stride, uint32_t ep, int metric,
+                             int device, uint32_t ell_stride, rg_index **out) {
+    rg_status st = pick_device(device);
+    if (st != RG_OK) return st;
+    if (dim == 0 || dim % 8 || stride < dim || stride % 4 || ((uintptr_t)d_base & 15))
+        return set_error(RG_ERR_ARG, "device base must be 16-byte aligned with dim % 8 == 0 and stride % 4 == 0");
+    rg_index *ix = new rg_index();
+    ix->device = device; ix->metric = metric; ix->nd = nd; ix->dim = dim; ix->stride = stride; ix->ep = ep;
+    ix->d_base = const_cast<float *>(d_base);
+    ix->ell_stride = ell_stride;
+    ix->max_deg = ell_stride - 1;
+    hipError_t e = hipMalloc(&ix->d_ell, (size_t)nd * ell_stride * 4);
+    if (e == hipSuccess) e = hipMemset(ix->d_ell, 0, (size_t)nd * ell_stride * 4);
+    if (e == hipSuccess) e = hipMalloc(&ix->d_counter, 64);
+    if (e == hipSuccess) e = hipMalloc(&ix->d_status, 64);
+    if (e == hipSuccess) e = hipHostMalloc(&ix->h_status, 64);
+    hipDeviceProp_t prop;
+    if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) { rg_index_close(ix); return set_error(RG_ERR_DEVICE, hipGetErrorString(e)); }
+    ix->num_cu = prop.multiProcessorCount;
+    *out = ix;
+    return RG_OK;
+}
+
+rg_status build_index_set_ell(rg_index *ix, const uint32_t *h_ell, void *stream) {
+    RG_HIP(hipSetDevice(ix->device));
+    RG_HIP(hipMemcpyAsync(ix->d_ell, h_ell, (size_t)ix->nd * ix->ell_stride * 4, hipMemcpyHostToDevice, (hipStream_t)stream));
     return RG_OK;
 }
 

@@ -22,6 +22,7 @@ ap.add_argument("--metric", default="ip")
 ap.add_argument("--threads", type=int, default=0)
 ap.add_argument("--L", default="10,20,50,100,200,500,1000")
 ap.add_argument("--out", default="")
+ap.add_argument("--build-device", type=int, default=-1, help=">= 0: phase 3 of the build on that GPU")
 a = ap.parse_args()
 ntrain = a.ntrain or a.nb
 threads = a.threads or min(64, os.cpu_count() or 1)   # README.md:92-97 builds with T=64
@@ -41,9 +42,11 @@ res["gt_train_distances_per_s"] = ntrain * a.nb / res["gt_train_s"]
 
 hb = base.cpu().numpy()
 t0 = time.perf_counter()
-off, nbrs, ep = build.build_roargraph(hb, ti.cpu().numpy().view(np.uint32), a.metric, 100, 35, 500, num_threads=threads)
+off, nbrs, ep = build.build_roargraph(hb, ti.cpu().numpy().view(np.uint32), a.metric, 100, 35, 500, num_threads=threads,
+                                      device=a.build_device if a.build_device >= 0 else None)
 res["build_s"] = time.perf_counter() - t0
 res["build_threads"] = threads
+res["build_phase3"] = "gpu" if a.build_device >= 0 else "cpu"
 deg = np.diff(off.astype(np.int64))
 res["degree_avg_min_max"] = [float(deg.mean()), int(deg.min()), int(deg.max())]
 

@@ -89,3 +89,26 @@ def test_end_to_end_pipeline_gt_build_search(oracle):
         assert (got[1].view(np.uint32) == want[1].view(np.uint32)).all()
     assert oracle.recall(got[0], gt, 10) > 0.97
     ix.close()
+
+
+def test_gpu_assisted_build(oracle, monkeypatch):
+    """rg_build_roargraph_gpu: phase 3's beam searches run on the GPU (K1 in build mode).  With RG_BUILD_VERIFY every
+    expansion list coming back from the GPU is compared, bit for bit, with the host search over the same frozen graph
+    snapshot; the finished index must respect the degree bound and search as well as the all-CPU build."""
+    from roargraph_amd import build
+    monkeypatch.setenv("RG_BUILD_VERIFY", "1")
+    rng = np.random.default_rng(33)
+    for metric, d in (("ip", 200), ("l2", 64)):
+        base = rng.standard_normal((5000, d)).astype(np.float32)
+        train = (rng.standard_normal((2500, d)) * 0.5 + 0.3).astype(np.float32)
+        q = (rng.standard_normal((150, d)) * 0.5 + 0.3).astype(np.float32)
+        knn, _, _ = oracle.groundtruth_f64(base, train, metric, 100, nthreads=16)
+        gt, _, _ = oracle.groundtruth_f64(base, q, metric, 100, nthreads=16)
+        off_c, nbrs_c, ep_c = build.build_roargraph(base, knn, metric, 100, 24, 150, num_threads=8)
+        off_g, nbrs_g, ep_g = build.build_roargraph(base, knn, metric, 100, 24, 150, num_threads=8, device=0, batch=700)
+        assert ep_c == ep_g
+        deg = np.diff(off_g.astype(np.int64))
+        assert deg.max() <= 48 and nbrs_g.max() < 5000
+        rc = oracle.recall(oracle.search(base, metric, off_c, nbrs_c, ep_c, q, 10, 100, nthreads=8)[0], gt, 10)
+        rg_ = oracle.recall(oracle.search(base, metric, off_g, nbrs_g, ep_g, q, 10, 100, nthreads=8)[0], gt, 10)
+        assert rg_ > rc - 0.03, (metric, rc, rg_)
