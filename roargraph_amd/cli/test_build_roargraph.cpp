@@ -29,6 +29,7 @@ int main(int argc, char **argv) {
     a.add("L_pjpq", false, "Priority queue length for projection graph searching", "32");
     a.add("num_threads", false, "Number of threads used for building index", ncpu, "T");
     a.add("learn_base_nn_path", true, "Path of learn-base NN file");
+    a.add("device", false, "HIP device for the phase-3 beam searches (-1 = all on the CPU, the reference's path)", "-1");
     if (!a.parse(argc, argv)) return -1;
     if (a.help()) { a.usage(std::cout); return 0; }
     std::cout << "sampled query: " << a.str("sampled_query_data_path") << std::endl;
@@ -53,8 +54,14 @@ int main(int argc, char **argv) {
     uint64_t *off = nullptr;
     // the reference passes the UNALIGNED dimension as the row length (test_build_roargraph.cpp:117) -- rows are zero
     // padded here, so scoring the padded stride gives the same values
-    CK(rg_build_roargraph(base, n, stride, stride, knn, knn_n, knn_k, metric, (uint32_t)a.u("M_sq"), (uint32_t)a.u("M_pjbp"),
-                          (uint32_t)a.u("L_pjpq"), (uint32_t)a.u("num_threads"), &ep, &off, &nbrs));
+    const int device = std::atoi(a.str("device").c_str());
+    if (device < 0)
+        CK(rg_build_roargraph(base, n, stride, stride, knn, knn_n, knn_k, metric, (uint32_t)a.u("M_sq"), (uint32_t)a.u("M_pjbp"),
+                              (uint32_t)a.u("L_pjpq"), (uint32_t)a.u("num_threads"), &ep, &off, &nbrs));
+    else
+        CK(rg_build_roargraph_gpu(base, n, stride, stride, knn, knn_n, knn_k, metric, (uint32_t)a.u("M_sq"),
+                                  (uint32_t)a.u("M_pjbp"), (uint32_t)a.u("L_pjpq"), (uint32_t)a.u("num_threads"), device, 0,
+                                  &ep, &off, &nbrs));
     const double secs = std::chrono::duration<double>(std::chrono::high_resolution_clock::now() - s).count();
     std::cout << "projection ep: " << ep << std::endl;
     std::cout << "Projection degree avg: " << (double)off[n] / n << std::endl;
