@@ -368,6 +368,8 @@ struct Builder {
         auto fail = [&](const std::string &m) { gpu_error = m; return false; };
         const uint32_t S = (2 * M + 1 + 15) / 16 * 16;
         const uint32_t cap = (2 * L + 63) / 64 * 64;
+        // batch schedule: a batch never exceeds a quarter of the nodes already linked (the graph changes fastest early
+        // on, when a stale snapshot hurts most), between 2,048 and Bmax nodes; a fixed size if the caller gave one
         const uint32_t B = gpu_batch ? gpu_batch : std::max<uint32_t>(8192, std::min<uint32_t>(131072, nd / 24));
         if (hipSetDevice(gpu_device) != hipSuccess) return fail("cannot select the build GPU");
         float *d_base = nullptr;
@@ -384,8 +386,18 @@ struct Builder {
         std::atomic<uint32_t> mismatches(0);
         std::vector<std::vector<uint32_t>> stamp(std::max(1, threads));
         std::vector<uint32_t> serial(std::max(1, threads), 0);
-        for (uint32_t b0 = 0; ok && b0 < nd; b0 += B) {
-            const uint32_t n = std::min(B, nd - b0);
+        // The projection graph is barely connected before phase 3 (searches from the entry point expand a handful of
+        // nodes), so the first nodes are linked one after another on the host, exactly as the reference does at one
+        // thread; the GPU takes over once the graph is navigable, in batches of at most a quarter of what is linked.
+        const uint32_t warm = gpu_batch ? 0u : std::min<uint32_t>(nd, 2048u);
+        for (uint32_t node = 0; ok && node < warm; ++node) {
+            std::vector<Nb> expanded;
+            search_live(node, stamp[0], serial[0], expanded);
+            link_from_search(node, expanded);
+        }
+        for (uint32_t b0 = warm, n = 0; ok && b0 < nd; b0 += n) {
+            n = gpu_batch ? B : std::min(B, std::max<uint32_t>(512, b0 / 4));
+            n = std::min(n, nd - b0);
             parallel_for(nd, 4096, [&](uint32_t i, int) {
                 uint32_t *row = h_ell.data() + (size_t)i * S;
                 const std::vector<uint32_t> &l = supply[i];
