@@ -56,6 +56,7 @@ def parse():
     ap.add_argument("--filter-log2", type=int, default=9)
     ap.add_argument("--waves-per-cu", type=int, default=0)
     ap.add_argument("--rows-per-pass", type=int, default=0)
+    ap.add_argument("--no-other-modes", action="store_true", help="skip timing the non-default visited modes (profiling runs)")
     ap.add_argument("--sweep", default="", help="comma list of extra L_pq values to report (not part of the timed metric)")
     ap.add_argument("--gt-nq", type=int, default=65536, help="queries of the ground-truth (K2) leg; 0 = skip")
     ap.add_argument("--gt-K", type=int, default=100)
@@ -165,6 +166,27 @@ def recall_check(args, dev):
             "index": "RoarGraph built by rg_build_roargraph (M_sq=100, M_pjbp=35, L_pjpq=500) on %d host threads in %.1f s; "
                      "degree avg %.1f max %d" % (threads, t_build, deg.mean(), deg.max()),
             "queries": nq, "curve": rows}
+
+
+def pmc_traffic(args):
+    """HBM bytes per launch of the search kernel from the committed rocprofv3 PMC passes (profiles/*/search_traffic.json,
+    written by scripts/profile_on_box.sh: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, FETCH_SIZE
+    with the gfx950 x2 correction).  Counters cannot be read from inside the timed process, so the figure is only
+    reported when the profiled workload is the one being benched; otherwise null."""
+    import glob
+    here = os.path.dirname(os.path.abspath(__file__))
+    key = {"nb": args.nb, "dim": args.dim, "nq": args.nq, "L": args.L, "k": args.k, "deg": args.deg,
+           "metric": args.metric, "visited": args.visited, "real_index": bool(args.real_index)}
+    for path in sorted(glob.glob(os.path.join(here, "profiles", "*", "search_traffic.json")), reverse=True):
+        try:
+            t = json.load(open(path))
+        except Exception:
+            continue
+        if t.get("workload") == key and t.get("fetch_bytes_corrected"):
+            total = float(t["fetch_bytes_corrected"]) + float(t.get("write_bytes") or 0.0)
+            return total, "%s (rocprofv3 --pmc FETCH_SIZE x2 gfx950 correction %.4g B + WRITE_SIZE %.4g B per launch)" % (
+                os.path.relpath(path, here), t["fetch_bytes_corrected"], t.get("write_bytes") or 0.0)
+    return None, None
 
 
 def main():
@@ -286,7 +308,7 @@ def main():
     del ti_q, tv_q
 
     other = None
-    if rank == 0:
+    if rank == 0 and not args.no_other_modes:
         other = []
         for om in (0, 1, 2):
             if om == args.visited:
@@ -353,6 +375,7 @@ def main():
         except Exception as e:  # the baseline is a reported extra; never lose the GPU line over it
             cpu = {"value": None, "unit": "QPS", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
 
+    traffic, traffic_src = pmc_traffic(args) if rank == 0 else (None, None)
     if rank == 0:
         line = {
             "metric": "QPS @ recall@10, t2i-10M d=200 IP (search, top-%d, L_pq=%d)" % (args.k, args.L),
@@ -374,7 +397,7 @@ def main():
                                    0: "exact visited words in HBM"}[args.visited],
                        "mean_evals_per_query": mean_cmps, "mean_evals_performed": mean_done, "mean_hops": mean_hops},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": None,
+                         "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "rg_search_kernel (+ rg_distinct_kernel in visited mode 2)", "kernel_ms_avg": kavg * 1e3,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "frac_of_measured_stream_ceiling_6290": achieved / 6290.0},

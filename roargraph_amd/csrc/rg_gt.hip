@@ -38,7 +38,6 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned long long u64;
 
 constexpr int kNB = 128;     // base rows per streamed tile
-constexpr int kBS = kNB + 1; // LDS row stride of the transposed base stage (bank spread for reads and transposed writes)
 
 // order-preserving float -> uint (ascending)
 __device__ __forceinline__ uint32_t f2ord(float f) {

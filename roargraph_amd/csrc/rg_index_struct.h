@@ -37,7 +37,8 @@ struct rg_index {
     size_t qlog_cap_total = 0;
     uint32_t qlog_nq = 0, logcap = 0;
     int log_cap_knob = 0;       // 0 = auto; tests force small logs to exercise the exact fallback
-    int count_table_log2 = 15;  // K4 LDS table: 2^15 ids = 128 KiB
+    int count_table_log2 = 15;  // K4 LDS table: 2^15 words = 128 KiB
+    bool count_full_ids = false; // K4: force the full-id bucket form (the half-word form is used when the remainder fits)
     struct Pending { bool active = false; const float *q = nullptr; uint32_t nq = 0, qstride = 0, k = 0, L = 0; uint32_t *ids = nullptr; float *dists = nullptr; uint32_t *cmps = nullptr, *hops = nullptr; } pending;
     int filter_log2 = 11;   // VIS=1: 2^11 16-bit entries = 4 KiB
     int num_cu = 256;

@@ -395,49 +395,103 @@ __global__ void __launch_bounds__(64) rg_search_kernel(SearchParams P) {
 
 // K4: exact number of DISTINCT ids a query scored == the reference's cmps (every unvisited neighbour is scored exactly
 // once there, index_bipartite.cpp:2378-2397).  The LDS visited filter of K1 may score a node twice; this pass counts the
-// distinct ids of the query's log with an exact hash set held in LDS (one workgroup per query, table of 2^tbits ids;
-// logs larger than the table are processed in hash partitions).  Queries whose log overflowed are listed for the
-// exact fallback pass.
-__global__ void __launch_bounds__(512) rg_distinct_kernel(const uint32_t *qlog, uint32_t logcap, const uint32_t *qlog_n,
-                                                          uint32_t nq, uint32_t *out_cmps, uint32_t *ovf_list,
-                                                          uint32_t *ovf_count, uint32_t tbits) {
+// distinct ids of the query's log with an exact set held in LDS, one 1024-thread workgroup per query (queries handed out
+// by an atomic counter).  The insert chain is latency bound, so the set is bucketed: one ds_read_b128 sees a whole
+// bucket and only the chosen empty slot is CAS'd (linear probing had probe tails of dozens of slots, and a wave pays the
+// longest of its 64 lanes).  Logs larger than one table are processed in hash partitions; queries whose log overflowed
+// (or whose overflow area filled up) are listed for the exact fallback pass.
+//
+// HALF = true (id_bits - bucket_bits <= 15): slots hold 16-bit remainders of the bijective hash id * odd mod 2^id_bits,
+// bucket = its top bits, 8 slots per 16-byte bucket, 0xffff = empty.  An id lives only in its home bucket; ids whose
+// bucket is full go to an exact side table of full ids (T/8 words).  2T slots in 4T bytes: ~40k ids per pass at T = 2^15.
+// HALF = false: 4 full ids per bucket, double hashing between buckets, 3T/4 ids per pass.
+template <bool HALF>
+__global__ void __launch_bounds__(1024) rg_distinct_kernel(const uint32_t *qlog, uint32_t logcap, const uint32_t *qlog_n,
+                                                           uint32_t nq, uint32_t *out_cmps, uint32_t *ovf_list,
+                                                           uint32_t *ovf_count, uint32_t *work, uint32_t tbits, uint32_t id_bits) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    uint32_t *tab = reinterpret_cast<uint32_t *>(smem);
-    __shared__ uint32_t s_cnt, s_fail;
-    const uint32_t T = 1u << tbits, cap = (T / 4u) * 3u;
+    uint32_t *tab = reinterpret_cast<uint32_t *>(smem);      // T words = T/4 buckets
+    __shared__ uint32_t s_cnt, s_fail, s_q;
+    const uint32_t T = 1u << tbits, bbits = tbits - 2u, bmask = (1u << bbits) - 1u;
+    const uint32_t OV = HALF ? T / 8u : 0u;                  // side table of full ids behind the buckets
+    uint32_t *side = tab + T;
+    const uint32_t cap = HALF ? (T / 4u) * 5u : (T / 4u) * 3u;
+    const uint32_t rbits = id_bits - bbits, hmask = id_bits >= 32u ? 0xffffffffu : (1u << id_bits) - 1u;
     const int tid = threadIdx.x;
-    for (uint32_t q = blockIdx.x; q < nq; q += gridDim.x) {
-        const uint32_t n = qlog_n[q];
-        if (tid == 0) { s_cnt = 0; s_fail = n > logcap ? 1u : 0u; }
+    for (;;) {
+        if (tid == 0) { s_q = atomicAdd(work, 1u); s_cnt = 0; }
         __syncthreads();
+        const uint32_t q = s_q;
+        if (q >= nq) break;
+        const uint32_t n = qlog_n[q];
+        if (tid == 0) s_fail = n > logcap ? 1u : 0u;
+        uint32_t mine = 0;
         if (n <= logcap && n > 0) {
             const uint32_t *log = qlog + (size_t)q * logcap;
             const uint32_t parts = (n + cap - 1) / cap;
-            uint32_t mine = 0;
             for (uint32_t p = 0; p < parts; ++p) {
-                for (uint32_t i = tid; i < T; i += blockDim.x) tab[i] = 0xffffffffu;
+                for (uint32_t i = tid * 4; i < T + OV; i += blockDim.x * 4)
+                    *reinterpret_cast<uint4 *>(tab + i) = make_uint4(~0u, ~0u, ~0u, ~0u);
                 __syncthreads();
-                // 8 independent loads per thread in flight, then the LDS inserts (a load-insert-load chain is latency bound)
-                for (uint32_t i0 = tid; i0 < n; i0 += blockDim.x * 8u) {
-                    uint32_t v[8];
+                for (uint32_t i0 = tid; i0 < n; i0 += blockDim.x * 4u) {
+                    uint32_t v[4];   // 4 independent loads in flight, then the inserts
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
+                    for (int u = 0; u < 4; ++u) {
                         const uint32_t i = i0 + (uint32_t)u * blockDim.x;
                         v[u] = i < n ? log[i] : 0xffffffffu;
                     }
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
+                    for (int u = 0; u < 4; ++u) {
                         const uint32_t id = v[u];
                         if (id == 0xffffffffu) continue;
                         if (parts > 1 && ((id * 0x85EBCA6Bu) >> 16) % parts != p) continue;
-                        uint32_t slot = (id * 0x9E3779B1u) >> (32u - tbits);
-                        uint32_t probes = 0;
-                        for (;;) {
-                            const uint32_t old = atomicCAS(&tab[slot], 0xffffffffu, id);
-                            if (old == 0xffffffffu) { ++mine; break; }
-                            if (old == id) break;
-                            slot = (slot + 1u) & (T - 1u);
-                            if (++probes >= T) { s_fail = 1; break; }
+                        if (HALF) {
+                            const uint32_t h = (id * 0x9E3779B1u) & hmask;
+                            const uint32_t b = h >> rbits, rem = h & ((1u << rbits) - 1u);
+                            for (;;) {
+                                const uint4 t = *reinterpret_cast<const uint4 *>(tab + 4u * b);
+                                const uint32_t w4[4] = {t.x, t.y, t.z, t.w};
+                                int e = 8;
+                                bool found = false;
+#pragma unroll
+                                for (int k = 7; k >= 0; --k) {
+                                    const uint32_t hv = (k & 1) ? w4[k >> 1] >> 16 : w4[k >> 1] & 0xffffu;
+                                    found |= hv == rem;
+                                    if (hv == 0xffffu) e = k;
+                                }
+                                if (found) break;
+                                if (e == 8) {   // home bucket full: exact side table
+                                    uint32_t slot = (id * 0x85EBCA6Bu) >> (32u - (tbits - 3u)), probes = 0;
+                                    for (;;) {
+                                        const uint32_t old = atomicCAS(&side[slot], 0xffffffffu, id);
+                                        if (old == 0xffffffffu) { ++mine; break; }
+                                        if (old == id) break;
+                                        slot = (slot + 1u) & (OV - 1u);
+                                        if (++probes >= OV) { s_fail = 1; break; }
+                                    }
+                                    break;
+                                }
+                                const uint32_t w = e < 2 ? t.x : e < 4 ? t.y : e < 6 ? t.z : t.w;
+                                const uint32_t nw = (e & 1) ? (w & 0x0000ffffu) | (rem << 16) : (w & 0xffff0000u) | rem;
+                                if (atomicCAS(&tab[4u * b + (uint32_t)(e >> 1)], w, nw) == w) { ++mine; break; }
+                            }
+                        } else {
+                            const uint32_t h = id * 0x9E3779B1u;
+                            uint32_t b = h >> (32u - bbits), probes = 0;
+                            const uint32_t step = ((h >> 3) | 1u) & bmask;
+                            for (;;) {
+                                const uint4 t = *reinterpret_cast<const uint4 *>(tab + 4u * b);
+                                if (t.x == id || t.y == id || t.z == id || t.w == id) break;
+                                const int e = t.x == ~0u ? 0 : t.y == ~0u ? 1 : t.z == ~0u ? 2 : t.w == ~0u ? 3 : 4;
+                                if (e == 4) {
+                                    b = (b + step) & bmask;
+                                    if (++probes > bmask) { s_fail = 1; break; }
+                                    continue;
+                                }
+                                const uint32_t old = atomicCAS(&tab[4u * b + (uint32_t)e], 0xffffffffu, id);
+                                if (old == 0xffffffffu) { ++mine; break; }
+                                if (old == id) break;
+                            }
                         }
                     }
                 }
@@ -698,7 +752,7 @@ static rg_status ensure_qlog(rg_index *ix, uint32_t nq) {
     ix->qlog_nq = 0;
     RG_HIP(hipMalloc(&ix->d_qlog, (size_t)nq * cap * 4));
     RG_HIP(hipMalloc(&ix->d_qlog_n, (size_t)nq * 4));
-    RG_HIP(hipMalloc(&ix->d_ovf, ((size_t)nq + 1) * 4));   // [0] = count, then the list
+    RG_HIP(hipMalloc(&ix->d_ovf, ((size_t)nq + 2) * 4));   // [0] = count, [1] = K4 work counter, then the list
     ix->qlog_nq = nq;
     ix->logcap = cap;
     return RG_OK;
@@ -721,14 +775,27 @@ static rg_status search_dev(rg_index *ix, const float *d_q, uint32_t nq, uint32_
     // exact pass inside rg_search_wait
     rg_status st = ensure_qlog(ix, nq);
     if (st != RG_OK) return st;
-    RG_HIP(hipMemsetAsync(ix->d_ovf, 0, 4, s));
+    RG_HIP(hipMemsetAsync(ix->d_ovf, 0, 8, s));
     st = launch_k1(ix, 1, d_q, nq, qstride, k, L, d_ids, d_dists, d_cmps, d_hops, nullptr, true, s);
     if (st != RG_OK) return st;
-    const uint32_t tbits = (uint32_t)std::max(6, std::min(15, ix->count_table_log2));  // default 32768 ids = 128 KiB of LDS
-    auto kern = rg_distinct_kernel;
-    RG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 4 << tbits));
-    hipLaunchKernelGGL(kern, dim3(std::min<uint32_t>(nq, (uint32_t)ix->num_cu)), dim3(512), (size_t)4 << tbits, s, ix->d_qlog,
-                       ix->logcap, ix->d_qlog_n, nq, d_cmps, ix->d_ovf + 1, ix->d_ovf, tbits);
+    // default table: 2^15 words = 128 KiB of LDS (+ 16 KiB side table in the half-word form)
+    const uint32_t tbits = (uint32_t)std::max(6, std::min(15, ix->count_table_log2));
+    const uint32_t bbits = tbits - 2u;
+    const uint32_t id_bits = std::max(id_bits_of(ix->nd), bbits + 1u);
+    const bool half = id_bits - bbits <= 15u && !ix->count_full_ids;
+    const size_t lds = half ? ((size_t)4 << tbits) + ((size_t)4 << (tbits - 3u)) : (size_t)4 << tbits;
+    const dim3 grid(std::min<uint32_t>(nq, (uint32_t)ix->num_cu));
+    if (half) {
+        auto kern = rg_distinct_kernel<true>;
+        RG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, grid, dim3(1024), lds, s, ix->d_qlog, ix->logcap, ix->d_qlog_n, nq, d_cmps, ix->d_ovf + 2,
+                           ix->d_ovf, ix->d_ovf + 1, tbits, id_bits);
+    } else {
+        auto kern = rg_distinct_kernel<false>;
+        RG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, grid, dim3(1024), lds, s, ix->d_qlog, ix->logcap, ix->d_qlog_n, nq, d_cmps, ix->d_ovf + 2,
+                           ix->d_ovf, ix->d_ovf + 1, tbits, id_bits);
+    }
     RG_HIP(hipGetLastError());
     ix->pending.active = true;
     ix->pending.q = d_q; ix->pending.nq = nq; ix->pending.qstride = qstride; ix->pending.k = k; ix->pending.L = L;
@@ -747,7 +814,7 @@ static rg_status search_wait(rg_index *ix, hipStream_t s, uint32_t k) {
         if (novf > 0 && v == ~0ull) {
             // logs that did not fit: recount those queries with the exact HBM visited words (only cmps is rewritten)
             const auto &pd = ix->pending;
-            rg_status st = launch_k1(ix, 0, pd.q, novf, pd.qstride, pd.k, pd.L, pd.ids, pd.dists, pd.cmps, pd.hops, ix->d_ovf + 1, false, s);
+            rg_status st = launch_k1(ix, 0, pd.q, novf, pd.qstride, pd.k, pd.L, pd.ids, pd.dists, pd.cmps, pd.hops, ix->d_ovf + 2, false, s);
             if (st != RG_OK) return st;
             RG_HIP(hipStreamSynchronize(s));
         }
@@ -944,6 +1011,7 @@ rg_status rg_index_set(rg_index *ix, const char *name, int value) {
     else if (!strcmp(name, "filter_log2")) ix->filter_log2 = value;
     else if (!strcmp(name, "log_cap")) ix->log_cap_knob = value;
     else if (!strcmp(name, "count_table_log2")) ix->count_table_log2 = value;
+    else if (!strcmp(name, "count_full_ids")) ix->count_full_ids = value != 0;
     else return set_error(RG_ERR_ARG, "unknown knob");
     return RG_OK;
 }

@@ -12,18 +12,20 @@ run() {  # name, rocprof args..., -- command
   rm -rf /tmp/rp_$name
   rocprofv3 "$@" > $OUT/$name.log 2>&1
   local db=$(ls /tmp/rp_$name/*.db 2>/dev/null | head -1)
-  if [ -n "$db" ]; then python $R/scripts/rocprof_summary.py $db > $OUT/$name.txt 2>&1; fi
+  if [ -n "$db" ]; then python $R/scripts/rocprof_summary.py --json $OUT/$name.pmc.json $db > $OUT/$name.txt 2>&1; fi
   grep -h '^{' $OUT/$name.log > $OUT/$name.json 2>/dev/null
   rm -rf /tmp/rp_$name
   # keep the logs small
   grep -v "simple_timer\|SQLite3" $OUT/$name.log | tail -20 > $OUT/$name.log.tail; rm -f $OUT/$name.log
 }
 if [ "$WHAT" = "search" ] || [ "$WHAT" = "all" ]; then
-  for vis in 1 0; do
-    B="python $R/bench.py --steps 3 --warmup 1 --cpu-seconds 0 --visited $vis"
+  # the default bench workload (visited mode 2) without the legs that are not the search kernel
+  for vis in ${VISITED:-2}; do
+    B="python $R/bench.py --steps 5 --warmup 2 --cpu-seconds 0 --gt-nq 0 --recall-nb 0 --no-other-modes --visited $vis"
     run search_v${vis}_trace --kernel-trace --stats -d /tmp/rp_search_v${vis}_trace -o s -- $B
     run search_v${vis}_fetch --pmc FETCH_SIZE -d /tmp/rp_search_v${vis}_fetch -o s -- $B
     run search_v${vis}_write --pmc WRITE_SIZE -d /tmp/rp_search_v${vis}_write -o s -- $B
+    python $R/scripts/make_traffic_json.py $vis $OUT/search_v${vis}_fetch.pmc.json $OUT/search_v${vis}_write.pmc.json > $OUT/search_traffic_v${vis}.json
   done
 fi
 if [ "$WHAT" = "gt" ] || [ "$WHAT" = "all" ]; then

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 rocpd databases (ROCm 7.2 writes sqlite, not CSV) into the text kept under profiles/.
 
-usage: rocprof_summary.py <results.db> [more.db ...]
+usage: rocprof_summary.py [--json out.json] <results.db> [more.db ...]
 Prints per-kernel call count / total / average duration (the `--stats` view) and, when the run collected PMC
 counters, the per-kernel per-launch average of each counter.  FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE
 under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md, HBM section) -- both raw and corrected are printed.
@@ -11,7 +11,11 @@ import sys
 
 
 def main():
-    for path in sys.argv[1:]:
+    argv = sys.argv[1:]
+    jpath, jout = None, {}
+    if argv and argv[0] == "--json":
+        jpath, argv = argv[1], argv[2:]
+    for path in argv:
         db = sqlite3.connect(path)
         cur = db.cursor()
         print("== %s" % path)
@@ -34,6 +38,10 @@ def main():
                 if c == "WRITE_SIZE":
                     extra = "  = %.2f GB (uncalibrated)" % (v * 1024 / 1e9)
                 print("%-70s | %-14s | %3d | %.4g%s" % (short, c, n, v, extra))
+                jout.setdefault(k, {})[c] = {"launches": n, "avg": v}
+    if jpath:
+        import json
+        json.dump(jout, open(jpath, "w"), indent=1)
 
 
 if __name__ == "__main__":

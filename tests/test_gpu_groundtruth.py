@@ -97,3 +97,16 @@ def test_gt_file_roundtrip(tmp_path, oracle):
     ref_ids, _, ref_s = oracle.groundtruth_f64(base, q, "ip", 100, nthreads=8)
     check_gt(base, q, "ip", 100, ids, ds, ref_ids, ref_s)
     assert (index.knn_ids_load(str(tmp_path / "gt.bin")) == ids).all()
+
+
+def test_single_process_multi_shard_path(oracle):
+    """rg_groundtruth_mem with several entries in `devices` shards the base by rows, one shard per entry, and merges with
+    K3.  On a one-GPU box the same device is listed three times: three shards, three streams, one merge."""
+    from roargraph_amd import groundtruth
+    base, q = synth.make_synth(41, 7001, 150, 200)
+    one_i, one_d = groundtruth.compute_groundtruth(base, q, "ip", 50)
+    three_i, three_d = groundtruth.compute_groundtruth(base, q, "ip", 50, devices=[0, 0, 0])
+    assert (one_i == three_i).all() and (one_d.view(np.uint32) == three_d.view(np.uint32)).all()
+    l2_i, l2_d = groundtruth.compute_groundtruth(base, q, "l2", 10, devices=[0, 0])
+    ref_i, _, ref_s = oracle.groundtruth_f64(base, q, "l2", 10, nthreads=8)
+    check_gt(base, q, "l2", 10, l2_i, l2_d, ref_i, ref_s)

@@ -36,7 +36,7 @@ def test_score_batch_bit_exact(rg, oracle, metric, d):
 
 
 @pytest.mark.parametrize("metric,d,nb", [("ip", 200, 4000), ("l2", 512, 2000), ("l2", 200, 3000), ("ip", 512, 1500)])
-@pytest.mark.parametrize("L,k", [(10, 10), (50, 10), (100, 100), (500, 10), (64, 1), (65, 65)])
+@pytest.mark.parametrize("L,k", [(10, 10), (50, 10), (100, 100), (500, 10), (64, 1), (65, 65), (2000, 100)])
 def test_search_bit_exact(rg, oracle, metric, d, nb, L, k):
     base, q, off, nbrs, ep = small_set(metric, nb, d)
     ix = rg.IndexBipartite.from_arrays(base, off, nbrs, ep, metric=metric)
@@ -69,15 +69,18 @@ def test_search_lds_filter_mode(rg, oracle, metric, d, nb, L, k, flt):
     ix.close()
 
 
-@pytest.mark.parametrize("log_cap,table", [(0, 15), (64, 15), (100000, 7), (700, 8)])
-def test_default_mode_exact_cmps_paths(rg, oracle, log_cap, table):
+@pytest.mark.parametrize("full_ids", [0, 1])
+@pytest.mark.parametrize("log_cap,table", [(0, 15), (64, 15), (100000, 7), (700, 8), (100000, 6), (100000, 11)])
+def test_default_mode_exact_cmps_paths(rg, oracle, log_cap, table, full_ids):
     """visited=2 (default): LDS filter + id log + exact distinct count.  Forced corner paths: logs that overflow
-    (exact fallback pass re-counts those queries) and a tiny K4 table (multi-partition counting)."""
+    (exact fallback pass re-counts those queries), tiny K4 tables (multi-partition counting, full buckets spilling into
+    the side table) and both K4 set layouts (16-bit remainders / full ids)."""
     base, q, off, nbrs, ep = small_set("ip", 4000, 200)
     ix = rg.IndexBipartite.from_arrays(base, off, nbrs, ep, metric="ip")
     ix.set("filter_log2", 6)            # forgetful filter -> plenty of re-scored nodes to de-duplicate
     ix.set("log_cap", log_cap)
     ix.set("count_table_log2", table)
+    ix.set("count_full_ids", full_ids)
     for L, k in ((10, 10), (200, 10)):
         got = ix.SearchRoarGraph(q, k, L)
         want = oracle.search(base, "ip", off, nbrs, ep, q, k, L, nthreads=4)
