@@ -305,7 +305,8 @@ __global__ void __launch_bounds__(512) rg_gt_kernel(GtParams P) {
 
 // K2-RS: "queries stationary in registers" form of K2 for the dimensions of the BASELINE configs (200, 512).
 // A wave keeps the MFMA A-operands of its 32*TMW queries for ALL k in VGPRs (DIM/2 registers per 32-query tile: lane l
-// holds Q[q = l&31][k = 2*kk + (l>>5)]), owns all four 32-column tiles of the streamed base tile, and therefore issues
+// holds, for k-quad kq, Q[q = l&31][4kq + 2*(l>>5)] and Q[q][4kq + 1 + 2*(l>>5)] -- the two MFMAs of a quad take the k
+// pairs (0,2) and (1,3) so that each half-wave needs two ADJACENT floats of the base row's quad), owns all four 32-column tiles of the streamed base tile, and therefore issues
 // 8*TMW MFMAs per k-pair with only the B fragments coming from LDS.  One wave per SIMD (4 waves = one workgroup per CU,
 // 128*TMW queries); LDS holds just the double-buffered base chunk, barriers are BK/2 * 8*TMW MFMAs apart (10k cycles at
 // d=200) and the base stream is shared by twice as many queries as in the LDS-resident form.  Everything in k is
@@ -343,10 +344,10 @@ __global__ void __launch_bounds__(256, WPS) rg_gt_rs_kernel(GtParams P) {
 #pragma unroll
         for (int m = 0; m < TMW; ++m) {
             const uint32_t q = q0 + qoff + 32 * m + (lane & 31);
-            const float *qrow = P.queries + (size_t)min(q, P.nq - 1u) * P.qstride + (hi ? 1 : 0);
+            const float *qrow = P.queries + (size_t)min(q, P.nq - 1u) * P.qstride + (hi ? 2 : 0);
             const float scale = q < P.nq ? 1.0f : 0.0f;
 #pragma unroll
-            for (int kk = 0; kk < DIM / 2; ++kk) areg[kk][m] = qrow[2 * kk] * scale;
+            for (int kk = 0; kk < DIM / 2; ++kk) areg[kk][m] = qrow[4 * (kk >> 1) + (kk & 1)] * scale;
         }
         for (int i = tid; i < MQB; i += 256) { thr[i] = -__builtin_inff(); cnt[i] = 0; }
         if (tid == 0) flag[0] = 0;
@@ -390,38 +391,42 @@ __global__ void __launch_bounds__(256, WPS) rg_gt_rs_kernel(GtParams P) {
                 constexpr int c = decltype(cc)::value;
                 const uint32_t buf = step & 1u;
                 // next chunk (of this tile or the first of the next tile) streams while this one is multiplied
-                if (c + 1 < NKC) stream_chunk(tile, c + 1, buf ^ 1u);
-                else if (tile + 1 < ntiles) stream_chunk(tile + 1, 0, buf ^ 1u);
-                const float4 *bq = Bq + (size_t)buf * KQC * kNB + (lane & 31);
-                float4 b0[4], b1[4];
+                if (!(P.diag & 1u)) {
+                    if (c + 1 < NKC) stream_chunk(tile, c + 1, buf ^ 1u);
+                    else if (tile + 1 < ntiles) stream_chunk(tile + 1, 0, buf ^ 1u);
+                }
+                // B fragments: the low half-wave reads elements (0,1) of its row's k-quad, the high half-wave (2,3): one
+                // conflict-free ds_read_b64 per lane feeds two MFMAs with no lane select.  Fragments of quad kq+1 are
+                // issued before the MFMAs of quad kq and pinned there (the scheduler otherwise sinks them to their use to
+                // save registers, exposing the LDS latency once per quad).
+                const float2 *bq = reinterpret_cast<const float2 *>(Bq + (size_t)buf * KQC * kNB + (lane & 31)) + (hi ? 1 : 0);
+                float2 b0[4], b1[4];
 #pragma unroll
-                for (int n = 0; n < 4; ++n) b0[n] = bq[32 * n];
+                for (int n = 0; n < 4; ++n) b0[n] = bq[2 * (32 * n)];
 #pragma unroll
                 for (int kq = 0; kq < KQC; ++kq) {
-                    float4 (&bc)[4] = (kq & 1) ? b1 : b0;
-                    float4 (&bn)[4] = (kq & 1) ? b0 : b1;
+                    float2 (&bc)[4] = (kq & 1) ? b1 : b0;
+                    float2 (&bn)[4] = (kq & 1) ? b0 : b1;
                     if (kq + 1 < KQC) {
 #pragma unroll
-                        for (int n = 0; n < 4; ++n) bn[n] = bq[(size_t)(kq + 1) * kNB + 32 * n];
+                        for (int n = 0; n < 4; ++n) bn[n] = bq[2 * ((kq + 1) * kNB + 32 * n)];
                     }
-                    const int kk = 2 * (c * KQC + kq);   // first k-pair of this quad
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int kk = 2 * (c * KQC + kq);   // A registers of this quad: kk -> elements (0|2), kk+1 -> (1|3)
 #pragma unroll
-                    for (int n = 0; n < 4; ++n) {
-                        const float bl = hi ? bc[n].y : bc[n].x;
+                    for (int n = 0; n < 4; ++n)
 #pragma unroll
                         for (int m = 0; m < TMW; ++m)
-                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[kk][m], bl, acc[m][n], 0, 0, 0);
-                    }
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[kk][m], bc[n].x, acc[m][n], 0, 0, 0);
 #pragma unroll
-                    for (int n = 0; n < 4; ++n) {
-                        const float bh = hi ? bc[n].w : bc[n].z;
+                    for (int n = 0; n < 4; ++n)
 #pragma unroll
                         for (int m = 0; m < TMW; ++m)
-                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[kk + 1][m], bh, acc[m][n], 0, 0, 0);
-                    }
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[kk + 1][m], bc[n].y, acc[m][n], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
                 ++step;
-                if (c + 1 == NKC) {
+                if (c + 1 == NKC && !(P.diag & 2u)) {
                     // tile finished: threshold filter (register thresholds), survivors -> candidate buffers
                     bool any_win = false;
 #pragma unroll
