@@ -303,6 +303,24 @@ __global__ void __launch_bounds__(512) rg_gt_kernel(GtParams P) {
     }
 }
 
+// one LDS-DMA wave instruction: 64 lanes x 16 B from src + OFF_BYTES to LDS.  The instruction's immediate offset is
+// added to BOTH the global and the LDS address (LDS address = M0 + offset + 16 * lane), hence M0 = lds_addr - OFF_BYTES.
+// Issued through inline asm on purpose (see rg_gt_kernel::stream_chunk).
+template <int OFF_BYTES>
+__device__ __forceinline__ void glds16(uint32_t lds_addr, const float *src) {
+    static_assert(OFF_BYTES >= 0 && OFF_BYTES < 4096, "immediate offset range");
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off offset:%2"
+                 :: "s"(lds_addr - (uint32_t)OFF_BYTES), "v"(src), "n"(OFF_BYTES) : "memory");
+}
+// N instructions: instruction i moves k-quad kq0 + 2i of the chunk (src advances 32 B, LDS 4 KiB = two 64-row halves)
+template <int I, int N>
+__device__ __forceinline__ void glds_run(uint32_t lds_addr, const float *src) {
+    if constexpr (I < N) {
+        glds16<32 * I>(lds_addr + 4096u * I, src);
+        glds_run<I + 1, N>(lds_addr, src);
+    }
+}
+
 // K2-RS: "queries stationary in registers" form of K2 for the dimensions of the BASELINE configs (200, 512).
 // A wave keeps the MFMA A-operands of its 32*TMW queries for ALL k in VGPRs (DIM/2 registers per 32-query tile: lane l
 // holds, for k-quad kq, Q[q = l&31][4kq + 2*(l>>5)] and Q[q][4kq + 1 + 2*(l>>5)] -- the two MFMAs of a quad take the k
@@ -317,7 +335,6 @@ __global__ void __launch_bounds__(256, WPS) rg_gt_rs_kernel(GtParams P) {
     constexpr int MQB = 128 * TMW;            // queries per workgroup
     constexpr int NKC = DIM / BK;             // k-chunks per base tile
     constexpr int KQC = BK / 4;               // k-quads per chunk
-    constexpr int NINSTR = KQC * 2;           // LDS-DMA wave instructions per chunk (64 rows of one k-quad each)
     static_assert(DIM % BK == 0 && BK % 4 == 0, "chunking");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -359,20 +376,25 @@ __global__ void __launch_bounds__(256, WPS) rg_gt_rs_kernel(GtParams P) {
             for (int r = 0; r < 16; ++r) thr_r[0][r] = -__builtin_inff();
         }
 
-        auto stream_chunk = [&](uint32_t tile, uint32_t c, uint32_t buf) {
-            float4 *dst = Bq + (size_t)buf * KQC * kNB;
-            for (uint32_t j = (uint32_t)w; j < (uint32_t)NINSTR; j += 4) {
-                const uint32_t kq = j >> 1, row = 64u * (j & 1u) + (uint32_t)lane;
-                const uint32_t gr = min(tile * kNB + row, P.nb - 1u);
-                const float *src = P.base + (size_t)gr * P.bstride + c * BK + 4 * kq;
-                const uint32_t lds_addr = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(lds_ptr_t *)(dst + (size_t)j * 64));
-                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" :: "s"(lds_addr), "v"(src) : "memory");
-            }
+        // LDS-DMA of a base chunk.  Wave w always moves row half (w & 1) and the k-quads (w >> 1) + 2i, so a lane's
+        // source is one row pointer per tile plus a per-chunk constant and an immediate: one 64-bit add per chunk and two
+        // scalar ops per instruction.
+        static_assert(KQC % 2 == 0, "k-quads per chunk");
+        const uint32_t lds_w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(lds_ptr_t *)Bq) +
+                               (2u * ((uint32_t)w >> 1) + ((uint32_t)w & 1u)) * 1024u;
+        auto row_ptr = [&](uint32_t tile) {
+            const uint32_t gr = min(tile * kNB + 64u * ((uint32_t)w & 1u) + (uint32_t)lane, P.nb - 1u);   // clamp: rows past the end are ignored
+            return P.base + (size_t)gr * P.bstride + 4u * ((uint32_t)w >> 1);
         };
+        auto stream_chunk = [&](auto cc, const float *rowp, uint32_t buf) __attribute__((always_inline)) {
+            constexpr int c = decltype(cc)::value;
+            glds_run<0, KQC / 2>(lds_w + buf * (uint32_t)(KQC * kNB * 16), rowp + c * BK);
+        };
+        const float *rowp = row_ptr(0);
 
         f32x16 acc[TMW][4];
         uint32_t step = 0;   // running chunk counter: LDS buffer = step & 1
-        stream_chunk(0, 0, 0);
+        stream_chunk(std::integral_constant<int, 0>{}, rowp, 0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         for (uint32_t tile = 0; tile < ntiles; ++tile) {
@@ -392,8 +414,12 @@ __global__ void __launch_bounds__(256, WPS) rg_gt_rs_kernel(GtParams P) {
                 const uint32_t buf = step & 1u;
                 // next chunk (of this tile or the first of the next tile) streams while this one is multiplied
                 if (!(P.diag & 1u)) {
-                    if (c + 1 < NKC) stream_chunk(tile, c + 1, buf ^ 1u);
-                    else if (tile + 1 < ntiles) stream_chunk(tile + 1, 0, buf ^ 1u);
+                    if constexpr (c + 1 < NKC) {
+                        stream_chunk(std::integral_constant<int, c + 1>{}, rowp, buf ^ 1u);
+                    } else if (tile + 1 < ntiles) {
+                        rowp = row_ptr(tile + 1);
+                        stream_chunk(std::integral_constant<int, 0>{}, rowp, buf ^ 1u);
+                    }
                 }
                 // B fragments: the low half-wave reads elements (0,1) of its row's k-quad, the high half-wave (2,3): one
                 // conflict-free ds_read_b64 per lane feeds two MFMAs with no lane select.  Fragments of quad kq+1 are
@@ -428,34 +454,37 @@ __global__ void __launch_bounds__(256, WPS) rg_gt_rs_kernel(GtParams P) {
                 ++step;
                 if (c + 1 == NKC && !(P.diag & 2u)) {
                     // tile finished: threshold filter (register thresholds), survivors -> candidate buffers
+                    // common case first: the best of a query row's four column tiles against its threshold (48 VALU ops
+                    // instead of 192); only lanes that hold a survivor walk the per-element path
                     bool any_win = false;
 #pragma unroll
-                    for (int n = 0; n < 4; ++n) {
-                        const uint32_t id = tile * kNB + 32 * n + (lane & 31);
+                    for (int m = 0; m < TMW; ++m)
 #pragma unroll
-                        for (int m = 0; m < TMW; ++m) {
-                            uint32_t win = 0;
+                        for (int r = 0; r < 16; ++r) {
+                            const float t = kThrRegs ? thr_r[kThrRegs ? m : 0][r]
+                                                     : thr[qoff + 32 * m + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)];
+                            const float mx = fmaxf(fmaxf(acc[m][0][r], acc[m][1][r]), fmaxf(acc[m][2][r], acc[m][3][r]));
+                            any_win |= mx > t;
+                        }
+                    if (any_win) {
 #pragma unroll
-                            for (int r = 0; r < 16; ++r) {
-                                const float t = kThrRegs ? thr_r[kThrRegs ? m : 0][r]
-                                                         : thr[qoff + 32 * m + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)];
-                                win |= (acc[m][n][r] > t ? 1u : 0u) << r;
-                            }
-                            if (id >= P.nb) win = 0;
-                            if (win) {
-                                any_win = true;
+                        for (int n = 0; n < 4; ++n) {
+                            const uint32_t id = tile * kNB + 32 * n + (lane & 31);
+                            if (id >= P.nb) continue;
 #pragma unroll
-                                for (int r = 0; r < 16; ++r)
-                                    if (win & (1u << r)) {
-                                        const int qi = qoff + 32 * m + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                            for (int m = 0; m < TMW; ++m)
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) {
+                                    const int qi = qoff + 32 * m + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                                    const float t = kThrRegs ? thr_r[kThrRegs ? m : 0][r] : thr[qi];
+                                    if (acc[m][n][r] > t) {
                                         const uint32_t slot = atomicAdd(&cnt[qi], 1u);
                                         cand[(size_t)qi * C + slot] = make_key(acc[m][n][r], id, true);
                                         if (slot + 1 + kNB > (uint32_t)C) flag[0] = 1;
                                     }
-                            }
+                                }
                         }
                     }
-                    (void)any_win;
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next chunk's DMA (and any candidate stores) landed
                 __syncthreads();
