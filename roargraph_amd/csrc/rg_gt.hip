@@ -457,33 +457,37 @@ __global__ void __launch_bounds__(256, WPS) rg_gt_rs_kernel(GtParams P) {
                     // common case first: the best of a query row's four column tiles against its threshold (48 VALU ops
                     // instead of 192); only lanes that hold a survivor walk the per-element path
                     bool any_win = false;
+                    float mx[TMW][16];
 #pragma unroll
                     for (int m = 0; m < TMW; ++m)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             const float t = kThrRegs ? thr_r[kThrRegs ? m : 0][r]
                                                      : thr[qoff + 32 * m + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)];
-                            const float mx = fmaxf(fmaxf(acc[m][0][r], acc[m][1][r]), fmaxf(acc[m][2][r], acc[m][3][r]));
-                            any_win |= mx > t;
+                            mx[m][r] = fmaxf(fmaxf(acc[m][0][r], acc[m][1][r]), fmaxf(acc[m][2][r], acc[m][3][r]));
+                            any_win |= mx[m][r] > t;
                         }
+                    // a wave sees a survivor or two on most tiles (1.6 K ln(N/K) per query over the pass), so this path
+                    // is hot too: one test per query row, the four column tiles only where that row's best beat it
                     if (any_win) {
 #pragma unroll
-                        for (int n = 0; n < 4; ++n) {
-                            const uint32_t id = tile * kNB + 32 * n + (lane & 31);
-                            if (id >= P.nb) continue;
+                        for (int m = 0; m < TMW; ++m)
 #pragma unroll
-                            for (int m = 0; m < TMW; ++m)
+                            for (int r = 0; r < 16; ++r) {
+                                const int qi = qoff + 32 * m + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                                const float t = kThrRegs ? thr_r[kThrRegs ? m : 0][r] : thr[qi];
+                                if (mx[m][r] > t) {
 #pragma unroll
-                                for (int r = 0; r < 16; ++r) {
-                                    const int qi = qoff + 32 * m + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                                    const float t = kThrRegs ? thr_r[kThrRegs ? m : 0][r] : thr[qi];
-                                    if (acc[m][n][r] > t) {
-                                        const uint32_t slot = atomicAdd(&cnt[qi], 1u);
-                                        cand[(size_t)qi * C + slot] = make_key(acc[m][n][r], id, true);
-                                        if (slot + 1 + kNB > (uint32_t)C) flag[0] = 1;
+                                    for (int n = 0; n < 4; ++n) {
+                                        const uint32_t id = tile * kNB + 32 * n + (lane & 31);
+                                        if (acc[m][n][r] > t && id < P.nb) {
+                                            const uint32_t slot = atomicAdd(&cnt[qi], 1u);
+                                            cand[(size_t)qi * C + slot] = make_key(acc[m][n][r], id, true);
+                                            if (slot + 1 + kNB > (uint32_t)C) flag[0] = 1;
+                                        }
                                     }
                                 }
-                        }
+                            }
                     }
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next chunk's DMA (and any candidate stores) landed
