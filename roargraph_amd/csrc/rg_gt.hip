@@ -140,9 +140,9 @@ typedef const __attribute__((address_space(1))) void glb_ptr_t;
 // LDS layout of both operands: k-quads, [k/4][row][4 floats] -- one 16-byte slot per (k-quad, row).
 //  * the base chunk arrives by LDS-DMA (global_load_lds_dwordx4): a wave instruction fills 64 consecutive slots
 //    (64 rows of one k-quad), no VGPR staging and no transposing ds_write pass;
-//  * an MFMA operand fetch is one conflict-free ds_read_b128 per lane (rows are consecutive slots) that serves TWO
-//    v_mfma_f32_32x32x2_f32: lanes 0-31 use elements 0 and 2, lanes 32-63 elements 1 and 3 (operand lane l holds
-//    k = l >> 5 of the pair).
+//  * an MFMA operand fetch is one conflict-free ds_read_b64 per lane (rows are consecutive slots) that serves TWO
+//    v_mfma_f32_32x32x2_f32: lanes 0-31 read elements (0,1) of the quad, lanes 32-63 elements (2,3); the first MFMA
+//    multiplies the k pair (0,2), the second (1,3) (operand lane l holds k-slot l >> 5 of the pair).
 template <int MQ, int ITEMS>
 __global__ void __launch_bounds__(512) rg_gt_kernel(GtParams P) {
     constexpr int C = 64 * ITEMS;
@@ -220,34 +220,34 @@ __global__ void __launch_bounds__(512) rg_gt_kernel(GtParams P) {
         for (uint32_t c = 0; c < nchunks; ++c) {
             const uint32_t buf = c & 1u;
             if (c + 1 < nchunks && !(P.diag & 1u)) stream_chunk(c + 1, buf ^ 1u);
-            const float4 *bq = Bq + (size_t)buf * kq_chunk * kNB + boff + (lane & 31);
-            const float4 *qq = Qq + (size_t)((c % nkc) * kq_chunk) * MQ + qoff + (lane & 31);
+            // operand fragments: the low half-wave takes elements (0,1) of a k-quad, the high half-wave (2,3) -- the two
+            // MFMAs of a quad multiply the k pairs (0,2) and (1,3), so one ds_read_b64 per operand feeds both with no
+            // lane select (the order of the k sum is free here)
+            const float2 *bq = reinterpret_cast<const float2 *>(Bq + (size_t)buf * kq_chunk * kNB + boff + (lane & 31)) + (hi ? 1 : 0);
+            const float2 *qq = reinterpret_cast<const float2 *>(Qq + (size_t)((c % nkc) * kq_chunk) * MQ + qoff + (lane & 31)) + (hi ? 1 : 0);
             // two k-quads per step: operands of step s+1 are read from LDS while the 4*TM MFMAs of step s issue
-            float4 a0[TM], b0, a1[TM], b1;
-            auto fetch = [&](uint32_t kq, float4 (&a)[TM], float4 &b) {
-                b = bq[(size_t)kq * kNB];
+            float2 a0[TM], b0, a1[TM], b1;
+            auto fetch = [&](uint32_t kq, float2 (&a)[TM], float2 &b) {
+                b = bq[2 * ((size_t)kq * kNB)];
 #pragma unroll
-                for (int m = 0; m < TM; ++m) a[m] = qq[(size_t)kq * MQ + 32 * m];
+                for (int m = 0; m < TM; ++m) a[m] = qq[2 * ((size_t)kq * MQ + 32 * m)];
             };
-            auto mfma_quad = [&](const float4 (&a)[TM], const float4 &b) {
-                const float bl = hi ? b.y : b.x, bh = hi ? b.w : b.z;
+            auto mfma_quad = [&](const float2 (&a)[TM], const float2 &b) {
 #pragma unroll
-                for (int m = 0; m < TM; ++m) {
-                    const float al = hi ? a[m].y : a[m].x;
-                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(al, bl, acc[m], 0, 0, 0);
-                }
+                for (int m = 0; m < TM; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].x, b.x, acc[m], 0, 0, 0);
 #pragma unroll
-                for (int m = 0; m < TM; ++m) {
-                    const float ah = hi ? a[m].w : a[m].z;
-                    acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(ah, bh, acc[m], 0, 0, 0);
-                }
+                for (int m = 0; m < TM; ++m) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m].y, b.y, acc[m], 0, 0, 0);
             };
             fetch(0, a0, b0);
             for (uint32_t kq = 0; kq < kq_chunk; kq += 2) {
                 if (kq + 1 < kq_chunk) fetch(kq + 1, a1, b1);
+                __builtin_amdgcn_sched_barrier(0);
                 mfma_quad(a0, b0);
+                __builtin_amdgcn_sched_barrier(0);
                 if (kq + 2 < kq_chunk) fetch(kq + 2, a0, b0);
+                __builtin_amdgcn_sched_barrier(0);
                 if (kq + 1 < kq_chunk) mfma_quad(a1, b1);
+                __builtin_amdgcn_sched_barrier(0);
             }
             if ((c + 1) % nkc == 0 && !(P.diag & 2u)) {
                 // tile finished: threshold filter, survivors -> candidate buffers
@@ -490,8 +490,8 @@ __global__ void __launch_bounds__(256, WPS) rg_gt_rs_kernel(GtParams P) {
                             }
                     }
                 }
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next chunk's DMA (and any candidate stores) landed
-                __syncthreads();
+                if (!(P.diag & 8u)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next chunk's DMA (and any candidate stores) landed
+                if (!(P.diag & 16u)) __syncthreads();
                 if (c + 1 == NKC && flag[0]) {
                     for (int qi = w; qi < MQB; qi += 4)
                         if (cnt[qi] + kNB > (uint32_t)C) gt_compact<ITEMS>(cand + (size_t)qi * C, &cnt[qi], &thr[qi], P.K, lane);
