@@ -35,7 +35,8 @@ struct rg_index {
     int visited_mode = 2;
     uint32_t *d_qlog = nullptr, *d_qlog_n = nullptr, *d_ovf = nullptr;
     size_t qlog_cap_total = 0;
-    uint32_t qlog_nq = 0, logcap = 0;
+    uint32_t qlog_nq = 0, logcap = 0, qlog_chunk = 0, ovf_nq = 0;
+    int log_budget_kb = 16 << 20;  // HBM budget of the id logs (KiB, default 16 GiB = 32768 queries): larger batches are searched in sub-batches
     int log_cap_knob = 0;       // 0 = auto; tests force small logs to exercise the exact fallback
     int count_table_log2 = 15;  // K4 LDS table: 2^15 words = 128 KiB
     bool count_full_ids = false; // K4: force the full-id bucket form (the half-word form is used when the remainder fits)

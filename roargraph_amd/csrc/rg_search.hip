@@ -67,6 +67,7 @@ struct SearchParams {
     uint32_t *counter;        // work-queue head
     unsigned long long *status;  // min over failing queries of (query << 32 | queue size); ~0 = none
     uint32_t stage_floats;    // floats per sub-pass staging buffer (ceil(dim/64)*256)
+    uint32_t qbase;           // index of queries[0] in the caller's batch (error reporting of chunked launches)
     uint32_t diag;            // diagnostics only (breaks parity): bit0 = skip the visited test
     uint32_t vf_slots_log2;   // VIS=1: log2 of the LDS visited-filter size (16-bit entries)
     uint32_t *qlog;           // VIS=1, optional: [nq][logcap] ids scored by each query (input of the exact distinct count)
@@ -319,13 +320,19 @@ __global__ void __launch_bounds__(64) rg_search_kernel(SearchParams P) {
                     cand_id[slot] = id;
                     if (VIS == 1 && qlog) logbuf[lbn + slot] = id;
                 }
+                // a full 64-id line of the log leaves LDS here but is STORED after this hop's gathers have been consumed:
+                // a store issued in front of them would sit at the head of the vmcnt queue and put its completion
+                // latency on the critical path of the first counted wait
+                bool flush = false;
+                uint32_t flush_v = 0, flush_pos = 0;
                 if (VIS == 1 && qlog) {
                     lbn += n;
                     if (lbn >= (uint32_t)kWave) {
                         lds_sync();
-                        const uint32_t pos = logn - (lbn - n);          // ids already flushed (multiple of 64)
-                        const uint32_t v = logbuf[lane], rest = logbuf[kWave + lane];
-                        if (pos + lane < P.logcap) qlog[pos + lane] = v;
+                        flush = true;
+                        flush_pos = logn - (lbn - n);                     // ids already flushed (multiple of 64)
+                        flush_v = logbuf[lane];
+                        const uint32_t rest = logbuf[kWave + lane];
                         lds_sync();
                         lbn -= kWave;
                         if ((uint32_t)lane < lbn) logbuf[lane] = rest;
@@ -358,6 +365,7 @@ __global__ void __launch_bounds__(64) rg_search_kernel(SearchParams P) {
                         }
                     }
                 }
+                if (VIS == 1 && flush && flush_pos + lane < P.logcap) qlog[flush_pos + lane] = flush_v;
                 // queue inserts (:2398)
                 const float cd = (uint32_t)lane < n ? cand_d[lane] : 0.0f;
                 const uint32_t cid = (uint32_t)lane < n ? cand_id[lane] : 0u;
@@ -370,7 +378,7 @@ __global__ void __launch_bounds__(64) rg_search_kernel(SearchParams P) {
         if (cmps_only || build) {
             if (build && lane == 0) P.out_nexp[qi] = hops;
         } else if (bm.size < P.k) {
-            if (lane == 0) atomicMin(P.status, ((unsigned long long)qi << 32) | bm.size);
+            if (lane == 0) atomicMin(P.status, ((unsigned long long)(qi + P.qbase) << 32) | bm.size);
         } else {
             for (uint32_t i = lane; i < P.k; i += kWave) {
                 const uint2 e = bm.ent[i];
@@ -408,7 +416,8 @@ __global__ void __launch_bounds__(64) rg_search_kernel(SearchParams P) {
 template <bool HALF>
 __global__ void __launch_bounds__(1024) rg_distinct_kernel(const uint32_t *qlog, uint32_t logcap, const uint32_t *qlog_n,
                                                            uint32_t nq, uint32_t *out_cmps, uint32_t *ovf_list,
-                                                           uint32_t *ovf_count, uint32_t *work, uint32_t tbits, uint32_t id_bits) {
+                                                           uint32_t *ovf_count, uint32_t *work, uint32_t tbits, uint32_t id_bits,
+                                                           uint32_t qbase) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *tab = reinterpret_cast<uint32_t *>(smem);      // T words = T/4 buckets
     __shared__ uint32_t s_cnt, s_fail, s_q;
@@ -502,7 +511,7 @@ __global__ void __launch_bounds__(1024) rg_distinct_kernel(const uint32_t *qlog,
         }
         __syncthreads();
         if (tid == 0) {
-            if (s_fail) ovf_list[atomicAdd(ovf_count, 1u)] = q;
+            if (s_fail) ovf_list[atomicAdd(ovf_count, 1u)] = q + qbase;   // out_cmps is already offset; the list is global
             else out_cmps[q] = s_cnt;
         }
         __syncthreads();
@@ -698,7 +707,8 @@ struct BuildOut { uint2_pod *exp; uint32_t exp_cap, node0; uint32_t *nexp; };
 // one K1 launch.  mode: 0 exact HBM visited words, 1 LDS filter (optionally logging the scored ids).
 static rg_status launch_k1(rg_index *ix, int mode, const float *d_q, uint32_t nq, uint32_t qstride, uint32_t k,
                            uint32_t L, uint32_t *d_ids, float *d_dists, uint32_t *d_cmps, uint32_t *d_hops,
-                           const uint32_t *qlist, bool with_log, hipStream_t s, const BuildOut *bp = nullptr) {
+                           const uint32_t *qlist, bool with_log, hipStream_t s, const BuildOut *bp = nullptr,
+                           uint32_t qbase = 0) {
     int R = std::max(1, std::min(4, ix->rows_per_pass / 4));
     if (R == 3) R = 2;
     const int saved_mode = ix->visited_mode;
@@ -725,6 +735,7 @@ static rg_status launch_k1(rg_index *ix, int mode, const float *d_q, uint32_t nq
     P.counter = ix->d_counter; P.status = ix->d_status;
     P.stage_floats = ((ix->dim + 63) / 64) * 256;
     P.diag = (uint32_t)ix->diag;
+    P.qbase = qbase;
     P.vf_slots_log2 = filter_log2_of(ix);
     P.id_bits = id_bits_of(ix->nd);
     P.qlog = with_log ? ix->d_qlog : nullptr; P.logcap = ix->logcap; P.qlog_n = with_log ? ix->d_qlog_n : nullptr;
@@ -739,21 +750,24 @@ static rg_status launch_k1(rg_index *ix, int mode, const float *d_q, uint32_t nq
 }
 
 static rg_status ensure_qlog(rg_index *ix, uint32_t nq) {
-    // per-query id log: up to 128K ids (512 KiB) each, within a 6 GiB budget; longer logs take the exact fallback pass
+    // per-query id log: 128K ids (512 KiB) each; a batch larger than the log budget allows is searched in sub-batches
+    // that reuse the same logs (search_dev).  Longer logs take the exact fallback pass.
     uint32_t cap = 1u << 17;
-    const size_t budget = (size_t)6 << 30;
-    while (cap > 4096 && (size_t)nq * cap * 4 > budget) cap >>= 1;
     if (ix->log_cap_knob > 0) cap = (uint32_t)ix->log_cap_knob;
-    if (ix->d_qlog && ix->qlog_nq >= nq && ix->logcap == cap) return RG_OK;
+    const size_t budget = (size_t)std::max(1, ix->log_budget_kb) << 10;
+    const uint32_t chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(nq, budget / ((size_t)cap * 4)));
+    if (ix->d_qlog && ix->qlog_nq >= chunk && ix->logcap == cap && ix->ovf_nq >= nq) { ix->qlog_chunk = chunk; return RG_OK; }
     if (ix->d_qlog) (void)hipFree(ix->d_qlog);
     if (ix->d_qlog_n) (void)hipFree(ix->d_qlog_n);
     if (ix->d_ovf) (void)hipFree(ix->d_ovf);
     ix->d_qlog = ix->d_qlog_n = ix->d_ovf = nullptr;
-    ix->qlog_nq = 0;
-    RG_HIP(hipMalloc(&ix->d_qlog, (size_t)nq * cap * 4));
-    RG_HIP(hipMalloc(&ix->d_qlog_n, (size_t)nq * 4));
+    ix->qlog_nq = ix->ovf_nq = 0;
+    RG_HIP(hipMalloc(&ix->d_qlog, (size_t)chunk * cap * 4));
+    RG_HIP(hipMalloc(&ix->d_qlog_n, (size_t)chunk * 4));
     RG_HIP(hipMalloc(&ix->d_ovf, ((size_t)nq + 2) * 4));   // [0] = count, [1] = K4 work counter, then the list
-    ix->qlog_nq = nq;
+    ix->qlog_nq = chunk;
+    ix->qlog_chunk = chunk;
+    ix->ovf_nq = nq;
     ix->logcap = cap;
     return RG_OK;
 }
@@ -776,25 +790,31 @@ static rg_status search_dev(rg_index *ix, const float *d_q, uint32_t nq, uint32_
     rg_status st = ensure_qlog(ix, nq);
     if (st != RG_OK) return st;
     RG_HIP(hipMemsetAsync(ix->d_ovf, 0, 8, s));
-    st = launch_k1(ix, 1, d_q, nq, qstride, k, L, d_ids, d_dists, d_cmps, d_hops, nullptr, true, s);
-    if (st != RG_OK) return st;
     // default table: 2^15 words = 128 KiB of LDS (+ 16 KiB side table in the half-word form)
     const uint32_t tbits = (uint32_t)std::max(6, std::min(15, ix->count_table_log2));
     const uint32_t bbits = tbits - 2u;
     const uint32_t id_bits = std::max(id_bits_of(ix->nd), bbits + 1u);
     const bool half = id_bits - bbits <= 15u && !ix->count_full_ids;
     const size_t lds = half ? ((size_t)4 << tbits) + ((size_t)4 << (tbits - 3u)) : (size_t)4 << tbits;
-    const dim3 grid(std::min<uint32_t>(nq, (uint32_t)ix->num_cu));
-    if (half) {
-        auto kern = rg_distinct_kernel<true>;
-        RG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, grid, dim3(1024), lds, s, ix->d_qlog, ix->logcap, ix->d_qlog_n, nq, d_cmps, ix->d_ovf + 2,
-                           ix->d_ovf, ix->d_ovf + 1, tbits, id_bits);
-    } else {
-        auto kern = rg_distinct_kernel<false>;
-        RG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(kern, grid, dim3(1024), lds, s, ix->d_qlog, ix->logcap, ix->d_qlog_n, nq, d_cmps, ix->d_ovf + 2,
-                           ix->d_ovf, ix->d_ovf + 1, tbits, id_bits);
+    for (uint32_t q0 = 0; q0 < nq; q0 += ix->qlog_chunk) {
+        const uint32_t nqc = std::min(ix->qlog_chunk, nq - q0);
+        if (q0) RG_HIP(hipMemsetAsync(ix->d_ovf + 1, 0, 4, s));   // K4 work counter; the overflow count keeps running
+        st = launch_k1(ix, 1, d_q + (size_t)q0 * qstride, nqc, qstride, k, L, d_ids ? d_ids + (size_t)q0 * k : nullptr,
+                       d_dists ? d_dists + (size_t)q0 * k : nullptr, d_cmps + q0, d_hops ? d_hops + q0 : nullptr, nullptr, true, s,
+                       nullptr, q0);
+        if (st != RG_OK) return st;
+        const dim3 grid(std::min<uint32_t>(nqc, (uint32_t)ix->num_cu));
+        if (half) {
+            auto kern = rg_distinct_kernel<true>;
+            RG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(kern, grid, dim3(1024), lds, s, ix->d_qlog, ix->logcap, ix->d_qlog_n, nqc, d_cmps + q0, ix->d_ovf + 2,
+                               ix->d_ovf, ix->d_ovf + 1, tbits, id_bits, q0);
+        } else {
+            auto kern = rg_distinct_kernel<false>;
+            RG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            hipLaunchKernelGGL(kern, grid, dim3(1024), lds, s, ix->d_qlog, ix->logcap, ix->d_qlog_n, nqc, d_cmps + q0, ix->d_ovf + 2,
+                               ix->d_ovf, ix->d_ovf + 1, tbits, id_bits, q0);
+        }
     }
     RG_HIP(hipGetLastError());
     ix->pending.active = true;
@@ -1010,6 +1030,7 @@ rg_status rg_index_set(rg_index *ix, const char *name, int value) {
     else if (!strcmp(name, "visited")) ix->visited_mode = value < 0 || value > 2 ? 2 : value;
     else if (!strcmp(name, "filter_log2")) ix->filter_log2 = value;
     else if (!strcmp(name, "log_cap")) ix->log_cap_knob = value;
+    else if (!strcmp(name, "log_budget_kb")) ix->log_budget_kb = value;
     else if (!strcmp(name, "count_table_log2")) ix->count_table_log2 = value;
     else if (!strcmp(name, "count_full_ids")) ix->count_full_ids = value != 0;
     else return set_error(RG_ERR_ARG, "unknown knob");

@@ -87,3 +87,19 @@ def test_default_mode_exact_cmps_paths(rg, oracle, log_cap, table, full_ids):
         assert (got[2] == want[2]).all(), "cmps differ"
         assert (got[3] == want[3]).all() and (got[0] == want[0]).all() and (bits(got[1]) == bits(want[1])).all()
     ix.close()
+
+
+@pytest.mark.parametrize("log_cap,budget_kb", [(65536, 1024), (8192, 1024), (300, 64)])
+def test_large_batch_is_searched_in_sub_batches(rg, oracle, log_cap, budget_kb):
+    """A batch whose id logs exceed the log budget runs as sub-batches over the same logs (4, 32 or 54 queries each
+    here): every output still equals the oracle's -- also when logs overflow into the exact fallback pass (cap 300)."""
+    base, q, off, nbrs, ep = small_set("ip", 4000, 200, nq=300)
+    ix = rg.IndexBipartite.from_arrays(base, off, nbrs, ep, metric="ip")
+    ix.set("filter_log2", 6)
+    ix.set("log_cap", log_cap)
+    ix.set("log_budget_kb", budget_kb)   # budget / (log_cap * 4 B) queries per sub-batch
+    got = ix.SearchRoarGraph(q, 10, 100)
+    want = oracle.search(base, "ip", off, nbrs, ep, q, 10, 100, nthreads=4)
+    assert (got[2] == want[2]).all(), "cmps differ"
+    assert (got[3] == want[3]).all() and (got[0] == want[0]).all() and (bits(got[1]) == bits(want[1])).all()
+    ix.close()
