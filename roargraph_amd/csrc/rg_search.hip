@@ -194,15 +194,17 @@ __device__ __forceinline__ void beam_merge(Beam &bm, float cd, uint32_t cid, uin
     wave_sync();
 }
 
-template <bool L2, bool ELL, int R, int VIS>
+// DIMC: 0 = any dimension (query staged in LDS), else the compile-time dimension (query in registers)
+template <bool L2, bool ELL, int R, int VIS, int DIMC>
 __global__ void __launch_bounds__(64) rg_search_kernel(SearchParams P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
     const int g = lane >> 4;
     // LDS carve (all offsets multiples of 16 B)
     float *stage = reinterpret_cast<float *>(smem);                       // R * stage_floats
-    float *qv = stage + (size_t)R * P.stage_floats;                       // dim
-    uint32_t *cand_id = reinterpret_cast<uint32_t *>(qv + P.dim);         // 64
+    float *qv = stage + (size_t)R * P.stage_floats;                       // dim (DIMC == 0 only)
+    uint32_t *cand_id = reinterpret_cast<uint32_t *>(qv + (DIMC ? 0u : P.dim));   // 64
+    float qr[DIMC ? (DIMC + 15) / 16 : 1];
     float *cand_d = reinterpret_cast<float *>(cand_id + kWave);           // 64
     Beam bm;
     bm.ent = reinterpret_cast<uint2 *>(cand_d + kWave);                   // L
@@ -230,7 +232,8 @@ __global__ void __launch_bounds__(64) rg_search_kernel(SearchParams P) {
         const float *query = P.queries + (size_t)qi * P.qstride;
         uint32_t *qlog = (VIS == 1 && P.qlog) ? P.qlog + (size_t)qi * P.logcap : nullptr;
         uint32_t logn = 0, lbn = 0;   // ids scored so far / ids waiting in logbuf
-        for (uint32_t i = lane; i < P.dim; i += kWave) qv[i] = query[i];
+        if constexpr (DIMC != 0) load_query_regs<DIMC>(query, qr, lane);
+        else for (uint32_t i = lane; i < P.dim; i += kWave) qv[i] = query[i];
         // new visited epoch (VisitedList::reset, visited_list_pool.h:20-26: ++curV, wipe on wrap)
         uint32_t etag = 0;
         if (VIS == 0) {
@@ -249,7 +252,11 @@ __global__ void __launch_bounds__(64) rg_search_kernel(SearchParams P) {
         // entry point: scored and queued, not marked visited (index_bipartite.cpp:2338-2352)
         gather_issue(P.base + (size_t)P.ep * P.stride, P.dim, g == 0, stage, lane);
         gather_wait(0);
-        const float epd = gather_score<L2>(stage, qv, P.dim, lane);
+        auto score = [&](const float *buf) __attribute__((always_inline)) {
+            if constexpr (DIMC != 0) return gather_score_q<L2, DIMC>(buf, qr, lane);
+            else return gather_score<L2>(buf, qv, P.dim, lane);
+        };
+        const float epd = score(stage);
         if (lane == 0) bm.ent[0] = make_uint2(__float_as_uint(epd), P.ep);
         bm.size = 1;
         bm.cur = 0;
@@ -355,7 +362,7 @@ __global__ void __launch_bounds__(64) rg_search_kernel(SearchParams P) {
                         gather_wait((last - p) * lpp);
                         float *buf = stage + (size_t)(p & (R - 1)) * P.stage_floats;
                         const uint32_t c = 4 * p + g;
-                        const float d = gather_score<L2>(buf, qv, P.dim, lane);
+                        const float d = score(buf);
                         if (c < n && (lane & 15) == 0) cand_d[c] = d;
                         lds_sync();
                         if (p + R < npass) {
@@ -654,9 +661,13 @@ static uint32_t filter_log2_of(const rg_index *ix) {  // remainder must fit 15 b
     if (bits > t + 15) t = bits - 15;
     return std::min(t, bits);
 }
+// dimensions with a register-query instantiation of K1 (the BASELINE configs); ELL adjacency only
+static int dimc_of(const rg_index *ix) {
+    return (ix->d_ell != nullptr && (ix->dim == 200 || ix->dim == 512) && !ix->query_in_lds) ? (int)ix->dim : 0;
+}
 static size_t search_lds_bytes(const rg_index *ix, uint32_t L, int R) {
     const size_t stage_floats = (size_t)((ix->dim + 63) / 64) * 256;
-    size_t b = (size_t)R * stage_floats * 4 + (size_t)ix->dim * 4 + 64 * 4 + 64 * 4 + (size_t)L * 8;
+    size_t b = (size_t)R * stage_floats * 4 + (dimc_of(ix) ? 0 : (size_t)ix->dim * 4) + 64 * 4 + 64 * 4 + (size_t)L * 8;
     if (ix->visited_mode != 0) b += 128 * 4 + std::max<size_t>(4, (size_t)2 << filter_log2_of(ix));
     return (b + 15) / 16 * 16;
 }
@@ -678,13 +689,23 @@ static rg_status ensure_scratch(rg_index *ix, uint32_t slots) {
     return RG_OK;
 }
 
-template <bool L2, bool ELL, int R, int VIS>
-static rg_status launch_search_v(rg_index *ix, const SearchParams &P, uint32_t grid, size_t lds, hipStream_t s) {
-    auto kern = rg_search_kernel<L2, ELL, R, VIS>;
+template <bool L2, bool ELL, int R, int VIS, int DIMC>
+static rg_status launch_search_d(rg_index *ix, const SearchParams &P, uint32_t grid, size_t lds, hipStream_t s) {
+    auto kern = rg_search_kernel<L2, ELL, R, VIS, DIMC>;
     RG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, s, P);
     RG_HIP(hipGetLastError());
     return RG_OK;
+}
+
+template <bool L2, bool ELL, int R, int VIS>
+static rg_status launch_search_v(rg_index *ix, const SearchParams &P, uint32_t grid, size_t lds, hipStream_t s) {
+    if constexpr (ELL) {
+        const int dc = dimc_of(ix);
+        if (dc == 200) return launch_search_d<L2, ELL, R, VIS, 200>(ix, P, grid, lds, s);
+        if (dc == 512) return launch_search_d<L2, ELL, R, VIS, 512>(ix, P, grid, lds, s);
+    }
+    return launch_search_d<L2, ELL, R, VIS, 0>(ix, P, grid, lds, s);
 }
 
 template <bool L2, bool ELL, int R>
@@ -1031,6 +1052,7 @@ rg_status rg_index_set(rg_index *ix, const char *name, int value) {
     else if (!strcmp(name, "filter_log2")) ix->filter_log2 = value;
     else if (!strcmp(name, "log_cap")) ix->log_cap_knob = value;
     else if (!strcmp(name, "log_budget_kb")) ix->log_budget_kb = value;
+    else if (!strcmp(name, "query_in_lds")) ix->query_in_lds = value != 0;
     else if (!strcmp(name, "count_table_log2")) ix->count_table_log2 = value;
     else if (!strcmp(name, "count_full_ids")) ix->count_full_ids = value != 0;
     else return set_error(RG_ERR_ARG, "unknown knob");

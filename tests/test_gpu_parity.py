@@ -103,3 +103,18 @@ def test_large_batch_is_searched_in_sub_batches(rg, oracle, log_cap, budget_kb):
     assert (got[2] == want[2]).all(), "cmps differ"
     assert (got[3] == want[3]).all() and (got[0] == want[0]).all() and (bits(got[1]) == bits(want[1])).all()
     ix.close()
+
+
+@pytest.mark.parametrize("metric,d,nb", [("ip", 200, 4000), ("l2", 512, 2000)])
+def test_register_and_lds_query_forms_agree(rg, oracle, metric, d, nb):
+    """d = 200 / 512 run the K1 instantiation that keeps the query in registers; "query_in_lds" forces the generic
+    one.  Both must equal the oracle bit for bit."""
+    base, q, off, nbrs, ep = small_set(metric, nb, d)
+    want = oracle.search(base, metric, off, nbrs, ep, q, 10, 100, nthreads=4)
+    for in_lds in (0, 1):
+        ix = rg.IndexBipartite.from_arrays(base, off, nbrs, ep, metric=metric)
+        ix.set("query_in_lds", in_lds)
+        got = ix.SearchRoarGraph(q, 10, 100)
+        assert (got[0] == want[0]).all() and (bits(got[1]) == bits(want[1])).all()
+        assert (got[2] == want[2]).all() and (got[3] == want[3]).all()
+        ix.close()
