@@ -63,6 +63,8 @@ def parse():
     ap.add_argument("--real-index", action="store_true",
                     help="build a genuine RoarGraph index for the bench base inside the run (K2 ground truth of --train "
                          "queries, GPU-assisted build; about 5 min at 10M) instead of the random graph")
+    ap.add_argument("--data", default="gaussian", help="gaussian (default, hardest: no structure) | lowrank (structured embeddings)")
+    ap.add_argument("--rank", type=int, default=32, help="latent rank of --data lowrank")
     ap.add_argument("--train", type=int, default=0, help="training queries for --real-index (default nb/5)")
     ap.add_argument("--recall-nb", type=int, default=200_000,
                     help="base size of the recall check on a genuine RoarGraph index built in the run; 0 = skip")
@@ -177,6 +179,8 @@ def pmc_traffic(args):
     here = os.path.dirname(os.path.abspath(__file__))
     key = {"nb": args.nb, "dim": args.dim, "nq": args.nq, "L": args.L, "k": args.k, "deg": args.deg,
            "metric": args.metric, "visited": args.visited, "real_index": bool(args.real_index)}
+    if args.data != "gaussian":
+        return None, None
     for path in sorted(glob.glob(os.path.join(here, "profiles", "*", "search_traffic.json")), reverse=True):
         try:
             t = json.load(open(path))
@@ -209,15 +213,25 @@ def main():
     # ---- synthetic t2i-10M-shaped inputs, resident in HBM before the timed region -------------------------------
     g = torch.Generator(device=dev)
     g.manual_seed(1234)  # same base + graph on every rank (replicated index)
-    base = torch.empty((args.nb, args.dim), dtype=torch.float32, device=dev)
-    chunk = 1 << 20
-    for s in range(0, args.nb, chunk):
-        base[s:s + chunk].normal_(generator=g)
+    ntrain = (args.train or args.nb // 5) if args.real_index else 0
+    lowrank = None
+    if args.data == "lowrank":
+        # embeddings with a low intrinsic dimension (the set the recall target is demonstrated on); rank 0 data on every rank
+        from roargraph_amd import synth
+        base, train, lowrank_q, data_desc = synth.make_device_set(dev, 1234, args.nb, ntrain, args.nq, args.dim, data="lowrank",
+                                                                  rank=args.rank)
+        lowrank = lowrank_q
+    else:
+        base = torch.empty((args.nb, args.dim), dtype=torch.float32, device=dev)
+        chunk = 1 << 20
+        for s in range(0, args.nb, chunk):
+            base[s:s + chunk].normal_(generator=g)
+        data_desc = "synthetic N(0,1) base"
     graph_desc = "random out-degree-%d graph" % args.deg
     if args.real_index:
         from roargraph_amd import build, groundtruth
-        ntrain = args.train or args.nb // 5
-        train = torch.empty((ntrain, args.dim), dtype=torch.float32, device=dev).normal_(generator=g) * 0.5 + 0.3
+        if lowrank is None:
+            train = torch.empty((ntrain, args.dim), dtype=torch.float32, device=dev).normal_(generator=g) * 0.5 + 0.3
         ti = torch.zeros((ntrain, 100), dtype=torch.int32, device=dev); tv = torch.zeros((ntrain, 100), device=dev)
         t0 = time.perf_counter()
         groundtruth.gt_shard_dev(base, train, args.metric, 100, 0, ti, tv, stream=torch.cuda.current_stream().cuda_stream)
@@ -237,7 +251,10 @@ def main():
         off = torch.arange(0, args.nb + 1, dtype=torch.int64, device=dev) * args.deg
         ep = 0
     g.manual_seed(99 + rank)  # each rank searches its own query batch
-    q = torch.empty((args.nq, args.dim), dtype=torch.float32, device=dev).normal_(generator=g) * 0.5 + 0.3
+    if lowrank is not None:
+        q = lowrank      # same query batch on every rank for this data set
+    else:
+        q = torch.empty((args.nq, args.dim), dtype=torch.float32, device=dev).normal_(generator=g) * 0.5 + 0.3
     ids = torch.zeros((args.nq, args.k), dtype=torch.int32, device=dev)
     dists = torch.zeros((args.nq, args.k), dtype=torch.float32, device=dev)
     cmps = torch.zeros(args.nq, dtype=torch.int32, device=dev)
@@ -304,7 +321,8 @@ def main():
     from roargraph_amd import groundtruth as _gtmod, index as _ixmod
     ti_q = torch.zeros((args.nq, 100), dtype=torch.int32, device=dev); tv_q = torch.zeros((args.nq, 100), device=dev)
     _gtmod.gt_shard_dev(base, q, args.metric, 100, 0, ti_q, tv_q, stream=stream); torch.cuda.synchronize()
-    recall10 = _ixmod.recall(ids.cpu().numpy().view(np.uint32), ti_q.cpu().numpy().view(np.uint32), 10) if args.k >= 10 else None
+    gt_np = ti_q.cpu().numpy().view(np.uint32)
+    recall10 = _ixmod.recall(ids.cpu().numpy().view(np.uint32), gt_np, 10) if args.k >= 10 else None
     del ti_q, tv_q
 
     other = None
@@ -332,6 +350,7 @@ def main():
             ms = a.elapsed_time(b)
             mc = float(cmps.float().mean().item())
             sweep.append({"L_pq": L, "qps": args.nq / (ms / 1e3), "mean_evals": mc,
+                          "recall_at_10": _ixmod.recall(ids.cpu().numpy().view(np.uint32), gt_np, 10) if args.k >= 10 else None,
                           "gbps": args.nq * mc * 4 * args.dim / (ms / 1e3) / 1e9})
         step(args.L); torch.cuda.synchronize()
 
@@ -383,8 +402,8 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": "t2i-10M-shaped: base %dx%d fp32 %s, %d queries/GPU/step, top-%d, L_pq=%d, "
-                                   "synthetic N(0,1) base, %s (replicated per GPU)"
-                                   % (args.nb, args.dim, args.metric, args.nq, args.k, args.L, graph_desc),
+                                   "%s, %s (replicated per GPU)"
+                                   % (args.nb, args.dim, args.metric, args.nq, args.k, args.L, data_desc, graph_desc),
                        "parallelism": "query-sharded x%d, index replicated" % world,
                        "recall_at_10": recall10,
                        "recall_note": ("recall of the timed search on the genuine index" if args.real_index else

@@ -84,3 +84,49 @@ def random_regular_csr(nd, deg, seed=11):
     nbrs = rng.integers(0, nd, size=(nd, deg), dtype=np.uint32)
     offsets = (np.arange(nd + 1, dtype=np.uint64) * np.uint64(deg))
     return offsets, nbrs.reshape(-1)
+
+
+def make_device_set(dev, seed, nb, ntrain, nq, d, data="gaussian", rank=24, noise=0.05):
+    """Base / training queries / test queries as torch tensors on `dev` (bench.py, scripts/e2e_pipeline.py).
+
+    "gaussian": base ~ N(0,1)^d, queries ~ N(0.3, 0.5^2)^d -- the hardest case (no structure: a graph index cannot
+                reach high recall on it at 10M points; used for throughput).
+    "lowrank":  embeddings with the structure real ones have, a low intrinsic dimension: x = z A + noise * eps with
+                z ~ N(0, I_rank) for the base and z ~ N(0.3, 0.5^2 I_rank) for the queries (the same out-of-distribution
+                shift, in the latent space), A a fixed rank x d matrix with N(0, 1/rank) entries.  This is the set the
+                recall target (>= 0.9 recall@10) is demonstrated on.
+    Returns (base, train, queries, description)."""
+    import torch
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    chunk = 1 << 20
+
+    def fill(n, mean, std, mix):
+        out = torch.empty((n, d), dtype=torch.float32, device=dev)
+        for s in range(0, n, chunk):
+            m = min(chunk, n - s)
+            if mix is None:
+                out[s:s + m].normal_(generator=g)
+                if mean != 0.0 or std != 1.0:
+                    out[s:s + m].mul_(std).add_(mean)
+            else:
+                z = torch.empty((m, rank), dtype=torch.float32, device=dev).normal_(generator=g) * std + mean
+                out[s:s + m] = z @ mix
+                out[s:s + m].add_(torch.empty((m, d), dtype=torch.float32, device=dev).normal_(generator=g), alpha=noise)
+        return out
+
+    if data == "gaussian":
+        base = fill(nb, 0.0, 1.0, None)
+        train = fill(ntrain, 0.3, 0.5, None) if ntrain else None
+        q = fill(nq, 0.3, 0.5, None)
+        desc = "base N(0,1) %dx%d, train/test queries N(0.3,0.5^2) (%d / %d)" % (nb, d, ntrain, nq)
+    elif data == "lowrank":
+        mix = torch.empty((rank, d), dtype=torch.float32, device=dev).normal_(generator=g) / float(rank) ** 0.5
+        base = fill(nb, 0.0, 1.0, mix)
+        train = fill(ntrain, 0.3, 0.5, mix) if ntrain else None
+        q = fill(nq, 0.3, 0.5, mix)
+        desc = ("low-rank embeddings %dx%d: x = zA + %.2f eps, latent rank %d, base z ~ N(0,1), train/test queries "
+                "z ~ N(0.3,0.5^2) (%d / %d)" % (nb, d, noise, rank, ntrain, nq))
+    else:
+        raise ValueError("data must be gaussian or lowrank")
+    return base, train, q, desc

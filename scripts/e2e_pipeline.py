@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
 import torch
-from roargraph_amd import build, groundtruth, index
+from roargraph_amd import build, groundtruth, index, synth
 from roargraph_amd.index import IndexBipartite
 
 ap = argparse.ArgumentParser()
@@ -22,17 +22,17 @@ ap.add_argument("--metric", default="ip")
 ap.add_argument("--threads", type=int, default=0)
 ap.add_argument("--L", default="10,20,50,100,200,500,1000")
 ap.add_argument("--out", default="")
+ap.add_argument("--data", default="gaussian", help="gaussian | lowrank (roargraph_amd.synth.make_device_set)")
+ap.add_argument("--rank", type=int, default=24)
+ap.add_argument("--noise", type=float, default=0.05)
 ap.add_argument("--build-device", type=int, default=-1, help=">= 0: phase 3 of the build on that GPU")
 a = ap.parse_args()
 ntrain = a.ntrain or a.nb
 threads = a.threads or min(64, os.cpu_count() or 1)   # README.md:92-97 builds with T=64
 dev = torch.device("cuda", 0)
-g = torch.Generator(device=dev); g.manual_seed(1234)
-base = torch.empty((a.nb, a.dim), device=dev).normal_(generator=g)
-train = torch.empty((ntrain, a.dim), device=dev).normal_(generator=g) * 0.5 + 0.3
-q = torch.empty((a.nq, a.dim), device=dev).normal_(generator=g) * 0.5 + 0.3
+base, train, q, desc = synth.make_device_set(dev, 1234, a.nb, ntrain, a.nq, a.dim, data=a.data, rank=a.rank, noise=a.noise)
 st = torch.cuda.current_stream().cuda_stream
-res = {"dataset": "base N(0,1) %dx%d, train/test queries N(0.3,0.5^2) (%d / %d), %s" % (a.nb, a.dim, ntrain, a.nq, a.metric)}
+res = {"dataset": "%s, %s" % (desc, a.metric)}
 
 t0 = time.perf_counter()
 ti = torch.zeros((ntrain, 100), dtype=torch.int32, device=dev); tv = torch.zeros((ntrain, 100), device=dev)
