@@ -170,6 +170,23 @@ def recall_check(args, dev):
             "queries": nq, "curve": rows}
 
 
+def gt_cpu_baseline(base, gq, args):
+    """CPU baseline of the ground-truth leg: oracle/gt_numpy.py (blocked SGEMM on all host cores + per-query top-K, the
+    shape of the reference's compute_groundtruth) on a bounded sample of the same workload."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "oracle"))
+    import gt_numpy
+    nbs, nqs = min(args.nb, 1_000_000), min(args.gt_nq, 2048)
+    hb = base[:nbs].cpu().numpy()
+    hq = gq[:nqs].cpu().numpy()
+    gt_numpy.groundtruth_blocked(hb[:65536], hq[:64], args.metric, args.gt_K)   # warm the BLAS threads
+    t0 = time.perf_counter()
+    gt_numpy.groundtruth_blocked(hb, hq, args.metric, args.gt_K)
+    dt = time.perf_counter() - t0
+    return {"value": float(nbs) * float(nqs) / dt, "unit": "distances/s", "cores": os.cpu_count() or 1, "kind": "port",
+            "sample": "%d queries x %d base rows, K=%d, numpy/OpenBLAS SGEMM + argpartition per 131072-row block "
+                      "(oracle/gt_numpy.py), %.1f s" % (nqs, nbs, args.gt_K, dt)}
+
+
 def pmc_traffic(args):
     """HBM bytes per launch of the search kernel from the committed rocprofv3 PMC passes (profiles/*/search_traffic.json,
     written by scripts/profile_on_box.sh: separate --pmc FETCH_SIZE / WRITE_SIZE runs of this same command, FETCH_SIZE
@@ -378,6 +395,11 @@ def main():
               "value": dps, "seconds": tg, "TFLOPs_fp32_mfma": 2.0 * args.dim * dps / 1e12,
               "roofline": {"bound": "mfma", "achieved": 2.0 * args.dim * dps / 1e12, "peak": 157.3 * world, "unit": "TFLOP/s",
                            "frac": 2.0 * args.dim * dps / 1e12 / (157.3 * world)}}
+        if rank == 0 and world == 1 and args.cpu_seconds > 0:
+            try:
+                gt["cpu_baseline"] = gt_cpu_baseline(base, gq, args)
+            except Exception as e:
+                gt["cpu_baseline"] = {"value": None, "unit": "distances/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
         del gi, gv, gq
 
     rcheck = None

@@ -27,7 +27,7 @@ struct rg_index {
     unsigned long long *h_status = nullptr;  // pinned
     // knobs
     int waves_per_cu = 0;   // 0 = auto
-    int rows_per_pass = 4;  // 4*R (R = staging ring depth)
+    int rows_per_pass = 0;  // 4*R (R = staging ring depth); 0 = auto: 8 on graphs of average out-degree >= 28, else 4
     int force_csr = 0;
     int diag = 0;
     // 0 = exact visited words in HBM; 1 = LDS exact-match filter only (cmps = evaluations performed);

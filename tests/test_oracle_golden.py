@@ -85,3 +85,19 @@ def test_search_edge_cases(oracle):
         oracle.search(base, "l2", off, np.zeros(0, np.uint32), 7, q, 2, 10)
     ids, ds, cmps, hops = oracle.search(base, "l2", off, np.zeros(0, np.uint32), 7, q, 1, 10)
     assert (ids == 7).all() and (cmps == 0).all() and (hops == 1).all()
+
+
+@pytest.mark.parametrize("metric", ["ip", "l2"])
+def test_blocked_sgemm_groundtruth_matches_fp64(oracle, metric):
+    """oracle/gt_numpy.py (the CPU baseline of the bench's ground-truth leg: blocked SGEMM + per-block top-K) against the
+    fp64 brute force: same ids up to fp32 near-ties, distances within 1e-4 relative."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle"))
+    import gt_numpy
+    rng = np.random.default_rng(5)
+    base = rng.standard_normal((6000, 40), dtype=np.float32)
+    q = (0.3 + 0.5 * rng.standard_normal((32, 40), dtype=np.float32)).astype(np.float32)
+    ids, ds = gt_numpy.groundtruth_blocked(base, q, metric, 50, block=1024)
+    i64, d64, _ = oracle.groundtruth_f64(base, q, metric, 50)
+    assert (ids == i64).mean() > 0.99
+    assert np.allclose(np.sort(ds, axis=1), np.sort(d64, axis=1), rtol=1e-4, atol=1e-4)
