@@ -22,6 +22,8 @@
 // mutex scheme is used and, exactly like the reference, the result depends on scheduling.
 #include <algorithm>
 #include <atomic>
+#include <chrono>
+#include <cstdio>
 #include <cmath>
 #include <cstdlib>
 #include <cstring>
@@ -395,20 +397,29 @@ struct Builder {
             search_live(node, stamp[0], serial[0], expanded);
             link_from_search(node, expanded);
         }
+        double t_snap = 0, t_gpu = 0, t_link = 0;
+        uint32_t nbatches = 0;
+        auto since = [](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
+        auto t_b = std::chrono::steady_clock::now();
+        if (timing) fprintf(stderr, "[rg_build]   phase 3 upload + warm-up  %8.2f s\n", since(t_mark));
         for (uint32_t b0 = warm, n = 0; ok && b0 < nd; b0 += n) {
             n = gpu_batch ? B : std::min(B, std::max<uint32_t>(512, b0 / 4));
             n = std::min(n, nd - b0);
+            t_link += since(t_b); t_b = std::chrono::steady_clock::now();
             parallel_for(nd, 4096, [&](uint32_t i, int) {
                 uint32_t *row = h_ell.data() + (size_t)i * S;
                 const std::vector<uint32_t> &l = supply[i];
                 row[0] = (uint32_t)l.size();
                 std::memcpy(row + 1, l.data(), l.size() * 4);
             });
+            t_snap += since(t_b); t_b = std::chrono::steady_clock::now();
             ok = build_index_set_ell(ix, h_ell.data(), nullptr) == RG_OK &&
                  build_search_dev(ix, b0, n, L, d_exp, cap, d_nexp, nullptr) == RG_OK &&
                  hipMemcpy(h_nexp.data(), d_nexp, (size_t)n * 4, hipMemcpyDeviceToHost) == hipSuccess &&
                  hipMemcpy(h_exp.data(), d_exp, (size_t)n * cap * 8, hipMemcpyDeviceToHost) == hipSuccess;
             if (!ok) break;
+            t_gpu += since(t_b); t_b = std::chrono::steady_clock::now();
+            ++nbatches;
             parallel_for(n, 64, [&](uint32_t i, int t) {
                 const uint32_t node = b0 + i;
                 std::vector<Nb> expanded;
@@ -434,6 +445,9 @@ struct Builder {
                 link_from_search(node, expanded);
             });
         }
+        t_link += since(t_b);
+        if (timing) fprintf(stderr, "[rg_build]   phase 3: %u batches, snapshot %.2f s, upload + GPU search + download %.2f s, host linking %.2f s\n",
+                            nbatches, t_snap, t_gpu, t_link);
         if (ix) rg_index_close(ix);
         if (d_base) (void)hipFree(d_base);
         if (d_exp) (void)hipFree(d_exp);
@@ -443,7 +457,17 @@ struct Builder {
         return true;
     }
 
+    // RG_BUILD_TIMING=1: per-phase wall times on stderr
+    bool timing = getenv("RG_BUILD_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t_mark = std::chrono::steady_clock::now();
+    void lap(const char *what) {
+        const auto now = std::chrono::steady_clock::now();
+        if (timing) fprintf(stderr, "[rg_build] %-28s %8.2f s\n", what, std::chrono::duration<double>(now - t_mark).count());
+        t_mark = now;
+    }
+
     bool run(const uint32_t *knn, uint32_t nq, uint32_t kdim) {
+        lap("setup");
         proj.assign(nd, {});
         supply.assign(nd, {});
         locks = std::vector<std::mutex>(nd);
@@ -465,6 +489,7 @@ struct Builder {
             }
             ep = best;
         }
+        lap("entry point");
         // ---- phase 1 (:1059-1097): every training query links its nearest base point to its other neighbours
         parallel_for(nq, 100, [&](uint32_t sq, int) {
             const uint32_t n = std::min(kdim, Nq);
@@ -482,6 +507,7 @@ struct Builder {
             }
             add_reverse(proj, tgt, M, false);
         });
+        lap("phase 1");
         // ---- phase 2 (:1100-1136)
         parallel_for(nd, 100, [&](uint32_t node, int) { add_reverse(proj, node, M, false); });
         parallel_for(nd, 2048, [&](uint32_t node, int) {
@@ -495,6 +521,7 @@ struct Builder {
             proj[node] = pruned;
         });
         for (uint32_t i = 0; i < nd; ++i) supply[i] = proj[i];   // :1183-1188
+        lap("phase 2 + supply copy");
         // ---- phase 3 (:1192-1220): connectivity enhancement -- beam search from the entry point towards every node
         if (gpu_device >= 0) {
             if (!phase3_gpu()) return false;
@@ -507,6 +534,7 @@ struct Builder {
                 link_from_search(node, expanded);
             });
         }
+        lap("phase 3");
         // ---- phase 4 (:1224-1248)
         parallel_for(nd, 2048, [&](uint32_t node, int) {
             if (supply[node].size() <= M) return;
@@ -517,6 +545,7 @@ struct Builder {
             std::lock_guard<std::mutex> guard(locks[node]);
             supply[node] = pruned;
         });
+        lap("phase 4");
         // ---- phase 5 (:1251-1264): append up to 2*M supply edges that the projection list lacks
         parallel_for(nd, 100, [&](uint32_t i, int) {
             std::vector<uint32_t> ok;
@@ -526,6 +555,7 @@ struct Builder {
             }
             proj[i].insert(proj[i].end(), ok.begin(), ok.end());
         });
+        lap("phase 5");
         return true;
     }
 };
