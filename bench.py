@@ -358,6 +358,32 @@ def main():
             other.append({"visited": om, "qps": args.nq / (oms / 1e3), "ms_avg": oms, "achieved_GBps": alg_bytes / (oms / 1e3) / 1e9})
         index.set("visited", args.visited)
 
+    # opt-in NON-parity fast mode (rg_index_set "fast_bf16"): reported separately, never as `value`
+    fast = None
+    if rank == 0 and not args.no_other_modes and args.dim in (200, 512):
+        try:
+            index.set("fast_bf16", 1)
+            f_ids = torch.zeros_like(ids); f_d = torch.zeros_like(dists); f_c = torch.zeros_like(cmps); f_h = torch.zeros_like(hops)
+            index.search_dev(q, args.k, args.L, f_ids, f_d, f_c, f_h, stream=stream); index.search_wait(stream)
+            fe = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(min(3, args.steps))]
+            for a, b in fe:
+                a.record(); index.search_dev(q, args.k, args.L, f_ids, f_d, f_c, f_h, stream=stream); b.record()
+            torch.cuda.synchronize(); index.search_wait(stream)
+            fms = float(np.mean([a.elapsed_time(b) for a, b in fe]))
+            fi, ei = f_ids.cpu().numpy().view(np.uint32), ref_ids.cpu().numpy().view(np.uint32)
+            same = float(np.mean([len(set(fi[i].tolist()) & set(ei[i].tolist())) / float(args.k) for i in range(args.nq)]))
+            row_b = (args.dim + 127) // 128 * 256
+            fast = {"mode": "fast_bf16 (opt-in, not parity: bf16 traversal + exact fp32 re-rank of the beam)",
+                    "qps": args.nq / (fms / 1e3), "ms_avg": fms, "overlap_with_exact_search_top%d" % args.k: same,
+                    "recall_at_10": _ixmod.recall(fi, gt_np, 10) if args.k >= 10 else None,
+                    "mean_evals_performed": float(f_c.float().mean().item()),
+                    "hbm_bytes_per_evaluation": row_b,
+                    "row_GBps": float(f_c.to(torch.int64).sum().item()) * row_b / (fms / 1e3) / 1e9}
+        except Exception as e:
+            fast = {"error": repr(e)}
+        index.set("fast_bf16", 0)
+        step(args.L); torch.cuda.synchronize(); index.search_wait(stream)
+
     sweep = []
     if args.sweep and rank == 0:
         for L in [int(x) for x in args.sweep.split(",")]:
@@ -444,6 +470,7 @@ def main():
                          "frac_of_measured_stream_ceiling_6290": achieved / 6290.0},
             "cpu_baseline": cpu,
             "other_visited_modes": other,
+            "fast_mode_bf16": fast,
             "gt_build": gt,
             "recall_check_roargraph_index": rcheck,
         }

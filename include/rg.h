@@ -94,12 +94,17 @@ rg_status rg_index_open_dev(const float *d_base, uint32_t nd, uint32_t dim, uint
 void rg_index_close(rg_index *idx);
 rg_status rg_index_info(const rg_index *idx, uint32_t *nd, uint32_t *dim, uint32_t *stride, uint32_t *ep,
                         float *avg_degree, uint32_t *max_degree, int *device);
-/* tuning knobs: "waves_per_cu", "rows_per_pass", "filter_log2", "log_cap", "log_budget_kb", "count_table_log2", "count_full_ids", "query_in_lds" never
- * change results.
+/* tuning knobs: "waves_per_cu", "rows_per_pass", "filter_log2", "log_cap", "log_budget_kb", "count_table_log2",
+ * "count_full_ids", "query_in_lds" never change results.
  * "visited" selects how the visited set is kept:
  *   2 (default) LDS exact-match filter + per-query id log + exact distinct count: ids, dists, hops AND cmps bit-exact
  *   1           LDS filter only: ids, dists, hops bit-exact; cmps = evaluations performed (>= the reference's)
- *   0           exact visited words in HBM (the reference's tag array, visited_list_pool.h): everything bit-exact */
+ *   0           exact visited words in HBM (the reference's tag array, visited_list_pool.h): everything bit-exact
+ * "fast_bf16" = 1 is an OPT-IN mode that is NOT parity with the reference; default 0.  The traversal
+ * scores a bf16 copy of the base (made on first use, nd * round_up(dim,128) * 2 bytes of HBM; d = 200 / 512 with the
+ * default adjacency layout only, otherwise the knob has no effect), then every beam entry is re-scored with the exact
+ * fp32 routine and the k best by exact (distance, id) are returned: out_dists are exact for the returned ids, the ids
+ * can differ from the reference's (recall is reported separately by bench.py), cmps = evaluations performed. */
 rg_status rg_index_set(rg_index *idx, const char *name, int value);
 
 /* ----------------------------------------------------------------- operator

@@ -195,16 +195,74 @@ __device__ __forceinline__ float gather_score_q(const float *stage, const float 
         RG_STEPQ(v3, qr[4 * b + 3]);
     }
     const float *s = stage + 256 * nfull;
-    if (nt > 0) RG_STEPQ(s[o0], qr[4 * nfull + 0]);
-    if (nt > 1) RG_STEPQ(s[o1], qr[4 * nfull + 1]);
-    if (nt > 2) RG_STEPQ(s[o2], qr[4 * nfull + 2]);
+    if constexpr (nt > 0) RG_STEPQ(s[o0], qr[4 * nfull + 0]);
+    if constexpr (nt > 1) RG_STEPQ(s[o1], qr[4 * nfull + 1]);
+    if constexpr (nt > 2) RG_STEPQ(s[o2], qr[4 * nfull + 2]);
     acc = acc + dpp_f<0x128>(acc);                       // 16 -> 8
-    if (rem & 8) {                                       // 8-wide tail on the folded sum
+    if constexpr ((rem & 8) != 0) {                      // 8-wide tail on the folded sum
         const int x = 16 * nt + (a & 7);
         const int off = 64 * g + ((x + 16 * g) & 63);
         RG_STEPQ(s[off], qr[(DIMC + 15) / 16 - 1]);
     }
 #undef RG_STEPQ
+    acc = acc + dpp_f<0x124>(acc);
+    acc = acc + dpp_f<0xB1>(acc);
+    acc = acc + dpp_f<0x4E>(acc);
+    return L2 ? acc : -acc;
+}
+
+// ---- opt-in fast mode (NOT parity): traversal over a bf16 copy of the base ---------------------------
+// Rows of the copy are padded with zeros to a multiple of 128 elements (256 B: whole LDS-DMA instructions, whole
+// 128-B lines: 512 B per d = 200 row instead of the 7 lines = 896 B of the fp32 row).  One 16-lane group per row as in
+// the exact path; lane p owns the 8 elements 128b + 8p .. +7 of every 128-element block b and reads back exactly the
+// 16 bytes it fetched.
+template <int NB>
+__device__ __forceinline__ void gather_issue_bf(const uint16_t *__restrict__ row, bool active, uint32_t *stage, int lane) {
+    const int p = lane & 15;
+    if (active) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+            __builtin_amdgcn_global_load_lds((glb_ptr_t *)(row + 128 * b + 8 * p), (lds_ptr_t *)(stage + 256 * b), 16, 0, 0);
+    }
+}
+
+// query fragment of the fast mode: qb[8b + i] = q[128b + 8p + i] (0 beyond the dimension)
+template <int DIMC>
+__device__ __forceinline__ void load_query_regs_bf(const float *query, float (&qb)[8 * ((DIMC + 127) / 128)], int lane) {
+    constexpr int NB = (DIMC + 127) / 128;
+    const int p = lane & 15;
+#pragma unroll
+    for (int b = 0; b < NB; ++b)
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int e = 128 * b + 8 * p + i;
+            qb[8 * b + i] = e < DIMC ? query[e] : 0.0f;
+        }
+}
+
+// approximate compare() of this lane's group row (bf16 elements, fp32 query, fp32 accumulation); valid in every lane
+template <bool L2, int NB>
+__device__ __forceinline__ float score_bf(const uint32_t *stage, const float (&qb)[8 * NB], int lane) {
+    float acc = 0.0f;
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const uint4 w = *reinterpret_cast<const uint4 *>(stage + 256 * b + 4 * lane);
+        const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float lo = __uint_as_float(ww[i] << 16), hi = __uint_as_float(ww[i] & 0xffff0000u);
+            const float q0 = qb[8 * b + 2 * i], q1 = qb[8 * b + 2 * i + 1];
+            if (L2) {
+                const float t0 = lo - q0, t1 = hi - q1;
+                acc = __builtin_fmaf(t0, t0, acc);
+                acc = __builtin_fmaf(t1, t1, acc);
+            } else {
+                acc = __builtin_fmaf(lo, q0, acc);
+                acc = __builtin_fmaf(hi, q1, acc);
+            }
+        }
+    }
+    acc = acc + dpp_f<0x128>(acc);
     acc = acc + dpp_f<0x124>(acc);
     acc = acc + dpp_f<0xB1>(acc);
     acc = acc + dpp_f<0x4E>(acc);

@@ -39,6 +39,10 @@ struct rg_index {
     int log_budget_kb = 16 << 20;  // HBM budget of the id logs (KiB, default 16 GiB = 32768 queries): larger batches are searched in sub-batches
     int log_cap_knob = 0;       // 0 = auto; tests force small logs to exercise the exact fallback
     int count_table_log2 = 15;  // K4 LDS table: 2^15 words = 128 KiB
+    bool fast_bf16 = false;      // opt-in non-parity mode: traverse a bf16 copy of the base, exact re-rank of the beam
+    bool bf_launch = false;      // transient: the launch being prepared uses the bf16 copy
+    uint16_t *d_base_bf = nullptr;
+    uint32_t stride_bf = 0;
     bool query_in_lds = false;   // K1: force the generic (query staged in LDS) instantiation for d = 200 / 512
     bool count_full_ids = false; // K4: force the full-id bucket form (the half-word form is used when the remainder fits)
     struct Pending { bool active = false; const float *q = nullptr; uint32_t nq = 0, qstride = 0, k = 0, L = 0; uint32_t *ids = nullptr; float *dists = nullptr; uint32_t *cmps = nullptr, *hops = nullptr; } pending;

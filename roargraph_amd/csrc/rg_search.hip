@@ -66,7 +66,8 @@ struct SearchParams {
     uint32_t *slot_epoch;     // [slots] last epoch used by the slot (persists across launches)
     uint32_t *counter;        // work-queue head
     unsigned long long *status;  // min over failing queries of (query << 32 | queue size); ~0 = none
-    uint32_t stage_floats;    // floats per sub-pass staging buffer (ceil(dim/64)*256)
+    uint32_t stage_floats;    // floats per sub-pass staging buffer (ceil(dim/64)*256; fast mode: 256 per 128 bf16 elements)
+    uint32_t stage_total;     // floats of the whole staging region (>= R * stage_floats; fast mode: >= one fp32 pass too)
     uint32_t qbase;           // index of queries[0] in the caller's batch (error reporting of chunked launches)
     uint32_t diag;            // diagnostics only (breaks parity): bit0 = skip the visited test
     uint32_t vf_slots_log2;   // VIS=1: log2 of the LDS visited-filter size (16-bit entries)
@@ -78,6 +79,8 @@ struct SearchParams {
     uint32_t exp_cap, tgt_base;
     uint32_t *out_nexp;       // [nq] number of expansions
     uint32_t id_bits;         // VIS=1: ceil(log2(nd))
+    const uint16_t *base_bf;  // fast mode (BF): bf16 copy of the base, rows padded to stride_bf elements (multiple of 128)
+    uint32_t stride_bf;
 };
 
 struct Beam {
@@ -195,16 +198,22 @@ __device__ __forceinline__ void beam_merge(Beam &bm, float cd, uint32_t cid, uin
 }
 
 // DIMC: 0 = any dimension (query staged in LDS), else the compile-time dimension (query in registers)
-template <bool L2, bool ELL, int R, int VIS, int DIMC>
+// BF:   opt-in fast mode, NOT parity: the traversal scores a bf16 copy of the base (4 instead of 7 HBM
+//       lines per d = 200 evaluation); at the end the whole beam is re-scored with the exact fp32 routine and the k best
+//       by exact (distance, id) are returned, so the reported distances are exact for the returned ids.
+template <bool L2, bool ELL, int R, int VIS, int DIMC, bool BF>
 __global__ void __launch_bounds__(64) rg_search_kernel(SearchParams P) {
+    static_assert(!BF || (DIMC != 0 && VIS == 1 && ELL), "fast mode: compile-time dimension, LDS filter, ELL adjacency");
+    constexpr int NB = (DIMC + 127) / 128;                                // fast mode: LDS-DMA instructions per bf16 row
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
     const int g = lane >> 4;
     // LDS carve (all offsets multiples of 16 B)
     float *stage = reinterpret_cast<float *>(smem);                       // R * stage_floats
-    float *qv = stage + (size_t)R * P.stage_floats;                       // dim (DIMC == 0 only)
+    float *qv = stage + P.stage_total;                                    // dim (DIMC == 0 only)
     uint32_t *cand_id = reinterpret_cast<uint32_t *>(qv + (DIMC ? 0u : P.dim));   // 64
     float qr[DIMC ? (DIMC + 15) / 16 : 1];
+    float qb[BF ? 8 * NB : 1];
     float *cand_d = reinterpret_cast<float *>(cand_id + kWave);           // 64
     Beam bm;
     bm.ent = reinterpret_cast<uint2 *>(cand_d + kWave);                   // L
@@ -234,6 +243,7 @@ __global__ void __launch_bounds__(64) rg_search_kernel(SearchParams P) {
         uint32_t logn = 0, lbn = 0;   // ids scored so far / ids waiting in logbuf
         if constexpr (DIMC != 0) load_query_regs<DIMC>(query, qr, lane);
         else for (uint32_t i = lane; i < P.dim; i += kWave) qv[i] = query[i];
+        if constexpr (BF) load_query_regs_bf<DIMC>(query, qb, lane);
         // new visited epoch (VisitedList::reset, visited_list_pool.h:20-26: ++curV, wipe on wrap)
         uint32_t etag = 0;
         if (VIS == 0) {
@@ -250,12 +260,21 @@ __global__ void __launch_bounds__(64) rg_search_kernel(SearchParams P) {
         wave_sync();
 
         // entry point: scored and queued, not marked visited (index_bipartite.cpp:2338-2352)
-        gather_issue(P.base + (size_t)P.ep * P.stride, P.dim, g == 0, stage, lane);
-        gather_wait(0);
-        auto score = [&](const float *buf) __attribute__((always_inline)) {
+        // exact fp32 score of a staged pass / traversal score (the same thing unless BF)
+        auto score_exact = [&](const float *buf) __attribute__((always_inline)) {
             if constexpr (DIMC != 0) return gather_score_q<L2, DIMC>(buf, qr, lane);
             else return gather_score<L2>(buf, qv, P.dim, lane);
         };
+        auto score = [&](const float *buf) __attribute__((always_inline)) {
+            if constexpr (BF) return score_bf<L2, NB>(reinterpret_cast<const uint32_t *>(buf), qb, lane);
+            else return score_exact(buf);
+        };
+        auto issue = [&](uint32_t rid, bool act, float *buf) __attribute__((always_inline)) {
+            if constexpr (BF) gather_issue_bf<NB>(P.base_bf + (size_t)rid * P.stride_bf, act, reinterpret_cast<uint32_t *>(buf), lane);
+            else gather_issue(P.base + (size_t)rid * P.stride, P.dim, act, buf, lane);
+        };
+        issue(P.ep, g == 0, stage);
+        gather_wait(0);
         const float epd = score(stage);
         if (lane == 0) bm.ent[0] = make_uint2(__float_as_uint(epd), P.ep);
         bm.size = 1;
@@ -351,11 +370,11 @@ __global__ void __launch_bounds__(64) rg_search_kernel(SearchParams P) {
                 // gather + score (:2387): 4 rows per pass, a ring of R staging buffers keeps up to R passes in flight;
                 // pass p is consumed once only the loads of the passes issued after it are still outstanding
                 {
-                    const uint32_t npass = (n + 3u) >> 2, lpp = loads_per_pass(P.dim);
+                    const uint32_t npass = (n + 3u) >> 2, lpp = BF ? (uint32_t)NB : loads_per_pass(P.dim);
                     for (uint32_t p = 0; p < (uint32_t)R && p < npass; ++p) {
                         const uint32_t c = 4 * p + g;
                         const uint32_t rid = c < n ? cand_id[c] : 0u;
-                        gather_issue(P.base + (size_t)rid * P.stride, P.dim, c < n, stage + (size_t)p * P.stage_floats, lane);
+                        issue(rid, c < n, stage + (size_t)p * P.stage_floats);
                     }
                     for (uint32_t p = 0; p < npass; ++p) {
                         const uint32_t last = min(npass, p + (uint32_t)R) - 1u;
@@ -368,7 +387,7 @@ __global__ void __launch_bounds__(64) rg_search_kernel(SearchParams P) {
                         if (p + R < npass) {
                             const uint32_t c2 = 4 * (p + R) + g;
                             const uint32_t rid = c2 < n ? cand_id[c2] : 0u;
-                            gather_issue(P.base + (size_t)rid * P.stride, P.dim, c2 < n, buf, lane);
+                            issue(rid, c2 < n, buf);
                         }
                     }
                 }
@@ -386,6 +405,37 @@ __global__ void __launch_bounds__(64) rg_search_kernel(SearchParams P) {
             if (build && lane == 0) P.out_nexp[qi] = hops;
         } else if (bm.size < P.k) {
             if (lane == 0) atomicMin(P.status, ((unsigned long long)(qi + P.qbase) << 32) | bm.size);
+        } else if (BF) {
+            // re-rank: exact fp32 distance of every beam entry (4 rows per pass through the exact routine), then the k
+            // best by exact (distance, id), selected k times with a wave-wide minimum over an order-preserving key
+            for (uint32_t i0 = 0; i0 < bm.size; i0 += 4) {
+                const uint32_t i = i0 + g;
+                const uint32_t rid = i < bm.size ? (bm.ent[i].y & ~kFlagBit) : 0u;
+                gather_issue(P.base + (size_t)rid * P.stride, P.dim, i < bm.size, stage, lane);
+                gather_wait(0);
+                const float d = score_exact(stage);
+                lds_sync();
+                if (i < bm.size && (lane & 15) == 0) bm.ent[i] = make_uint2(__float_as_uint(d), rid);   // flag cleared
+            }
+            wave_sync();
+            for (uint32_t r = 0; r < P.k; ++r) {
+                uint32_t bh = 0xffffffffu, bl = 0xffffffffu, bi = 0xffffffffu;   // (ordered distance, id, beam index)
+                for (uint32_t i = lane; i < bm.size; i += kWave) {
+                    const uint2 e = bm.ent[i];
+                    if (e.y & kFlagBit) continue;
+                    const uint32_t u = e.x, o = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+                    if (o < bh || (o == bh && e.y < bl)) { bh = o; bl = e.y; bi = i; }
+                }
+                const uint32_t mh = wave_min_u32(bh);
+                const uint32_t ml = wave_min_u32(bh == mh ? bl : 0xffffffffu);
+                if (bh == mh && bl == ml && bi != 0xffffffffu) {   // ids are unique in the beam: exactly one lane
+                    const uint2 e = bm.ent[bi];
+                    bm.ent[bi].y = e.y | kFlagBit;
+                    P.out_ids[(size_t)qi * P.k + r] = e.y;
+                    P.out_dists[(size_t)qi * P.k + r] = __uint_as_float(e.x);
+                }
+                wave_sync();
+            }
         } else {
             for (uint32_t i = lane; i < P.k; i += kWave) {
                 const uint2 e = bm.ent[i];
@@ -561,6 +611,21 @@ __global__ void __launch_bounds__(64) rg_score_kernel(const float *__restrict__ 
     }
 }
 
+// fp32 base -> bf16 copy (round to nearest even), rows zero-padded to stride_bf elements
+__global__ void rg_base_to_bf16_kernel(const float *__restrict__ base, uint32_t nd, uint32_t dim, uint32_t stride,
+                                       uint16_t *__restrict__ out, uint32_t stride_bf) {
+    const size_t total = (size_t)nd * stride_bf;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t r = (uint32_t)(i / stride_bf), c = (uint32_t)(i % stride_bf);
+        uint16_t v = 0;
+        if (c < dim) {
+            const uint32_t u = __float_as_uint(base[(size_t)r * stride + c]);
+            v = (u & 0x7f800000u) == 0x7f800000u ? (uint16_t)(u >> 16) : (uint16_t)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+        }
+        out[i] = v;
+    }
+}
+
 // CSR -> ELL ([deg, ids...] per node at a fixed stride), one wave per node
 __global__ void rg_csr_to_ell_kernel(const uint64_t *offsets, const uint32_t *nbrs, uint32_t nd, uint32_t *ell,
                                      uint32_t ell_stride) {
@@ -665,9 +730,15 @@ static uint32_t filter_log2_of(const rg_index *ix) {  // remainder must fit 15 b
 static int dimc_of(const rg_index *ix) {
     return (ix->d_ell != nullptr && (ix->dim == 200 || ix->dim == 512) && !ix->query_in_lds) ? (int)ix->dim : 0;
 }
+static bool fast_bf16_on(const rg_index *ix) { return ix->bf_launch; }   // decided per launch in launch_k1
+static size_t stage_pass_floats(const rg_index *ix) {
+    return fast_bf16_on(ix) ? (size_t)((ix->dim + 127) / 128) * 256 : (size_t)((ix->dim + 63) / 64) * 256;
+}
+static size_t stage_total_floats(const rg_index *ix, int R) {   // the fast mode's exact re-rank needs one fp32 pass
+    return std::max((size_t)R * stage_pass_floats(ix), (size_t)((ix->dim + 63) / 64) * 256);
+}
 static size_t search_lds_bytes(const rg_index *ix, uint32_t L, int R) {
-    const size_t stage_floats = (size_t)((ix->dim + 63) / 64) * 256;
-    size_t b = (size_t)R * stage_floats * 4 + (dimc_of(ix) ? 0 : (size_t)ix->dim * 4) + 64 * 4 + 64 * 4 + (size_t)L * 8;
+    size_t b = stage_total_floats(ix, R) * 4 + (dimc_of(ix) ? 0 : (size_t)ix->dim * 4) + 64 * 4 + 64 * 4 + (size_t)L * 8;
     if (ix->visited_mode != 0) b += 128 * 4 + std::max<size_t>(4, (size_t)2 << filter_log2_of(ix));
     return (b + 15) / 16 * 16;
 }
@@ -689,9 +760,9 @@ static rg_status ensure_scratch(rg_index *ix, uint32_t slots) {
     return RG_OK;
 }
 
-template <bool L2, bool ELL, int R, int VIS, int DIMC>
+template <bool L2, bool ELL, int R, int VIS, int DIMC, bool BF = false>
 static rg_status launch_search_d(rg_index *ix, const SearchParams &P, uint32_t grid, size_t lds, hipStream_t s) {
-    auto kern = rg_search_kernel<L2, ELL, R, VIS, DIMC>;
+    auto kern = rg_search_kernel<L2, ELL, R, VIS, DIMC, BF>;
     RG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, s, P);
     RG_HIP(hipGetLastError());
@@ -702,6 +773,10 @@ template <bool L2, bool ELL, int R, int VIS>
 static rg_status launch_search_v(rg_index *ix, const SearchParams &P, uint32_t grid, size_t lds, hipStream_t s) {
     if constexpr (ELL) {
         const int dc = dimc_of(ix);
+        if constexpr (VIS == 1 && R <= 2) {
+            if (P.base_bf && dc == 200) return launch_search_d<L2, ELL, R, VIS, 200, true>(ix, P, grid, lds, s);
+            if (P.base_bf && dc == 512) return launch_search_d<L2, ELL, R, VIS, 512, true>(ix, P, grid, lds, s);
+        }
         if (dc == 200) return launch_search_d<L2, ELL, R, VIS, 200>(ix, P, grid, lds, s);
         if (dc == 512) return launch_search_d<L2, ELL, R, VIS, 512>(ix, P, grid, lds, s);
     }
@@ -735,6 +810,10 @@ static rg_status launch_k1(rg_index *ix, int mode, const float *d_q, uint32_t nq
     const int rpp = ix->rows_per_pass > 0 ? ix->rows_per_pass : ((double)ix->n_edges >= 28.0 * ix->nd ? 8 : 4);
     int R = std::max(1, std::min(4, rpp / 4));
     if (R == 3) R = 2;
+    // opt-in fast mode: plain top-k searches with the LDS filter only (never the logging / recount / build launches)
+    const bool bf = ix->fast_bf16 && ix->d_base_bf && dimc_of(ix) && mode != 0 && !with_log && !bp && !qlist;
+    ix->bf_launch = bf;
+    if (bf) R = std::min(R, 2);
     const int saved_mode = ix->visited_mode;
     ix->visited_mode = mode;  // search_lds_bytes() looks at it
     size_t lds = search_lds_bytes(ix, L, R);
@@ -757,7 +836,9 @@ static rg_status launch_k1(rg_index *ix, int mode, const float *d_q, uint32_t nq
     P.out_ids = d_ids; P.out_dists = d_dists; P.out_cmps = d_cmps; P.out_hops = d_hops;
     P.visited = mode == 0 ? ix->d_visited : nullptr; P.vwords = ix->vwords; P.slot_epoch = ix->d_epoch;
     P.counter = ix->d_counter; P.status = ix->d_status;
-    P.stage_floats = ((ix->dim + 63) / 64) * 256;
+    P.stage_floats = (uint32_t)stage_pass_floats(ix);
+    P.stage_total = (uint32_t)stage_total_floats(ix, R);
+    P.base_bf = bf ? ix->d_base_bf : nullptr; P.stride_bf = ix->stride_bf;
     P.diag = (uint32_t)ix->diag;
     P.qbase = qbase;
     P.vf_slots_log2 = filter_log2_of(ix);
@@ -806,7 +887,8 @@ static rg_status search_dev(rg_index *ix, const float *d_q, uint32_t nq, uint32_
     RG_HIP(hipSetDevice(ix->device));
     RG_HIP(hipMemsetAsync(ix->d_status, 0xff, 8, s));
     ix->pending.active = false;
-    const bool exact_count = ix->visited_mode == 2 && d_cmps != nullptr;
+    const bool fast = ix->fast_bf16 && ix->d_base_bf && dimc_of(ix) && ix->visited_mode != 0;
+    const bool exact_count = ix->visited_mode == 2 && d_cmps != nullptr && !fast;
     if (!exact_count)
         return launch_k1(ix, ix->visited_mode == 0 ? 0 : 1, d_q, nq, qstride, k, L, d_ids, d_dists, d_cmps, d_hops, nullptr, false, s);
     // mode 2: LDS-filter search with id log, then the exact distinct count (K4); overflowed logs are re-counted by an
@@ -953,6 +1035,7 @@ void rg_index_close(rg_index *ix) {
     if (ix->d_epoch) (void)hipFree(ix->d_epoch);
     if (ix->d_qlog) (void)hipFree(ix->d_qlog);
     if (ix->d_qlog_n) (void)hipFree(ix->d_qlog_n);
+    if (ix->d_base_bf) (void)hipFree(ix->d_base_bf);
     if (ix->d_ovf) (void)hipFree(ix->d_ovf);
     if (ix->d_counter) (void)hipFree(ix->d_counter);
     if (ix->d_status) (void)hipFree(ix->d_status);
@@ -1056,6 +1139,19 @@ rg_status rg_index_set(rg_index *ix, const char *name, int value) {
     else if (!strcmp(name, "log_cap")) ix->log_cap_knob = value;
     else if (!strcmp(name, "log_budget_kb")) ix->log_budget_kb = value;
     else if (!strcmp(name, "query_in_lds")) ix->query_in_lds = value != 0;
+    else if (!strcmp(name, "fast_bf16")) {
+        // opt-in, NOT parity (see rg.h): the bf16 copy of the base is made on first use
+        if (value && !ix->d_base_bf) {
+            if (hipSetDevice(ix->device) != hipSuccess) return set_error(RG_ERR_DEVICE, "cannot select the index device");
+            ix->stride_bf = (ix->dim + 127u) / 128u * 128u;
+            RG_HIP(hipMalloc(&ix->d_base_bf, (size_t)ix->nd * ix->stride_bf * 2));
+            hipLaunchKernelGGL(rg::rg_base_to_bf16_kernel, dim3(ix->num_cu * 8), dim3(256), 0, 0, ix->d_base, ix->nd, ix->dim, ix->stride,
+                               ix->d_base_bf, ix->stride_bf);
+            RG_HIP(hipGetLastError());
+            RG_HIP(hipDeviceSynchronize());
+        }
+        ix->fast_bf16 = value != 0;
+    }
     else if (!strcmp(name, "count_table_log2")) ix->count_table_log2 = value;
     else if (!strcmp(name, "count_full_ids")) ix->count_full_ids = value != 0;
     else return set_error(RG_ERR_ARG, "unknown knob");

@@ -1,0 +1,55 @@
+"""-m gpu: the opt-in bf16 fast mode (rg_index_set "fast_bf16").  It is NOT a parity mode, so the checks
+are properties: the distances returned are the exact fp32 compare() values of the returned ids, the list is ordered by
+(distance, id) without repeats, runs are deterministic, the overlap with the exact search is high, and the knob changes
+nothing where the mode does not apply."""
+import numpy as np
+import pytest
+
+from helpers import bits, small_set
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def rg():
+    from roargraph_amd import index
+    from roargraph_amd._lib import lib
+    assert lib().rg_device_count() >= 1, "no GPU visible: the HIP path cannot run and there is no fallback"
+    return index
+
+
+@pytest.mark.parametrize("metric,d,nb", [("ip", 200, 4000), ("l2", 512, 2000), ("l2", 200, 3000), ("ip", 512, 1500)])
+@pytest.mark.parametrize("L,k", [(100, 10), (500, 100), (64, 1)])
+def test_fast_mode_properties(rg, oracle, metric, d, nb, L, k):
+    base, q, off, nbrs, ep = small_set(metric, nb, d)
+    ix = rg.IndexBipartite.from_arrays(base, off, nbrs, ep, metric=metric)
+    exact = ix.SearchRoarGraph(q, k, L)
+    ix.set("fast_bf16", 1)
+    ids, dists, cmps, hops = ix.SearchRoarGraph(q, k, L)
+    ids2, dists2, _, _ = ix.SearchRoarGraph(q, k, L)
+    assert (ids == ids2).all() and (bits(dists) == bits(dists2)).all(), "not deterministic"
+    overlap = 0
+    for i in range(q.shape[0]):
+        assert len(set(ids[i].tolist())) == k, "repeated id"
+        want = ix.score_batch(q[i], ids[i])                 # the exact operator (bit-exact vs the reference, other tests)
+        assert (bits(dists[i]) == bits(want)).all(), "returned distances are not the exact fp32 distances of the ids"
+        key = list(zip(dists[i].tolist(), ids[i].tolist()))
+        assert key == sorted(key), "not ordered by (distance, id)"
+        overlap += len(set(ids[i].tolist()) & set(exact[0][i].tolist()))
+    assert overlap / (q.shape[0] * k) >= 0.9, "fast mode lost more than 10 % of the exact search's neighbours"
+    assert (cmps > 0).all() and (hops > 0).all()
+    ix.set("fast_bf16", 0)                                   # switching it off restores parity
+    back = ix.SearchRoarGraph(q, k, L)
+    assert (back[0] == exact[0]).all() and (bits(back[1]) == bits(exact[1])).all() and (back[2] == exact[2]).all()
+    ix.close()
+
+
+def test_fast_mode_is_a_no_op_where_it_does_not_apply(rg, oracle):
+    """Other dimensions than 200 / 512 have no bf16 instantiation: the knob must leave the result bit-exact."""
+    base, q, off, nbrs, ep = small_set("l2", 3000, 24)
+    ix = rg.IndexBipartite.from_arrays(base, off, nbrs, ep, metric="l2")
+    ix.set("fast_bf16", 1)
+    got = ix.SearchRoarGraph(q, 10, 100)
+    want = oracle.search(base, "l2", off, nbrs, ep, q, 10, 100, nthreads=4)
+    assert (got[0] == want[0]).all() and (bits(got[1]) == bits(want[1])).all() and (got[2] == want[2]).all()
+    ix.close()
