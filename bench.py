@@ -392,9 +392,17 @@ def main():
             a.record(); step(L); b.record(); torch.cuda.synchronize()
             ms = a.elapsed_time(b)
             mc = float(cmps.float().mean().item())
-            sweep.append({"L_pq": L, "qps": args.nq / (ms / 1e3), "mean_evals": mc,
-                          "recall_at_10": _ixmod.recall(ids.cpu().numpy().view(np.uint32), gt_np, 10) if args.k >= 10 else None,
-                          "gbps": args.nq * mc * 4 * args.dim / (ms / 1e3) / 1e9})
+            row = {"L_pq": L, "qps": args.nq / (ms / 1e3), "mean_evals": mc,
+                   "recall_at_10": _ixmod.recall(ids.cpu().numpy().view(np.uint32), gt_np, 10) if args.k >= 10 else None,
+                   "gbps": args.nq * mc * 4 * args.dim / (ms / 1e3) / 1e9}
+            if fast is not None and "error" not in fast:   # the opt-in non-parity mode at the same L_pq, reported beside it
+                index.set("fast_bf16", 1)
+                step(L); torch.cuda.synchronize()
+                a.record(); step(L); b.record(); torch.cuda.synchronize()
+                row["fast_bf16_qps"] = args.nq / (a.elapsed_time(b) / 1e3)
+                row["fast_bf16_recall_at_10"] = _ixmod.recall(ids.cpu().numpy().view(np.uint32), gt_np, 10) if args.k >= 10 else None
+                index.set("fast_bf16", 0)
+            sweep.append(row)
         step(args.L); torch.cuda.synchronize()
 
     # ---- second BASELINE metric: ground-truth build, distances/s.  Base rows sharded over the ranks (each rank scores

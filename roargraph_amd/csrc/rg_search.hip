@@ -692,10 +692,12 @@ static rg_status finish_graph(rg_index *ix, const uint64_t *d_off, const uint32_
     if (ne > 0 && st[1] >= ix->nd) return set_error(RG_ERR_FORMAT, "index file references a node id >= npts");
     if (ix->ep >= ix->nd) return set_error(RG_ERR_FORMAT, "entry point >= npts");
     if (ix->nd >= 0x80000000u) return set_error(RG_ERR_ARG, "more than 2^31-1 base points are not supported");
-    // ELL when it costs at most 2.5x the CSR bytes (real RoarGraph indexes: max degree <= 2*M_pjbp, avg ~ 0.6*max)
+    // ELL (one load per hop instead of two dependent ones) when it costs at most 2.5x the CSR bytes (real RoarGraph
+    // indexes: max degree <= 2*M_pjbp, avg ~ 0.6*max) or fits 16 GiB anyway (288 GB of HBM: a 10M-node index of maximum
+    // degree 70 is 3.2 GB)
     const uint32_t es = (ix->max_deg + 1 + 15) / 16 * 16;
     const double ell_bytes = (double)ix->nd * es * 4.0, csr_bytes = (double)ne * 4.0 + (double)ix->nd * 8.0;
-    if (!ix->force_csr && ell_bytes <= 2.5 * csr_bytes + (64 << 20)) {
+    if (!ix->force_csr && (ell_bytes <= 2.5 * csr_bytes + (64 << 20) || ell_bytes <= 16.0 * (1ull << 30))) {
         ix->ell_stride = es;
         RG_HIP(hipMalloc(&ix->d_ell, (size_t)ix->nd * es * 4));
         hipLaunchKernelGGL(rg_csr_to_ell_kernel, dim3(4096), dim3(256), 0, 0, d_off, d_nb, ix->nd, ix->d_ell, es);
