@@ -8,6 +8,7 @@
 //   timing              QPS uses a nanosecond clock around the device-resident batch (queries already in HBM); the
 //                       reference's integer-millisecond clock (:210-213) cannot resolve a 10k-query batch on a GPU
 //   warm-up             min(100, q_pts) queries, as :198-200
+//   --fast_bf16 1       opt-in non-parity mode of the library (default 0 = the reference's results bit for bit)
 #include <hip/hip_runtime.h>
 
 #include <chrono>
@@ -44,6 +45,7 @@ int main(int argc, char **argv) {
     a.add("evaluation_save_path", false, "Path prefix for saving evaluation results", "");
     a.add("num_threads", false, "accepted for compatibility (ignored on the GPU path)", "0", "T");
     a.add("device", false, "HIP device index", "0");
+    a.add("fast_bf16", false, "1 = opt-in NON-parity mode: bf16 traversal + exact fp32 re-rank (rg.h)", "0");
     if (!a.parse(argc, argv)) return -1;
     if (a.help()) { a.usage(std::cout); return 0; }
 
@@ -73,6 +75,10 @@ int main(int argc, char **argv) {
     uint32_t nd, dim, stride, ep, maxdeg;
     float avgdeg;
     CK(rg_index_info(index, &nd, &dim, &stride, &ep, &avgdeg, &maxdeg, nullptr));
+    if (a.u("fast_bf16")) {
+        CK(rg_index_set(index, "fast_bf16", 1));
+        std::cout << "fast_bf16: traversal on a bf16 copy of the base, exact re-rank (results are NOT the reference's)" << std::endl;
+    }
     std::cout << "Projection graph, ep: " << ep << std::endl;
     std::cout << "Projection graph, avg_degree: " << avgdeg << std::endl;
     if (q_stride != dim) { std::cerr << "base and query dimension mismatch" << std::endl; return -1; }
