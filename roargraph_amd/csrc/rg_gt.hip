@@ -671,16 +671,25 @@ rg_status rg_gt_shard_dev(const float *d_base, uint32_t nb, uint32_t bstride, co
     const uint32_t nblocks = (nq + mq - 1) / mq;
     const uint32_t per_cu = (rs_tmw == 1 && dim == 200) ? 2 : 1;
     const uint32_t grid = std::min<uint32_t>(nblocks, (uint32_t)prop.multiProcessorCount * per_cu);
+    // stream-ordered scratch, released on every exit path
+    struct Scratch {
+        hipStream_t s;
+        void *p[3] = {nullptr, nullptr, nullptr};
+        ~Scratch() { for (void *q : p) if (q) (void)hipFreeAsync(q, s); }
+    } scratch{s};
     float *bias = nullptr;
     u64 *cand = nullptr;
     uint32_t *counter = nullptr;
     float *vals = d_dists;
     if (metric == RG_METRIC_L2) {
-        RG_HIP(hipMallocAsync((void **)&bias, (size_t)nb * 4, s));
+        RG_HIP(hipMallocAsync(&scratch.p[0], (size_t)nb * 4, s));
+        bias = static_cast<float *>(scratch.p[0]);
         hipLaunchKernelGGL(rg_gt_bias_kernel, dim3((nb * 16 + 255) / 256), dim3(256), 0, s, d_base, nb, bstride, dim, bias);
     }
-    RG_HIP(hipMallocAsync((void **)&cand, (size_t)grid * mq * 64 * items * 8, s));
-    RG_HIP(hipMallocAsync((void **)&counter, 64, s));
+    RG_HIP(hipMallocAsync(&scratch.p[1], (size_t)grid * mq * 64 * items * 8, s));
+    cand = static_cast<u64 *>(scratch.p[1]);
+    RG_HIP(hipMallocAsync(&scratch.p[2], 64, s));
+    counter = static_cast<uint32_t *>(scratch.p[2]);
     RG_HIP(hipMemsetAsync(counter, 0, 4, s));
     GtParams P;
     P.base = d_base; P.nb = nb; P.bstride = bstride; P.queries = d_queries; P.nq = nq; P.qstride = qstride; P.dim = dim;
@@ -716,9 +725,6 @@ rg_status rg_gt_shard_dev(const float *d_base, uint32_t nb, uint32_t bstride, co
             default: hipLaunchKernelGGL((rg_gt_rescore_kernel<16>), dim3(g2), dim3(64), 0, s, d_base, bstride, d_queries, qstride, dim, nq, K, id_base, d_ids, d_dists); break;
         }
     }
-    if (bias) (void)hipFreeAsync(bias, s);
-    (void)hipFreeAsync(cand, s);
-    (void)hipFreeAsync(counter, s);
     if (st != RG_OK) return st;
     RG_HIP(hipGetLastError());
     return RG_OK;
@@ -774,8 +780,24 @@ rg_status rg_groundtruth_mem(const float *base, uint32_t nb, uint32_t bstride, c
     const int m = metric == RG_METRIC_COSINE ? RG_METRIC_IP : metric;
     std::vector<uint32_t> all_ids((size_t)nd * nq * K);
     std::vector<float> all_vals((size_t)nd * nq * K);
-    struct Dev { float *b = nullptr, *q = nullptr, *v = nullptr; uint32_t *i = nullptr; hipStream_t s = nullptr; };
+    struct Dev {   // buffers and stream of one shard, released on every exit path
+        int dev = 0;
+        float *b = nullptr, *q = nullptr, *v = nullptr;
+        uint32_t *i = nullptr;
+        hipStream_t s = nullptr;
+        ~Dev() {
+            if (!b && !q && !v && !i && !s) return;
+            (void)hipSetDevice(dev);
+            if (s) (void)hipStreamSynchronize(s);
+            if (b) (void)hipFree(b);
+            if (q) (void)hipFree(q);
+            if (i) (void)hipFree(i);
+            if (v) (void)hipFree(v);
+            if (s) (void)hipStreamDestroy(s);
+        }
+    };
     std::vector<Dev> D(nd);
+    for (uint32_t r = 0; r < nd; ++r) D[r].dev = devs[r];
     rg_status st = RG_OK;
     const uint32_t per = (nb + nd - 1) / nd;
     for (uint32_t r = 0; r < nd && st == RG_OK; ++r) {
@@ -807,8 +829,13 @@ rg_status rg_groundtruth_mem(const float *base, uint32_t nb, uint32_t bstride, c
         } else {
             // K3 on device 0 (single-process form; the one-process-per-GPU form exchanges these lists over RCCL)
             (void)hipSetDevice(devs[0]);
-            uint32_t *di = nullptr, *doi = nullptr;
-            float *dv = nullptr, *dov = nullptr;
+            struct Merge {
+                uint32_t *di = nullptr, *doi = nullptr;
+                float *dv = nullptr, *dov = nullptr;
+                ~Merge() { (void)hipFree(di); (void)hipFree(dv); (void)hipFree(doi); (void)hipFree(dov); }
+            } M;
+            uint32_t *&di = M.di, *&doi = M.doi;
+            float *&dv = M.dv, *&dov = M.dov;
             RG_HIP(hipMalloc(&di, all_ids.size() * 4));
             RG_HIP(hipMalloc(&dv, all_vals.size() * 4));
             RG_HIP(hipMalloc(&doi, (size_t)nq * K * 4));
@@ -820,16 +847,7 @@ rg_status rg_groundtruth_mem(const float *base, uint32_t nb, uint32_t bstride, c
                 RG_HIP(hipMemcpy(out_ids, doi, (size_t)nq * K * 4, hipMemcpyDeviceToHost));
                 RG_HIP(hipMemcpy(out_dists, dov, (size_t)nq * K * 4, hipMemcpyDeviceToHost));
             }
-            (void)hipFree(di); (void)hipFree(dv); (void)hipFree(doi); (void)hipFree(dov);
         }
-    }
-    for (uint32_t r = 0; r < nd; ++r) {
-        (void)hipSetDevice(devs[r]);
-        if (D[r].b) (void)hipFree(D[r].b);
-        if (D[r].q) (void)hipFree(D[r].q);
-        if (D[r].i) (void)hipFree(D[r].i);
-        if (D[r].v) (void)hipFree(D[r].v);
-        if (D[r].s) (void)hipStreamDestroy(D[r].s);
     }
     return st;
 }

@@ -678,13 +678,13 @@ static rg_status pick_device(int device) {
 
 static rg_status finish_graph(rg_index *ix, const uint64_t *d_off, const uint32_t *d_nb) {
     // stats + validation
-    uint32_t *d_stat = nullptr;
-    RG_HIP(hipMalloc(&d_stat, 8));
+    DevBuf<uint32_t> stat_buf;
+    RG_HIP(stat_buf.alloc(2));
+    uint32_t *d_stat = stat_buf.p;
     RG_HIP(hipMemset(d_stat, 0, 8));
     hipLaunchKernelGGL(rg_graph_stats_kernel, dim3(2048), dim3(256), 0, 0, d_off, d_nb, ix->nd, d_stat, d_stat + 1);
     uint32_t st[2];
     RG_HIP(hipMemcpy(st, d_stat, 8, hipMemcpyDeviceToHost));
-    RG_HIP(hipFree(d_stat));
     uint64_t ne = 0;
     RG_HIP(hipMemcpy(&ne, d_off + ix->nd, 8, hipMemcpyDeviceToHost));
     ix->max_deg = st[0];
