@@ -137,6 +137,12 @@ __device__ __forceinline__ void gt_compact(u64 *buf, uint32_t *cnt, float *thr, 
 typedef __attribute__((address_space(3))) void lds_ptr_t;
 typedef const __attribute__((address_space(1))) void glb_ptr_t;
 
+// out-of-line form for call sites inside register-saturated loops (the rare path pays the call, the loop keeps its registers)
+template <int ITEMS>
+__device__ __attribute__((noinline)) void gt_compact_call(u64 *buf, uint32_t *cnt, float *thr, uint32_t K, int lane) {
+    gt_compact<ITEMS>(buf, cnt, thr, K, lane);
+}
+
 // LDS layout of both operands: k-quads, [k/4][row][4 floats] -- one 16-byte slot per (k-quad, row).
 //  * the base chunk arrives by LDS-DMA (global_load_lds_dwordx4): a wave instruction fills 64 consecutive slots
 //    (64 rows of one k-quad), no VGPR staging and no transposing ds_write pass;
@@ -346,6 +352,7 @@ __global__ void __launch_bounds__(256, WPS) rg_gt_rs_kernel(GtParams P) {
     float *thr = reinterpret_cast<float *>(Bq + 2 * (size_t)KQC * kNB);          // [MQB]
     uint32_t *cnt = reinterpret_cast<uint32_t *>(thr + MQB);                     // [MQB]
     uint32_t *flag = cnt + MQB;                                                  // [4]
+    float *bias_l = reinterpret_cast<float *>(flag + 4);                         // [2][128] -|b|^2/2 of the tile's rows (L2)
     u64 *cand = P.cand + (size_t)blockIdx.x * MQB * C;
     const uint32_t ntiles = (P.nb + kNB - 1) / kNB;
 
@@ -369,7 +376,7 @@ __global__ void __launch_bounds__(256, WPS) rg_gt_rs_kernel(GtParams P) {
         for (int i = tid; i < MQB; i += 256) { thr[i] = -__builtin_inff(); cnt[i] = 0; }
         if (tid == 0) flag[0] = 0;
         // thresholds of this lane's query rows: kept in registers when the budget allows (TMW == 1), else read from LDS
-        constexpr bool kThrRegs = TMW == 1;
+        constexpr bool kThrRegs = TMW == 1 && DIM > 256;   // d = 200 runs at the 256-VGPR limit of two workgroups per CU
         float thr_r[kThrRegs ? TMW : 1][16];
         if (kThrRegs) {
 #pragma unroll
@@ -394,125 +401,151 @@ __global__ void __launch_bounds__(256, WPS) rg_gt_rs_kernel(GtParams P) {
 
         f32x16 acc[TMW][4];
         uint32_t step = 0;   // running chunk counter: LDS buffer = step & 1
-        stream_chunk(std::integral_constant<int, 0>{}, rowp, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        for (uint32_t tile = 0; tile < ntiles; ++tile) {
-#pragma unroll
-            for (int n = 0; n < 4; ++n) {
-                const uint32_t id = tile * kNB + 32 * n + (lane & 31);
-                const float b = (P.bias && id < P.nb) ? P.bias[id] : 0.0f;
-#pragma unroll
-                for (int m = 0; m < TMW; ++m)
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) acc[m][n][r] = b;
-            }
-            // one instantiation per chunk index (a generic lambda over integral_constant): the register array of A
-            // operands needs compile-time indices, and hipcc declines to unroll a loop body of this size
-            auto chunk = [&](auto cc) __attribute__((always_inline)) {
-                constexpr int c = decltype(cc)::value;
-                const uint32_t buf = step & 1u;
-                // next chunk (of this tile or the first of the next tile) streams while this one is multiplied
-                if (!(P.diag & 1u)) {
-                    if constexpr (c + 1 < NKC) {
-                        stream_chunk(std::integral_constant<int, c + 1>{}, rowp, buf ^ 1u);
-                    } else if (tile + 1 < ntiles) {
-                        rowp = row_ptr(tile + 1);
-                        stream_chunk(std::integral_constant<int, 0>{}, rowp, buf ^ 1u);
-                    }
+        {
+            // The chunk's closing barrier sits BEFORE its last k-quad.  After it a wave issues the DMA
+            // of the chunk after next into the buffer just read, prefetches the first fragments of the next chunk, and
+            // only then multiplies its last quad: DMA issue, LDS latency and barrier skew hide behind 8 MFMAs instead
+            // of opening every chunk.  The compaction check rides on the barrier of a tile's first chunk; the L2 bias of
+            // a tile arrives with its first chunk (one more DMA instruction) instead of a per-tile global load.
+            static_assert(NKC >= 2 && NKC <= 8 && KQC % 2 == 0, "chunking");
+            float2 b0[4], b1[4];
+            const uint32_t lds_bias = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(lds_ptr_t *)bias_l);
+            auto stream_bias = [&](uint32_t tile, uint32_t slot) __attribute__((always_inline)) {
+                if (P.bias && w < 2) {   // waves 0/1: rows 0-63 / 64-127 of the tile
+                    const uint32_t id = min(tile * kNB + 64u * (uint32_t)w + (uint32_t)lane, P.nb - 1u);
+                    const float *src = P.bias + id;
+                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off"
+                                 :: "s"(lds_bias + slot * 512u + 256u * (uint32_t)w), "v"(src) : "memory");
                 }
-                // B fragments: the low half-wave reads elements (0,1) of its row's k-quad, the high half-wave (2,3): one
-                // conflict-free ds_read_b64 per lane feeds two MFMAs with no lane select.  Fragments of quad kq+1 are
-                // issued before the MFMAs of quad kq and pinned there (the scheduler otherwise sinks them to their use to
-                // save registers, exposing the LDS latency once per quad).
-                const float2 *bq = reinterpret_cast<const float2 *>(Bq + (size_t)buf * KQC * kNB + (lane & 31)) + (hi ? 1 : 0);
-                float2 b0[4], b1[4];
+            };
+            const float *rowp_next = rowp;
+            stream_chunk(std::integral_constant<int, 0>{}, rowp, 0);
+            stream_bias(0, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            stream_chunk(std::integral_constant<int, 1>{}, rowp, 1);
+            {
+                const float2 *bq = reinterpret_cast<const float2 *>(Bq + (lane & 31)) + (hi ? 1 : 0);
 #pragma unroll
                 for (int n = 0; n < 4; ++n) b0[n] = bq[2 * (32 * n)];
+            }
+            for (uint32_t tile = 0; tile < ntiles; ++tile) {
 #pragma unroll
-                for (int kq = 0; kq < KQC; ++kq) {
-                    float2 (&bc)[4] = (kq & 1) ? b1 : b0;
-                    float2 (&bn)[4] = (kq & 1) ? b0 : b1;
-                    if (kq + 1 < KQC) {
-#pragma unroll
-                        for (int n = 0; n < 4; ++n) bn[n] = bq[2 * ((kq + 1) * kNB + 32 * n)];
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                    const int kk = 2 * (c * KQC + kq);   // A registers of this quad: kk -> elements (0|2), kk+1 -> (1|3)
-#pragma unroll
-                    for (int n = 0; n < 4; ++n)
-#pragma unroll
-                        for (int m = 0; m < TMW; ++m)
-                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[kk][m], bc[n].x, acc[m][n], 0, 0, 0);
-#pragma unroll
-                    for (int n = 0; n < 4; ++n)
-#pragma unroll
-                        for (int m = 0; m < TMW; ++m)
-                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[kk + 1][m], bc[n].y, acc[m][n], 0, 0, 0);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-                ++step;
-                if (c + 1 == NKC && !(P.diag & 2u)) {
-                    // tile finished: threshold filter (register thresholds), survivors -> candidate buffers
-                    // common case first: the best of a query row's four column tiles against its threshold (48 VALU ops
-                    // instead of 192); only lanes that hold a survivor walk the per-element path
-                    bool any_win = false;
-                    float mx[TMW][16];
+                for (int n = 0; n < 4; ++n) {
+                    const float b = P.bias ? bias_l[(tile & 1u) * 128u + 32 * n + (lane & 31)] : 0.0f;
 #pragma unroll
                     for (int m = 0; m < TMW; ++m)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const float t = kThrRegs ? thr_r[kThrRegs ? m : 0][r]
-                                                     : thr[qoff + 32 * m + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)];
-                            mx[m][r] = fmaxf(fmaxf(acc[m][0][r], acc[m][1][r]), fmaxf(acc[m][2][r], acc[m][3][r]));
-                            any_win |= mx[m][r] > t;
+                        for (int r = 0; r < 16; ++r) acc[m][n][r] = b;
+                }
+                auto chunk = [&](auto cc) __attribute__((always_inline)) {
+                    constexpr int c = decltype(cc)::value;
+                    const uint32_t buf = step & 1u;
+                    const float2 *bq = reinterpret_cast<const float2 *>(Bq + (size_t)buf * KQC * kNB + (lane & 31)) + (hi ? 1 : 0);
+                    const float2 *bqn = reinterpret_cast<const float2 *>(Bq + (size_t)(buf ^ 1u) * KQC * kNB + (lane & 31)) + (hi ? 1 : 0);
+#pragma unroll
+                    for (int kq = 0; kq < KQC; ++kq) {
+                        float2 (&bc)[4] = (kq & 1) ? b1 : b0;
+                        float2 (&bn)[4] = (kq & 1) ? b0 : b1;
+                        if (kq + 1 < KQC) {
+#pragma unroll
+                            for (int n = 0; n < 4; ++n) bn[n] = bq[2 * ((kq + 1) * kNB + 32 * n)];
+                        } else {
+                            // every LDS read of this buffer has landed (the last quad's fragments are in registers), the
+                            // next chunk's DMA (and this wave's candidate stores) too: close the chunk
+                            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                            __syncthreads();
+                            if (c == 0 && flag[0]) {   // set by the previous tile's filter
+                                for (int qi = w; qi < MQB; qi += 4)
+                                    if (cnt[qi] + kNB > (uint32_t)C) gt_compact_call<ITEMS>(cand + (size_t)qi * C, &cnt[qi], &thr[qi], P.K, lane);
+                                __syncthreads();
+                                if (tid == 0) flag[0] = 0;
+                                if (kThrRegs) {
+#pragma unroll
+                                    for (int r = 0; r < 16; ++r) thr_r[0][r] = thr[qoff + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)];
+                                }
+                                __syncthreads();
+                            }
+                            // chunk after next -> the buffer this chunk was read from
+                            if (!(P.diag & 1u)) {
+                                if constexpr (c + 2 < NKC) {
+                                    stream_chunk(std::integral_constant<int, c + 2>{}, rowp, buf);
+                                } else if (tile + 1 < ntiles) {
+                                    if constexpr (c + 2 == NKC) {
+                                        rowp_next = row_ptr(tile + 1);
+                                        stream_bias(tile + 1, (tile + 1) & 1u);
+                                    }
+                                    stream_chunk(std::integral_constant<int, c + 2 - NKC>{}, rowp_next, buf);
+                                }
+                            }
+                            // first fragments of the next chunk (its DMA landed before the barrier above)
+                            if (c + 1 < NKC || tile + 1 < ntiles) {
+#pragma unroll
+                                for (int n = 0; n < 4; ++n) bn[n] = bqn[2 * (32 * n)];
+                            }
                         }
-                    // a wave sees a survivor or two on most tiles (1.6 K ln(N/K) per query over the pass), so this path
-                    // is hot too: one test per query row, the four column tiles only where that row's best beat it
-                    if (any_win) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        const int kk = 2 * (c * KQC + kq);
+#pragma unroll
+                        for (int n = 0; n < 4; ++n)
+#pragma unroll
+                            for (int m = 0; m < TMW; ++m)
+                                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[kk][m], bc[n].x, acc[m][n], 0, 0, 0);
+#pragma unroll
+                        for (int n = 0; n < 4; ++n)
+#pragma unroll
+                            for (int m = 0; m < TMW; ++m)
+                                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[kk + 1][m], bc[n].y, acc[m][n], 0, 0, 0);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    ++step;
+                    if (c + 1 == NKC && !(P.diag & 2u)) {
+                        // tile finished: threshold filter (no barrier here: the compaction check is at the next barrier)
+                        bool any_win = false;
+                        float mx[TMW][16];
 #pragma unroll
                         for (int m = 0; m < TMW; ++m)
 #pragma unroll
                             for (int r = 0; r < 16; ++r) {
-                                const int qi = qoff + 32 * m + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                                const float t = kThrRegs ? thr_r[kThrRegs ? m : 0][r] : thr[qi];
-                                if (mx[m][r] > t) {
+                                const float t = kThrRegs ? thr_r[kThrRegs ? m : 0][r]
+                                                         : thr[qoff + 32 * m + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)];
+                                mx[m][r] = fmaxf(fmaxf(acc[m][0][r], acc[m][1][r]), fmaxf(acc[m][2][r], acc[m][3][r]));
+                                any_win |= mx[m][r] > t;
+                            }
+                        if (any_win) {
 #pragma unroll
-                                    for (int n = 0; n < 4; ++n) {
-                                        const uint32_t id = tile * kNB + 32 * n + (lane & 31);
-                                        if (acc[m][n][r] > t && id < P.nb) {
-                                            const uint32_t slot = atomicAdd(&cnt[qi], 1u);
-                                            cand[(size_t)qi * C + slot] = make_key(acc[m][n][r], id, true);
-                                            if (slot + 1 + kNB > (uint32_t)C) flag[0] = 1;
+                            for (int m = 0; m < TMW; ++m)
+#pragma unroll
+                                for (int r = 0; r < 16; ++r) {
+                                    const int qi = qoff + 32 * m + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                                    const float t = kThrRegs ? thr_r[kThrRegs ? m : 0][r] : thr[qi];
+                                    if (mx[m][r] > t) {
+#pragma unroll
+                                        for (int n = 0; n < 4; ++n) {
+                                            const uint32_t id = tile * kNB + 32 * n + (lane & 31);
+                                            if (acc[m][n][r] > t && id < P.nb) {
+                                                const uint32_t slot = atomicAdd(&cnt[qi], 1u);
+                                                cand[(size_t)qi * C + slot] = make_key(acc[m][n][r], id, true);
+                                                if (slot + 1 + kNB > (uint32_t)C) flag[0] = 1;
+                                            }
                                         }
                                     }
                                 }
-                            }
+                        }
                     }
-                }
-                if (!(P.diag & 8u)) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next chunk's DMA (and any candidate stores) landed
-                if (!(P.diag & 16u)) __syncthreads();
-                if (c + 1 == NKC && flag[0]) {
-                    for (int qi = w; qi < MQB; qi += 4)
-                        if (cnt[qi] + kNB > (uint32_t)C) gt_compact<ITEMS>(cand + (size_t)qi * C, &cnt[qi], &thr[qi], P.K, lane);
-                    __syncthreads();
-                    if (tid == 0) flag[0] = 0;
-                    if (kThrRegs) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) thr_r[0][r] = thr[qoff + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)];
-                    }
-                    __syncthreads();
-                }
-            };
-            if constexpr (0 < NKC) chunk(std::integral_constant<int, 0>{});
-            if constexpr (1 < NKC) chunk(std::integral_constant<int, 1>{});
-            if constexpr (2 < NKC) chunk(std::integral_constant<int, 2>{});
-            if constexpr (3 < NKC) chunk(std::integral_constant<int, 3>{});
-            if constexpr (4 < NKC) chunk(std::integral_constant<int, 4>{});
-            if constexpr (5 < NKC) chunk(std::integral_constant<int, 5>{});
-            if constexpr (6 < NKC) chunk(std::integral_constant<int, 6>{});
-            if constexpr (7 < NKC) chunk(std::integral_constant<int, 7>{});
-            static_assert(NKC <= 8, "add chunk calls");
+                    if (c + 1 == NKC) rowp = rowp_next;
+                };
+                if constexpr (0 < NKC) chunk(std::integral_constant<int, 0>{});
+                if constexpr (1 < NKC) chunk(std::integral_constant<int, 1>{});
+                if constexpr (2 < NKC) chunk(std::integral_constant<int, 2>{});
+                if constexpr (3 < NKC) chunk(std::integral_constant<int, 3>{});
+                if constexpr (4 < NKC) chunk(std::integral_constant<int, 4>{});
+                if constexpr (5 < NKC) chunk(std::integral_constant<int, 5>{});
+                if constexpr (6 < NKC) chunk(std::integral_constant<int, 6>{});
+                if constexpr (7 < NKC) chunk(std::integral_constant<int, 7>{});
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last tile's candidate stores
+            __syncthreads();
         }
         // final selection + output
         for (int qi = w; qi < MQB; qi += 4) {
@@ -663,13 +696,13 @@ rg_status rg_gt_shard_dev(const float *d_base, uint32_t nb, uint32_t bstride, co
     // register-stationary kernel for the BASELINE dimensions when the sort fits ITEMS=4 (K <= 128)
     uint32_t rs_tmw = 0, rs_bk = 0, rs_mqb = 0;
     if (items == 4 && !getenv("RG_GT_GENERIC")) {
-        if (dim == 200) { rs_tmw = getenv("RG_GT_RS_TMW2") ? 2 : 1; rs_bk = 40; }   // default: 32 queries per wave, two workgroups per CU
+        if (dim == 200) { rs_tmw = 1; rs_bk = 40; }   // 32 queries per wave, two workgroups per CU
         else if (dim == 512) { rs_tmw = 1; rs_bk = 64; }
         rs_mqb = 128 * rs_tmw;
     }
     if (rs_tmw) mq = rs_mqb;
     const uint32_t nblocks = (nq + mq - 1) / mq;
-    const uint32_t per_cu = (rs_tmw == 1 && dim == 200) ? 2 : 1;
+    const uint32_t per_cu = (rs_tmw == 1 && dim == 200) ? 2 : 1;   // matches the kernel's launch bounds
     const uint32_t grid = std::min<uint32_t>(nblocks, (uint32_t)prop.multiProcessorCount * per_cu);
     // stream-ordered scratch, released on every exit path
     struct Scratch {
@@ -698,13 +731,9 @@ rg_status rg_gt_shard_dev(const float *d_base, uint32_t nb, uint32_t bstride, co
     P.diag = getenv("RG_GT_DIAG") ? (uint32_t)atoi(getenv("RG_GT_DIAG")) : 0u;
     rg_status st;
     if (rs_tmw) {
-        const size_t lds_rs = ((size_t)2 * rs_bk * kNB + 2 * rs_mqb + 8) * 4;
-        if (dim == 200 && rs_tmw == 1) {
+        const size_t lds_rs = ((size_t)2 * rs_bk * kNB + 2 * rs_mqb + 8 + 256) * 4;
+        if (dim == 200) {
             auto kern = rg_gt_rs_kernel<200, 40, 1, 4, 2>;
-            RG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rs));
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_rs, s, P);
-        } else if (dim == 200) {
-            auto kern = rg_gt_rs_kernel<200, 40, 2, 4, 1>;
             RG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rs));
             hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_rs, s, P);
         } else {
