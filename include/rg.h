@@ -125,6 +125,14 @@ rg_status rg_score_batch_dev(rg_index *idx, const float *d_query, const uint32_t
  *         RG_ERR_NOT_ENOUGH "not enough results: N, expected: K" for the first failing query. */
 rg_status rg_search(rg_index *idx, const float *queries, uint32_t nq, uint32_t qstride, uint32_t k, uint32_t L_pq,
                     uint32_t *out_ids, float *out_dists, uint32_t *out_cmps, uint32_t *out_hops);
+/* Query-sharded form over index REPLICAS, one per device (the index is replicated -- 10 GB for t2i-10M --
+ * and the queries are split, no data-path collective).  Replica r searches the r-th contiguous slice of the batch on
+ * its own device and stream, all slices run concurrently, results land in the caller's host arrays in query order and
+ * are identical to rg_search on a single replica.  The one-process-per-GPU form of the same thing is
+ * roargraph_amd/dist.py (torch.distributed); this is the single-process form a C++ host links. */
+rg_status rg_search_sharded(rg_index *const *replicas, int nreplicas, const float *queries, uint32_t nq, uint32_t qstride,
+                            uint32_t k, uint32_t L_pq, uint32_t *out_ids, float *out_dists, uint32_t *out_cmps,
+                            uint32_t *out_hops);
 /* device-resident form; enqueues on `stream` and returns without synchronising.
  * rg_search_wait() synchronises that stream and reports the deferred RG_ERR_NOT_ENOUGH, if any. */
 rg_status rg_search_dev(rg_index *idx, const float *d_queries, uint32_t nq, uint32_t qstride, uint32_t k,

@@ -8,6 +8,8 @@
 //   timing              QPS uses a nanosecond clock around the device-resident batch (queries already in HBM); the
 //                       reference's integer-millisecond clock (:210-213) cannot resolve a 10k-query batch on a GPU
 //   warm-up             min(100, q_pts) queries, as :198-200
+//   --devices 0 1 ...   one index replica per listed GPU, the query batch split between them (host buffers in the timed
+//                       region: rg_search_sharded); --device is ignored when this is given
 //   --fast_bf16 1       opt-in non-parity mode of the library (default 0 = the reference's results bit for bit)
 #include <hip/hip_runtime.h>
 
@@ -45,6 +47,7 @@ int main(int argc, char **argv) {
     a.add("evaluation_save_path", false, "Path prefix for saving evaluation results", "");
     a.add("num_threads", false, "accepted for compatibility (ignored on the GPU path)", "0", "T");
     a.add("device", false, "HIP device index", "0");
+    a.add("devices", false, "several HIP devices: one index replica each, queries sharded (rg_search_sharded)", "");
     a.add("fast_bf16", false, "1 = opt-in NON-parity mode: bf16 traversal + exact fp32 re-rank (rg.h)", "0");
     if (!a.parse(argc, argv)) return -1;
     if (a.help()) { a.usage(std::cout); return 0; }
@@ -68,15 +71,25 @@ int main(int argc, char **argv) {
         std::ifstream probe(a.str("projection_index_save_path"));
         if (!probe.good()) { std::cout << "projection index file does not exist." << std::endl; return -1; }
     }
-    const int device = (int)a.u("device");
+    std::vector<int> devices;
+    for (const std::string &d : a.list("devices"))
+        if (!d.empty()) devices.push_back((int)std::strtol(d.c_str(), nullptr, 10));
+    const int device = devices.empty() ? (int)a.u("device") : devices[0];
     rg_index *index = nullptr;
     std::cout << "Load graph index: " << a.str("projection_index_save_path") << std::endl;
     CK(rg_index_open(a.str("base_data_path").c_str(), a.str("projection_index_save_path").c_str(), metric, device, &index));
+    std::vector<rg_index *> replicas{index};
+    for (size_t r = 1; r < devices.size(); ++r) {
+        rg_index *rep = nullptr;
+        CK(rg_index_open(a.str("base_data_path").c_str(), a.str("projection_index_save_path").c_str(), metric, devices[r], &rep));
+        replicas.push_back(rep);
+    }
+    if (replicas.size() > 1) std::cout << "Index replicated on " << replicas.size() << " devices, queries sharded" << std::endl;
     uint32_t nd, dim, stride, ep, maxdeg;
     float avgdeg;
     CK(rg_index_info(index, &nd, &dim, &stride, &ep, &avgdeg, &maxdeg, nullptr));
     if (a.u("fast_bf16")) {
-        CK(rg_index_set(index, "fast_bf16", 1));
+        for (rg_index *rep : replicas) CK(rg_index_set(rep, "fast_bf16", 1));
         std::cout << "fast_bf16: traversal on a bf16 copy of the base, exact re-rank (results are NOT the reference's)" << std::endl;
     }
     std::cout << "Projection graph, ep: " << ep << std::endl;
@@ -108,16 +121,28 @@ int main(int argc, char **argv) {
         const uint32_t L_pq = (uint32_t)std::strtoul(ls.c_str(), nullptr, 10);
         if (k > L_pq) { std::cout << "L_pq must greater or equal than k" << std::endl; return 1; }
         const uint32_t warm = q_pts < 100 ? q_pts : 100;
-        CK(rg_search_dev(index, d_q, warm, q_stride, k, L_pq, d_ids, d_dist, d_cmps, d_hops, nullptr));
-        CK(rg_search_wait(index, nullptr));
-        auto t0 = std::chrono::high_resolution_clock::now();
-        CK(rg_search_dev(index, d_q, q_pts, q_stride, k, L_pq, d_ids, d_dist, d_cmps, d_hops, nullptr));
-        CK(rg_search_wait(index, nullptr));
-        auto t1 = std::chrono::high_resolution_clock::now();
-        const double ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
-        HK(hipMemcpy(res.data(), d_ids, res.size() * 4, hipMemcpyDeviceToHost));
-        HK(hipMemcpy(cmps.data(), d_cmps, cmps.size() * 4, hipMemcpyDeviceToHost));
-        HK(hipMemcpy(hops.data(), d_hops, hops.size() * 4, hipMemcpyDeviceToHost));
+        double ms = 0.0;
+        if (replicas.size() > 1) {
+            std::vector<float> dist_h((size_t)q_pts * k);
+            CK(rg_search_sharded(replicas.data(), (int)replicas.size(), query, warm, q_stride, k, L_pq, res.data(), dist_h.data(),
+                                 cmps.data(), hops.data()));
+            auto t0 = std::chrono::high_resolution_clock::now();
+            CK(rg_search_sharded(replicas.data(), (int)replicas.size(), query, q_pts, q_stride, k, L_pq, res.data(), dist_h.data(),
+                                 cmps.data(), hops.data()));
+            auto t1 = std::chrono::high_resolution_clock::now();
+            ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+        } else {
+            CK(rg_search_dev(index, d_q, warm, q_stride, k, L_pq, d_ids, d_dist, d_cmps, d_hops, nullptr));
+            CK(rg_search_wait(index, nullptr));
+            auto t0 = std::chrono::high_resolution_clock::now();
+            CK(rg_search_dev(index, d_q, q_pts, q_stride, k, L_pq, d_ids, d_dist, d_cmps, d_hops, nullptr));
+            CK(rg_search_wait(index, nullptr));
+            auto t1 = std::chrono::high_resolution_clock::now();
+            ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+            HK(hipMemcpy(res.data(), d_ids, res.size() * 4, hipMemcpyDeviceToHost));
+            HK(hipMemcpy(cmps.data(), d_cmps, cmps.size() * 4, hipMemcpyDeviceToHost));
+            HK(hipMemcpy(hops.data(), d_hops, hops.size() * 4, hipMemcpyDeviceToHost));
+        }
         const float qps = (float)q_pts / ((float)ms / 1000.0f);
         const float recall = rg_recall(q_pts, k, gt_dim, res.data(), gt_ids);
         float avg_cmps = 0.0f, avg_hops = 0.0f;
@@ -131,7 +156,7 @@ int main(int argc, char **argv) {
                            << avg_hops << std::endl;
     }
     if (evaluation_out.is_open()) evaluation_out.close();
-    rg_index_close(index);
+    for (rg_index *rep : replicas) rg_index_close(rep);
     rg_free(query); rg_free(gt_ids); rg_free(gt_dists);
     (void)hipFree(d_q); (void)hipFree(d_ids); (void)hipFree(d_dist); (void)hipFree(d_cmps); (void)hipFree(d_hops);
     return 0;

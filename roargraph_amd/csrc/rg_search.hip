@@ -1202,6 +1202,76 @@ rg_status rg_search(rg_index *ix, const float *queries, uint32_t nq, uint32_t qs
     return st;
 }
 
+rg_status rg_search_sharded(rg_index *const *replicas, int nrep, const float *queries, uint32_t nq, uint32_t qstride,
+                            uint32_t k, uint32_t L_pq, uint32_t *out_ids, float *out_dists, uint32_t *out_cmps,
+                            uint32_t *out_hops) {
+    if (!replicas || nrep <= 0 || !queries || !out_ids || !out_dists) return set_error(RG_ERR_ARG, "null argument");
+    for (int r = 0; r < nrep; ++r) {
+        if (!replicas[r]) return set_error(RG_ERR_ARG, "null replica");
+        if (replicas[r]->dim != replicas[0]->dim || replicas[r]->nd != replicas[0]->nd || replicas[r]->metric != replicas[0]->metric)
+            return set_error(RG_ERR_ARG, "replicas describe different indexes");
+    }
+    if (k > L_pq) return set_error(RG_ERR_ARG, "L_pq must greater or equal than k");
+    if (nq == 0) return RG_OK;
+    const uint32_t d = replicas[0]->dim, use = std::min(qstride, d);
+    std::vector<float> hq((size_t)nq * d, 0.0f);
+    for (size_t i = 0; i < nq; ++i) std::memcpy(hq.data() + i * d, queries + i * (size_t)qstride, (size_t)use * 4);
+    if (replicas[0]->metric == RG_METRIC_COSINE) rg_normalize_rows(hq.data(), nq, d, d);
+    struct Shard {   // buffers and stream of one replica's slice, released on every exit path
+        int dev = 0;
+        uint32_t lo = 0, n = 0;
+        float *q = nullptr, *dist = nullptr;
+        uint32_t *ids = nullptr, *ch = nullptr;
+        hipStream_t s = nullptr;
+        ~Shard() {
+            if (!q && !dist && !ids && !ch && !s) return;
+            (void)hipSetDevice(dev);
+            if (s) (void)hipStreamSynchronize(s);
+            (void)hipFree(q); (void)hipFree(dist); (void)hipFree(ids); (void)hipFree(ch);
+            if (s) (void)hipStreamDestroy(s);
+        }
+    };
+    std::vector<Shard> S((size_t)nrep);
+    const uint32_t per = (nq + (uint32_t)nrep - 1) / (uint32_t)nrep;
+    rg_status st = RG_OK;
+    for (int r = 0; r < nrep && st == RG_OK; ++r) {
+        Shard &sh = S[(size_t)r];
+        rg_index *ix = replicas[r];
+        sh.dev = ix->device;
+        sh.lo = std::min(nq, (uint32_t)r * per);
+        sh.n = std::min(nq, sh.lo + per) - sh.lo;
+        if (sh.n == 0) continue;
+        RG_HIP(hipSetDevice(ix->device));
+        RG_HIP(hipStreamCreate(&sh.s));
+        RG_HIP(hipMalloc(&sh.q, (size_t)sh.n * d * 4));
+        RG_HIP(hipMalloc(&sh.ids, (size_t)sh.n * k * 4));
+        RG_HIP(hipMalloc(&sh.dist, (size_t)sh.n * k * 4));
+        RG_HIP(hipMalloc(&sh.ch, (size_t)sh.n * 2 * 4));
+        RG_HIP(hipMemcpyAsync(sh.q, hq.data() + (size_t)sh.lo * d, (size_t)sh.n * d * 4, hipMemcpyHostToDevice, sh.s));
+        RG_HIP(hipMemsetAsync(sh.ids, 0, (size_t)sh.n * k * 4, sh.s));
+        RG_HIP(hipMemsetAsync(sh.dist, 0, (size_t)sh.n * k * 4, sh.s));
+        st = rg::search_dev(ix, sh.q, sh.n, d, k, L_pq, sh.ids, sh.dist, sh.ch, sh.ch + sh.n, sh.s);
+    }
+    // every launched slice is waited for, whatever happened to the others; the first failure (in query order) is reported
+    rg_status first = st;
+    std::string first_msg = st != RG_OK ? rg_last_error() : "";
+    for (int r = 0; r < nrep; ++r) {
+        Shard &sh = S[(size_t)r];
+        if (!sh.s || sh.n == 0) continue;
+        (void)hipSetDevice(sh.dev);
+        rg_status w = rg::search_wait(replicas[r], sh.s, k);
+        if (w == RG_OK || w == RG_ERR_NOT_ENOUGH) {
+            (void)hipMemcpy(out_ids + (size_t)sh.lo * k, sh.ids, (size_t)sh.n * k * 4, hipMemcpyDeviceToHost);
+            (void)hipMemcpy(out_dists + (size_t)sh.lo * k, sh.dist, (size_t)sh.n * k * 4, hipMemcpyDeviceToHost);
+            if (out_cmps) (void)hipMemcpy(out_cmps + sh.lo, sh.ch, (size_t)sh.n * 4, hipMemcpyDeviceToHost);
+            if (out_hops) (void)hipMemcpy(out_hops + sh.lo, sh.ch + sh.n, (size_t)sh.n * 4, hipMemcpyDeviceToHost);
+        }
+        if (w != RG_OK && first == RG_OK) { first = w; first_msg = rg_last_error(); }
+    }
+    if (first != RG_OK) return set_error(first, first_msg);
+    return RG_OK;
+}
+
 rg_status rg_score_batch_dev(rg_index *ix, const float *d_query, const uint32_t *d_ids, uint32_t n, float *d_out,
                              void *stream) {
     return rg::score_dev(ix, d_query, d_ids, n, d_out, (hipStream_t)stream);

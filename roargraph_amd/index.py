@@ -137,6 +137,21 @@ class IndexBipartite:
         check(lib().rg_search_wait(self.handle, C.c_void_p(stream)))
 
 
+def search_sharded(replicas, queries, k, L_pq):
+    """rg_search_sharded: one IndexBipartite replica per device, the query batch split in contiguous slices that run
+    concurrently; returns (indices, res_dists, cmps, hops) in query order, identical to one replica's SearchRoarGraph."""
+    queries = np.ascontiguousarray(queries, np.float32)
+    nq = queries.shape[0]
+    ids = np.zeros((nq, k), np.uint32)
+    dists = np.zeros((nq, k), np.float32)
+    cmps = np.zeros(nq, np.uint32)
+    hops = np.zeros(nq, np.uint32)
+    handles = (C.c_void_p * len(replicas))(*[r.handle for r in replicas])
+    check(lib().rg_search_sharded(handles, C.c_int(len(replicas)), _vp(queries), C.c_uint32(nq), C.c_uint32(queries.shape[1]),
+                                  C.c_uint32(k), C.c_uint32(L_pq), _vp(ids), _vp(dists), _vp(cmps), _vp(hops)))
+    return ids, dists, cmps, hops
+
+
 # ---- formats through the C ABI -----------------------------------------------------------------------------
 def fbin_meta(path):
     n, d = C.c_uint32(), C.c_uint32()

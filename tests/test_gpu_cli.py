@@ -51,6 +51,16 @@ def test_compute_groundtruth_then_search_cli(bins, oracle, tmp_path):
         assert float(row[5]) == pytest.approx(float(hops.mean()), rel=1e-5)
         assert float(row[4]) == pytest.approx(oracle.recall(ids, gt_ids, 10), abs=1e-6)
         assert float(row[1]) > 0
+    # the same search with the index replicated on "two devices" (both device 0 here) and the queries sharded: the
+    # recall / avg_visited / avg_hops columns do not change
+    csv2 = str(tmp_path / "eval2.csv")
+    r = subprocess.run([os.path.join(bins, "test_search_roargraph"), "--data_type", "float", "--dist", "ip",
+                        "--base_data_path", bf, "--query_path", qf, "--gt_path", gtf,
+                        "--projection_index_save_path", gf, "--L_pq", "20", "100", "--k", "10", "--devices", "0", "0",
+                        "--evaluation_save_path", csv2], capture_output=True, text=True)
+    assert r.returncode == 0, r.stdout + r.stderr
+    rows2 = [l.split(",") for l in open(csv2).read().strip().splitlines()]
+    assert [(x[0], x[2], x[4], x[5]) for x in rows2] == [(x[0], x[2], x[4], x[5]) for x in rows]
 
 
 def test_cli_errors(bins, tmp_path):

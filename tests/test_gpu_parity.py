@@ -118,3 +118,20 @@ def test_register_and_lds_query_forms_agree(rg, oracle, metric, d, nb):
         assert (got[0] == want[0]).all() and (bits(got[1]) == bits(want[1])).all()
         assert (got[2] == want[2]).all() and (got[3] == want[3]).all()
         ix.close()
+
+
+@pytest.mark.parametrize("nrep", [1, 2, 3])
+def test_query_sharded_search_over_replicas(rg, oracle, nrep):
+    """rg_search_sharded: replicas of the index (here all on device 0, which exercises the same code as one per GPU)
+    search contiguous slices of the batch concurrently; the assembled result equals the oracle's, including a batch
+    that does not divide evenly and a deferred not-enough-results report that names the query in the whole batch."""
+    base, q, off, nbrs, ep = small_set("ip", 4000, 200, nq=101)
+    reps = [rg.IndexBipartite.from_arrays(base, off, nbrs, ep, metric="ip") for _ in range(nrep)]
+    got = rg.search_sharded(reps, q, 10, 100)
+    want = oracle.search(base, "ip", off, nbrs, ep, q, 10, 100, nthreads=4)
+    assert (got[0] == want[0]).all() and (bits(got[1]) == bits(want[1])).all()
+    assert (got[2] == want[2]).all() and (got[3] == want[3]).all()
+    with pytest.raises(Exception, match="L_pq must greater or equal than k"):
+        rg.search_sharded(reps, q, 20, 10)
+    for r in reps:
+        r.close()
