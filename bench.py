@@ -42,6 +42,8 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL; gloo only to "
+                    "exercise the multi-rank control flow on a box with one GPU)")
     ap.add_argument("--nb", type=int, default=10_000_000)
     ap.add_argument("--dim", type=int, default=200)
     ap.add_argument("--nq", type=int, default=10_000)
@@ -222,10 +224,14 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if lib().rg_device_count() < 1:
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    local = local % torch.cuda.device_count()   # (control-flow tests run several ranks on one GPU with --backend gloo)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     # ---- synthetic t2i-10M-shaped inputs, resident in HBM before the timed region -------------------------------
     g = torch.Generator(device=dev)
@@ -316,7 +322,7 @@ def main():
     elapsed = t1 - t0
     kernel_ms = [a.elapsed_time(b) for a, b in evs]
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     total_q = args.nq * args.steps * world
@@ -421,7 +427,7 @@ def main():
         sync_all()
         tg = time.perf_counter() - tg0
         if world > 1:
-            t = torch.tensor([tg], dtype=torch.float64, device=dev)
+            t = torch.tensor([tg], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             tg = float(t.item())
         dps = float(args.gt_nq) * float(args.nb) / tg

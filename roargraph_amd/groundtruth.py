@@ -96,10 +96,26 @@ def groundtruth_distributed(base_shard, id_base, queries, metric, K, group=None,
     for j, (lo, hi) in enumerate(ranges):
         send_i[j, : hi - lo] = ids[lo:hi]
         send_v[j, : hi - lo] = vals[lo:hi]
-    recv_i = torch.empty_like(send_i)
-    recv_v = torch.empty_like(send_v)
-    dist.all_to_all_single(recv_i, send_i, group=group)
-    dist.all_to_all_single(recv_v, send_v, group=group)
+    if dist.get_backend(group) == "nccl" or not send_i.is_cuda:
+        recv_i = torch.empty_like(send_i)
+        recv_v = torch.empty_like(send_v)
+        dist.all_to_all_single(recv_i, send_i, group=group)
+        dist.all_to_all_single(recv_v, send_v, group=group)
+    else:
+        # gloo has no all-to-all on device tensors (control-flow tests of the multi-rank path on one GPU): pairwise
+        # exchange through host memory, same result
+        hi_, hv_ = send_i.cpu(), send_v.cpu()
+        ri, rv = torch.empty_like(hi_), torch.empty_like(hv_)
+        ri[rank], rv[rank] = hi_[rank], hv_[rank]
+        ops = []
+        for peer in range(world):
+            if peer == rank:
+                continue
+            ops += [dist.P2POp(dist.isend, hi_[peer].contiguous(), peer, group), dist.P2POp(dist.isend, hv_[peer].contiguous(), peer, group),
+                    dist.P2POp(dist.irecv, ri[peer], peer, group), dist.P2POp(dist.irecv, rv[peer], peer, group)]
+        for w_ in dist.batch_isend_irecv(ops):
+            w_.wait()
+        recv_i, recv_v = ri.to(dev), rv.to(dev)
     lo, hi = ranges[rank]
     n_own = hi - lo
     out_i = torch.zeros((per, K), dtype=torch.int32, device=dev)

@@ -122,3 +122,21 @@ def test_gpu_assisted_build(oracle, monkeypatch):
         rc = oracle.recall(oracle.search(base, metric, off_c, nbrs_c, ep_c, q, 10, 100, nthreads=8)[0], gt, 10)
         rg_ = oracle.recall(oracle.search(base, metric, off_g, nbrs_g, ep_g, q, 10, 100, nthreads=8)[0], gt, 10)
         assert rg_ > rc - 0.03, (metric, rc, rg_)
+
+
+def test_bench_multi_rank_control_flow_on_one_gpu():
+    """bench.py as the driver launches it for N > 1 (torch.distributed.run, one process per rank), here with two ranks on
+    the one visible GPU and the gloo backend: rank/LOCAL_RANK handling, barriers, max-over-ranks timing, the sharded
+    ground-truth leg with its all-to-all and K3 merge, one JSON line from rank 0."""
+    import json
+    import sys
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--backend", "gloo", "--nb", "200000", "--nq", "512", "--gt-nq", "4096", "--recall-nb", "0", "--cpu-seconds", "0"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line, from rank 0"
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
+    assert d["gt_build"]["value"] > 0 and "sharded x2" in d["gt_build"]["metric"]
