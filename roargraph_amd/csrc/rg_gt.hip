@@ -376,7 +376,7 @@ __global__ void __launch_bounds__(256, WPS) rg_gt_rs_kernel(GtParams P) {
         for (int i = tid; i < MQB; i += 256) { thr[i] = -__builtin_inff(); cnt[i] = 0; }
         if (tid == 0) flag[0] = 0;
         // thresholds of this lane's query rows: kept in registers when the budget allows (TMW == 1), else read from LDS
-        constexpr bool kThrRegs = TMW == 1 && DIM > 256;   // d = 200 runs at the 256-VGPR limit of two workgroups per CU
+        constexpr bool kThrRegs = TMW == 1 && WPS == 1;   // two workgroups per CU run at the 256-VGPR limit: thresholds from LDS
         float thr_r[kThrRegs ? TMW : 1][16];
         if (kThrRegs) {
 #pragma unroll
@@ -694,15 +694,20 @@ rg_status rg_gt_shard_dev(const float *d_base, uint32_t nb, uint32_t bstride, co
     const size_t lds = gt_lds(dim, mq, bk);
     const int items = items_for(K + kNB);
     // register-stationary kernel for the BASELINE dimensions when the sort fits ITEMS=4 (K <= 128)
-    uint32_t rs_tmw = 0, rs_bk = 0, rs_mqb = 0;
+    // (dimension, k-chunk, workgroups per CU) of the register-stationary instantiations: the BASELINE dimensions plus
+    // the common embedding widths that satisfy its constraints (A operands dim/2 <= 256 registers, an even number of
+    // k-quads per chunk, 2..8 chunks per tile)
+    struct RsCfg { uint32_t dim, bk, per_cu; };
+    static const RsCfg kRs[] = {{200, 40, 2}, {512, 64, 1}, {96, 48, 2}, {128, 64, 2}, {256, 64, 1}, {384, 64, 1}};
+    uint32_t rs_tmw = 0, rs_bk = 0, rs_mqb = 0, rs_per_cu = 1;
     if (items == 4 && !getenv("RG_GT_GENERIC")) {
-        if (dim == 200) { rs_tmw = 1; rs_bk = 40; }   // 32 queries per wave, two workgroups per CU
-        else if (dim == 512) { rs_tmw = 1; rs_bk = 64; }
+        for (const RsCfg &c : kRs)
+            if (c.dim == dim) { rs_tmw = 1; rs_bk = c.bk; rs_per_cu = c.per_cu; }
         rs_mqb = 128 * rs_tmw;
     }
     if (rs_tmw) mq = rs_mqb;
     const uint32_t nblocks = (nq + mq - 1) / mq;
-    const uint32_t per_cu = (rs_tmw == 1 && dim == 200) ? 2 : 1;   // matches the kernel's launch bounds
+    const uint32_t per_cu = rs_tmw ? rs_per_cu : 1;   // matches the kernel's launch bounds
     const uint32_t grid = std::min<uint32_t>(nblocks, (uint32_t)prop.multiProcessorCount * per_cu);
     // stream-ordered scratch, released on every exit path
     struct Scratch {
@@ -732,15 +737,21 @@ rg_status rg_gt_shard_dev(const float *d_base, uint32_t nb, uint32_t bstride, co
     rg_status st;
     if (rs_tmw) {
         const size_t lds_rs = ((size_t)2 * rs_bk * kNB + 2 * rs_mqb + 8 + 256) * 4;
-        if (dim == 200) {
-            auto kern = rg_gt_rs_kernel<200, 40, 1, 4, 2>;
-            RG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rs));
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_rs, s, P);
-        } else {
-            auto kern = rg_gt_rs_kernel<512, 64, 1, 4, 1>;
-            RG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rs));
-            hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_rs, s, P);
+#define RG_RS_LAUNCH(D, BKV, WPSV)                                                                                           \
+    {                                                                                                                        \
+        auto kern = rg_gt_rs_kernel<D, BKV, 1, 4, WPSV>;                                                                     \
+        RG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rs)); \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_rs, s, P);                                                       \
+    }
+        switch (dim) {
+            case 200: RG_RS_LAUNCH(200, 40, 2) break;
+            case 512: RG_RS_LAUNCH(512, 64, 1) break;
+            case 96: RG_RS_LAUNCH(96, 48, 2) break;
+            case 128: RG_RS_LAUNCH(128, 64, 2) break;
+            case 256: RG_RS_LAUNCH(256, 64, 1) break;
+            default: RG_RS_LAUNCH(384, 64, 1) break;
         }
+#undef RG_RS_LAUNCH
         st = hipGetLastError() == hipSuccess ? RG_OK : set_error(RG_ERR_DEVICE, "K2-RS launch failed");
     } else {
         st = mq == 128 ? launch_gt_items<128>(items, P, grid, lds, s) : launch_gt_items<64>(items, P, grid, lds, s);

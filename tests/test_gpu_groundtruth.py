@@ -42,7 +42,10 @@ def check_gt(base, q, metric, K, ids, dists, ref_ids, ref_s64, tol=1e-5):
 @pytest.mark.parametrize("metric,d,nb,nq,K", [("ip", 200, 20000, 300, 100), ("l2", 512, 6000, 130, 100),
                                               ("ip", 200, 1000, 5, 10), ("l2", 24, 3000, 257, 1),
                                               ("ip", 104, 5000, 64, 100), ("ip", 200, 130, 128, 128),
-                                              ("l2", 200, 4000, 100, 300)])
+                                              ("l2", 200, 4000, 100, 300),
+                                              # the other register-stationary instantiations (common embedding widths)
+                                              ("l2", 96, 9000, 200, 100), ("ip", 128, 9000, 200, 100),
+                                              ("l2", 256, 5000, 150, 100), ("ip", 384, 5000, 150, 50)])
 def test_groundtruth_vs_fp64(oracle, metric, d, nb, nq, K):
     from roargraph_amd import groundtruth
     base, q = synth.make_synth(77, nb, nq, d)
