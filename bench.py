@@ -55,7 +55,7 @@ def parse():
     ap.add_argument("--visited", type=int, default=2,
                     help="2 = LDS visited filter + id log + exact distinct count (library default; ids, dists, hops and "
                          "cmps bit-exact); 1 = LDS filter only (cmps = evaluations performed); 0 = visited words in HBM")
-    ap.add_argument("--filter-log2", type=int, default=9)
+    ap.add_argument("--filter-log2", type=int, default=0, help="LDS visited-filter size (log2 entries); 0 = the library's automatic choice")
     ap.add_argument("--waves-per-cu", type=int, default=0)
     ap.add_argument("--rows-per-pass", type=int, default=0)
     ap.add_argument("--no-other-modes", action="store_true", help="skip timing the non-default visited modes (profiling runs)")
@@ -288,7 +288,8 @@ def main():
     if args.rows_per_pass:
         index.set("rows_per_pass", args.rows_per_pass)
     stream = torch.cuda.current_stream().cuda_stream
-    index.set("filter_log2", args.filter_log2)
+    if args.filter_log2:
+        index.set("filter_log2", args.filter_log2)
 
     # reference-equivalent evaluation counts (exact visited mode), and a parity check between the two modes
     index.set("visited", 0)
@@ -472,9 +473,9 @@ def main():
                                        "random graph: same HBM access pattern as a real index, recall not meaningful (the value "
                                        "above is what it is); recall IS meaningful on the genuine RoarGraph index built in this run "
                                        "(smaller base) in recall_check_roargraph_index, and with --real-index"),
-                       "visited": {2: "lds-filter 2^%d + id log + exact distinct count (ids/dists/hops/cmps bit-exact vs the "
-                                      "HBM-visited mode, checked in this run)" % args.filter_log2,
-                                   1: "lds-filter 2^%d only (ids/dists/hops bit-exact; cmps = evaluations performed)" % args.filter_log2,
+                       "visited": {2: "lds-filter (%s) + id log + exact distinct count (ids/dists/hops/cmps bit-exact vs the "
+                                      "HBM-visited mode, checked in this run)" % ("2^%d" % args.filter_log2 if args.filter_log2 else "auto size"),
+                                   1: "lds-filter (%s) only (ids/dists/hops bit-exact; cmps = evaluations performed)" % ("2^%d" % args.filter_log2 if args.filter_log2 else "auto size"),
                                    0: "exact visited words in HBM"}[args.visited],
                        "mean_evals_per_query": mean_cmps, "mean_evals_performed": mean_done, "mean_hops": mean_hops},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",

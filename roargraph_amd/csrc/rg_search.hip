@@ -724,7 +724,7 @@ static uint32_t id_bits_of(uint32_t nd) {
 }
 static uint32_t filter_log2_of(const rg_index *ix) {  // remainder must fit 15 bits
     const uint32_t bits = id_bits_of(ix->nd);
-    uint32_t t = (uint32_t)std::max(4, std::min(14, ix->filter_log2));
+    uint32_t t = (uint32_t)std::max(4, std::min(14, ix->filter_log2 > 0 ? ix->filter_log2 : ix->filter_auto));
     if (bits > t + 15) t = bits - 15;
     return std::min(t, bits);
 }
@@ -818,6 +818,13 @@ static rg_status launch_k1(rg_index *ix, int mode, const float *d_q, uint32_t nq
     if (bf) R = std::min(R, 2);
     const int saved_mode = ix->visited_mode;
     ix->visited_mode = mode;  // search_lds_bytes() looks at it
+    // LDS visited filter, automatic size: the largest of 2^12 .. 2^9 entries that still leaves 14 resident queries per
+    // CU (on genuine indexes a forgetful filter re-scores up to 50 % more nodes; past that point the lost residency
+    // costs more than the repeats -- scripts/exp/filter_real.py)
+    for (int f = 12; f >= 9; --f) {
+        ix->filter_auto = f;
+        if (f == 9 || ix->lds_per_cu / search_lds_bytes(ix, L, R) >= 14) break;
+    }
     size_t lds = search_lds_bytes(ix, L, R);
     while (lds > ix->lds_per_cu && R > 1) { R >>= 1; lds = search_lds_bytes(ix, L, R); }
     ix->visited_mode = saved_mode;
