@@ -474,7 +474,7 @@ template <bool HALF>
 __global__ void __launch_bounds__(1024) rg_distinct_kernel(const uint32_t *qlog, uint32_t logcap, const uint32_t *qlog_n,
                                                            uint32_t nq, uint32_t *out_cmps, uint32_t *ovf_list,
                                                            uint32_t *ovf_count, uint32_t *work, uint32_t tbits, uint32_t id_bits,
-                                                           uint32_t qbase) {
+                                                           uint32_t qbase, unsigned long long *totals) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     uint32_t *tab = reinterpret_cast<uint32_t *>(smem);      // T words = T/4 buckets
     __shared__ uint32_t s_cnt, s_fail, s_q;
@@ -569,7 +569,11 @@ __global__ void __launch_bounds__(1024) rg_distinct_kernel(const uint32_t *qlog,
         __syncthreads();
         if (tid == 0) {
             if (s_fail) ovf_list[atomicAdd(ovf_count, 1u)] = q + qbase;   // out_cmps is already offset; the list is global
-            else out_cmps[q] = s_cnt;
+            else {
+                out_cmps[q] = s_cnt;
+                atomicAdd(&totals[0], (unsigned long long)n);       // evaluations performed / distinct nodes: how much the
+                atomicAdd(&totals[1], (unsigned long long)s_cnt);   // forgetful filter re-scored (search_wait looks at it)
+            }
         }
         __syncthreads();
     }
@@ -897,7 +901,13 @@ static rg_status search_dev(rg_index *ix, const float *d_q, uint32_t nq, uint32_
     RG_HIP(hipMemsetAsync(ix->d_status, 0xff, 8, s));
     ix->pending.active = false;
     const bool fast = ix->fast_bf16 && ix->d_base_bf && dimc_of(ix) && ix->visited_mode != 0;
-    const bool exact_count = ix->visited_mode == 2 && d_cmps != nullptr && !fast;
+    bool exact_count = ix->visited_mode == 2 && d_cmps != nullptr && !fast;
+    // Adaptive default: both forms return the same bits.  When an earlier batch showed the LDS filter re-scoring nodes
+    // wholesale at this beam width (performed > 1.45 x distinct: long searches on indexes with locality), the exact
+    // HBM-word form is the cheaper way to the same answer (scripts/exp/visited_modes_real.py).
+    if (exact_count && ix->filter_log2 <= 0 && L >= ix->exact_from_L)
+        return launch_k1(ix, 0, d_q, nq, qstride, k, L, d_ids, d_dists, d_cmps, d_hops, nullptr, false, s);
+    if (exact_count) RG_HIP(hipMemsetAsync(ix->d_status + 1, 0, 16, s));
     if (!exact_count)
         return launch_k1(ix, ix->visited_mode == 0 ? 0 : 1, d_q, nq, qstride, k, L, d_ids, d_dists, d_cmps, d_hops, nullptr, false, s);
     // mode 2: LDS-filter search with id log, then the exact distinct count (K4); overflowed logs are re-counted by an
@@ -923,12 +933,12 @@ static rg_status search_dev(rg_index *ix, const float *d_q, uint32_t nq, uint32_
             auto kern = rg_distinct_kernel<true>;
             RG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(kern, grid, dim3(1024), lds, s, ix->d_qlog, ix->logcap, ix->d_qlog_n, nqc, d_cmps + q0, ix->d_ovf + 2,
-                               ix->d_ovf, ix->d_ovf + 1, tbits, id_bits, q0);
+                               ix->d_ovf, ix->d_ovf + 1, tbits, id_bits, q0, ix->d_status + 1);
         } else {
             auto kern = rg_distinct_kernel<false>;
             RG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             hipLaunchKernelGGL(kern, grid, dim3(1024), lds, s, ix->d_qlog, ix->logcap, ix->d_qlog_n, nqc, d_cmps + q0, ix->d_ovf + 2,
-                               ix->d_ovf, ix->d_ovf + 1, tbits, id_bits, q0);
+                               ix->d_ovf, ix->d_ovf + 1, tbits, id_bits, q0, ix->d_status + 1);
         }
     }
     RG_HIP(hipGetLastError());
@@ -940,11 +950,16 @@ static rg_status search_dev(rg_index *ix, const float *d_q, uint32_t nq, uint32_
 
 static rg_status search_wait(rg_index *ix, hipStream_t s, uint32_t k) {
     RG_HIP(hipMemcpyAsync(ix->h_status, ix->d_status, 8, hipMemcpyDeviceToHost, s));
-    if (ix->pending.active) RG_HIP(hipMemcpyAsync(ix->h_status + 1, ix->d_ovf, 4, hipMemcpyDeviceToHost, s));
+    if (ix->pending.active) {
+        RG_HIP(hipMemcpyAsync(ix->h_status + 1, ix->d_ovf, 4, hipMemcpyDeviceToHost, s));
+        RG_HIP(hipMemcpyAsync(ix->h_status + 2, ix->d_status + 1, 16, hipMemcpyDeviceToHost, s));
+    }
     RG_HIP(hipStreamSynchronize(s));
     const unsigned long long v = *ix->h_status;
     if (ix->pending.active) {
         ix->pending.active = false;
+        const unsigned long long performed = ix->h_status[2], distinct = ix->h_status[3];
+        if (distinct > 0 && (double)performed > 1.45 * (double)distinct) ix->exact_from_L = std::min(ix->exact_from_L, ix->pending.L);
         const uint32_t novf = (uint32_t)(ix->h_status[1] & 0xffffffffu);
         if (novf > 0 && v == ~0ull) {
             // logs that did not fit: recount those queries with the exact HBM visited words (only cmps is rewritten)
