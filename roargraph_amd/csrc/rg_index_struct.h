@@ -43,6 +43,7 @@ struct rg_index {
     bool bf_launch = false;      // transient: the launch being prepared uses the bf16 copy
     uint16_t *d_base_bf = nullptr;
     uint32_t stride_bf = 0;
+    bool exact_filter = true;    // mode 0: the LDS filter screens the exact HBM words (hits skip the atomics)
     bool query_in_lds = false;   // K1: force the generic (query staged in LDS) instantiation for d = 200 / 512
     bool count_full_ids = false; // K4: force the full-id bucket form (the half-word form is used when the remainder fits)
     struct Pending { bool active = false; const float *q = nullptr; uint32_t nq = 0, qstride = 0, k = 0, L = 0; uint32_t *ids = nullptr; float *dists = nullptr; uint32_t *cmps = nullptr, *hops = nullptr; } pending;

@@ -70,7 +70,8 @@ struct SearchParams {
     uint32_t stage_total;     // floats of the whole staging region (>= R * stage_floats; fast mode: >= one fp32 pass too)
     uint32_t qbase;           // index of queries[0] in the caller's batch (error reporting of chunked launches)
     uint32_t diag;            // diagnostics only (breaks parity): bit0 = skip the visited test
-    uint32_t vf_slots_log2;   // VIS=1: log2 of the LDS visited-filter size (16-bit entries)
+    uint32_t vf_slots_log2;   // log2 of the LDS visited-filter size (16-bit entries)
+    uint32_t vf_front;        // VIS=0: 1 = the LDS filter screens the exact HBM words
     uint32_t *qlog;           // VIS=1, optional: [nq][logcap] ids scored by each query (input of the exact distinct count)
     uint32_t logcap;
     uint32_t *qlog_n;         // [nq] number of ids scored (may exceed logcap: overflow)
@@ -253,7 +254,8 @@ __global__ void __launch_bounds__(64) rg_search_kernel(SearchParams P) {
                 epoch = 1;
             }
             etag = epoch << 16;
-        } else {
+        }
+        if (VIS == 1 || P.vf_front) {
             uint32_t *vt32 = reinterpret_cast<uint32_t *>(vtab);
             for (uint32_t i = lane; i < (1u << P.vf_slots_log2) / 2u; i += kWave) vt32[i] = 0xffffffffu;
         }
@@ -332,11 +334,23 @@ __global__ void __launch_bounds__(64) rg_search_kernel(SearchParams P) {
                     __hip_atomic_fetch_or(w, 1u << (id & 15u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     fresh = true;
                 } else if (have) {
-                    uint32_t *w = &vmap[id >> 4];
-                    const uint32_t bit = 1u << (id & 15u);
-                    atomicMax(w, etag);                    // stale epoch -> word becomes (epoch, no bits)
-                    const uint32_t old = atomicOr(w, bit); // same address, same lane: ordered behind the max
-                    fresh = !(old & bit);
+                    // the LDS filter in front of the exact words: a hit proves "visited" and saves the two atomics (most
+                    // repeat encounters on indexes with locality); a miss goes to the words, which decide
+                    bool known = false;
+                    if (P.vf_front) {
+                        const uint32_t x = (id * 0x9E3779B1u) & vf_id_mask;
+                        const uint32_t slot = x >> vf_rem_bits;
+                        const uint16_t rem = (uint16_t)(x & ((1u << vf_rem_bits) - 1u));
+                        known = vtab[slot] == rem;
+                        if (!known) vtab[slot] = rem;
+                    }
+                    if (!known) {
+                        uint32_t *w = &vmap[id >> 4];
+                        const uint32_t bit = 1u << (id & 15u);
+                        atomicMax(w, etag);                    // stale epoch -> word becomes (epoch, no bits)
+                        const uint32_t old = atomicOr(w, bit); // same address, same lane: ordered behind the max
+                        fresh = !(old & bit);
+                    }
                 }
                 const unsigned long long fm = __ballot(fresh);
                 const uint32_t n = __popcll(fm);
@@ -745,7 +759,7 @@ static size_t stage_total_floats(const rg_index *ix, int R) {   // the fast mode
 }
 static size_t search_lds_bytes(const rg_index *ix, uint32_t L, int R) {
     size_t b = stage_total_floats(ix, R) * 4 + (dimc_of(ix) ? 0 : (size_t)ix->dim * 4) + 64 * 4 + 64 * 4 + (size_t)L * 8;
-    if (ix->visited_mode != 0) b += 128 * 4 + std::max<size_t>(4, (size_t)2 << filter_log2_of(ix));
+    if (ix->visited_mode != 0 || ix->exact_filter) b += 128 * 4 + std::max<size_t>(4, (size_t)2 << filter_log2_of(ix));
     return (b + 15) / 16 * 16;
 }
 
@@ -855,6 +869,7 @@ static rg_status launch_k1(rg_index *ix, int mode, const float *d_q, uint32_t nq
     P.diag = (uint32_t)ix->diag;
     P.qbase = qbase;
     P.vf_slots_log2 = filter_log2_of(ix);
+    P.vf_front = (mode == 0 && ix->exact_filter) ? 1u : 0u;
     P.id_bits = id_bits_of(ix->nd);
     P.qlog = with_log ? ix->d_qlog : nullptr; P.logcap = ix->logcap; P.qlog_n = with_log ? ix->d_qlog_n : nullptr;
     P.qlist = qlist;
@@ -903,7 +918,7 @@ static rg_status search_dev(rg_index *ix, const float *d_q, uint32_t nq, uint32_
     const bool fast = ix->fast_bf16 && ix->d_base_bf && dimc_of(ix) && ix->visited_mode != 0;
     bool exact_count = ix->visited_mode == 2 && d_cmps != nullptr && !fast;
     // Adaptive default: both forms return the same bits.  When an earlier batch showed the LDS filter re-scoring nodes
-    // wholesale at this beam width (performed > 1.45 x distinct: long searches on indexes with locality), the exact
+    // wholesale at this beam width (performed > 1.3 x distinct: long searches on indexes with locality), the exact
     // HBM-word form is the cheaper way to the same answer (scripts/exp/visited_modes_real.py).
     if (exact_count && ix->filter_log2 <= 0 && L >= ix->exact_from_L)
         return launch_k1(ix, 0, d_q, nq, qstride, k, L, d_ids, d_dists, d_cmps, d_hops, nullptr, false, s);
@@ -959,7 +974,7 @@ static rg_status search_wait(rg_index *ix, hipStream_t s, uint32_t k) {
     if (ix->pending.active) {
         ix->pending.active = false;
         const unsigned long long performed = ix->h_status[2], distinct = ix->h_status[3];
-        if (distinct > 0 && (double)performed > 1.45 * (double)distinct) ix->exact_from_L = std::min(ix->exact_from_L, ix->pending.L);
+        if (distinct > 0 && (double)performed > 1.3 * (double)distinct) ix->exact_from_L = std::min(ix->exact_from_L, ix->pending.L);
         const uint32_t novf = (uint32_t)(ix->h_status[1] & 0xffffffffu);
         if (novf > 0 && v == ~0ull) {
             // logs that did not fit: recount those queries with the exact HBM visited words (only cmps is rewritten)
@@ -1163,6 +1178,7 @@ rg_status rg_index_set(rg_index *ix, const char *name, int value) {
     else if (!strcmp(name, "log_cap")) ix->log_cap_knob = value;
     else if (!strcmp(name, "log_budget_kb")) ix->log_budget_kb = value;
     else if (!strcmp(name, "query_in_lds")) ix->query_in_lds = value != 0;
+    else if (!strcmp(name, "exact_filter")) ix->exact_filter = value != 0;
     else if (!strcmp(name, "fast_bf16")) {
         // opt-in, NOT parity (see rg.h): the bf16 copy of the base is made on first use
         if (value && !ix->d_base_bf) {

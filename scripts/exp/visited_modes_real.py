@@ -18,10 +18,10 @@ ids = torch.zeros((nq, k), dtype=torch.int32, device=dev); ds = torch.zeros((nq,
 cm = torch.zeros(nq, dtype=torch.int32, device=dev); hp = torch.zeros(nq, dtype=torch.int32, device=dev)
 for L in (100, 200, 500, 1000, 2000):
     row = {"L": L}
-    for vis in (0, 1, 2):
-        ix.set("visited", vis)
+    for vis, name in ((0, "mode0_nofilter"), (0, "mode0"), (1, "mode1"), (2, "mode2")):
+        ix.set("visited", vis); ix.set("exact_filter", 0 if name == "mode0_nofilter" else 1)
         ix.search_dev(q, k, L, ids, ds, cm, hp, stream=st); ix.search_wait(st)
-        if vis < 2: row["evals_mode%d" % vis] = round(float(cm.float().mean()))
+        if vis < 2: row["evals_%s" % name] = round(float(cm.float().mean()))
         best = 0
         for rep in range(2):
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -30,5 +30,5 @@ for L in (100, 200, 500, 1000, 2000):
                 ix.search_dev(q, k, L, ids, ds, cm, hp, stream=st)
             b.record(); torch.cuda.synchronize(); ix.search_wait(st)
             best = max(best, round(nq / (a.elapsed_time(b) / 3) * 1e3))
-        row["qps_mode%d" % vis] = best
+        row["qps_%s" % name] = best
     print(json.dumps(row), flush=True)

@@ -138,7 +138,7 @@ def test_query_sharded_search_over_replicas(rg, oracle, nrep):
 
 
 def test_default_mode_stays_exact_when_it_switches_to_the_exact_words(rg, oracle):
-    """The default visited mode is adaptive: after a batch in which the LDS filter re-scored more than 45 % extra nodes,
+    """The default visited mode is adaptive: after a batch in which the LDS filter re-scored more than 30 % extra nodes,
     later batches at that beam width (or wider) use the exact HBM words.  Every call, before and after the switch, must
     return the oracle's ids / distances / cmps / hops."""
     base, q, off, nbrs, ep = small_set("ip", 4000, 200)
