@@ -49,6 +49,13 @@ struct rg_index {
     struct Pending { bool active = false; const float *q = nullptr; uint32_t nq = 0, qstride = 0, k = 0, L = 0; uint32_t *ids = nullptr; float *dists = nullptr; uint32_t *cmps = nullptr, *hops = nullptr; } pending;
     int filter_log2 = 0;    // VIS=1: log2 of the LDS filter's 16-bit entries; 0 = automatic (launch_k1)
     uint32_t exact_from_L = 0xffffffffu;   // adaptive default mode: beam widths from here on use the exact HBM words
+    struct Tune {                          // timed trial behind that decision (search_dev / search_wait)
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;
+        bool timed = false, is_trial = false;
+        int mode = 2;
+        uint32_t L = 0, nq = 0, trial_L = 0, filter_ok_upto = 0;
+        float filter_per_q = 0.0f;
+    } tune;
     int filter_auto = 9;    // the automatic choice of the launch being prepared
     int num_cu = 256;
     size_t lds_per_cu = 160 * 1024;

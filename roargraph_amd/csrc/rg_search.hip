@@ -729,6 +729,8 @@ static rg_status finish_graph(rg_index *ix, const uint64_t *d_off, const uint32_
     RG_HIP(hipMalloc(&ix->d_counter, 64));
     RG_HIP(hipMalloc(&ix->d_status, 64));
     RG_HIP(hipHostMalloc(&ix->h_status, 64));
+    RG_HIP(hipEventCreate(&ix->tune.ev0));
+    RG_HIP(hipEventCreate(&ix->tune.ev1));
     hipDeviceProp_t prop;
     RG_HIP(hipGetDeviceProperties(&prop, ix->device));
     ix->num_cu = prop.multiProcessorCount;
@@ -917,11 +919,23 @@ static rg_status search_dev(rg_index *ix, const float *d_q, uint32_t nq, uint32_
     ix->pending.active = false;
     const bool fast = ix->fast_bf16 && ix->d_base_bf && dimc_of(ix) && ix->visited_mode != 0;
     bool exact_count = ix->visited_mode == 2 && d_cmps != nullptr && !fast;
-    // Adaptive default: both forms return the same bits.  When an earlier batch showed the LDS filter re-scoring nodes
-    // wholesale at this beam width (performed > 1.3 x distinct: long searches on indexes with locality), the exact
-    // HBM-word form is the cheaper way to the same answer (scripts/exp/visited_modes_real.py).
-    if (exact_count && ix->filter_log2 <= 0 && L >= ix->exact_from_L)
-        return launch_k1(ix, 0, d_q, nq, qstride, k, L, d_ids, d_dists, d_cmps, d_hops, nullptr, false, s);
+    // Adaptive default: both exact forms return the same bits.  When a batch showed the LDS filter re-scoring nodes
+    // wholesale at this beam width (performed > 1.3 x distinct: long searches on indexes with locality), the next batch
+    // of that width runs on the exact HBM words as a timed trial; the faster form is kept from that width on (which one
+    // wins depends on the index: the words of a 10M-node index are 10 GB of random atomics, those of a 2M-node index
+    // mostly cache resident -- scripts/exp/visited_modes_real.py).
+    ix->tune.timed = false;
+    if (exact_count && ix->filter_log2 <= 0 && ix->tune.ev0) {
+        const bool trial = ix->tune.trial_L == L && nq >= 1000;
+        ix->tune.timed = true; ix->tune.mode = (L >= ix->exact_from_L || trial) ? 0 : 2; ix->tune.L = L; ix->tune.nq = nq;
+        ix->tune.is_trial = trial && L < ix->exact_from_L;
+        RG_HIP(hipEventRecord(ix->tune.ev0, s));
+        if (ix->tune.mode == 0) {
+            rg_status st0 = launch_k1(ix, 0, d_q, nq, qstride, k, L, d_ids, d_dists, d_cmps, d_hops, nullptr, false, s);
+            if (st0 == RG_OK) RG_HIP(hipEventRecord(ix->tune.ev1, s));
+            return st0;
+        }
+    }
     if (exact_count) RG_HIP(hipMemsetAsync(ix->d_status + 1, 0, 16, s));
     if (!exact_count)
         return launch_k1(ix, ix->visited_mode == 0 ? 0 : 1, d_q, nq, qstride, k, L, d_ids, d_dists, d_cmps, d_hops, nullptr, false, s);
@@ -957,6 +971,7 @@ static rg_status search_dev(rg_index *ix, const float *d_q, uint32_t nq, uint32_
         }
     }
     RG_HIP(hipGetLastError());
+    if (ix->tune.timed) RG_HIP(hipEventRecord(ix->tune.ev1, s));
     ix->pending.active = true;
     ix->pending.q = d_q; ix->pending.nq = nq; ix->pending.qstride = qstride; ix->pending.k = k; ix->pending.L = L;
     ix->pending.ids = d_ids; ix->pending.dists = d_dists; ix->pending.cmps = d_cmps; ix->pending.hops = d_hops;
@@ -971,10 +986,25 @@ static rg_status search_wait(rg_index *ix, hipStream_t s, uint32_t k) {
     }
     RG_HIP(hipStreamSynchronize(s));
     const unsigned long long v = *ix->h_status;
+    float per_q = 0.0f;   // time per query of the batch just finished (adaptive default only)
+    if (ix->tune.timed) {
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, ix->tune.ev0, ix->tune.ev1) == hipSuccess && ix->tune.nq) per_q = ms / (float)ix->tune.nq;
+        ix->tune.timed = false;
+        if (ix->tune.mode == 0 && ix->tune.is_trial && per_q > 0.0f) {   // verdict of the trial
+            if (per_q < 0.97f * ix->tune.filter_per_q) ix->exact_from_L = std::min(ix->exact_from_L, ix->tune.L);
+            else ix->tune.filter_ok_upto = std::max(ix->tune.filter_ok_upto, ix->tune.L);
+            ix->tune.trial_L = 0;
+        }
+    }
     if (ix->pending.active) {
         ix->pending.active = false;
         const unsigned long long performed = ix->h_status[2], distinct = ix->h_status[3];
-        if (distinct > 0 && (double)performed > 1.3 * (double)distinct) ix->exact_from_L = std::min(ix->exact_from_L, ix->pending.L);
+        if (distinct > 0 && (double)performed > 1.3 * (double)distinct && per_q > 0.0f && ix->pending.nq >= 1000 &&
+            ix->pending.L > ix->tune.filter_ok_upto && ix->pending.L < ix->exact_from_L) {
+            ix->tune.trial_L = ix->pending.L;      // next batch of this width: the exact words, timed
+            ix->tune.filter_per_q = per_q;
+        }
         const uint32_t novf = (uint32_t)(ix->h_status[1] & 0xffffffffu);
         if (novf > 0 && v == ~0ull) {
             // logs that did not fit: recount those queries with the exact HBM visited words (only cmps is rewritten)
@@ -1079,6 +1109,8 @@ void rg_index_close(rg_index *ix) {
     if (ix->d_counter) (void)hipFree(ix->d_counter);
     if (ix->d_status) (void)hipFree(ix->d_status);
     if (ix->h_status) (void)hipHostFree(ix->h_status);
+    if (ix->tune.ev0) (void)hipEventDestroy(ix->tune.ev0);
+    if (ix->tune.ev1) (void)hipEventDestroy(ix->tune.ev1);
     delete ix;
 }
 

@@ -138,12 +138,13 @@ def test_query_sharded_search_over_replicas(rg, oracle, nrep):
 
 
 def test_default_mode_stays_exact_when_it_switches_to_the_exact_words(rg, oracle):
-    """The default visited mode is adaptive: after a batch in which the LDS filter re-scored more than 30 % extra nodes,
-    later batches at that beam width (or wider) use the exact HBM words.  Every call, before and after the switch, must
-    return the oracle's ids / distances / cmps / hops."""
-    base, q, off, nbrs, ep = small_set("ip", 4000, 200)
+    """The default visited mode is adaptive: after a batch (of >= 1000 queries) in which the LDS filter re-scored more than
+    30 % extra nodes, the next batch at that beam width runs on the exact HBM words as a timed trial and the faster
+    form is kept.  Every call -- before, during and after the trial -- must return the oracle's ids / distances /
+    cmps / hops."""
+    base, q, off, nbrs, ep = small_set("ip", 4000, 200, nq=1200)
     ix = rg.IndexBipartite.from_arrays(base, off, nbrs, ep, metric="ip")
-    for L in (500, 500, 1000, 100, 500):
+    for L in (500, 500, 500, 1000, 1000, 100, 500):
         got = ix.SearchRoarGraph(q, 10, L)
         want = oracle.search(base, "ip", off, nbrs, ep, q, 10, L, nthreads=4)
         assert (got[0] == want[0]).all() and (bits(got[1]) == bits(want[1])).all()
