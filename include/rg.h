@@ -99,7 +99,8 @@ rg_status rg_index_info(const rg_index *idx, uint32_t *nd, uint32_t *dim, uint32
  * "visited" selects how the visited set is kept:
  *   2 (default) LDS exact-match filter + per-query id log + exact distinct count: ids, dists, hops AND cmps bit-exact.
  *               Adaptive: once a batch shows the filter re-scoring > 30 % extra nodes at some L_pq (long searches on
- *               indexes with locality), later batches at that L_pq or wider run as mode 0 -- the same bits, cheaper
+ *               indexes with locality), the next batch of that L_pq is a timed trial of mode 0 and the faster of the two
+ *               exact forms is kept from that L_pq on -- the same bits either way
  *   1           LDS filter only: ids, dists, hops bit-exact; cmps = evaluations performed (>= the reference's)
  *   0           exact visited words in HBM (the reference's tag array, visited_list_pool.h): everything bit-exact
  * "fast_bf16" = 1 is an OPT-IN mode that is NOT parity with the reference; default 0.  The traversal
