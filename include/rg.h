@@ -107,7 +107,8 @@ rg_status rg_index_info(const rg_index *idx, uint32_t *nd, uint32_t *dim, uint32
  * scores a bf16 copy of the base (made on first use, nd * round_up(dim,128) * 2 bytes of HBM; d = 200 / 512 with the
  * default adjacency layout only, otherwise the knob has no effect), then every beam entry is re-scored with the exact
  * fp32 routine and the k best by exact (distance, id) are returned: out_dists are exact for the returned ids, the ids
- * can differ from the reference's (recall is reported separately by bench.py), cmps = evaluations performed. */
+ * can differ from the reference's (recall is reported separately by bench.py), cmps = evaluations performed.
+ * It combines with "visited": 0 = exact HBM words (no repeated evaluations), 1 / 2 = LDS filter only. */
 rg_status rg_index_set(rg_index *idx, const char *name, int value);
 
 /* ----------------------------------------------------------------- operator

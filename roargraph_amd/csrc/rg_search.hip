@@ -204,7 +204,7 @@ __device__ __forceinline__ void beam_merge(Beam &bm, float cd, uint32_t cid, uin
 //       by exact (distance, id) are returned, so the reported distances are exact for the returned ids.
 template <bool L2, bool ELL, int R, int VIS, int DIMC, bool BF>
 __global__ void __launch_bounds__(64) rg_search_kernel(SearchParams P) {
-    static_assert(!BF || (DIMC != 0 && VIS == 1 && ELL), "fast mode: compile-time dimension, LDS filter, ELL adjacency");
+    static_assert(!BF || (DIMC != 0 && ELL), "fast mode: compile-time dimension, ELL adjacency");
     constexpr int NB = (DIMC + 127) / 128;                                // fast mode: LDS-DMA instructions per bf16 row
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
@@ -795,7 +795,7 @@ template <bool L2, bool ELL, int R, int VIS>
 static rg_status launch_search_v(rg_index *ix, const SearchParams &P, uint32_t grid, size_t lds, hipStream_t s) {
     if constexpr (ELL) {
         const int dc = dimc_of(ix);
-        if constexpr (VIS == 1 && R <= 2) {
+        if constexpr (R <= 2) {
             if (P.base_bf && dc == 200) return launch_search_d<L2, ELL, R, VIS, 200, true>(ix, P, grid, lds, s);
             if (P.base_bf && dc == 512) return launch_search_d<L2, ELL, R, VIS, 512, true>(ix, P, grid, lds, s);
         }
@@ -832,8 +832,8 @@ static rg_status launch_k1(rg_index *ix, int mode, const float *d_q, uint32_t nq
     const int rpp = ix->rows_per_pass > 0 ? ix->rows_per_pass : ((double)ix->n_edges >= 28.0 * ix->nd ? 8 : 4);
     int R = std::max(1, std::min(4, rpp / 4));
     if (R == 3) R = 2;
-    // opt-in fast mode: plain top-k searches with the LDS filter only (never the logging / recount / build launches)
-    const bool bf = ix->fast_bf16 && ix->d_base_bf && dimc_of(ix) && mode != 0 && !with_log && !bp && !qlist;
+    // opt-in fast mode: plain top-k searches only (never the logging / recount / build launches)
+    const bool bf = ix->fast_bf16 && ix->d_base_bf && dimc_of(ix) && !with_log && !bp && !qlist;
     ix->bf_launch = bf;
     if (bf) R = std::min(R, 2);
     const int saved_mode = ix->visited_mode;
@@ -917,8 +917,12 @@ static rg_status search_dev(rg_index *ix, const float *d_q, uint32_t nq, uint32_
     RG_HIP(hipSetDevice(ix->device));
     RG_HIP(hipMemsetAsync(ix->d_status, 0xff, 8, s));
     ix->pending.active = false;
-    const bool fast = ix->fast_bf16 && ix->d_base_bf && dimc_of(ix) && ix->visited_mode != 0;
+    const bool fast = ix->fast_bf16 && ix->d_base_bf && dimc_of(ix);
     bool exact_count = ix->visited_mode == 2 && d_cmps != nullptr && !fast;
+    // fast mode under the default visited mode: the exact words from the beam width on at which the parity batches (if
+    // there were any) found them faster, the LDS filter alone below it; "visited" 0 / 1 force one or the other
+    if (fast && ix->visited_mode == 2 && L >= ix->exact_from_L)
+        return launch_k1(ix, 0, d_q, nq, qstride, k, L, d_ids, d_dists, d_cmps, d_hops, nullptr, false, s);
     // Adaptive default: both exact forms return the same bits.  When a batch showed the LDS filter re-scoring nodes
     // wholesale at this beam width (performed > 1.3 x distinct: long searches on indexes with locality), the next batch
     // of that width runs on the exact HBM words as a timed trial; the faster form is kept from that width on (which one

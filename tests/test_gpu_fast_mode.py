@@ -20,10 +20,12 @@ def rg():
 
 @pytest.mark.parametrize("metric,d,nb", [("ip", 200, 4000), ("l2", 512, 2000), ("l2", 200, 3000), ("ip", 512, 1500)])
 @pytest.mark.parametrize("L,k", [(100, 10), (500, 100), (64, 1)])
-def test_fast_mode_properties(rg, oracle, metric, d, nb, L, k):
+@pytest.mark.parametrize("visited", [2, 0])
+def test_fast_mode_properties(rg, oracle, metric, d, nb, L, k, visited):
     base, q, off, nbrs, ep = small_set(metric, nb, d)
     ix = rg.IndexBipartite.from_arrays(base, off, nbrs, ep, metric=metric)
     exact = ix.SearchRoarGraph(q, k, L)
+    ix.set("visited", visited)           # 2: LDS filter only under the fast mode, 0: exact HBM words
     ix.set("fast_bf16", 1)
     ids, dists, cmps, hops = ix.SearchRoarGraph(q, k, L)
     ids2, dists2, _, _ = ix.SearchRoarGraph(q, k, L)
@@ -39,6 +41,7 @@ def test_fast_mode_properties(rg, oracle, metric, d, nb, L, k):
     assert overlap / (q.shape[0] * k) >= 0.9, "fast mode lost more than 10 % of the exact search's neighbours"
     assert (cmps > 0).all() and (hops > 0).all()
     ix.set("fast_bf16", 0)                                   # switching it off restores parity
+    ix.set("visited", 2)
     back = ix.SearchRoarGraph(q, k, L)
     assert (back[0] == exact[0]).all() and (bits(back[1]) == bits(exact[1])).all() and (back[2] == exact[2]).all()
     ix.close()
