@@ -466,23 +466,46 @@ __global__ void __launch_bounds__(256, WPS) rg_gt_rs_kernel(GtParams P) {
                                 }
                                 __syncthreads();
                             }
-                            // chunk after next -> the buffer this chunk was read from
+                            // chunk after next -> the buffer this chunk was read from.  Its DMA instructions and the first
+                            // fragments of the next chunk are issued BETWEEN the last quad's MFMAs (one per MFMA), so that
+                            // each goes out in the shadow of a running MFMA instead of in front of the first one
+                            const float *dsrc = nullptr;
                             if (!(P.diag & 1u)) {
                                 if constexpr (c + 2 < NKC) {
-                                    stream_chunk(std::integral_constant<int, c + 2>{}, rowp, buf);
+                                    dsrc = rowp + (c + 2) * BK;
                                 } else if (tile + 1 < ntiles) {
                                     if constexpr (c + 2 == NKC) {
                                         rowp_next = row_ptr(tile + 1);
                                         stream_bias(tile + 1, (tile + 1) & 1u);
                                     }
-                                    stream_chunk(std::integral_constant<int, c + 2 - NKC>{}, rowp_next, buf);
+                                    dsrc = rowp_next + (c + 2 - NKC) * BK;
                                 }
                             }
-                            // first fragments of the next chunk (its DMA landed before the barrier above)
-                            if (c + 1 < NKC || tile + 1 < ntiles) {
+                            const uint32_t dlds = lds_w + buf * (uint32_t)(KQC * kNB * 16);
+                            const bool next_frags = c + 1 < NKC || tile + 1 < ntiles;
+                            const int kkt = 2 * (c * KQC + kq);
+                            auto tail_step = [&](auto jj) __attribute__((always_inline)) {
+                                constexpr int j = decltype(jj)::value;
+                                constexpr int n = j & 3;
 #pragma unroll
-                                for (int n = 0; n < 4; ++n) bn[n] = bqn[2 * (32 * n)];
-                            }
+                                for (int m = 0; m < TMW; ++m)
+                                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[kkt + (j >> 2)][m], (j < 4) ? bc[n].x : bc[n].y,
+                                                                                     acc[m][n], 0, 0, 0);
+                                __builtin_amdgcn_sched_barrier(0);
+                                if constexpr (j < KQC / 2) {
+                                    if (dsrc) glds16<32 * j>(dlds + 4096u * j, dsrc);
+                                }
+                                if constexpr (j >= 4) {   // the .x halves of bc are consumed: refill that register set's slot n
+                                    if (next_frags) bn[n] = bqn[2 * (32 * n)];
+                                }
+                                __builtin_amdgcn_sched_barrier(0);
+                            };
+                            __builtin_amdgcn_sched_barrier(0);
+                            tail_step(std::integral_constant<int, 0>{}); tail_step(std::integral_constant<int, 1>{});
+                            tail_step(std::integral_constant<int, 2>{}); tail_step(std::integral_constant<int, 3>{});
+                            tail_step(std::integral_constant<int, 4>{}); tail_step(std::integral_constant<int, 5>{});
+                            tail_step(std::integral_constant<int, 6>{}); tail_step(std::integral_constant<int, 7>{});
+                            continue;
                         }
                         __builtin_amdgcn_sched_barrier(0);
                         const int kk = 2 * (c * KQC + kq);
