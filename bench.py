@@ -474,8 +474,9 @@ def main():
                                        "random graph: same HBM access pattern as a real index, recall not meaningful (the value "
                                        "above is what it is); recall IS meaningful on the genuine RoarGraph index built in this run "
                                        "(smaller base) in recall_check_roargraph_index, and with --real-index"),
-                       "visited": {2: "lds-filter (%s) + id log + exact distinct count (ids/dists/hops/cmps bit-exact vs the "
-                                      "HBM-visited mode, checked in this run)" % ("2^%d" % args.filter_log2 if args.filter_log2 else "auto size"),
+                       "visited": {2: "default: lds-filter (%s) + id log + exact distinct count, adaptive to the exact HBM words where "
+                                      "a timed trial finds them faster (ids/dists/hops/cmps bit-exact vs the HBM-visited mode, "
+                                      "checked in this run)" % ("2^%d" % args.filter_log2 if args.filter_log2 else "auto size"),
                                    1: "lds-filter (%s) only (ids/dists/hops bit-exact; cmps = evaluations performed)" % ("2^%d" % args.filter_log2 if args.filter_log2 else "auto size"),
                                    0: "exact visited words in HBM"}[args.visited],
                        "mean_evals_per_query": mean_cmps, "mean_evals_performed": mean_done, "mean_hops": mean_hops},
