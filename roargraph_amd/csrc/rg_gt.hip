@@ -106,7 +106,28 @@ struct GtParams {
     uint32_t *counter;
     uint32_t BK;
     uint32_t diag;  // ablation switches for profiling only (wrong results): 1 no base streaming, 2 no epilogue, 4 no per-chunk barrier
+    // few query blocks for the chip: the base shard is also cut in nseg row segments, a work item is (query block, segment),
+    // per-segment lists go to seg_ids / seg_vals [nseg][nq][K] and K3 merges them
+    uint32_t nseg, seg_rows;
+    uint32_t *seg_ids;
+    float *seg_vals;
 };
+
+// the parameters of work item `item` = (query block, segment): the segment's rows, bias, id offset and output lists
+__device__ __forceinline__ GtParams gt_segment(const GtParams &P0, uint32_t item, uint32_t &qblk) {
+    GtParams P = P0;
+    qblk = item / P0.nseg;
+    if (P0.nseg > 1) {
+        const uint32_t seg = item % P0.nseg, r0 = seg * P0.seg_rows;
+        P.base = P0.base + (size_t)r0 * P0.bstride;
+        P.nb = min(P0.seg_rows, P0.nb - r0);
+        if (P0.bias) P.bias = P0.bias + r0;
+        P.id_base = P0.id_base + r0;
+        P.out_ids = P0.seg_ids + (size_t)seg * P0.nq * P0.K;
+        P.out_vals = P0.seg_vals + (size_t)seg * P0.nq * P0.K;
+    }
+    return P;
+}
 
 // keep the best K of the query's candidate buffer, publish the new threshold
 template <int ITEMS>
@@ -150,7 +171,7 @@ __device__ __attribute__((noinline)) void gt_compact_call(u64 *buf, uint32_t *cn
 //    v_mfma_f32_32x32x2_f32: lanes 0-31 read elements (0,1) of the quad, lanes 32-63 elements (2,3); the first MFMA
 //    multiplies the k pair (0,2), the second (1,3) (operand lane l holds k-slot l >> 5 of the pair).
 template <int MQ, int ITEMS>
-__global__ void __launch_bounds__(512) rg_gt_kernel(GtParams P) {
+__global__ void __launch_bounds__(512) rg_gt_kernel(GtParams P0) {
     constexpr int C = 64 * ITEMS;
     constexpr int TM = MQ / 64;              // 32-row query tiles per wave (2 for MQ=128, 1 for MQ=64)
     constexpr int NW = 8;                    // waves per workgroup: 2 (query axis) x 4 (base axis), two per SIMD
@@ -159,7 +180,7 @@ __global__ void __launch_bounds__(512) rg_gt_kernel(GtParams P) {
     const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wn = w & 3, wm = w >> 2;
     const int qoff = 32 * TM * wm, boff = 32 * wn;
-    const uint32_t BK = P.BK, dim = P.dim;
+    const uint32_t BK = P0.BK, dim = P0.dim;
     const uint32_t kq_chunk = BK / 4;                               // k-quads per chunk
 
     float4 *Qq = reinterpret_cast<float4 *>(smem);                  // [dim/4][MQ]
@@ -167,19 +188,21 @@ __global__ void __launch_bounds__(512) rg_gt_kernel(GtParams P) {
     float *thr = reinterpret_cast<float *>(Bq + 2 * (size_t)kq_chunk * kNB);   // [MQ]
     uint32_t *cnt = reinterpret_cast<uint32_t *>(thr + MQ);         // [MQ]
     uint32_t *flag = cnt + MQ;                                      // [4]
-    u64 *cand = P.cand + (size_t)blockIdx.x * MQ * C;
+    u64 *cand = P0.cand + (size_t)blockIdx.x * MQ * C;
 
-    const uint32_t ntiles = (P.nb + kNB - 1) / kNB;
     const uint32_t nkc = dim / BK;
     const uint32_t ninstr = kq_chunk * (kNB / 64);                  // LDS-DMA wave instructions per chunk (2 per k-quad)
     const bool hi = lane >= 32;
 
     for (;;) {
-        if (tid == 0) flag[1] = atomicAdd(P.counter, 1u);
+        if (tid == 0) flag[1] = atomicAdd(P0.counter, 1u);
         __syncthreads();
-        const uint32_t blk = flag[1];
+        const uint32_t item = flag[1];
         __syncthreads();
+        uint32_t blk;
+        const GtParams P = gt_segment(P0, item, blk);
         if ((uint64_t)blk * MQ >= P.nq) break;
+        const uint32_t ntiles = (P.nb + kNB - 1) / kNB;
         const uint32_t q0 = blk * MQ;
         // stage the query block: Qq[k/4][q] (16-byte stores, consecutive rows -> consecutive slots)
         for (uint32_t idx = tid; idx < (uint32_t)MQ * (dim / 4); idx += 512) {
@@ -336,7 +359,7 @@ __device__ __forceinline__ void glds_run(uint32_t lds_addr, const float *src) {
 // d=200) and the base stream is shared by twice as many queries as in the LDS-resident form.  Everything in k is
 // unrolled at compile time (register arrays need static indices), hence the DIM template parameter.
 template <int DIM, int BK, int TMW, int ITEMS, int WPS>
-__global__ void __launch_bounds__(256, WPS) rg_gt_rs_kernel(GtParams P) {
+__global__ void __launch_bounds__(256, WPS) rg_gt_rs_kernel(GtParams P0) {
     constexpr int C = 64 * ITEMS;
     constexpr int MQB = 128 * TMW;            // queries per workgroup
     constexpr int NKC = DIM / BK;             // k-chunks per base tile
@@ -353,15 +376,17 @@ __global__ void __launch_bounds__(256, WPS) rg_gt_rs_kernel(GtParams P) {
     uint32_t *cnt = reinterpret_cast<uint32_t *>(thr + MQB);                     // [MQB]
     uint32_t *flag = cnt + MQB;                                                  // [4]
     float *bias_l = reinterpret_cast<float *>(flag + 4);                         // [2][128] -|b|^2/2 of the tile's rows (L2)
-    u64 *cand = P.cand + (size_t)blockIdx.x * MQB * C;
-    const uint32_t ntiles = (P.nb + kNB - 1) / kNB;
+    u64 *cand = P0.cand + (size_t)blockIdx.x * MQB * C;
 
     for (;;) {
-        if (tid == 0) flag[1] = atomicAdd(P.counter, 1u);
+        if (tid == 0) flag[1] = atomicAdd(P0.counter, 1u);
         __syncthreads();
-        const uint32_t blk = flag[1];
+        const uint32_t item = flag[1];
         __syncthreads();
+        uint32_t blk;
+        const GtParams P = gt_segment(P0, item, blk);
         if ((uint64_t)blk * MQB >= P.nq) break;
+        const uint32_t ntiles = (P.nb + kNB - 1) / kNB;
         const uint32_t q0 = blk * MQB;
         // A operands of this wave's queries, all k, into registers
         float areg[DIM / 2][TMW];
@@ -731,11 +756,23 @@ rg_status rg_gt_shard_dev(const float *d_base, uint32_t nb, uint32_t bstride, co
     if (rs_tmw) mq = rs_mqb;
     const uint32_t nblocks = (nq + mq - 1) / mq;
     const uint32_t per_cu = rs_tmw ? rs_per_cu : 1;   // matches the kernel's launch bounds
-    const uint32_t grid = std::min<uint32_t>(nblocks, (uint32_t)prop.multiProcessorCount * per_cu);
+    const uint32_t slots = (uint32_t)prop.multiProcessorCount * per_cu;
+    // Few query blocks (a 10k-query test set is 79 blocks for 512 slots): cut the shard's rows in segments as well, one
+    // work item per (block, segment), and merge the per-segment lists with K3.  Segments are whole tiles, keep at least
+    // 4096 rows (and K) each, and nseg * K stays within K3's 1024 keys.
+    uint32_t nseg = 1, seg_rows = nb;
+    if (!getenv("RG_GT_NOSEG") && nblocks * 2 <= slots) {
+        nseg = std::min<uint32_t>({slots / nblocks, 1024u / K, 16u, std::max<uint32_t>(1u, nb / std::max<uint32_t>(4096u, K))});
+        nseg = std::max<uint32_t>(nseg, 1u);
+        seg_rows = ((nb + nseg - 1) / nseg + kNB - 1) / kNB * kNB;
+        nseg = (nb + seg_rows - 1) / seg_rows;
+        if (nb - (nseg - 1) * seg_rows < K) nseg = 1, seg_rows = nb;   // the last segment must still hold K rows
+    }
+    const uint32_t grid = std::min<uint32_t>(nblocks * nseg, slots);
     // stream-ordered scratch, released on every exit path
     struct Scratch {
         hipStream_t s;
-        void *p[3] = {nullptr, nullptr, nullptr};
+        void *p[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
         ~Scratch() { for (void *q : p) if (q) (void)hipFreeAsync(q, s); }
     } scratch{s};
     float *bias = nullptr;
@@ -757,6 +794,13 @@ rg_status rg_gt_shard_dev(const float *d_base, uint32_t nb, uint32_t bstride, co
     P.bias = bias; P.K = K; P.id_base = id_base; P.out_ids = d_ids; P.out_vals = vals; P.cand = cand;
     P.counter = counter; P.BK = bk;
     P.diag = getenv("RG_GT_DIAG") ? (uint32_t)atoi(getenv("RG_GT_DIAG")) : 0u;
+    P.nseg = nseg; P.seg_rows = seg_rows; P.seg_ids = nullptr; P.seg_vals = nullptr;
+    if (nseg > 1) {
+        RG_HIP(hipMallocAsync(&scratch.p[3], (size_t)nseg * nq * K * 4, s));
+        RG_HIP(hipMallocAsync(&scratch.p[4], (size_t)nseg * nq * K * 4, s));
+        P.seg_ids = static_cast<uint32_t *>(scratch.p[3]);
+        P.seg_vals = static_cast<float *>(scratch.p[4]);
+    }
     rg_status st;
     if (rs_tmw) {
         const size_t lds_rs = ((size_t)2 * rs_bk * kNB + 2 * rs_mqb + 8 + 256) * 4;
@@ -778,6 +822,14 @@ rg_status rg_gt_shard_dev(const float *d_base, uint32_t nb, uint32_t bstride, co
         st = hipGetLastError() == hipSuccess ? RG_OK : set_error(RG_ERR_DEVICE, "K2-RS launch failed");
     } else {
         st = mq == 128 ? launch_gt_items<128>(items, P, grid, lds, s) : launch_gt_items<64>(items, P, grid, lds, s);
+    }
+    if (st == RG_OK && nseg > 1) {   // per-segment lists (ranking value, larger first) -> the shard's list
+        const uint32_t gm = std::min<uint32_t>(nq, 256u * 16u);
+        switch (items_for(nseg * K)) {
+            case 4: hipLaunchKernelGGL((rg_gt_merge_kernel<4>), dim3(gm), dim3(64), 0, s, P.seg_ids, P.seg_vals, nseg, nq, K, 1, d_ids, vals); break;
+            case 8: hipLaunchKernelGGL((rg_gt_merge_kernel<8>), dim3(gm), dim3(64), 0, s, P.seg_ids, P.seg_vals, nseg, nq, K, 1, d_ids, vals); break;
+            default: hipLaunchKernelGGL((rg_gt_merge_kernel<16>), dim3(gm), dim3(64), 0, s, P.seg_ids, P.seg_vals, nseg, nq, K, 1, d_ids, vals); break;
+        }
     }
     if (st == RG_OK && metric == RG_METRIC_L2) {
         const uint32_t g2 = std::min<uint32_t>(nq, (uint32_t)prop.multiProcessorCount * 16u);
