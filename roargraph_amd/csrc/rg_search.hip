@@ -829,7 +829,11 @@ static rg_status launch_k1(rg_index *ix, int mode, const float *d_q, uint32_t nq
                            uint32_t qbase = 0) {
     // rows in flight per query: two passes of four pay on graphs with many fresh neighbours per hop (measured: +4 % at
     // out-degree 40, -4 % at 16, where the extra staging only costs resident queries)
-    const int rpp = ix->rows_per_pass > 0 ? ix->rows_per_pass : ((double)ix->n_edges >= 28.0 * ix->nd ? 8 : 4);
+    // A batch that leaves most wave slots empty is latency bound per query: LDS is plentiful then, so each query keeps
+    // 16 rows in flight (two hop-latency round trips instead of five to ten).
+    const int rpp = ix->rows_per_pass > 0 ? ix->rows_per_pass
+                    : (nq <= (uint32_t)ix->num_cu * 6u && !bp) ? 16
+                    : ((double)ix->n_edges >= 28.0 * ix->nd ? 8 : 4);
     int R = std::max(1, std::min(4, rpp / 4));
     if (R == 3) R = 2;
     // opt-in fast mode: plain top-k searches only (never the logging / recount / build launches)
