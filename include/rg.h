@@ -95,7 +95,8 @@ void rg_index_close(rg_index *idx);
 rg_status rg_index_info(const rg_index *idx, uint32_t *nd, uint32_t *dim, uint32_t *stride, uint32_t *ep,
                         float *avg_degree, uint32_t *max_degree, int *device);
 /* tuning knobs: "waves_per_cu", "rows_per_pass", "filter_log2", "log_cap", "log_budget_kb", "count_table_log2",
- * "count_full_ids", "query_in_lds" never change results.
+ * "count_full_ids", "query_in_lds", "exact_filter" never change results (0 = automatic where a knob has an automatic
+ * choice: "rows_per_pass", "filter_log2", "waves_per_cu").
  * "visited" selects how the visited set is kept:
  *   2 (default) LDS exact-match filter + per-query id log + exact distinct count: ids, dists, hops AND cmps bit-exact.
  *               Adaptive: once a batch shows the filter re-scoring > 30 % extra nodes at some L_pq (long searches on
