@@ -98,6 +98,17 @@ __device__ __forceinline__ void gather_wait(uint32_t n) {
 #undef RG_W
     __builtin_amdgcn_wave_barrier();
 }
+// Same wait for `mult` passes of LPP loads each when LPP is a compile-time constant (mult <= 3: ring depth <= 4): four
+// immediates instead of the 48-way switch (a dozen scalar branch instructions per wait in the generic form).
+template <int LPP>
+__device__ __forceinline__ void gather_wait_passes(uint32_t mult) {
+    static_assert(3 * LPP <= 63, "vmcnt immediate range");
+    if (mult == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (mult == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(LPP) : "memory");
+    else if (mult == 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * LPP) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" :: "n"(3 * LPP) : "memory");
+    __builtin_amdgcn_wave_barrier();
+}
 // LDS-only ordering point inside a wave (does not drain the vector-memory queue, unlike wave_sync)
 __device__ __forceinline__ void lds_sync() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");

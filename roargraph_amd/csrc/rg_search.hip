@@ -392,7 +392,12 @@ __global__ void __launch_bounds__(64) rg_search_kernel(SearchParams P) {
                     }
                     for (uint32_t p = 0; p < npass; ++p) {
                         const uint32_t last = min(npass, p + (uint32_t)R) - 1u;
-                        gather_wait((last - p) * lpp);
+                        if constexpr (DIMC != 0) {
+                            constexpr int LPPC = BF ? NB : (DIMC + 63) / 64;
+                            gather_wait_passes<LPPC>(last - p);
+                        } else {
+                            gather_wait((last - p) * lpp);
+                        }
                         float *buf = stage + (size_t)(p & (R - 1)) * P.stage_floats;
                         const uint32_t c = 4 * p + g;
                         const float d = score(buf);
