@@ -328,6 +328,8 @@ struct Builder {
                 std::lock_guard<std::mutex> guard(locks[cur.id]);
                 nbrs = supply[cur.id];
             }
+            for (uint32_t nb : nbrs)
+                if (seen[nb] != tag && nb != node) prefetch_row(nb);
             for (uint32_t nb : nbrs) {
                 if (seen[nb] == tag || nb == node) continue;
                 seen[nb] = tag;
