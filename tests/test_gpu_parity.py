@@ -150,3 +150,25 @@ def test_default_mode_stays_exact_when_it_switches_to_the_exact_words(rg, oracle
         assert (got[0] == want[0]).all() and (bits(got[1]) == bits(want[1])).all()
         assert (got[2] == want[2]).all() and (got[3] == want[3]).all()
     ix.close()
+
+
+@pytest.mark.parametrize("layout", ["ell", "csr"])
+def test_wide_and_empty_adjacency_rows(rg, oracle, layout, monkeypatch):
+    """Adjacency rows wider than one 64-word read (degrees up to 150) and rows of degree 0, both layouts."""
+    monkeypatch.setenv("RG_FORCE_CSR", "1" if layout == "csr" else "0")
+    rng = np.random.default_rng(17)
+    nb, d = 3000, 200
+    base = rng.standard_normal((nb, d)).astype(np.float32)
+    q = (rng.standard_normal((48, d)) * 0.5 + 0.3).astype(np.float32)
+    deg = rng.integers(0, 151, nb)
+    deg[rng.integers(0, nb, 200)] = 0
+    deg[0] = 150                                        # the entry point is well connected
+    off = np.zeros(nb + 1, np.uint64); off[1:] = np.cumsum(deg)
+    nbrs = np.concatenate([rng.choice(nb, int(k), replace=False) for k in deg]).astype(np.uint32)
+    ix = rg.IndexBipartite.from_arrays(base, off, nbrs, 0, metric="ip")
+    for L in (50, 500):
+        got = ix.SearchRoarGraph(q, 10, L)
+        want = oracle.search(base, "ip", off, nbrs, 0, q, 10, L, nthreads=4)
+        assert (got[0] == want[0]).all() and (bits(got[1]) == bits(want[1])).all()
+        assert (got[2] == want[2]).all() and (got[3] == want[3]).all()
+    ix.close()
