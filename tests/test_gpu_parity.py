@@ -172,3 +172,32 @@ def test_wide_and_empty_adjacency_rows(rg, oracle, layout, monkeypatch):
         assert (got[0] == want[0]).all() and (bits(got[1]) == bits(want[1])).all()
         assert (got[2] == want[2]).all() and (got[3] == want[3]).all()
     ix.close()
+
+
+@pytest.mark.parametrize("metric", ["ip", "l2"])
+def test_ties_duplicate_edges_and_self_loops(rg, oracle, metric):
+    """Exact distance ties (every base row appears four times), repeated edges, self-loops and a single-query batch: the
+    (distance, id) order and the visited rules must still match the oracle bit for bit, with k == L_pq too."""
+    rng = np.random.default_rng(23)
+    uniq, d = 700, 200
+    base = np.tile(rng.standard_normal((uniq, d)).astype(np.float32), (4, 1))
+    nb = base.shape[0]
+    q = (rng.standard_normal((33, d)) * 0.5 + 0.3).astype(np.float32)
+    lists = []
+    for i in range(nb):
+        a = rng.integers(0, nb, 20)
+        a[:3] = a[3:6]                                   # repeated edges
+        a[6] = i                                         # self-loop
+        lists.append(a.astype(np.uint32))
+    off = np.zeros(nb + 1, np.uint64); off[1:] = np.cumsum([len(x) for x in lists])
+    nbrs = np.concatenate(lists)
+    ix = rg.IndexBipartite.from_arrays(base, off, nbrs, 5, metric=metric)
+    for vis in (2, 1, 0):
+        ix.set("visited", vis)
+        for qq, k, L in ((q, 10, 100), (q[:1], 1, 1), (q, 64, 64), (q[:2], 100, 300)):
+            got = ix.SearchRoarGraph(qq, k, L)
+            want = oracle.search(base, metric, off, nbrs, 5, qq, k, L, nthreads=4)
+            assert (got[0] == want[0]).all() and (bits(got[1]) == bits(want[1])).all() and (got[3] == want[3]).all()
+            if vis != 1:
+                assert (got[2] == want[2]).all()
+    ix.close()
