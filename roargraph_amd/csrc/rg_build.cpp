@@ -392,11 +392,15 @@ struct Builder {
         uint32_t *d_nexp = nullptr;
         rg_index *ix = nullptr;
         std::vector<uint32_t> h_ell((size_t)nd * S);
-        std::vector<uint2_pod> h_exp((size_t)B * cap);
-        std::vector<uint32_t> h_nexp(B);
+        uint2_pod *h_exp = nullptr;     // pinned: the downloads of one half overlap the search of the other
+        uint32_t *h_nexp = nullptr;
+        hipStream_t st = nullptr;
+        hipEvent_t evA = nullptr, evB = nullptr;
         bool ok = hipMalloc(&d_base, (size_t)nd * stride * 4) == hipSuccess &&
                   hipMemcpy(d_base, base, (size_t)nd * stride * 4, hipMemcpyHostToDevice) == hipSuccess &&
-                  hipMalloc(&d_exp, (size_t)B * cap * 8) == hipSuccess && hipMalloc(&d_nexp, (size_t)B * 4) == hipSuccess;
+                  hipMalloc(&d_exp, (size_t)B * cap * 8) == hipSuccess && hipMalloc(&d_nexp, (size_t)B * 4) == hipSuccess &&
+                  hipHostMalloc(&h_exp, (size_t)B * cap * 8) == hipSuccess && hipHostMalloc(&h_nexp, (size_t)B * 4) == hipSuccess &&
+                  hipStreamCreate(&st) == hipSuccess && hipEventCreate(&evA) == hipSuccess && hipEventCreate(&evB) == hipSuccess;
         if (ok) ok = build_index_create(d_base, nd, dim, (uint32_t)stride, ep, l2 ? RG_METRIC_L2 : RG_METRIC_IP, gpu_device, S, &ix) == RG_OK;
         std::atomic<uint32_t> mismatches(0);
         std::vector<std::vector<uint32_t>> stamp(std::max(1, threads));
@@ -426,21 +430,40 @@ struct Builder {
                 std::memcpy(row + 1, l.data(), l.size() * 4);
             });
             t_snap += since(t_b); t_b = std::chrono::steady_clock::now();
+            // the batch goes to the GPU in two halves over the same snapshot: the host links the first half while the
+            // GPU searches the second (same semantics as one launch: every node of the batch searched the snapshot)
+            const uint32_t nA = n >= 4096 ? n / 2 : n, nB = n - nA;
             ok = build_index_set_ell(ix, h_ell.data(), nullptr) == RG_OK &&
-                 build_search_dev(ix, b0, n, L, d_exp, cap, d_nexp, nullptr) == RG_OK &&
-                 hipMemcpy(h_nexp.data(), d_nexp, (size_t)n * 4, hipMemcpyDeviceToHost) == hipSuccess &&
-                 hipMemcpy(h_exp.data(), d_exp, (size_t)n * cap * 8, hipMemcpyDeviceToHost) == hipSuccess;
+                 build_search_dev(ix, b0, nA, L, d_exp, cap, d_nexp, st) == RG_OK &&
+                 hipMemcpyAsync(h_nexp, d_nexp, (size_t)nA * 4, hipMemcpyDeviceToHost, st) == hipSuccess &&
+                 hipMemcpyAsync(h_exp, d_exp, (size_t)nA * cap * 8, hipMemcpyDeviceToHost, st) == hipSuccess &&
+                 hipEventRecord(evA, st) == hipSuccess;
+            if (ok && nB)
+                ok = build_search_dev(ix, b0 + nA, nB, L, d_exp + (size_t)nA * cap, cap, d_nexp + nA, st) == RG_OK &&
+                     hipMemcpyAsync(h_nexp + nA, d_nexp + nA, (size_t)nB * 4, hipMemcpyDeviceToHost, st) == hipSuccess &&
+                     hipMemcpyAsync(h_exp + (size_t)nA * cap, d_exp + (size_t)nA * cap, (size_t)nB * cap * 8, hipMemcpyDeviceToHost, st) == hipSuccess &&
+                     hipEventRecord(evB, st) == hipSuccess;
+            if (ok) ok = hipEventSynchronize(evA) == hipSuccess;
             if (!ok) break;
             t_gpu += since(t_b); t_b = std::chrono::steady_clock::now();
             ++nbatches;
-            parallel_for(n, 64, [&](uint32_t i, int t) {
+            for (int half = 0; half < (nB ? 2 : 1) && ok; ++half) {
+            const uint32_t h0 = half ? nA : 0u, hn = half ? nB : nA;
+            if (half) {
+                t_link += since(t_b); t_b = std::chrono::steady_clock::now();
+                ok = hipEventSynchronize(evB) == hipSuccess;
+                t_gpu += since(t_b); t_b = std::chrono::steady_clock::now();
+                if (!ok) break;
+            }
+            parallel_for(hn, 64, [&](uint32_t ii, int t) {
+                const uint32_t i = h0 + ii;
                 const uint32_t node = b0 + i;
                 std::vector<Nb> expanded;
                 if (h_nexp[i] > cap) {
                     search_snapshot(node, h_ell.data(), S, stamp[t], serial[t], expanded);   // expansion list did not fit
                 } else {
                     expanded.resize(h_nexp[i]);
-                    const uint2_pod *e = h_exp.data() + (size_t)i * cap;
+                    const uint2_pod *e = h_exp + (size_t)i * cap;
                     for (uint32_t j = 0; j < h_nexp[i]; ++j) {
                         float d;
                         std::memcpy(&d, &e[j].x, 4);
@@ -457,6 +480,7 @@ struct Builder {
                 }
                 link_from_search(node, expanded);
             });
+            }
         }
         t_link += since(t_b);
         if (timing) fprintf(stderr, "[rg_build]   phase 3: %u batches, snapshot %.2f s, upload + GPU search + download %.2f s, host linking %.2f s\n",
@@ -465,6 +489,12 @@ struct Builder {
         if (d_base) (void)hipFree(d_base);
         if (d_exp) (void)hipFree(d_exp);
         if (d_nexp) (void)hipFree(d_nexp);
+        if (st) (void)hipStreamSynchronize(st);
+        if (h_exp) (void)hipHostFree(h_exp);
+        if (h_nexp) (void)hipHostFree(h_nexp);
+        if (evA) (void)hipEventDestroy(evA);
+        if (evB) (void)hipEventDestroy(evB);
+        if (st) (void)hipStreamDestroy(st);
         if (!ok) return fail(std::string("GPU phase 3 failed: ") + rg_last_error());
         if (mismatches.load()) return fail("GPU phase 3: " + std::to_string(mismatches.load()) + " expansion lists differ from the host search");
         return true;
