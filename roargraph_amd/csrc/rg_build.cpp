@@ -534,7 +534,7 @@ struct Builder {
         }
         lap("entry point");
         // ---- phase 1 (:1059-1097): every training query links its nearest base point to its other neighbours
-        parallel_for(nq, 100, [&](uint32_t sq, int) {
+        auto phase1_query = [&](uint32_t sq) {
             const uint32_t n = std::min(kdim, Nq);
             if (n == 0) return;
             const uint32_t *nn = knn + (size_t)sq * kdim;
@@ -550,7 +550,30 @@ struct Builder {
                 proj[tgt] = pruned;
             }
             add_reverse(proj, tgt, M, false);
-        });
+        };
+        if (threads <= 1) {
+            for (uint32_t sq = 0; sq < nq; ++sq) phase1_query(sq);   // the reference's order
+        } else {
+            // Training queries that share their nearest base point all rewrite that point's list (hubs collect thousands of
+            // them): one thread takes all queries of a base point, in query order, biggest groups first -- no two threads
+            // fight over the same list, and per base point the sequence is the one-thread sequence.
+            std::vector<uint32_t> order(nq);
+            for (uint32_t i = 0; i < nq; ++i) order[i] = i;
+            std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return knn[(size_t)a * kdim] < knn[(size_t)b * kdim]; });
+            std::vector<std::pair<uint32_t, uint32_t>> groups;   // [begin, end) in `order`
+            for (uint32_t i = 0; i < nq;) {
+                uint32_t j = i + 1;
+                while (j < nq && knn[(size_t)order[j] * kdim] == knn[(size_t)order[i] * kdim]) ++j;
+                groups.emplace_back(i, j);
+                i = j;
+            }
+            std::stable_sort(groups.begin(), groups.end(), [](const std::pair<uint32_t, uint32_t> &a, const std::pair<uint32_t, uint32_t> &b) {
+                return a.second - a.first > b.second - b.first;
+            });
+            parallel_for((uint32_t)groups.size(), 4, [&](uint32_t gi, int) {
+                for (uint32_t i = groups[gi].first; i < groups[gi].second; ++i) phase1_query(order[i]);
+            });
+        }
         lap("phase 1");
         // ---- phase 2 (:1100-1136)
         parallel_for(nd, 100, [&](uint32_t node, int) { add_reverse(proj, node, M, false); });
