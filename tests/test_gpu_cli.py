@@ -129,9 +129,13 @@ def test_bench_multi_rank_control_flow_on_one_gpu():
     the one visible GPU and the gloo backend: rank/LOCAL_RANK handling, barriers, max-over-ranks timing, the sharded
     ground-truth leg with its all-to-all and K3 merge, one JSON line from rank 0."""
     import json
+    import socket
     import sys
+    with socket.socket() as sk:            # a port nobody is using right now
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", "29533", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
            "--backend", "gloo", "--nb", "200000", "--nq", "512", "--gt-nq", "4096", "--recall-nb", "0", "--cpu-seconds", "0"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
