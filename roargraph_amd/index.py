@@ -222,6 +222,7 @@ def graph_save(path, offsets, nbrs, ep):
 
 def recall(res, gt, k):
     """ComputeRecall (tests/test_search_roargraph.cpp:23-36)"""
-    res = np.ascontiguousarray(res, np.uint32)
+    res = np.ascontiguousarray(np.asarray(res)[:, :k], np.uint32)   # rg_recall reads k ids per row: recall@k of the first k
     gt = np.ascontiguousarray(gt, np.uint32)
+    assert res.shape[1] == k and gt.shape[1] >= k
     return float(lib().rg_recall(C.c_uint32(res.shape[0]), C.c_uint32(k), C.c_uint32(gt.shape[1]), _vp(res), _vp(gt)))

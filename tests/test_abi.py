@@ -120,6 +120,9 @@ def test_recall_matches_oracle(rg, oracle):
     res = rng.integers(0, 50, (30, 10)).astype(np.uint32)
     gt = rng.integers(0, 50, (30, 25)).astype(np.uint32)
     assert rg.recall(res, gt, 10) == oracle.recall(res, gt, 10)
+    # a result matrix wider than k (top-100 searches scored at recall@10): the first k ids of every row count
+    wide = np.concatenate([res, rng.integers(0, 50, (30, 90)).astype(np.uint32)], axis=1)
+    assert rg.recall(wide, gt, 10) == oracle.recall(res, gt, 10)
 
 
 def test_normalize_matches_oracle(rg, oracle):
