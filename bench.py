@@ -127,7 +127,7 @@ def cpu_baseline(args, base_t, off_t, nbrs_t, ep, q_t, ids_gpu, budget_s):
     return out
 
 
-def recall_check(args, dev):
+def recall_check(args, dev, structured=False):
     """QPS @ recall@10 on a GENUINE RoarGraph index (rank 0, N=1), built here with the reference's own pipeline and
     parameters on synthetic cross-modal data: K2 ground truth of the training queries -> rg_build_roargraph on the host
     cores (M_sq=100, M_pjbp=35, L_pjpq=500, README.md:92-97) -> K1 search, K2 truth for the test queries.
@@ -137,17 +137,25 @@ def recall_check(args, dev):
     from roargraph_amd import build, groundtruth, index
     from roargraph_amd.index import IndexBipartite
     nb, ntrain, nq, dim, metric = args.recall_nb, args.recall_nb // 2, 5000, args.dim, args.metric
-    g = torch.Generator(device=dev); g.manual_seed(1234)
-    base = torch.empty((nb, dim), device=dev).normal_(generator=g)
-    train = torch.empty((ntrain, dim), device=dev).normal_(generator=g) * 0.5 + 0.3
-    q = torch.empty((nq, dim), device=dev).normal_(generator=g) * 0.5 + 0.3
+    if structured:
+        # the second check: embeddings with a low intrinsic dimension (where a graph index reaches high recall), five times
+        # the rows, phase 3 of the build on the GPU
+        from roargraph_amd import synth
+        nb, ntrain = 5 * args.recall_nb, args.recall_nb
+        base, train, q, desc = synth.make_device_set(dev, 1234, nb, ntrain, nq, dim, data="lowrank", rank=args.rank)
+    else:
+        g = torch.Generator(device=dev); g.manual_seed(1234)
+        base = torch.empty((nb, dim), device=dev).normal_(generator=g)
+        train = torch.empty((ntrain, dim), device=dev).normal_(generator=g) * 0.5 + 0.3
+        q = torch.empty((nq, dim), device=dev).normal_(generator=g) * 0.5 + 0.3
+        desc = "base N(0,1) %d x %d, %d train / %d test queries N(0.3,0.5^2)" % (nb, dim, ntrain, nq)
     st = torch.cuda.current_stream().cuda_stream
     ti = torch.zeros((ntrain, 100), dtype=torch.int32, device=dev); tv = torch.zeros((ntrain, 100), device=dev)
     groundtruth.gt_shard_dev(base, train, metric, 100, 0, ti, tv, stream=st); torch.cuda.synchronize()
     threads = min(128, os.cpu_count() or 1)
     t0 = time.perf_counter()
     off, nbrs, ep = build.build_roargraph(base.cpu().numpy(), ti.cpu().numpy().view(np.uint32), metric, 100, 35, 500,
-                                          num_threads=threads)
+                                          num_threads=threads, device=(dev.index or 0) if structured else None)
     t_build = time.perf_counter() - t0
     deg = np.diff(off.astype(np.int64))
     gi = torch.zeros((nq, 100), dtype=torch.int32, device=dev); gv = torch.zeros((nq, 100), device=dev)
@@ -166,9 +174,10 @@ def recall_check(args, dev):
         rows.append({"L_pq": L, "qps": nq / (ms / 1e3), "recall_at_10": index.recall(ids.cpu().numpy().view(np.uint32), gt, 10),
                      "mean_evals": float(cm.float().mean()), "mean_hops": float(hp.float().mean())})
     ix.close()
-    return {"dataset": "base N(0,1) %d x %d, %d train / %d test queries N(0.3,0.5^2), %s" % (nb, dim, ntrain, nq, metric),
-            "index": "RoarGraph built by rg_build_roargraph (M_sq=100, M_pjbp=35, L_pjpq=500) on %d host threads in %.1f s; "
-                     "degree avg %.1f max %d" % (threads, t_build, deg.mean(), deg.max()),
+    return {"dataset": "%s, %s" % (desc, metric),
+            "index": "RoarGraph built by %s (M_sq=100, M_pjbp=35, L_pjpq=500) on %d host threads in %.1f s; "
+                     "degree avg %.1f max %d" % ("rg_build_roargraph_gpu" if structured else "rg_build_roargraph", threads, t_build,
+                                                 deg.mean(), deg.max()),
             "queries": nq, "curve": rows}
 
 
@@ -444,12 +453,16 @@ def main():
                 gt["cpu_baseline"] = {"value": None, "unit": "distances/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
         del gi, gv, gq
 
-    rcheck = None
+    rcheck = rcheck2 = None
     if rank == 0 and world == 1 and args.recall_nb > 0:
         try:
             rcheck = recall_check(args, dev)
         except Exception as e:
             rcheck = {"error": repr(e)}
+        try:
+            rcheck2 = recall_check(args, dev, structured=True)
+        except Exception as e:
+            rcheck2 = {"error": repr(e)}
 
     cpu = None
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
@@ -473,7 +486,7 @@ def main():
                        "recall_note": ("recall of the timed search on the genuine index" if args.real_index else
                                        "random graph: same HBM access pattern as a real index, recall not meaningful (the value "
                                        "above is what it is); recall IS meaningful on the genuine RoarGraph index built in this run "
-                                       "(smaller base) in recall_check_roargraph_index, and with --real-index"),
+                                       "(smaller bases) in recall_check_roargraph_index / recall_check_structured_data, and with --real-index"),
                        "visited": {2: "default: lds-filter (%s) + id log + exact distinct count, adaptive to the exact HBM words where "
                                       "a timed trial finds them faster (ids/dists/hops/cmps bit-exact vs the HBM-visited mode, "
                                       "checked in this run)" % ("2^%d" % args.filter_log2 if args.filter_log2 else "auto size"),
@@ -490,6 +503,7 @@ def main():
             "fast_mode_bf16": fast,
             "gt_build": gt,
             "recall_check_roargraph_index": rcheck,
+            "recall_check_structured_data": rcheck2,
         }
         if sweep:
             line["L_pq_sweep"] = sweep
