@@ -7,7 +7,9 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "librg_hip.so")
+# RG_HIP_LIB selects another BUILD of the same library (the instrumented `make prof` build used by scripts/exp/); it is
+# still the HIP path -- there is no CPU fallback behind this switch
+LIB_PATH = os.environ.get("RG_HIP_LIB") or os.path.join(HERE, "librg_hip.so")
 
 RG_OK = 0
 RG_ERR_IO, RG_ERR_FORMAT, RG_ERR_ARG, RG_ERR_DEVICE, RG_ERR_NOT_ENOUGH, RG_ERR_OOM = -1, -2, -3, -4, -5, -6

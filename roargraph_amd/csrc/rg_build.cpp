@@ -169,7 +169,7 @@ struct Builder {
     // miss, so the rows a rule is about to touch are requested ahead of the arithmetic
     void prefetch_row(uint32_t id) const {
         const char *r = reinterpret_cast<const char *>(base + (size_t)id * stride);
-        for (size_t o = 0; o < (size_t)dim * 4; o += 64) _mm_prefetch(r + o, _MM_HINT_T0);
+        for (size_t o = 0; o < (size_t)dim * 4; o += 64) __builtin_prefetch(r + o, 0, 3);
     }
 
     bool occluded(const Nb &p, const std::vector<uint32_t> &result) const {

@@ -622,11 +622,15 @@ __global__ void rg_gt_bias_kernel(const float *base, uint32_t nb, uint32_t bstri
     if (sub == 0) bias[gid] = -0.5f * s;
 }
 
-// L2 finalisation: exact squared distance of each selected pair, then re-sort the row by (dist, id).  One wave per query.
+// L2 finalisation: exact squared distance of each of the Kin >= K pairs the approximate ranking kept, re-sort the row by
+// (dist, id), write the first K.  Kin > K is the safety margin at the K boundary: the ranking value q.b - |b|^2/2 carries
+// fp32 rounding of its own, so a true top-K member may sit a few places below rank K in it (unit-norm embeddings at 10M
+// rows have rank-K / rank-K+1 gaps near that rounding).  One wave per query.
 template <int ITEMS>
 __global__ void __launch_bounds__(64) rg_gt_rescore_kernel(const float *base, uint32_t bstride, const float *queries,
-                                                           uint32_t qstride, uint32_t dim, uint32_t nq, uint32_t K,
-                                                           uint32_t id_base, uint32_t *ids, float *vals) {
+                                                           uint32_t qstride, uint32_t dim, uint32_t nq, uint32_t Kin,
+                                                           uint32_t K, uint32_t id_base, const uint32_t *ids_in,
+                                                           uint32_t *ids, float *vals) {
     const int lane = threadIdx.x;
     for (uint32_t q = blockIdx.x; q < nq; q += gridDim.x) {
         const float *qv = queries + (size_t)q * qstride;
@@ -635,8 +639,8 @@ __global__ void __launch_bounds__(64) rg_gt_rescore_kernel(const float *base, ui
         for (int it = 0; it < ITEMS; ++it) {
             const uint32_t e = it * 64 + lane;
             key[it] = ~0ull;
-            if (e < K) {
-                const uint32_t id = ids[(size_t)q * K + e];
+            if (e < Kin) {
+                const uint32_t id = ids_in[(size_t)q * Kin + e];
                 const float *row = base + (size_t)(id - id_base) * bstride;
                 float s = 0.f;
                 for (uint32_t j = 0; j < dim; ++j) { const float t = qv[j] - row[j]; s = __builtin_fmaf(t, t, s); }
@@ -725,6 +729,15 @@ rg_status rg_gt_shard_dev(const float *d_base, uint32_t nb, uint32_t bstride, co
     if (K == 0 || K > nb) return set_error(RG_ERR_ARG, "K must be in [1, number of base rows in the shard]");
     if (K + kNB > 1024) return set_error(RG_ERR_ARG, "K larger than 896 is not supported");
     if (nq == 0) return RG_OK;
+    // L2 ranks by the fp32 value q.b - |b|^2/2 and re-scores the survivors exactly: keep a margin of up to 32 extra
+    // survivors (as many as fit the same sort width and the shard) so that rounding of the ranking value at the K
+    // boundary cannot drop a true top-K member before the exact re-score (rg_gt_rescore_kernel)
+    const uint32_t K_out = K;
+    if (metric == RG_METRIC_L2 && !getenv("RG_GT_NO_MARGIN")) {
+        uint32_t kin = std::min<uint32_t>({K + 32u, nb, 1024u - kNB});
+        while (kin > K && items_for(kin + kNB) != items_for(K + kNB)) --kin;
+        K = kin;
+    }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return set_error(RG_ERR_DEVICE, "no HIP device visible: the gfx950 path cannot run (there is no CPU fallback)");
@@ -772,13 +785,20 @@ rg_status rg_gt_shard_dev(const float *d_base, uint32_t nb, uint32_t bstride, co
     // stream-ordered scratch, released on every exit path
     struct Scratch {
         hipStream_t s;
-        void *p[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+        void *p[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
         ~Scratch() { for (void *q : p) if (q) (void)hipFreeAsync(q, s); }
     } scratch{s};
     float *bias = nullptr;
     u64 *cand = nullptr;
     uint32_t *counter = nullptr;
     float *vals = d_dists;
+    uint32_t *ids_k2 = d_ids;            // where K2 (and the segment merge) leave their K-lists
+    if (K != K_out) {                    // L2 with a margin: K2 writes K-wide scratch lists, the re-score writes the K_out-wide result
+        RG_HIP(hipMallocAsync(&scratch.p[5], (size_t)nq * K * 4, s));
+        RG_HIP(hipMallocAsync(&scratch.p[6], (size_t)nq * K * 4, s));
+        ids_k2 = static_cast<uint32_t *>(scratch.p[5]);
+        vals = static_cast<float *>(scratch.p[6]);
+    }
     if (metric == RG_METRIC_L2) {
         RG_HIP(hipMallocAsync(&scratch.p[0], (size_t)nb * 4, s));
         bias = static_cast<float *>(scratch.p[0]);
@@ -791,7 +811,7 @@ rg_status rg_gt_shard_dev(const float *d_base, uint32_t nb, uint32_t bstride, co
     RG_HIP(hipMemsetAsync(counter, 0, 4, s));
     GtParams P;
     P.base = d_base; P.nb = nb; P.bstride = bstride; P.queries = d_queries; P.nq = nq; P.qstride = qstride; P.dim = dim;
-    P.bias = bias; P.K = K; P.id_base = id_base; P.out_ids = d_ids; P.out_vals = vals; P.cand = cand;
+    P.bias = bias; P.K = K; P.id_base = id_base; P.out_ids = ids_k2; P.out_vals = vals; P.cand = cand;
     P.counter = counter; P.BK = bk;
     P.diag = getenv("RG_GT_DIAG") ? (uint32_t)atoi(getenv("RG_GT_DIAG")) : 0u;
     P.nseg = nseg; P.seg_rows = seg_rows; P.seg_ids = nullptr; P.seg_vals = nullptr;
@@ -826,18 +846,18 @@ rg_status rg_gt_shard_dev(const float *d_base, uint32_t nb, uint32_t bstride, co
     if (st == RG_OK && nseg > 1) {   // per-segment lists (ranking value, larger first) -> the shard's list
         const uint32_t gm = std::min<uint32_t>(nq, 256u * 16u);
         switch (items_for(nseg * K)) {
-            case 4: hipLaunchKernelGGL((rg_gt_merge_kernel<4>), dim3(gm), dim3(64), 0, s, P.seg_ids, P.seg_vals, nseg, nq, K, 1, d_ids, vals); break;
-            case 8: hipLaunchKernelGGL((rg_gt_merge_kernel<8>), dim3(gm), dim3(64), 0, s, P.seg_ids, P.seg_vals, nseg, nq, K, 1, d_ids, vals); break;
-            default: hipLaunchKernelGGL((rg_gt_merge_kernel<16>), dim3(gm), dim3(64), 0, s, P.seg_ids, P.seg_vals, nseg, nq, K, 1, d_ids, vals); break;
+            case 4: hipLaunchKernelGGL((rg_gt_merge_kernel<4>), dim3(gm), dim3(64), 0, s, P.seg_ids, P.seg_vals, nseg, nq, K, 1, ids_k2, vals); break;
+            case 8: hipLaunchKernelGGL((rg_gt_merge_kernel<8>), dim3(gm), dim3(64), 0, s, P.seg_ids, P.seg_vals, nseg, nq, K, 1, ids_k2, vals); break;
+            default: hipLaunchKernelGGL((rg_gt_merge_kernel<16>), dim3(gm), dim3(64), 0, s, P.seg_ids, P.seg_vals, nseg, nq, K, 1, ids_k2, vals); break;
         }
     }
     if (st == RG_OK && metric == RG_METRIC_L2) {
         const uint32_t g2 = std::min<uint32_t>(nq, (uint32_t)prop.multiProcessorCount * 16u);
         const int it2 = items_for(K);
         switch (it2) {
-            case 4: hipLaunchKernelGGL((rg_gt_rescore_kernel<4>), dim3(g2), dim3(64), 0, s, d_base, bstride, d_queries, qstride, dim, nq, K, id_base, d_ids, d_dists); break;
-            case 8: hipLaunchKernelGGL((rg_gt_rescore_kernel<8>), dim3(g2), dim3(64), 0, s, d_base, bstride, d_queries, qstride, dim, nq, K, id_base, d_ids, d_dists); break;
-            default: hipLaunchKernelGGL((rg_gt_rescore_kernel<16>), dim3(g2), dim3(64), 0, s, d_base, bstride, d_queries, qstride, dim, nq, K, id_base, d_ids, d_dists); break;
+            case 4: hipLaunchKernelGGL((rg_gt_rescore_kernel<4>), dim3(g2), dim3(64), 0, s, d_base, bstride, d_queries, qstride, dim, nq, K, K_out, id_base, ids_k2, d_ids, d_dists); break;
+            case 8: hipLaunchKernelGGL((rg_gt_rescore_kernel<8>), dim3(g2), dim3(64), 0, s, d_base, bstride, d_queries, qstride, dim, nq, K, K_out, id_base, ids_k2, d_ids, d_dists); break;
+            default: hipLaunchKernelGGL((rg_gt_rescore_kernel<16>), dim3(g2), dim3(64), 0, s, d_base, bstride, d_queries, qstride, dim, nq, K, K_out, id_base, ids_k2, d_ids, d_dists); break;
         }
     }
     if (st != RG_OK) return st;
@@ -914,9 +934,11 @@ rg_status rg_groundtruth_mem(const float *base, uint32_t nb, uint32_t bstride, c
     std::vector<Dev> D(nd);
     for (uint32_t r = 0; r < nd; ++r) D[r].dev = devs[r];
     rg_status st = RG_OK;
-    const uint32_t per = (nb + nd - 1) / nd;
+    // balanced shards: floor(nb/nd) rows each, the first nb % nd shards one more (every shard holds >= K rows: the device
+    // list was trimmed to nb / nd >= K above)
+    const uint32_t per = nb / nd, extra = nb % nd;
     for (uint32_t r = 0; r < nd && st == RG_OK; ++r) {
-        const uint32_t lo = std::min(nb, r * per), hi = std::min(nb, lo + per);
+        const uint32_t lo = r * per + std::min(r, extra), hi = lo + per + (r < extra ? 1u : 0u);
         RG_HIP(hipSetDevice(devs[r]));
         RG_HIP(hipStreamCreate(&D[r].s));
         RG_HIP(hipMalloc(&D[r].b, std::max<size_t>((size_t)(hi - lo) * ad * 4, 16)));

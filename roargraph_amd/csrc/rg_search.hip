@@ -82,7 +82,21 @@ struct SearchParams {
     uint32_t id_bits;         // VIS=1: ceil(log2(nd))
     const uint16_t *base_bf;  // fast mode (BF): bf16 copy of the base, rows padded to stride_bf elements (multiple of 128)
     uint32_t stride_bf;
+#ifdef RG_K1_PROF
+    unsigned long long *prof; // instrumented build only: [nq][16] per-phase cycle sums and event counts
+#endif
 };
+
+#ifdef RG_K1_PROF
+// instrumented build (make prof): s_memtime at the phase boundaries of a hop, summed per query
+#define RG_PROF_DECL unsigned long long pf_t = clock64(), pf_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pf_cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0}
+#define RG_PROF(i) { const unsigned long long t_ = clock64(); pf_acc[i] += t_ - pf_t; pf_t = t_; }
+#define RG_PROF_CNT(i, v) { pf_cnt[i] += (v); }
+#else
+#define RG_PROF_DECL
+#define RG_PROF(i)
+#define RG_PROF_CNT(i, v)
+#endif
 
 struct Beam {
     uint2 *ent;  // LDS: x = distance bits, y = id | kFlagBit
@@ -242,6 +256,7 @@ __global__ void __launch_bounds__(64) rg_search_kernel(SearchParams P) {
         const float *query = P.queries + (size_t)qi * P.qstride;
         uint32_t *qlog = (VIS == 1 && P.qlog) ? P.qlog + (size_t)qi * P.logcap : nullptr;
         uint32_t logn = 0, lbn = 0;   // ids scored so far / ids waiting in logbuf
+        RG_PROF_DECL;
         if constexpr (DIMC != 0) load_query_regs<DIMC>(query, qr, lane);
         else for (uint32_t i = lane; i < P.dim; i += kWave) qv[i] = query[i];
         if constexpr (BF) load_query_regs_bf<DIMC>(query, qb, lane);
@@ -284,8 +299,14 @@ __global__ void __launch_bounds__(64) rg_search_kernel(SearchParams P) {
         wave_sync();
 
         uint32_t cmps = 0, hops = 0;
+        RG_PROF(5);
         while (bm.cur < bm.size) {                                         // has_unexpanded_node, :2356
             const uint2 popped = beam_pop(bm, lane);                       // :2358
+            RG_PROF(0);
+#ifdef RG_K1_PROF
+            const uint32_t pf_next = bm.cur < bm.size ? (bm.ent[bm.cur].y & ~kFlagBit) : 0xffffffffu;
+            const uint32_t pf_cur0 = bm.cur;
+#endif
             const uint32_t node = popped.y;
             if (build && lane == 0 && hops < P.exp_cap) P.out_exp[(size_t)qi * P.exp_cap + hops] = popped;   // full_retset, :1319
             ++hops;                                                        // :2366
@@ -302,6 +323,10 @@ __global__ void __launch_bounds__(64) rg_search_kernel(SearchParams P) {
                 deg = (uint32_t)(o1 - o0);
                 list = P.nbrs + o0;
             }
+#ifdef RG_K1_PROF
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+            RG_PROF(1);
             for (uint32_t c0 = 0; c0 < deg; c0 += kWave) {                 // neighbour loop, :2368
                 uint32_t id = 0;
                 bool have;
@@ -354,7 +379,8 @@ __global__ void __launch_bounds__(64) rg_search_kernel(SearchParams P) {
                 }
                 const unsigned long long fm = __ballot(fresh);
                 const uint32_t n = __popcll(fm);
-                if (n == 0) continue;
+                RG_PROF_CNT(0, 1); RG_PROF_CNT(1, n);
+                if (n == 0) { RG_PROF(2); continue; }
                 if (fresh) {
                     const uint32_t slot = __popcll(fm & ((1ull << lane) - 1ull));
                     cand_id[slot] = id;
@@ -381,6 +407,7 @@ __global__ void __launch_bounds__(64) rg_search_kernel(SearchParams P) {
                 logn += n;
                 cmps += n;                                                 // :2397
                 wave_sync();
+                RG_PROF(2);
                 // gather + score (:2387): 4 rows per pass, a ring of R staging buffers keeps up to R passes in flight;
                 // pass p is consumed once only the loads of the passes issued after it are still outstanding
                 {
@@ -415,8 +442,24 @@ __global__ void __launch_bounds__(64) rg_search_kernel(SearchParams P) {
                 const float cd = (uint32_t)lane < n ? cand_d[lane] : 0.0f;
                 const uint32_t cid = (uint32_t)lane < n ? cand_id[lane] : 0u;
                 wave_sync();
+                RG_PROF(3);
+#ifdef RG_K1_PROF
+                { const uint32_t sz0 = bm.size; (void)sz0; }
+#endif
                 beam_merge<VIS == 1>(bm, cd, cid, n, P.ep, lane);
+                RG_PROF(4);
             }
+#ifdef RG_K1_PROF
+            // would a speculative expansion of the next-to-pop node have been consumed?  (prediction = the entry that was
+            // first unflagged right after the pop is still the first unflagged one after the merges)
+            if (pf_next != 0xffffffffu) {
+                RG_PROF_CNT(2, 1);
+                const bool hit = bm.cur < bm.size && (bm.ent[bm.cur].y & ~kFlagBit) == pf_next;
+                RG_PROF_CNT(3, hit ? 1 : 0);
+                RG_PROF_CNT(4, bm.cur < pf_cur0 ? 1 : 0);   // cursor moved backwards: a candidate landed in front
+            }
+            RG_PROF_CNT(5, deg);
+#endif
         }
 
         // results (:2408-2418)
@@ -467,6 +510,12 @@ __global__ void __launch_bounds__(64) rg_search_kernel(SearchParams P) {
             const uint32_t pos = logn - lbn;
             if ((uint32_t)lane < lbn && pos + lane < P.logcap) qlog[pos + lane] = logbuf[lane];
         }
+#ifdef RG_K1_PROF
+        RG_PROF(5);
+        if (P.prof && lane == 0) {
+            for (int i = 0; i < 8; ++i) { P.prof[(size_t)qi * 16 + i] = pf_acc[i]; P.prof[(size_t)qi * 16 + 8 + i] = pf_cnt[i]; }
+        }
+#endif
         if (lane == 0) {
             if (P.out_cmps) P.out_cmps[qi] = cmps;
             if (P.out_hops && !cmps_only) P.out_hops[qi] = hops;
@@ -826,6 +875,9 @@ static rg_status launch_search_r(rg_index *ix, const SearchParams &P, uint32_t g
 }
 
 struct BuildOut { uint2_pod *exp; uint32_t exp_cap, node0; uint32_t *nexp; };
+#ifdef RG_K1_PROF
+static unsigned long long *g_prof_buf = nullptr;   // [nq][16], set through rg_prof_buffer (instrumented build only)
+#endif
 
 // one K1 launch.  mode: 0 exact HBM visited words, 1 LDS filter (optionally logging the scored ids).
 static rg_status launch_k1(rg_index *ix, int mode, const float *d_q, uint32_t nq, uint32_t qstride, uint32_t k,
@@ -884,6 +936,9 @@ static rg_status launch_k1(rg_index *ix, int mode, const float *d_q, uint32_t nq
     P.id_bits = id_bits_of(ix->nd);
     P.qlog = with_log ? ix->d_qlog : nullptr; P.logcap = ix->logcap; P.qlog_n = with_log ? ix->d_qlog_n : nullptr;
     P.qlist = qlist;
+#ifdef RG_K1_PROF
+    P.prof = (qlist || bp) ? nullptr : g_prof_buf;
+#endif
     P.out_exp = nullptr; P.exp_cap = 0; P.tgt_base = 0; P.out_nexp = nullptr;
     if (bp) { P.out_exp = reinterpret_cast<uint2 *>(bp->exp); P.exp_cap = bp->exp_cap; P.tgt_base = bp->node0; P.out_nexp = bp->nexp; }
     const bool l2 = ix->metric == RG_METRIC_L2, ell = ix->d_ell != nullptr;
@@ -1099,6 +1154,10 @@ rg_status build_index_set_ell(rg_index *ix, const uint32_t *h_ell, void *stream)
 }  // namespace rg
 
 extern "C" {
+
+#ifdef RG_K1_PROF
+void rg_prof_buffer(void *d_buf) { rg::g_prof_buf = static_cast<unsigned long long *>(d_buf); }
+#endif
 
 int rg_device_count(void) {
     int n = 0;

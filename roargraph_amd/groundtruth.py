@@ -61,8 +61,10 @@ def query_ranges(nq, world):
 
 
 def shard_rows(nb, world):
-    per = (nb + world - 1) // world
-    return [(min(nb, r * per), min(nb, (r + 1) * per)) for r in range(world)]
+    """Balanced contiguous row shards: floor(nb/world) rows each, the first nb % world ranks one more (so that no shard
+    ends up shorter than K, or empty, when nb is not a multiple of world)."""
+    per, extra = divmod(nb, world)
+    return [(r * per + min(r, extra), (r + 1) * per + min(r + 1, extra)) for r in range(world)]
 
 
 def groundtruth_distributed(base_shard, id_base, queries, metric, K, group=None, shard_fn=None, merge_fn=None):

@@ -65,7 +65,8 @@ class IndexBipartite:
     def from_device(cls, base_t, offsets_t, nbrs_t, ep, metric="ip", dim=None):
         """torch CUDA tensors already in HBM; base is borrowed (kept alive by this object)."""
         self = cls(metric=metric, device=base_t.device.index or 0)
-        assert base_t.is_cuda and base_t.dtype.is_floating_point and base_t.is_contiguous()
+        import torch
+        assert base_t.is_cuda and base_t.dtype == torch.float32 and base_t.is_contiguous(), "the kernels read the base as fp32 rows"
         nd, stride = base_t.shape
         check(lib().rg_index_open_dev(C.c_void_p(base_t.data_ptr()), C.c_uint32(nd), C.c_uint32(dim or stride),
                                       C.c_uint32(stride), C.c_void_p(offsets_t.data_ptr()),

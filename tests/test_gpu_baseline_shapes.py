@@ -1,0 +1,142 @@
+"""-m gpu: the BASELINE.json configurations at their own shapes.
+
+  config 5  webvid-shaped d = 512 inner product, end to end: ground truth (K2) -> graph construction -> search (K1),
+            every leg checked (fp64 brute force for the truth, the CPU oracle's SearchRoarGraph over the SAME index
+            for the search), plus the query-sharded search over index replicas
+            (tests/test_build_roargraph.cpp:117-136 and tests/test_search_roargraph.cpp:160-209 are the call
+            sequences this mirrors)
+  config 2  t2i-10M-shaped: 10M x 200 inner product, top-10, L_pq = 500 -- a 256-query sample of the HIP path against
+            the oracle on the full-size base (a parity failure at 10M is a red test here, not a string in bench.py)
+  config 4  LAION-shaped ground truth: unit-norm clustered embeddings, L2, K = 100, at 1M rows, where the rank-100 /
+            rank-101 gap is of the order of the fp32 rounding of the ranking value
+"""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import bits
+from test_gpu_groundtruth import check_gt
+
+pytestmark = pytest.mark.gpu
+
+
+def _search_equal(got, want, cmps=True):
+    assert (got[3] == want[3]).all(), "hops differ"
+    assert (got[0] == want[0]).all(), "neighbour ids differ"
+    assert (bits(got[1]) == bits(want[1])).all(), "distance bits differ"
+    if cmps:
+        assert (got[2] == want[2]).all(), "cmps differ"
+
+
+@pytest.mark.parametrize("gpu_build", [False, True])
+def test_config5_d512_ip_end_to_end(oracle, gpu_build):
+    from roargraph_amd import build, groundtruth, index, synth
+    metric, d, nb, ntrain, nq = "ip", 512, 6000, 1500, 96
+    base, train = synth.make_synth(2025, nb, ntrain, d)
+    q = synth.make_synth(2026, nb, nq, d)[1]
+    # 1. ground truth of the training queries (the bipartite graph's input), K = 100 as in README.md:70-74
+    tr_ids, tr_d = groundtruth.compute_groundtruth(base, train, metric, 100)
+    ref_ids, _, ref_s = oracle.groundtruth_f64(base, train, metric, 100, nthreads=16)
+    check_gt(base, train, metric, 100, tr_ids, tr_d, ref_ids, ref_s)
+    # 2. graph construction at d = 512 (paper parameters, README.md:92-97)
+    off, nbrs, ep = build.build_roargraph(base, tr_ids, metric, 100, 35, 500, num_threads=1 if not gpu_build else 8,
+                                          device=0 if gpu_build else None)
+    deg = np.diff(off.astype(np.int64))
+    assert off.shape[0] == nb + 1 and int(off[-1]) == nbrs.shape[0] and ep < nb
+    assert deg.max() <= 70 and deg.mean() > 10 and (nbrs < nb).all()          # <= 2 * M_pjbp, no dangling ids
+    for i in (0, 17, nb - 1):
+        row = nbrs[int(off[i]):int(off[i + 1])]
+        assert len(set(row.tolist())) == row.shape[0] and i not in row          # no duplicate edges, no self loops
+    # 3. search: HIP against the oracle over the SAME index, several beam widths, top-10 and top-100
+    ix = index.IndexBipartite.from_arrays(base, off, nbrs, ep, metric=metric)
+    ev_ids, ev_d = groundtruth.compute_groundtruth(base, q, metric, 100)
+    ref_ids, _, ref_s = oracle.groundtruth_f64(base, q, metric, 100, nthreads=16)
+    check_gt(base, q, metric, 100, ev_ids, ev_d, ref_ids, ref_s)
+    recalls = {}
+    for k, L in ((10, 20), (10, 100), (10, 500), (100, 200)):
+        got = ix.SearchRoarGraph(q, k, L)
+        want = oracle.search(base, metric, off, nbrs, ep, q, k, L, nthreads=8)
+        _search_equal(got, want)
+        recalls[(k, L)] = index.recall(got[0], ev_ids, 10)
+        assert recalls[(k, L)] == pytest.approx(oracle.recall(want[0][:, :10].copy(), ref_ids, 10), abs=1e-6)
+    assert recalls[(10, 500)] > 0.9 and recalls[(10, 500)] >= recalls[(10, 20)]
+    # 4. config 5's search leg: index replicated, queries sharded (two replicas on the one GPU of the test box)
+    rep = index.IndexBipartite.from_arrays(base, off, nbrs, ep, metric=metric)
+    got = index.search_sharded([ix, rep], q, 10, 100)
+    _search_equal(got, oracle.search(base, metric, off, nbrs, ep, q, 10, 100, nthreads=8))
+    rep.close()
+    ix.close()
+
+
+def test_config2_10m_x_200_parity_sample(oracle):
+    """10M x 200 IP, top-10, L_pq = 500: 256 queries of a 4,096-query batch, every output against the oracle run on the
+    same full-size inputs.  The adjacency mixes uniformly random edges with edges to nearby ids, so that nodes are met
+    again and again (the LDS filter forgets, the id log + exact distinct count has work to do) -- a random graph alone
+    never revisits anything at this size."""
+    import torch
+    from roargraph_amd.index import IndexBipartite
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev); g.manual_seed(20252)
+    nb, d, deg, nq, k, L, ns = 10_000_000, 200, 40, 4096, 10, 500, 256
+    base = torch.empty((nb, d), device=dev)
+    for s in range(0, nb, 1 << 20):
+        base[s:s + (1 << 20)].normal_(generator=g)
+    nbrs = torch.randint(0, nb, (nb, deg), dtype=torch.int64, device=dev, generator=g)
+    near = (torch.arange(nb, device=dev)[:, None] + torch.randint(-48, 49, (nb, deg // 2), device=dev, generator=g)).clamp_(0, nb - 1)
+    nbrs[:, : deg // 2] = near
+    nbrs = nbrs.to(torch.int32).reshape(-1)
+    off = torch.arange(0, nb + 1, dtype=torch.int64, device=dev) * deg
+    q = torch.empty((nq, d), device=dev).normal_(generator=g) * 0.5 + 0.3
+    ix = IndexBipartite.from_device(base, off, nbrs, 12345, metric="ip")
+    outs = {}
+    for vis in (2, 0):
+        ix.set("visited", vis)
+        ids = torch.zeros((nq, k), dtype=torch.int32, device=dev); ds = torch.zeros((nq, k), device=dev)
+        cm = torch.zeros(nq, dtype=torch.int32, device=dev); hp = torch.zeros(nq, dtype=torch.int32, device=dev)
+        ix.search_dev(q, k, L, ids, ds, cm, hp); ix.search_wait()
+        outs[vis] = tuple(x.cpu().numpy() for x in (ids, ds, cm, hp))
+    ix.close()
+    hb, hq = base.cpu().numpy(), q[:ns].cpu().numpy()
+    hoff, hn = off.cpu().numpy().view(np.uint64), nbrs.cpu().numpy().view(np.uint32)
+    del base, nbrs, near
+    want = oracle.search(hb, "ip", hoff, hn, 12345, hq, k, L, nthreads=min(32, os.cpu_count() or 1))
+    assert want[2].mean() > 2000, "the sample should be a long search"
+    for vis in (2, 0):
+        got = tuple(x[:ns] for x in outs[vis])
+        _search_equal((got[0].view(np.uint32), got[1], got[2].view(np.uint32), got[3].view(np.uint32)), want)
+    # the whole batch: both exact visited forms agree bit for bit
+    for a, b in zip(outs[2], outs[0]):
+        assert (a.view(np.uint32) == b.view(np.uint32)).all()
+
+
+def test_config4_gt_unit_norm_clustered_l2_k100(oracle):
+    """Unit-norm clustered embeddings (CLIP-like), L2, K = 100, 1M rows: neighbours of a query sit in one tight cluster,
+    so the gap between rank 100 and rank 101 is of the order of the fp32 rounding of q.b - |b|^2/2.  K2 keeps a margin
+    of survivors past K through the exact re-score (rg_gt_rescore_kernel); every returned id must be a member of the
+    fp64 top-100 up to the tie band."""
+    import torch
+    from roargraph_amd import groundtruth
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev); g.manual_seed(404)
+    nb, d, ncl, nq, K = 1_000_000, 512, 1000, 128, 100
+    centers = torch.nn.functional.normalize(torch.empty((ncl, d), device=dev).normal_(generator=g), dim=1)
+    assign = torch.randint(0, ncl, (nb,), device=dev, generator=g)
+    base = centers[assign] + 0.05 * torch.empty((nb, d), device=dev).normal_(generator=g) / d ** 0.5
+    base = torch.nn.functional.normalize(base, dim=1).contiguous()
+    qa = torch.randint(0, ncl, (nq,), device=dev, generator=g)
+    q = torch.nn.functional.normalize(centers[qa] + 0.05 * torch.empty((nq, d), device=dev).normal_(generator=g) / d ** 0.5, dim=1).contiguous()
+    ids = torch.zeros((nq, K), dtype=torch.int32, device=dev); vals = torch.zeros((nq, K), device=dev)
+    groundtruth.gt_shard_dev(base, q, "l2", K, 0, ids, vals); torch.cuda.synchronize()
+    hb, hq = base.cpu().numpy(), q.cpu().numpy()
+    ref_ids, _, ref_s = oracle.groundtruth_f64(hb, hq, "l2", K, nthreads=min(32, os.cpu_count() or 1))
+    gap = ref_s[:, -1] - ref_s[:, -2]
+    assert np.median(gap) < 1e-4 * ref_s[:, -1].mean(), "the set is meant to have tight rank-K boundaries"
+    check_gt(hb, hq, "l2", K, ids.cpu().numpy().view(np.uint32), vals.cpu().numpy(), ref_ids, ref_s, tol=2e-6)
+    # and sharded over three row ranges + K3: the same lists
+    parts_i = torch.zeros((3, nq, K), dtype=torch.int32, device=dev); parts_v = torch.zeros((3, nq, K), device=dev)
+    for r, (lo, hi) in enumerate(groundtruth.shard_rows(nb, 3)):
+        groundtruth.gt_shard_dev(base[lo:hi], q, "l2", K, lo, parts_i[r], parts_v[r])
+    mi = torch.zeros_like(ids); mv = torch.zeros_like(vals)
+    groundtruth.gt_merge_dev(parts_i, parts_v, 3, nq, K, "l2", mi, mv); torch.cuda.synchronize()
+    assert torch.equal(mi, ids) and torch.equal(mv.view(torch.int32), vals.view(torch.int32))
