@@ -1,9 +1,61 @@
 // rg_index_struct.h -- the opaque rg_index of include/rg.h (shared by rg_search.hip and the GPU-assisted build)
+//
+// The index proper (base, adjacency, knobs) is immutable after open.  Everything a search launch writes lives in a
+// SearchCtx: one per stream with batches in flight, handed out under the index mutex, so that host threads searching one
+// index on distinct streams never share mutable state -- the reference calls SearchRoarGraph from many OpenMP threads
+// against one index (tests/test_search_roargraph.cpp:203-209; the only shared mutable state there is the visited-list
+// pool behind its mutex, visited_list_pool.h:47-65).
 #pragma once
+#include <hip/hip_runtime.h>
+
 #include <cstddef>
 #include <cstdint>
+#include <mutex>
+#include <vector>
 
 #include "rg.h"
+
+namespace rg {
+
+// one rg_search_dev call in flight: what rg_search_wait needs to finish it (small; pooled per context)
+struct Batch {
+    unsigned long long *d_stat = nullptr;  // [0] min over failing queries of (query << 32 | queue size), ~0 = none;
+                                           // [1], [2] K4 totals: evaluations performed / distinct nodes
+    unsigned long long *h_stat = nullptr;  // pinned copy of d_stat[0..2]; [3] = number of overflowed id logs
+    uint32_t *d_ovf = nullptr;             // [0] overflow count, [1] K4 work counter, [2..] queries whose log overflowed
+    uint32_t ovf_cap = 0;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    const float *q = nullptr;
+    uint32_t nq = 0, qstride = 0, k = 0, L = 0;
+    uint32_t *ids = nullptr;
+    float *dists = nullptr;
+    uint32_t *cmps = nullptr, *hops = nullptr;
+    bool counted = false;   // filter + id log + K4 ran: logs that overflowed are recounted in rg_search_wait
+    bool timed = false;     // adaptive default: ev0/ev1 bracket the batch
+    bool is_trial = false;
+    int mode = 2;           // the exact form the batch ran in (0 = HBM words, 2 = filter + log + K4)
+};
+
+// per-stream launch state: work-queue head, visited words, id logs, host-form staging; grow-only
+struct SearchCtx {
+    hipStream_t key = nullptr;   // the caller's stream this context currently serves
+    bool keyed = false;          // key is valid (batches pending on it, or reserved)
+    bool reserved = false;       // held by a host-form call (rg_search) on its private stream
+    hipStream_t own = nullptr;   // private stream for host-form calls
+    uint32_t *d_counter = nullptr;
+    unsigned long long *d_scratch_stat = nullptr;   // status sink of launches nobody waits for (build mode, recounts)
+    uint32_t *d_visited = nullptr, *d_epoch = nullptr;
+    uint32_t slots = 0, vwords = 0;
+    uint32_t *d_qlog = nullptr, *d_qlog_n = nullptr;
+    uint32_t qlog_nq = 0, logcap = 0, qlog_chunk = 0;
+    std::vector<Batch *> pending, spare;
+    // host-form staging (rg_search): queries up, results down
+    float *d_q = nullptr, *d_dist = nullptr;
+    uint32_t *d_ids = nullptr, *d_ch = nullptr;
+    size_t q_cap = 0, res_cap = 0, ch_cap = 0;
+};
+
+}  // namespace rg
 
 struct rg_index {
     int device = 0;
@@ -18,14 +70,7 @@ struct rg_index {
     uint32_t ell_stride = 0;
     uint64_t n_edges = 0;
     uint32_t max_deg = 0;
-    // search scratch (lazily sized)
-    uint32_t *d_visited = nullptr;
-    uint32_t *d_epoch = nullptr;
-    uint32_t slots = 0, vwords = 0;
-    uint32_t *d_counter = nullptr;
-    unsigned long long *d_status = nullptr;
-    unsigned long long *h_status = nullptr;  // pinned
-    // knobs
+    // knobs (rg_index_set; read by every launch, written only between searches)
     int waves_per_cu = 0;   // 0 = auto
     int rows_per_pass = 0;  // 4*R (R = staging ring depth); 0 = auto: 8 on graphs of average out-degree >= 28, else 4
     int force_csr = 0;
@@ -33,32 +78,27 @@ struct rg_index {
     // 0 = exact visited words in HBM; 1 = LDS exact-match filter only (cmps = evaluations performed);
     // 2 = LDS filter + id log + exact distinct count (K4): everything bit-exact incl. cmps (default)
     int visited_mode = 2;
-    uint32_t *d_qlog = nullptr, *d_qlog_n = nullptr, *d_ovf = nullptr;
-    size_t qlog_cap_total = 0;
-    uint32_t qlog_nq = 0, logcap = 0, qlog_chunk = 0, ovf_nq = 0;
-    int log_budget_kb = 16 << 20;  // HBM budget of the id logs (KiB, default 16 GiB = 32768 queries): larger batches are searched in sub-batches
+    int log_budget_kb = 16 << 20;  // HBM budget of the id logs per context (KiB, default 16 GiB = 32768 queries): larger batches are searched in sub-batches
     int log_cap_knob = 0;       // 0 = auto; tests force small logs to exercise the exact fallback
     int count_table_log2 = 15;  // K4 LDS table: 2^15 words = 128 KiB
     bool fast_bf16 = false;      // opt-in non-parity mode: traverse a bf16 copy of the base, exact re-rank of the beam
-    bool bf_launch = false;      // transient: the launch being prepared uses the bf16 copy
+    int spec = -1;               // speculative second expansion per hop (bit-exact either way): -1 = auto, 0 = off, 1 = on
+    int multi_expand = 0;        // opt-in non-parity mode: the speculated expansion is merged unconditionally
     uint16_t *d_base_bf = nullptr;
     uint32_t stride_bf = 0;
     bool exact_filter = true;    // mode 0: the LDS filter screens the exact HBM words (hits skip the atomics)
     bool query_in_lds = false;   // K1: force the generic (query staged in LDS) instantiation for d = 200 / 512
     bool count_full_ids = false; // K4: force the full-id bucket form (the half-word form is used when the remainder fits)
-    struct Pending { bool active = false; const float *q = nullptr; uint32_t nq = 0, qstride = 0, k = 0, L = 0; uint32_t *ids = nullptr; float *dists = nullptr; uint32_t *cmps = nullptr, *hops = nullptr; } pending;
-    int filter_log2 = 0;    // VIS=1: log2 of the LDS filter's 16-bit entries; 0 = automatic (launch_k1)
-    uint32_t exact_from_L = 0xffffffffu;   // adaptive default mode: beam widths from here on use the exact HBM words
-    struct Tune {                          // timed trial behind that decision (search_dev / search_wait)
-        hipEvent_t ev0 = nullptr, ev1 = nullptr;
-        bool timed = false, is_trial = false;
-        int mode = 2;
-        uint32_t L = 0, nq = 0, trial_L = 0, filter_ok_upto = 0;
-        float filter_per_q = 0.0f;
-    } tune;
-    int filter_auto = 9;    // the automatic choice of the launch being prepared
+    int filter_log2 = 0;    // VIS=1: log2 of the LDS filter's 16-bit entries; 0 = automatic (per launch)
     int num_cu = 256;
     size_t lds_per_cu = 160 * 1024;
+    // ---- mutable state, all behind `mu`
+    std::mutex mu;
+    std::vector<rg::SearchCtx *> ctxs;
+    // adaptive default visited mode: beam widths from exact_from_L on use the exact HBM words; decided by a timed trial
+    uint32_t exact_from_L = 0xffffffffu;
+    uint32_t trial_L = 0, filter_ok_upto = 0;
+    float filter_per_q = 0.0f;
 };
 
 namespace rg {

@@ -1,18 +1,12 @@
-// rg_search.hip -- gfx950 kernels and C-ABI entry points of the search path.
+// rg_search.hip -- host side of the search path and its small kernels.
 //
-//   K1  rg_search_kernel   persistent beam search, one wave64 per in-flight query
-//                          == IndexBipartite::SearchRoarGraph (src/index_bipartite.cpp:2311-2420)
+//   K1  rg_search_kernel   persistent beam search (rg_search_kernel.h, instantiated in rg_search_inst_*.hip)
+//   K4  rg_distinct_kernel exact distinct count of a query's id log (the reference's cmps)
 //   K1b rg_score_kernel    batched Distance::compare (include/efanna2e/distance.h:18)
 //
-// Per query (one wave, one single-wave workgroup, all state wave-private):
-//   LDS   : sorted beam of L_pq (dist, id|expanded) pairs  == NeighborPriorityQueue (neighbor.h:138-223)
-//           query vector, 64-entry candidate id/score scratch, LDS-DMA staging for the row gather
-//   HBM   : epoch-tagged visited words per slot             == VisitedList (visited_list_pool.h:8-29): like the
-//           reference's curV tag array, a word is "set for this query" only if its 16-bit epoch equals the query's,
-//           so nothing is ever cleared between queries (a wipe happens once per 65,535 queries of a slot)
-// Per hop (hop-synchronous, see SURVEY.md Appendix C-11 for why this reproduces the sequential inserts):
-//   pop closest unexpanded -> read its adjacency row -> atomicOr visited bits -> ballot-compact the unvisited ids
-//   -> gather + score them 4 rows per sub-pass -> rank-merge the survivors into the beam.
+// Host state: the rg_index is immutable after open; every launch-time buffer lives in a per-stream SearchCtx handed out
+// under the index mutex (rg_index_struct.h), so searches on distinct streams / from distinct host threads do not share
+// anything mutable, and several batches may be in flight on one stream before rg_search_wait collects them.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -25,15 +19,10 @@
 #include "rg.h"
 #include "rg_device.h"
 #include "rg_internal.h"
+#include "rg_search_kernel.h"
+#include "rg_index_struct.h"
 
 namespace rg {
-
-#define RG_HIP(expr)                                                                                   \
-    do {                                                                                               \
-        hipError_t e_ = (expr);                                                                        \
-        if (e_ != hipSuccess)                                                                          \
-            return set_error(RG_ERR_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e_));        \
-    } while (0)
 
 // device allocation released on every exit path of a host wrapper
 template <typename T>
@@ -46,485 +35,6 @@ struct DevBuf {
     DevBuf(const DevBuf &) = delete;
     DevBuf &operator=(const DevBuf &) = delete;
 };
-
-// ------------------------------------------------------------------------------------------------ device
-struct SearchParams {
-    const float *base;
-    uint32_t stride, dim, nd;
-    const uint32_t *ell;      // [nd][ell_stride]: word 0 = degree, then neighbour ids (null -> CSR)
-    uint32_t ell_stride;
-    const uint64_t *offsets;  // CSR
-    const uint32_t *nbrs;
-    uint32_t ep;
-    const float *queries;
-    uint32_t nq, qstride, k, L;
-    uint32_t *out_ids;
-    float *out_dists;
-    uint32_t *out_cmps, *out_hops;
-    uint32_t *visited;        // [slots][vwords]; word = epoch16 << 16 | 16 visited bits (nodes 16w .. 16w+15)
-    uint32_t vwords;
-    uint32_t *slot_epoch;     // [slots] last epoch used by the slot (persists across launches)
-    uint32_t *counter;        // work-queue head
-    unsigned long long *status;  // min over failing queries of (query << 32 | queue size); ~0 = none
-    uint32_t stage_floats;    // floats per sub-pass staging buffer (ceil(dim/64)*256; fast mode: 256 per 128 bf16 elements)
-    uint32_t stage_total;     // floats of the whole staging region (>= R * stage_floats; fast mode: >= one fp32 pass too)
-    uint32_t qbase;           // index of queries[0] in the caller's batch (error reporting of chunked launches)
-    uint32_t diag;            // diagnostics only (breaks parity): bit0 = skip the visited test
-    uint32_t vf_slots_log2;   // log2 of the LDS visited-filter size (16-bit entries)
-    uint32_t vf_front;        // VIS=0: 1 = the LDS filter screens the exact HBM words
-    uint32_t *qlog;           // VIS=1, optional: [nq][logcap] ids scored by each query (input of the exact distinct count)
-    uint32_t logcap;
-    uint32_t *qlog_n;         // [nq] number of ids scored (may exceed logcap: overflow)
-    const uint32_t *qlist;    // optional: work item i is query qlist[i] (fallback pass), results other than cmps untouched
-    uint2 *out_exp;           // build mode (graph construction phase 3): [nq][exp_cap] expanded (dist bits, id) in pop order
-    uint32_t exp_cap, tgt_base;
-    uint32_t *out_nexp;       // [nq] number of expansions
-    uint32_t id_bits;         // VIS=1: ceil(log2(nd))
-    const uint16_t *base_bf;  // fast mode (BF): bf16 copy of the base, rows padded to stride_bf elements (multiple of 128)
-    uint32_t stride_bf;
-#ifdef RG_K1_PROF
-    unsigned long long *prof; // instrumented build only: [nq][16] per-phase cycle sums and event counts
-#endif
-};
-
-#ifdef RG_K1_PROF
-// instrumented build (make prof): s_memtime at the phase boundaries of a hop, summed per query
-#define RG_PROF_DECL unsigned long long pf_t = clock64(), pf_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pf_cnt[8] = {0, 0, 0, 0, 0, 0, 0, 0}
-#define RG_PROF(i) { const unsigned long long t_ = clock64(); pf_acc[i] += t_ - pf_t; pf_t = t_; }
-#define RG_PROF_CNT(i, v) { pf_cnt[i] += (v); }
-#else
-#define RG_PROF_DECL
-#define RG_PROF(i)
-#define RG_PROF_CNT(i, v)
-#endif
-
-struct Beam {
-    uint2 *ent;  // LDS: x = distance bits, y = id | kFlagBit
-    uint32_t size, cur, cap;
-};
-
-// closest_unexpanded (neighbor.h:185-192): flag the entry at cur, move cur to the next unflagged entry
-__device__ __forceinline__ uint2 beam_pop(Beam &bm, int lane) {
-    uint2 e = bm.ent[bm.cur];
-    if (lane == 0) bm.ent[bm.cur].y = e.y | kFlagBit;
-    uint32_t c = bm.cur + 1;
-    for (;;) {
-        if (c >= bm.size) { c = bm.size; break; }
-        uint32_t idx = c + lane;
-        bool open = idx < bm.size && !(bm.ent[idx].y & kFlagBit);
-        unsigned long long m = __ballot(open);
-        if (m) { c += __ffsll((long long)m) - 1; break; }
-        c += kWave;
-    }
-    bm.cur = c;
-    wave_sync();
-    return make_uint2(e.x, e.y & ~kFlagBit);
-}
-
-// Insert the n (<= 64) scored candidates (lane i holds candidate i) -- the net effect of n calls of
-// NeighborPriorityQueue::insert (neighbor.h:150-183).  The beam is the top-cap of everything inserted so far
-// under the total order (distance, id); candidates are distinct unvisited nodes, the only possible repeat is the
-// entry point (never marked visited, index_bipartite.cpp:2349), whose second insert the reference drops.
-template <bool DEDUP>
-__device__ __forceinline__ void beam_merge(Beam &bm, float cd, uint32_t cid, uint32_t n, uint32_t ep, int lane) {
-    bool valid = (uint32_t)lane < n && cid != ep;
-    if (bm.size == bm.cap) {  // full: only candidates better than the current worst can enter (neighbor.h:151-153)
-        uint2 w = bm.ent[bm.cap - 1];
-        valid = valid && nb_less(cd, cid, __uint_as_float(w.x), w.y & ~kFlagBit);
-    }
-    if (!__any(valid)) return;
-    // rank among the beam entries: lower bound under (distance, id)
-    uint32_t lo = 0, hi = valid ? bm.size : 0;
-    while (__any(lo < hi)) {
-        if (lo < hi) {
-            const uint32_t mid = (lo + hi) >> 1;
-            const uint2 e = bm.ent[mid];
-            if (nb_less(__uint_as_float(e.x), e.y & ~kFlagBit, cd, cid)) lo = mid + 1;
-            else hi = mid;
-        }
-    }
-    if (DEDUP) {
-        // With the lossy visited filter a node can be scored again.  Its distance bits are the same, so the lower bound
-        // lands exactly on its beam entry if it is still there: drop it (the reference's equal-id rule, neighbor.h:161);
-        // if it was evicted the tail test above already rejected it.  Same id twice in one hop: keep the lowest lane.
-        if (valid && lo < bm.size && (bm.ent[lo].y & ~kFlagBit) == cid) valid = false;
-        const unsigned long long m0 = __ballot(valid);
-        bool dup = false;
-        for (unsigned long long m = m0; m; m &= m - 1) {
-            const int s = __ffsll((long long)m) - 1;
-            dup = dup || (readlane_u(cid, s) == cid && s < lane);
-        }
-        valid = valid && !dup;
-    }
-    const unsigned long long vmask = __ballot(valid);
-    if (!vmask) return;
-    const uint32_t nc = __popcll(vmask);
-    // rank among the candidates
-    uint32_t crank = 0;
-    for (unsigned long long m = vmask; m; m &= m - 1) {
-        const int s = __ffsll((long long)m) - 1;
-        const float od = readlane_f(cd, s);
-        const uint32_t oi = readlane_u(cid, s);
-        crank += nb_less(od, oi, cd, cid) ? 1u : 0u;
-    }
-    const uint32_t qrank = valid ? lo : 0xffffffffu;
-    const uint32_t fpos = lo + crank;
-    const bool keep = valid && fpos < bm.cap;
-    // first beam index that moves
-    const uint32_t minq = wave_min_u32(qrank);
-    // new cursor: first unflagged entry after the merge
-    uint32_t ncur = 0xffffffffu;
-    if (bm.cur < bm.size) {
-        const uint32_t sh = __popcll(__ballot(valid && qrank <= bm.cur));
-        if (bm.cur + sh < bm.cap) ncur = bm.cur + sh;
-    }
-    ncur = min(ncur, wave_min_u32(keep ? fpos : 0xffffffffu));
-    // shift entries [minq, size) right by the number of candidates ranked at or before them.  Done in place, top group
-    // first; a group is up to 8 chunks of 64 entries held in registers, so its reads all complete before its writes
-    // (which only land on indices >= the ones read, i.e. inside the group or in groups already moved).
-    constexpr int G = 8;
-    for (int top = (int)bm.size - 1; top >= (int)minq; top -= kWave * G) {
-        uint2 e[G];
-        uint32_t sh[G];
-#pragma unroll
-        for (int g2 = 0; g2 < G; ++g2) {
-            const int i = top - kWave * g2 - lane;
-            e[g2] = i >= (int)minq ? bm.ent[i] : make_uint2(0, 0);
-            sh[g2] = 0;
-        }
-        for (unsigned long long m = vmask; m; m &= m - 1) {
-            const int s = __ffsll((long long)m) - 1;
-            const int q = (int)readlane_u(qrank, s);
-#pragma unroll
-            for (int g2 = 0; g2 < G; ++g2) sh[g2] += q <= top - kWave * g2 - lane ? 1u : 0u;
-        }
-        wave_sync();
-#pragma unroll
-        for (int g2 = 0; g2 < G; ++g2) {
-            const int i = top - kWave * g2 - lane;
-            if (i >= (int)minq && (uint32_t)i + sh[g2] < bm.cap) bm.ent[(uint32_t)i + sh[g2]] = e[g2];
-        }
-        wave_sync();
-    }
-    if (keep) bm.ent[fpos] = make_uint2(__float_as_uint(cd), cid);
-    bm.size = min(bm.cap, bm.size + nc);
-    bm.cur = ncur == 0xffffffffu ? bm.size : ncur;
-    wave_sync();
-}
-
-// DIMC: 0 = any dimension (query staged in LDS), else the compile-time dimension (query in registers)
-// BF:   opt-in fast mode, NOT parity: the traversal scores a bf16 copy of the base (4 instead of 7 HBM
-//       lines per d = 200 evaluation); at the end the whole beam is re-scored with the exact fp32 routine and the k best
-//       by exact (distance, id) are returned, so the reported distances are exact for the returned ids.
-template <bool L2, bool ELL, int R, int VIS, int DIMC, bool BF>
-__global__ void __launch_bounds__(64) rg_search_kernel(SearchParams P) {
-    static_assert(!BF || (DIMC != 0 && ELL), "fast mode: compile-time dimension, ELL adjacency");
-    constexpr int NB = (DIMC + 127) / 128;                                // fast mode: LDS-DMA instructions per bf16 row
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int lane = threadIdx.x;
-    const int g = lane >> 4;
-    // LDS carve (all offsets multiples of 16 B)
-    float *stage = reinterpret_cast<float *>(smem);                       // R * stage_floats
-    float *qv = stage + P.stage_total;                                    // dim (DIMC == 0 only)
-    uint32_t *cand_id = reinterpret_cast<uint32_t *>(qv + (DIMC ? 0u : P.dim));   // 64
-    float qr[DIMC ? (DIMC + 15) / 16 : 1];
-    float qb[BF ? 8 * NB : 1];
-    float *cand_d = reinterpret_cast<float *>(cand_id + kWave);           // 64
-    Beam bm;
-    bm.ent = reinterpret_cast<uint2 *>(cand_d + kWave);                   // L
-    bm.cap = P.L;
-    // VIS=1: lossy exact-match visited filter (direct mapped, 16-bit remainders of a bijective id hash)
-    // id-log staging: ids are appended here and flushed to HBM 64 at a time (256-B aligned full-line stores; small
-    // unaligned appends would turn into read-modify-writes at the memory side once the line has left L2)
-    uint32_t *logbuf = reinterpret_cast<uint32_t *>(bm.ent + P.L);        // 128
-    uint16_t *vtab = reinterpret_cast<uint16_t *>(logbuf + 128);
-    const uint32_t vf_rem_bits = P.id_bits > P.vf_slots_log2 ? P.id_bits - P.vf_slots_log2 : 0u;
-    const uint32_t vf_id_mask = P.id_bits >= 32u ? 0xffffffffu : ((1u << P.id_bits) - 1u);
-
-    uint32_t *vmap = P.visited + (size_t)blockIdx.x * P.vwords;
-    uint32_t epoch = VIS == 0 ? P.slot_epoch[blockIdx.x] : 0u;
-
-    for (;;) {
-        uint32_t qi = 0;
-        if (lane == 0) qi = atomicAdd(P.counter, 1u);
-        qi = readlane_u(qi, 0);
-        if (qi >= P.nq) break;
-        const bool cmps_only = P.qlist != nullptr;
-        const bool build = P.out_exp != nullptr;
-        const uint32_t tgt = P.tgt_base + qi;   // build mode: the node being linked is never scored (:1327)
-        if (cmps_only) qi = P.qlist[qi];
-        const float *query = P.queries + (size_t)qi * P.qstride;
-        uint32_t *qlog = (VIS == 1 && P.qlog) ? P.qlog + (size_t)qi * P.logcap : nullptr;
-        uint32_t logn = 0, lbn = 0;   // ids scored so far / ids waiting in logbuf
-        RG_PROF_DECL;
-        if constexpr (DIMC != 0) load_query_regs<DIMC>(query, qr, lane);
-        else for (uint32_t i = lane; i < P.dim; i += kWave) qv[i] = query[i];
-        if constexpr (BF) load_query_regs_bf<DIMC>(query, qb, lane);
-        // new visited epoch (VisitedList::reset, visited_list_pool.h:20-26: ++curV, wipe on wrap)
-        uint32_t etag = 0;
-        if (VIS == 0) {
-            if (++epoch == 0x10000u) {
-                for (uint32_t w = lane; w < P.vwords; w += kWave) vmap[w] = 0u;
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                epoch = 1;
-            }
-            etag = epoch << 16;
-        }
-        if (VIS == 1 || P.vf_front) {
-            uint32_t *vt32 = reinterpret_cast<uint32_t *>(vtab);
-            for (uint32_t i = lane; i < (1u << P.vf_slots_log2) / 2u; i += kWave) vt32[i] = 0xffffffffu;
-        }
-        wave_sync();
-
-        // entry point: scored and queued, not marked visited (index_bipartite.cpp:2338-2352)
-        // exact fp32 score of a staged pass / traversal score (the same thing unless BF)
-        auto score_exact = [&](const float *buf) __attribute__((always_inline)) {
-            if constexpr (DIMC != 0) return gather_score_q<L2, DIMC>(buf, qr, lane);
-            else return gather_score<L2>(buf, qv, P.dim, lane);
-        };
-        auto score = [&](const float *buf) __attribute__((always_inline)) {
-            if constexpr (BF) return score_bf<L2, NB>(reinterpret_cast<const uint32_t *>(buf), qb, lane);
-            else return score_exact(buf);
-        };
-        auto issue = [&](uint32_t rid, bool act, float *buf) __attribute__((always_inline)) {
-            if constexpr (BF) gather_issue_bf<NB>(P.base_bf + (size_t)rid * P.stride_bf, act, reinterpret_cast<uint32_t *>(buf), lane);
-            else gather_issue(P.base + (size_t)rid * P.stride, P.dim, act, buf, lane);
-        };
-        issue(P.ep, g == 0, stage);
-        gather_wait(0);
-        const float epd = score(stage);
-        if (lane == 0) bm.ent[0] = make_uint2(__float_as_uint(epd), P.ep);
-        bm.size = 1;
-        bm.cur = 0;
-        wave_sync();
-
-        uint32_t cmps = 0, hops = 0;
-        RG_PROF(5);
-        while (bm.cur < bm.size) {                                         // has_unexpanded_node, :2356
-            const uint2 popped = beam_pop(bm, lane);                       // :2358
-            RG_PROF(0);
-#ifdef RG_K1_PROF
-            const uint32_t pf_next = bm.cur < bm.size ? (bm.ent[bm.cur].y & ~kFlagBit) : 0xffffffffu;
-            const uint32_t pf_cur0 = bm.cur;
-#endif
-            const uint32_t node = popped.y;
-            if (build && lane == 0 && hops < P.exp_cap) P.out_exp[(size_t)qi * P.exp_cap + hops] = popped;   // full_retset, :1319
-            ++hops;                                                        // :2366
-            // adjacency of `node`, 64 words at a time
-            uint32_t deg, first = 0;
-            const uint32_t *list;
-            if (ELL) {
-                const uint32_t *row = P.ell + (size_t)node * P.ell_stride;
-                first = (uint32_t)lane < P.ell_stride ? row[lane] : 0u;
-                deg = readlane_u(first, 0);
-                list = row + 1;
-            } else {
-                const uint64_t o0 = P.offsets[node], o1 = P.offsets[node + 1];
-                deg = (uint32_t)(o1 - o0);
-                list = P.nbrs + o0;
-            }
-#ifdef RG_K1_PROF
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
-            RG_PROF(1);
-            for (uint32_t c0 = 0; c0 < deg; c0 += kWave) {                 // neighbour loop, :2368
-                uint32_t id = 0;
-                bool have;
-                if (ELL && c0 == 0) {
-                    // words 1..63 of the row were fetched with the degree: neighbours 0..62
-                    id = (uint32_t)__shfl_down((int)first, 1, 64);
-                    have = (uint32_t)lane < min(deg, 63u);
-                    if (lane == 63 && deg > 63u) { id = list[63]; have = true; }
-                } else {
-                    have = c0 + lane < deg;
-                    if (have) id = list[c0 + lane];
-                }
-                if (build && id == tgt) have = false;
-                // visited test-and-set (:2378, :2385); same-hop duplicates are resolved by the atomic's order
-                bool fresh = false;
-                if (VIS == 1) {
-                    // exact-match lookup: a hit proves "visited"; a miss is treated as fresh (may re-score a node whose
-                    // entry was overwritten -- harmless for the beam, see beam_merge<true>)
-                    if (have) {
-                        const uint32_t x = (id * 0x9E3779B1u) & vf_id_mask;   // odd multiplier: bijection on id_bits bits
-                        const uint32_t slot = x >> vf_rem_bits;
-                        const uint16_t rem = (uint16_t)(x & ((1u << vf_rem_bits) - 1u));
-                        fresh = vtab[slot] != rem;
-                        if (fresh) vtab[slot] = rem;
-                    }
-                } else if (have && (P.diag & 1u)) fresh = true;
-                else if (have && (P.diag & 2u)) {  // traffic without the dependency: fire-and-forget atomics
-                    uint32_t *w = &vmap[id >> 4];
-                    atomicMax(w, etag);
-                    __hip_atomic_fetch_or(w, 1u << (id & 15u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    fresh = true;
-                } else if (have) {
-                    // the LDS filter in front of the exact words: a hit proves "visited" and saves the two atomics (most
-                    // repeat encounters on indexes with locality); a miss goes to the words, which decide
-                    bool known = false;
-                    if (P.vf_front) {
-                        const uint32_t x = (id * 0x9E3779B1u) & vf_id_mask;
-                        const uint32_t slot = x >> vf_rem_bits;
-                        const uint16_t rem = (uint16_t)(x & ((1u << vf_rem_bits) - 1u));
-                        known = vtab[slot] == rem;
-                        if (!known) vtab[slot] = rem;
-                    }
-                    if (!known) {
-                        uint32_t *w = &vmap[id >> 4];
-                        const uint32_t bit = 1u << (id & 15u);
-                        atomicMax(w, etag);                    // stale epoch -> word becomes (epoch, no bits)
-                        const uint32_t old = atomicOr(w, bit); // same address, same lane: ordered behind the max
-                        fresh = !(old & bit);
-                    }
-                }
-                const unsigned long long fm = __ballot(fresh);
-                const uint32_t n = __popcll(fm);
-                RG_PROF_CNT(0, 1); RG_PROF_CNT(1, n);
-                if (n == 0) { RG_PROF(2); continue; }
-                if (fresh) {
-                    const uint32_t slot = __popcll(fm & ((1ull << lane) - 1ull));
-                    cand_id[slot] = id;
-                    if (VIS == 1 && qlog) logbuf[lbn + slot] = id;
-                }
-                // a full 64-id line of the log leaves LDS here but is STORED after this hop's gathers have been consumed:
-                // a store issued in front of them would sit at the head of the vmcnt queue and put its completion
-                // latency on the critical path of the first counted wait
-                bool flush = false;
-                uint32_t flush_v = 0, flush_pos = 0;
-                if (VIS == 1 && qlog) {
-                    lbn += n;
-                    if (lbn >= (uint32_t)kWave) {
-                        lds_sync();
-                        flush = true;
-                        flush_pos = logn - (lbn - n);                     // ids already flushed (multiple of 64)
-                        flush_v = logbuf[lane];
-                        const uint32_t rest = logbuf[kWave + lane];
-                        lds_sync();
-                        lbn -= kWave;
-                        if ((uint32_t)lane < lbn) logbuf[lane] = rest;
-                    }
-                }
-                logn += n;
-                cmps += n;                                                 // :2397
-                wave_sync();
-                RG_PROF(2);
-                // gather + score (:2387): 4 rows per pass, a ring of R staging buffers keeps up to R passes in flight;
-                // pass p is consumed once only the loads of the passes issued after it are still outstanding
-                {
-                    const uint32_t npass = (n + 3u) >> 2, lpp = BF ? (uint32_t)NB : loads_per_pass(P.dim);
-                    for (uint32_t p = 0; p < (uint32_t)R && p < npass; ++p) {
-                        const uint32_t c = 4 * p + g;
-                        const uint32_t rid = c < n ? cand_id[c] : 0u;
-                        issue(rid, c < n, stage + (size_t)p * P.stage_floats);
-                    }
-                    for (uint32_t p = 0; p < npass; ++p) {
-                        const uint32_t last = min(npass, p + (uint32_t)R) - 1u;
-                        if constexpr (DIMC != 0) {
-                            constexpr int LPPC = BF ? NB : (DIMC + 63) / 64;
-                            gather_wait_passes<LPPC>(last - p);
-                        } else {
-                            gather_wait((last - p) * lpp);
-                        }
-                        float *buf = stage + (size_t)(p & (R - 1)) * P.stage_floats;
-                        const uint32_t c = 4 * p + g;
-                        const float d = score(buf);
-                        if (c < n && (lane & 15) == 0) cand_d[c] = d;
-                        lds_sync();
-                        if (p + R < npass) {
-                            const uint32_t c2 = 4 * (p + R) + g;
-                            const uint32_t rid = c2 < n ? cand_id[c2] : 0u;
-                            issue(rid, c2 < n, buf);
-                        }
-                    }
-                }
-                if (VIS == 1 && flush && flush_pos + lane < P.logcap) qlog[flush_pos + lane] = flush_v;
-                // queue inserts (:2398)
-                const float cd = (uint32_t)lane < n ? cand_d[lane] : 0.0f;
-                const uint32_t cid = (uint32_t)lane < n ? cand_id[lane] : 0u;
-                wave_sync();
-                RG_PROF(3);
-#ifdef RG_K1_PROF
-                { const uint32_t sz0 = bm.size; (void)sz0; }
-#endif
-                beam_merge<VIS == 1>(bm, cd, cid, n, P.ep, lane);
-                RG_PROF(4);
-            }
-#ifdef RG_K1_PROF
-            // would a speculative expansion of the next-to-pop node have been consumed?  (prediction = the entry that was
-            // first unflagged right after the pop is still the first unflagged one after the merges)
-            if (pf_next != 0xffffffffu) {
-                RG_PROF_CNT(2, 1);
-                const bool hit = bm.cur < bm.size && (bm.ent[bm.cur].y & ~kFlagBit) == pf_next;
-                RG_PROF_CNT(3, hit ? 1 : 0);
-                RG_PROF_CNT(4, bm.cur < pf_cur0 ? 1 : 0);   // cursor moved backwards: a candidate landed in front
-            }
-            RG_PROF_CNT(5, deg);
-#endif
-        }
-
-        // results (:2408-2418)
-        if (cmps_only || build) {
-            if (build && lane == 0) P.out_nexp[qi] = hops;
-        } else if (bm.size < P.k) {
-            if (lane == 0) atomicMin(P.status, ((unsigned long long)(qi + P.qbase) << 32) | bm.size);
-        } else if (BF) {
-            // re-rank: exact fp32 distance of every beam entry (4 rows per pass through the exact routine), then the k
-            // best by exact (distance, id), selected k times with a wave-wide minimum over an order-preserving key
-            for (uint32_t i0 = 0; i0 < bm.size; i0 += 4) {
-                const uint32_t i = i0 + g;
-                const uint32_t rid = i < bm.size ? (bm.ent[i].y & ~kFlagBit) : 0u;
-                gather_issue(P.base + (size_t)rid * P.stride, P.dim, i < bm.size, stage, lane);
-                gather_wait(0);
-                const float d = score_exact(stage);
-                lds_sync();
-                if (i < bm.size && (lane & 15) == 0) bm.ent[i] = make_uint2(__float_as_uint(d), rid);   // flag cleared
-            }
-            wave_sync();
-            for (uint32_t r = 0; r < P.k; ++r) {
-                uint32_t bh = 0xffffffffu, bl = 0xffffffffu, bi = 0xffffffffu;   // (ordered distance, id, beam index)
-                for (uint32_t i = lane; i < bm.size; i += kWave) {
-                    const uint2 e = bm.ent[i];
-                    if (e.y & kFlagBit) continue;
-                    const uint32_t u = e.x, o = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
-                    if (o < bh || (o == bh && e.y < bl)) { bh = o; bl = e.y; bi = i; }
-                }
-                const uint32_t mh = wave_min_u32(bh);
-                const uint32_t ml = wave_min_u32(bh == mh ? bl : 0xffffffffu);
-                if (bh == mh && bl == ml && bi != 0xffffffffu) {   // ids are unique in the beam: exactly one lane
-                    const uint2 e = bm.ent[bi];
-                    bm.ent[bi].y = e.y | kFlagBit;
-                    P.out_ids[(size_t)qi * P.k + r] = e.y;
-                    P.out_dists[(size_t)qi * P.k + r] = __uint_as_float(e.x);
-                }
-                wave_sync();
-            }
-        } else {
-            for (uint32_t i = lane; i < P.k; i += kWave) {
-                const uint2 e = bm.ent[i];
-                P.out_ids[(size_t)qi * P.k + i] = e.y & ~kFlagBit;
-                P.out_dists[(size_t)qi * P.k + i] = __uint_as_float(e.x);
-            }
-        }
-        if (VIS == 1 && qlog && lbn) {   // tail of the id log
-            lds_sync();
-            const uint32_t pos = logn - lbn;
-            if ((uint32_t)lane < lbn && pos + lane < P.logcap) qlog[pos + lane] = logbuf[lane];
-        }
-#ifdef RG_K1_PROF
-        RG_PROF(5);
-        if (P.prof && lane == 0) {
-            for (int i = 0; i < 8; ++i) { P.prof[(size_t)qi * 16 + i] = pf_acc[i]; P.prof[(size_t)qi * 16 + 8 + i] = pf_cnt[i]; }
-        }
-#endif
-        if (lane == 0) {
-            if (P.out_cmps) P.out_cmps[qi] = cmps;
-            if (P.out_hops && !cmps_only) P.out_hops[qi] = hops;
-            if (VIS == 1 && P.qlog_n) P.qlog_n[qi] = logn;
-        }
-        wave_sync();
-    }
-    if (VIS == 0 && lane == 0) P.slot_epoch[blockIdx.x] = epoch;
-}
 
 // K4: exact number of DISTINCT ids a query scored == the reference's cmps (every unvisited neighbour is scored exactly
 // once there, index_bipartite.cpp:2378-2397).  The LDS visited filter of K1 may score a node twice; this pass counts the
@@ -730,15 +240,8 @@ __global__ void rg_graph_stats_kernel(const uint64_t *offsets, const uint32_t *n
     }
 }
 
-}  // namespace rg
 
 // -------------------------------------------------------------------------------------------------- host
-using rg::set_error;
-
-#include "rg_index_struct.h"
-
-namespace rg {
-
 static rg_status pick_device(int device) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0)
@@ -780,25 +283,108 @@ static rg_status finish_graph(rg_index *ix, const uint64_t *d_off, const uint32_
         RG_HIP(hipMemcpy(ix->d_offsets, d_off, ((size_t)ix->nd + 1) * 8, hipMemcpyDeviceToDevice));
         RG_HIP(hipMemcpy(ix->d_nbrs, d_nb, ne * 4, hipMemcpyDeviceToDevice));
     }
-    RG_HIP(hipMalloc(&ix->d_counter, 64));
-    RG_HIP(hipMalloc(&ix->d_status, 64));
-    RG_HIP(hipHostMalloc(&ix->h_status, 64));
-    RG_HIP(hipEventCreate(&ix->tune.ev0));
-    RG_HIP(hipEventCreate(&ix->tune.ev1));
     hipDeviceProp_t prop;
     RG_HIP(hipGetDeviceProperties(&prop, ix->device));
     ix->num_cu = prop.multiProcessorCount;
     return RG_OK;
 }
 
+// ---- per-stream contexts ---------------------------------------------------------------------------------------
+static void free_batch(Batch *b) {
+    if (!b) return;
+    if (b->d_stat) (void)hipFree(b->d_stat);
+    if (b->h_stat) (void)hipHostFree(b->h_stat);
+    if (b->d_ovf) (void)hipFree(b->d_ovf);
+    if (b->ev0) (void)hipEventDestroy(b->ev0);
+    if (b->ev1) (void)hipEventDestroy(b->ev1);
+    delete b;
+}
+
+static void free_ctx(SearchCtx *cx) {
+    if (!cx) return;
+    for (Batch *b : cx->pending) free_batch(b);
+    for (Batch *b : cx->spare) free_batch(b);
+    if (cx->own) (void)hipStreamDestroy(cx->own);
+    void *bufs[] = {cx->d_counter, cx->d_scratch_stat, cx->d_visited, cx->d_epoch, cx->d_qlog, cx->d_qlog_n,
+                    cx->d_q, cx->d_dist, cx->d_ids, cx->d_ch};
+    for (void *p : bufs)
+        if (p) (void)hipFree(p);
+    delete cx;
+}
+
+static rg_status new_ctx(SearchCtx **out) {
+    SearchCtx *cx = new SearchCtx();
+    hipError_t e = hipMalloc(&cx->d_counter, 64);
+    if (e == hipSuccess) e = hipMalloc(&cx->d_scratch_stat, 64);
+    if (e != hipSuccess) { free_ctx(cx); return set_error(RG_ERR_DEVICE, hipGetErrorString(e)); }
+    *out = cx;
+    return RG_OK;
+}
+
+// the context serving `s`: the one already keyed to it, else an idle one, else a new one.  `priv`: a host-form call
+// wants a context nobody else touches and a stream of its own (concurrent rg_search calls from several host threads).
+static rg_status acquire_ctx(rg_index *ix, hipStream_t s, bool priv, SearchCtx **out) {
+    std::lock_guard<std::mutex> lk(ix->mu);
+    SearchCtx *cx = nullptr;
+    if (!priv)
+        for (SearchCtx *c : ix->ctxs)
+            if (c->keyed && !c->reserved && c->key == s) { cx = c; break; }
+    if (!cx)
+        for (SearchCtx *c : ix->ctxs)
+            if (!c->keyed && !c->reserved) { cx = c; break; }
+    if (!cx) {
+        rg_status st = new_ctx(&cx);
+        if (st != RG_OK) return st;
+        ix->ctxs.push_back(cx);
+    }
+    if (priv) {
+        if (!cx->own) {
+            if (hipStreamCreateWithFlags(&cx->own, hipStreamNonBlocking) != hipSuccess) return set_error(RG_ERR_DEVICE, "cannot create a stream");
+        }
+        cx->reserved = true;
+        cx->key = cx->own;
+    } else {
+        cx->key = s;
+    }
+    cx->keyed = true;
+    *out = cx;
+    return RG_OK;
+}
+
+static void release_ctx(rg_index *ix, SearchCtx *cx) {
+    std::lock_guard<std::mutex> lk(ix->mu);
+    if (cx->pending.empty()) { cx->keyed = false; cx->reserved = false; }
+}
+
+static rg_status take_batch(SearchCtx *cx, uint32_t nq, Batch **out) {
+    Batch *b = nullptr;
+    if (!cx->spare.empty()) { b = cx->spare.back(); cx->spare.pop_back(); }
+    else b = new Batch();
+    hipError_t e = hipSuccess;
+    if (!b->d_stat) e = hipMalloc(&b->d_stat, 64);
+    if (e == hipSuccess && !b->h_stat) e = hipHostMalloc(&b->h_stat, 64);
+    if (e == hipSuccess && b->ovf_cap < nq + 2) {
+        if (b->d_ovf) (void)hipFree(b->d_ovf);
+        b->d_ovf = nullptr; b->ovf_cap = 0;
+        e = hipMalloc(&b->d_ovf, ((size_t)nq + 2) * 4);
+        if (e == hipSuccess) b->ovf_cap = nq + 2;
+    }
+    if (e != hipSuccess) { free_batch(b); return set_error(RG_ERR_DEVICE, hipGetErrorString(e)); }
+    b->counted = b->timed = b->is_trial = false;
+    b->mode = 2;
+    *out = b;
+    return RG_OK;
+}
+
+// ---- launch planning ----------------------------------------------------------------------------------------------
 static uint32_t id_bits_of(uint32_t nd) {
     uint32_t b = 1;
     while (b < 32 && (1ull << b) < nd) ++b;
     return b;
 }
-static uint32_t filter_log2_of(const rg_index *ix) {  // remainder must fit 15 bits
+static uint32_t filter_log2_of(const rg_index *ix, int automatic) {  // remainder must fit 15 bits
     const uint32_t bits = id_bits_of(ix->nd);
-    uint32_t t = (uint32_t)std::max(4, std::min(14, ix->filter_log2 > 0 ? ix->filter_log2 : ix->filter_auto));
+    uint32_t t = (uint32_t)std::max(4, std::min(14, ix->filter_log2 > 0 ? ix->filter_log2 : automatic));
     if (bits > t + 15) t = bits - 15;
     return std::min(t, bits);
 }
@@ -806,72 +392,33 @@ static uint32_t filter_log2_of(const rg_index *ix) {  // remainder must fit 15 b
 static int dimc_of(const rg_index *ix) {
     return (ix->d_ell != nullptr && (ix->dim == 200 || ix->dim == 512) && !ix->query_in_lds) ? (int)ix->dim : 0;
 }
-static bool fast_bf16_on(const rg_index *ix) { return ix->bf_launch; }   // decided per launch in launch_k1
-static size_t stage_pass_floats(const rg_index *ix) {
-    return fast_bf16_on(ix) ? (size_t)((ix->dim + 127) / 128) * 256 : (size_t)((ix->dim + 63) / 64) * 256;
+static size_t stage_pass_floats(const rg_index *ix, bool bf) {
+    return bf ? (size_t)((ix->dim + 127) / 128) * 256 : (size_t)((ix->dim + 63) / 64) * 256;
 }
-static size_t stage_total_floats(const rg_index *ix, int R) {   // the fast mode's exact re-rank needs one fp32 pass
-    return std::max((size_t)R * stage_pass_floats(ix), (size_t)((ix->dim + 63) / 64) * 256);
+static size_t stage_total_floats(const rg_index *ix, int R, bool bf) {   // the fast mode's exact re-rank needs one fp32 pass
+    return std::max((size_t)R * stage_pass_floats(ix, bf), (size_t)((ix->dim + 63) / 64) * 256);
 }
-static size_t search_lds_bytes(const rg_index *ix, uint32_t L, int R) {
-    size_t b = stage_total_floats(ix, R) * 4 + (dimc_of(ix) ? 0 : (size_t)ix->dim * 4) + 64 * 4 + 64 * 4 + (size_t)L * 8;
-    if (ix->visited_mode != 0 || ix->exact_filter) b += 128 * 4 + std::max<size_t>(4, (size_t)2 << filter_log2_of(ix));
+static size_t search_lds_bytes(const rg_index *ix, uint32_t L, int R, int mode, bool bf, int filter_auto) {
+    size_t b = stage_total_floats(ix, R, bf) * 4 + (dimc_of(ix) ? 0 : (size_t)ix->dim * 4) + kCand * 4 + kCand * 4 + (size_t)L * 8;
+    if (mode != 0 || ix->exact_filter) b += 128 * 4 + std::max<size_t>(4, (size_t)2 << filter_log2_of(ix, filter_auto));
     return (b + 15) / 16 * 16;
 }
 
-static rg_status ensure_scratch(rg_index *ix, uint32_t slots) {
+static rg_status ensure_visited(rg_index *ix, SearchCtx *cx, uint32_t slots) {
     const uint32_t vwords = (ix->nd + 15) / 16;
-    if (ix->slots >= slots && ix->vwords == vwords) return RG_OK;
-    if (ix->d_visited) (void)hipFree(ix->d_visited);
-    if (ix->d_epoch) (void)hipFree(ix->d_epoch);
-    ix->d_visited = nullptr;
-    ix->d_epoch = nullptr;
-    ix->slots = 0;
-    RG_HIP(hipMalloc(&ix->d_visited, (size_t)slots * vwords * 4));
-    RG_HIP(hipMemset(ix->d_visited, 0, (size_t)slots * vwords * 4));
-    RG_HIP(hipMalloc(&ix->d_epoch, (size_t)slots * 4));
-    RG_HIP(hipMemset(ix->d_epoch, 0, (size_t)slots * 4));
-    ix->slots = slots;
-    ix->vwords = vwords;
+    if (cx->slots >= slots && cx->vwords == vwords) return RG_OK;
+    if (cx->d_visited) (void)hipFree(cx->d_visited);
+    if (cx->d_epoch) (void)hipFree(cx->d_epoch);
+    cx->d_visited = nullptr;
+    cx->d_epoch = nullptr;
+    cx->slots = 0;
+    RG_HIP(hipMalloc(&cx->d_visited, (size_t)slots * vwords * 4));
+    RG_HIP(hipMemset(cx->d_visited, 0, (size_t)slots * vwords * 4));
+    RG_HIP(hipMalloc(&cx->d_epoch, (size_t)slots * 4));
+    RG_HIP(hipMemset(cx->d_epoch, 0, (size_t)slots * 4));
+    cx->slots = slots;
+    cx->vwords = vwords;
     return RG_OK;
-}
-
-template <bool L2, bool ELL, int R, int VIS, int DIMC, bool BF = false>
-static rg_status launch_search_d(rg_index *ix, const SearchParams &P, uint32_t grid, size_t lds, hipStream_t s) {
-    auto kern = rg_search_kernel<L2, ELL, R, VIS, DIMC, BF>;
-    RG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(64), lds, s, P);
-    RG_HIP(hipGetLastError());
-    return RG_OK;
-}
-
-template <bool L2, bool ELL, int R, int VIS>
-static rg_status launch_search_v(rg_index *ix, const SearchParams &P, uint32_t grid, size_t lds, hipStream_t s) {
-    if constexpr (ELL) {
-        const int dc = dimc_of(ix);
-        if constexpr (R <= 2) {
-            if (P.base_bf && dc == 200) return launch_search_d<L2, ELL, R, VIS, 200, true>(ix, P, grid, lds, s);
-            if (P.base_bf && dc == 512) return launch_search_d<L2, ELL, R, VIS, 512, true>(ix, P, grid, lds, s);
-        }
-        if (dc == 200) return launch_search_d<L2, ELL, R, VIS, 200>(ix, P, grid, lds, s);
-        if (dc == 512) return launch_search_d<L2, ELL, R, VIS, 512>(ix, P, grid, lds, s);
-    }
-    return launch_search_d<L2, ELL, R, VIS, 0>(ix, P, grid, lds, s);
-}
-
-template <bool L2, bool ELL, int R>
-static rg_status launch_search_t(rg_index *ix, const SearchParams &P, uint32_t grid, size_t lds, hipStream_t s) {
-    return P.visited == nullptr ? launch_search_v<L2, ELL, R, 1>(ix, P, grid, lds, s)
-                                 : launch_search_v<L2, ELL, R, 0>(ix, P, grid, lds, s);
-}
-
-template <bool L2, bool ELL>
-static rg_status launch_search_r(rg_index *ix, const SearchParams &P, uint32_t grid, size_t lds, int R, hipStream_t s) {
-    switch (R) {
-        case 1: return launch_search_t<L2, ELL, 1>(ix, P, grid, lds, s);
-        case 2: return launch_search_t<L2, ELL, 2>(ix, P, grid, lds, s);
-        default: return launch_search_t<L2, ELL, 4>(ix, P, grid, lds, s);
-    }
 }
 
 struct BuildOut { uint2_pod *exp; uint32_t exp_cap, node0; uint32_t *nexp; };
@@ -880,10 +427,10 @@ static unsigned long long *g_prof_buf = nullptr;   // [nq][16], set through rg_p
 #endif
 
 // one K1 launch.  mode: 0 exact HBM visited words, 1 LDS filter (optionally logging the scored ids).
-static rg_status launch_k1(rg_index *ix, int mode, const float *d_q, uint32_t nq, uint32_t qstride, uint32_t k,
+static rg_status launch_k1(rg_index *ix, SearchCtx *cx, int mode, const float *d_q, uint32_t nq, uint32_t qstride, uint32_t k,
                            uint32_t L, uint32_t *d_ids, float *d_dists, uint32_t *d_cmps, uint32_t *d_hops,
-                           const uint32_t *qlist, bool with_log, hipStream_t s, const BuildOut *bp = nullptr,
-                           uint32_t qbase = 0) {
+                           const uint32_t *qlist, bool with_log, unsigned long long *d_status, hipStream_t s,
+                           const BuildOut *bp = nullptr, uint32_t qbase = 0) {
     // rows in flight per query: two passes of four pay on graphs with many fresh neighbours per hop (measured: +4 % at
     // out-degree 40, -4 % at 16, where the extra staging only costs resident queries)
     // A batch that leaves most wave slots empty is latency bound per query: LDS is plentiful then, so each query keeps
@@ -895,199 +442,247 @@ static rg_status launch_k1(rg_index *ix, int mode, const float *d_q, uint32_t nq
     if (R == 3) R = 2;
     // opt-in fast mode: plain top-k searches only (never the logging / recount / build launches)
     const bool bf = ix->fast_bf16 && ix->d_base_bf && dimc_of(ix) && !with_log && !bp && !qlist;
-    ix->bf_launch = bf;
     if (bf) R = std::min(R, 2);
-    const int saved_mode = ix->visited_mode;
-    ix->visited_mode = mode;  // search_lds_bytes() looks at it
     // LDS visited filter, automatic size: the largest of 2^12 .. 2^9 entries that still leaves 14 resident queries per
     // CU (on genuine indexes a forgetful filter re-scores up to 50 % more nodes; past that point the lost residency
     // costs more than the repeats -- scripts/exp/filter_real.py)
+    int filter_auto = 9;
     for (int f = 12; f >= 9; --f) {
-        ix->filter_auto = f;
-        if (f == 9 || ix->lds_per_cu / search_lds_bytes(ix, L, R) >= 14) break;
+        filter_auto = f;
+        if (f == 9 || ix->lds_per_cu / search_lds_bytes(ix, L, R, mode, bf, f) >= 14) break;
     }
-    size_t lds = search_lds_bytes(ix, L, R);
-    while (lds > ix->lds_per_cu && R > 1) { R >>= 1; lds = search_lds_bytes(ix, L, R); }
-    ix->visited_mode = saved_mode;
+    size_t lds = search_lds_bytes(ix, L, R, mode, bf, filter_auto);
+    while (lds > ix->lds_per_cu && R > 1) { R >>= 1; lds = search_lds_bytes(ix, L, R, mode, bf, filter_auto); }
     if (lds > ix->lds_per_cu) return set_error(RG_ERR_ARG, "L_pq too large for the 160 KiB LDS of one CU");
     int wpc = (int)std::min<size_t>(ix->lds_per_cu / lds, 32);
     if (ix->waves_per_cu > 0) wpc = std::min(wpc, ix->waves_per_cu);
     else wpc = std::min(wpc, 24);
-    const uint32_t grid = (uint32_t)std::min<uint64_t>(nq, (uint64_t)ix->num_cu * wpc);
+    K1Launch c;
+    c.R = R; c.vis = mode == 0 ? 0 : 1; c.dimc = dimc_of(ix); c.bf = bf; c.lds = lds;
+    c.grid = (uint32_t)std::min<uint64_t>(nq, (uint64_t)ix->num_cu * wpc);
     if (mode == 0) {
-        rg_status st = ensure_scratch(ix, grid);
+        rg_status st = ensure_visited(ix, cx, c.grid);
         if (st != RG_OK) return st;
     }
-    RG_HIP(hipMemsetAsync(ix->d_counter, 0, 4, s));
+    RG_HIP(hipMemsetAsync(cx->d_counter, 0, 4, s));
     SearchParams P;
     P.base = ix->d_base; P.stride = ix->stride; P.dim = ix->dim; P.nd = ix->nd;
     P.ell = ix->d_ell; P.ell_stride = ix->ell_stride; P.offsets = ix->d_offsets; P.nbrs = ix->d_nbrs;
     P.ep = ix->ep; P.queries = d_q; P.nq = nq; P.qstride = qstride; P.k = k; P.L = L;
     P.out_ids = d_ids; P.out_dists = d_dists; P.out_cmps = d_cmps; P.out_hops = d_hops;
-    P.visited = mode == 0 ? ix->d_visited : nullptr; P.vwords = ix->vwords; P.slot_epoch = ix->d_epoch;
-    P.counter = ix->d_counter; P.status = ix->d_status;
-    P.stage_floats = (uint32_t)stage_pass_floats(ix);
-    P.stage_total = (uint32_t)stage_total_floats(ix, R);
+    P.visited = mode == 0 ? cx->d_visited : nullptr; P.vwords = cx->vwords; P.slot_epoch = cx->d_epoch;
+    P.counter = cx->d_counter; P.status = d_status;
+    P.stage_floats = (uint32_t)stage_pass_floats(ix, bf);
+    P.stage_total = (uint32_t)stage_total_floats(ix, R, bf);
     P.base_bf = bf ? ix->d_base_bf : nullptr; P.stride_bf = ix->stride_bf;
     P.diag = (uint32_t)ix->diag;
     P.qbase = qbase;
-    P.vf_slots_log2 = filter_log2_of(ix);
+    P.vf_slots_log2 = filter_log2_of(ix, filter_auto);
     P.vf_front = (mode == 0 && ix->exact_filter) ? 1u : 0u;
     P.id_bits = id_bits_of(ix->nd);
-    P.qlog = with_log ? ix->d_qlog : nullptr; P.logcap = ix->logcap; P.qlog_n = with_log ? ix->d_qlog_n : nullptr;
+    P.qlog = with_log ? cx->d_qlog : nullptr; P.logcap = cx->logcap; P.qlog_n = with_log ? cx->d_qlog_n : nullptr;
     P.qlist = qlist;
+    P.spec = 0;
 #ifdef RG_K1_PROF
     P.prof = (qlist || bp) ? nullptr : g_prof_buf;
 #endif
     P.out_exp = nullptr; P.exp_cap = 0; P.tgt_base = 0; P.out_nexp = nullptr;
     if (bp) { P.out_exp = reinterpret_cast<uint2 *>(bp->exp); P.exp_cap = bp->exp_cap; P.tgt_base = bp->node0; P.out_nexp = bp->nexp; }
     const bool l2 = ix->metric == RG_METRIC_L2, ell = ix->d_ell != nullptr;
-    if (l2 && ell) return launch_search_r<true, true>(ix, P, grid, lds, R, s);
-    if (l2) return launch_search_r<true, false>(ix, P, grid, lds, R, s);
-    if (ell) return launch_search_r<false, true>(ix, P, grid, lds, R, s);
-    return launch_search_r<false, false>(ix, P, grid, lds, R, s);
+    if (l2 && ell) return launch_search_l2_ell(P, c, s);
+    if (l2) return launch_search_l2_csr(P, c, s);
+    if (ell) return launch_search_ip_ell(P, c, s);
+    return launch_search_ip_csr(P, c, s);
 }
 
-static rg_status ensure_qlog(rg_index *ix, uint32_t nq) {
+static rg_status ensure_qlog(rg_index *ix, SearchCtx *cx, uint32_t nq) {
     // per-query id log: 128K ids (512 KiB) each; a batch larger than the log budget allows is searched in sub-batches
     // that reuse the same logs (search_dev).  Longer logs take the exact fallback pass.
     uint32_t cap = 1u << 17;
     if (ix->log_cap_knob > 0) cap = (uint32_t)ix->log_cap_knob;
     const size_t budget = (size_t)std::max(1, ix->log_budget_kb) << 10;
     const uint32_t chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(nq, budget / ((size_t)cap * 4)));
-    if (ix->d_qlog && ix->qlog_nq >= chunk && ix->logcap == cap && ix->ovf_nq >= nq) { ix->qlog_chunk = chunk; return RG_OK; }
-    if (ix->d_qlog) (void)hipFree(ix->d_qlog);
-    if (ix->d_qlog_n) (void)hipFree(ix->d_qlog_n);
-    if (ix->d_ovf) (void)hipFree(ix->d_ovf);
-    ix->d_qlog = ix->d_qlog_n = ix->d_ovf = nullptr;
-    ix->qlog_nq = ix->ovf_nq = 0;
-    RG_HIP(hipMalloc(&ix->d_qlog, (size_t)chunk * cap * 4));
-    RG_HIP(hipMalloc(&ix->d_qlog_n, (size_t)chunk * 4));
-    RG_HIP(hipMalloc(&ix->d_ovf, ((size_t)nq + 2) * 4));   // [0] = count, [1] = K4 work counter, then the list
-    ix->qlog_nq = chunk;
-    ix->qlog_chunk = chunk;
-    ix->ovf_nq = nq;
-    ix->logcap = cap;
+    if (cx->d_qlog && cx->qlog_nq >= chunk && cx->logcap == cap) { cx->qlog_chunk = chunk; return RG_OK; }
+    if (cx->d_qlog) (void)hipFree(cx->d_qlog);
+    if (cx->d_qlog_n) (void)hipFree(cx->d_qlog_n);
+    cx->d_qlog = cx->d_qlog_n = nullptr;
+    cx->qlog_nq = 0;
+    RG_HIP(hipMalloc(&cx->d_qlog, (size_t)chunk * cap * 4));
+    RG_HIP(hipMalloc(&cx->d_qlog_n, (size_t)chunk * 4));
+    cx->qlog_nq = chunk;
+    cx->qlog_chunk = chunk;
+    cx->logcap = cap;
     return RG_OK;
 }
 
-static rg_status search_dev(rg_index *ix, const float *d_q, uint32_t nq, uint32_t qstride, uint32_t k, uint32_t L,
+static rg_status finish_batches(rg_index *ix, SearchCtx *cx, hipStream_t s, uint32_t k);
+
+// enqueue one batch on `s` (no synchronisation); the batch record joins cx->pending
+static rg_status search_dev(rg_index *ix, SearchCtx *cx, const float *d_q, uint32_t nq, uint32_t qstride, uint32_t k, uint32_t L,
                             uint32_t *d_ids, float *d_dists, uint32_t *d_cmps, uint32_t *d_hops, hipStream_t s) {
-    if (!ix) return set_error(RG_ERR_ARG, "null index");
-    if (k > L) return set_error(RG_ERR_ARG, "L_pq must greater or equal than k");  // test_search_roargraph.cpp:192-195
-    if (k == 0 || L == 0) return set_error(RG_ERR_ARG, "k and L_pq must be positive");
-    if (qstride < ix->dim) return set_error(RG_ERR_ARG, "query stride smaller than the index dimension");
-    if (nq == 0) return RG_OK;
-    RG_HIP(hipSetDevice(ix->device));
-    RG_HIP(hipMemsetAsync(ix->d_status, 0xff, 8, s));
-    ix->pending.active = false;
+    // a caller that never waits must not pile up batch records: collect the finished ones first (errors stay deferred)
+    if (cx->pending.size() >= 32) {
+        rg_status st = finish_batches(ix, cx, s, 0);
+        if (st != RG_OK && st != RG_ERR_NOT_ENOUGH) return st;
+    }
+    Batch *b = nullptr;
+    rg_status st = take_batch(cx, nq, &b);
+    if (st != RG_OK) return st;
+    auto fail = [&](rg_status e) { cx->spare.push_back(b); return e; };
+    b->q = d_q; b->nq = nq; b->qstride = qstride; b->k = k; b->L = L;
+    b->ids = d_ids; b->dists = d_dists; b->cmps = d_cmps; b->hops = d_hops;
+    if (hipMemsetAsync(b->d_stat, 0xff, 8, s) != hipSuccess || hipMemsetAsync(b->d_stat + 1, 0, 16, s) != hipSuccess)
+        return fail(set_error(RG_ERR_DEVICE, "hipMemsetAsync failed"));
     const bool fast = ix->fast_bf16 && ix->d_base_bf && dimc_of(ix);
-    bool exact_count = ix->visited_mode == 2 && d_cmps != nullptr && !fast;
+    const bool exact_count = ix->visited_mode == 2 && d_cmps != nullptr && !fast;
+    uint32_t exact_from_L, trial_L;
+    {
+        std::lock_guard<std::mutex> lk(ix->mu);
+        exact_from_L = ix->exact_from_L;
+        trial_L = ix->trial_L;
+    }
+    auto done = [&]() -> rg_status {
+        b->h_stat[3] = 0;
+        if (hipMemcpyAsync(b->h_stat, b->d_stat, 24, hipMemcpyDeviceToHost, s) != hipSuccess)
+            return fail(set_error(RG_ERR_DEVICE, "hipMemcpyAsync failed"));
+        if (b->counted && hipMemcpyAsync(b->h_stat + 3, b->d_ovf, 4, hipMemcpyDeviceToHost, s) != hipSuccess)
+            return fail(set_error(RG_ERR_DEVICE, "hipMemcpyAsync failed"));
+        std::lock_guard<std::mutex> lk(ix->mu);
+        cx->pending.push_back(b);
+        return RG_OK;
+    };
     // fast mode under the default visited mode: the exact words from the beam width on at which the parity batches (if
     // there were any) found them faster, the LDS filter alone below it; "visited" 0 / 1 force one or the other
-    if (fast && ix->visited_mode == 2 && L >= ix->exact_from_L)
-        return launch_k1(ix, 0, d_q, nq, qstride, k, L, d_ids, d_dists, d_cmps, d_hops, nullptr, false, s);
+    if (fast && ix->visited_mode == 2 && L >= exact_from_L) {
+        st = launch_k1(ix, cx, 0, d_q, nq, qstride, k, L, d_ids, d_dists, d_cmps, d_hops, nullptr, false, b->d_stat, s);
+        return st == RG_OK ? done() : fail(st);
+    }
     // Adaptive default: both exact forms return the same bits.  When a batch showed the LDS filter re-scoring nodes
     // wholesale at this beam width (performed > 1.3 x distinct: long searches on indexes with locality), the next batch
     // of that width runs on the exact HBM words as a timed trial; the faster form is kept from that width on (which one
     // wins depends on the index: the words of a 10M-node index are 10 GB of random atomics, those of a 2M-node index
     // mostly cache resident -- scripts/exp/visited_modes_real.py).
-    ix->tune.timed = false;
-    if (exact_count && ix->filter_log2 <= 0 && ix->tune.ev0) {
-        const bool trial = ix->tune.trial_L == L && nq >= 1000;
-        ix->tune.timed = true; ix->tune.mode = (L >= ix->exact_from_L || trial) ? 0 : 2; ix->tune.L = L; ix->tune.nq = nq;
-        ix->tune.is_trial = trial && L < ix->exact_from_L;
-        RG_HIP(hipEventRecord(ix->tune.ev0, s));
-        if (ix->tune.mode == 0) {
-            rg_status st0 = launch_k1(ix, 0, d_q, nq, qstride, k, L, d_ids, d_dists, d_cmps, d_hops, nullptr, false, s);
-            if (st0 == RG_OK) RG_HIP(hipEventRecord(ix->tune.ev1, s));
-            return st0;
+    if (exact_count && ix->filter_log2 <= 0) {
+        if (!b->ev0 && (hipEventCreate(&b->ev0) != hipSuccess || hipEventCreate(&b->ev1) != hipSuccess))
+            return fail(set_error(RG_ERR_DEVICE, "hipEventCreate failed"));
+        const bool trial = trial_L == L && nq >= 1000;
+        b->timed = true;
+        b->mode = (L >= exact_from_L || trial) ? 0 : 2;
+        b->is_trial = trial && L < exact_from_L;
+        (void)hipEventRecord(b->ev0, s);
+        if (b->mode == 0) {
+            st = launch_k1(ix, cx, 0, d_q, nq, qstride, k, L, d_ids, d_dists, d_cmps, d_hops, nullptr, false, b->d_stat, s);
+            if (st != RG_OK) return fail(st);
+            (void)hipEventRecord(b->ev1, s);
+            return done();
         }
     }
-    if (exact_count) RG_HIP(hipMemsetAsync(ix->d_status + 1, 0, 16, s));
-    if (!exact_count)
-        return launch_k1(ix, ix->visited_mode == 0 ? 0 : 1, d_q, nq, qstride, k, L, d_ids, d_dists, d_cmps, d_hops, nullptr, false, s);
+    if (!exact_count) {
+        st = launch_k1(ix, cx, ix->visited_mode == 0 ? 0 : 1, d_q, nq, qstride, k, L, d_ids, d_dists, d_cmps, d_hops, nullptr, false,
+                       b->d_stat, s);
+        return st == RG_OK ? done() : fail(st);
+    }
     // mode 2: LDS-filter search with id log, then the exact distinct count (K4); overflowed logs are re-counted by an
     // exact pass inside rg_search_wait
-    rg_status st = ensure_qlog(ix, nq);
-    if (st != RG_OK) return st;
-    RG_HIP(hipMemsetAsync(ix->d_ovf, 0, 8, s));
+    st = ensure_qlog(ix, cx, nq);
+    if (st != RG_OK) return fail(st);
+    if (hipMemsetAsync(b->d_ovf, 0, 8, s) != hipSuccess) return fail(set_error(RG_ERR_DEVICE, "hipMemsetAsync failed"));
     // default table: 2^15 words = 128 KiB of LDS (+ 16 KiB side table in the half-word form)
     const uint32_t tbits = (uint32_t)std::max(6, std::min(15, ix->count_table_log2));
     const uint32_t bbits = tbits - 2u;
     const uint32_t id_bits = std::max(id_bits_of(ix->nd), bbits + 1u);
     const bool half = id_bits - bbits <= 15u && !ix->count_full_ids;
     const size_t lds = half ? ((size_t)4 << tbits) + ((size_t)4 << (tbits - 3u)) : (size_t)4 << tbits;
-    for (uint32_t q0 = 0; q0 < nq; q0 += ix->qlog_chunk) {
-        const uint32_t nqc = std::min(ix->qlog_chunk, nq - q0);
-        if (q0) RG_HIP(hipMemsetAsync(ix->d_ovf + 1, 0, 4, s));   // K4 work counter; the overflow count keeps running
-        st = launch_k1(ix, 1, d_q + (size_t)q0 * qstride, nqc, qstride, k, L, d_ids ? d_ids + (size_t)q0 * k : nullptr,
-                       d_dists ? d_dists + (size_t)q0 * k : nullptr, d_cmps + q0, d_hops ? d_hops + q0 : nullptr, nullptr, true, s,
-                       nullptr, q0);
-        if (st != RG_OK) return st;
+    for (uint32_t q0 = 0; q0 < nq; q0 += cx->qlog_chunk) {
+        const uint32_t nqc = std::min(cx->qlog_chunk, nq - q0);
+        if (q0) (void)hipMemsetAsync(b->d_ovf + 1, 0, 4, s);   // K4 work counter; the overflow count keeps running
+        st = launch_k1(ix, cx, 1, d_q + (size_t)q0 * qstride, nqc, qstride, k, L, d_ids ? d_ids + (size_t)q0 * k : nullptr,
+                       d_dists ? d_dists + (size_t)q0 * k : nullptr, d_cmps + q0, d_hops ? d_hops + q0 : nullptr, nullptr, true,
+                       b->d_stat, s, nullptr, q0);
+        if (st != RG_OK) return fail(st);
         const dim3 grid(std::min<uint32_t>(nqc, (uint32_t)ix->num_cu));
         if (half) {
             auto kern = rg_distinct_kernel<true>;
-            RG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(kern, grid, dim3(1024), lds, s, ix->d_qlog, ix->logcap, ix->d_qlog_n, nqc, d_cmps + q0, ix->d_ovf + 2,
-                               ix->d_ovf, ix->d_ovf + 1, tbits, id_bits, q0, ix->d_status + 1);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(kern, grid, dim3(1024), lds, s, cx->d_qlog, cx->logcap, cx->d_qlog_n, nqc, d_cmps + q0, b->d_ovf + 2,
+                               b->d_ovf, b->d_ovf + 1, tbits, id_bits, q0, b->d_stat + 1);
         } else {
             auto kern = rg_distinct_kernel<false>;
-            RG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            hipLaunchKernelGGL(kern, grid, dim3(1024), lds, s, ix->d_qlog, ix->logcap, ix->d_qlog_n, nqc, d_cmps + q0, ix->d_ovf + 2,
-                               ix->d_ovf, ix->d_ovf + 1, tbits, id_bits, q0, ix->d_status + 1);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            hipLaunchKernelGGL(kern, grid, dim3(1024), lds, s, cx->d_qlog, cx->logcap, cx->d_qlog_n, nqc, d_cmps + q0, b->d_ovf + 2,
+                               b->d_ovf, b->d_ovf + 1, tbits, id_bits, q0, b->d_stat + 1);
         }
     }
-    RG_HIP(hipGetLastError());
-    if (ix->tune.timed) RG_HIP(hipEventRecord(ix->tune.ev1, s));
-    ix->pending.active = true;
-    ix->pending.q = d_q; ix->pending.nq = nq; ix->pending.qstride = qstride; ix->pending.k = k; ix->pending.L = L;
-    ix->pending.ids = d_ids; ix->pending.dists = d_dists; ix->pending.cmps = d_cmps; ix->pending.hops = d_hops;
+    if (hipGetLastError() != hipSuccess) return fail(set_error(RG_ERR_DEVICE, "K4 launch failed"));
+    if (b->timed) (void)hipEventRecord(b->ev1, s);
+    b->counted = true;
+    return done();
+}
+
+// synchronise `s` and finish every batch pending on the context, in order: adaptive-mode bookkeeping, the exact recount
+// of overflowed id logs, and the first deferred "not enough results" (index_bipartite.cpp:2408-2412)
+static rg_status finish_batches(rg_index *ix, SearchCtx *cx, hipStream_t s, uint32_t k) {
+    std::vector<Batch *> todo;
+    {
+        std::lock_guard<std::mutex> lk(ix->mu);
+        todo.swap(cx->pending);
+    }
+    RG_HIP(hipStreamSynchronize(s));
+    rg_status first = RG_OK;
+    std::string first_msg;
+    for (Batch *b : todo) {
+        const unsigned long long v = b->h_stat[0];
+        float per_q = 0.0f;   // time per query of the batch (adaptive default only)
+        if (b->timed) {
+            float ms = 0.0f;
+            if (hipEventElapsedTime(&ms, b->ev0, b->ev1) == hipSuccess && b->nq) per_q = ms / (float)b->nq;
+            std::lock_guard<std::mutex> lk(ix->mu);
+            if (b->mode == 0 && b->is_trial && per_q > 0.0f) {   // verdict of the trial
+                if (per_q < 0.97f * ix->filter_per_q) ix->exact_from_L = std::min(ix->exact_from_L, b->L);
+                else ix->filter_ok_upto = std::max(ix->filter_ok_upto, b->L);
+                if (ix->trial_L == b->L) ix->trial_L = 0;
+            }
+        }
+        if (b->counted) {
+            const unsigned long long performed = b->h_stat[1], distinct = b->h_stat[2];
+            {
+                std::lock_guard<std::mutex> lk(ix->mu);
+                if (distinct > 0 && (double)performed > 1.3 * (double)distinct && per_q > 0.0f && b->nq >= 1000 &&
+                    b->L > ix->filter_ok_upto && b->L < ix->exact_from_L) {
+                    ix->trial_L = b->L;      // next batch of this width: the exact words, timed
+                    ix->filter_per_q = per_q;
+                }
+            }
+            const uint32_t novf = (uint32_t)(b->h_stat[3] & 0xffffffffu);
+            if (novf > 0 && v == ~0ull && first == RG_OK) {
+                // logs that did not fit: recount those queries with the exact HBM visited words (only cmps is rewritten)
+                rg_status st = launch_k1(ix, cx, 0, b->q, novf, b->qstride, b->k, b->L, b->ids, b->dists, b->cmps, b->hops, b->d_ovf + 2,
+                                         false, cx->d_scratch_stat, s);
+                if (st == RG_OK && hipStreamSynchronize(s) != hipSuccess) st = set_error(RG_ERR_DEVICE, "recount pass failed");
+                if (st != RG_OK) { first = st; first_msg = rg_last_error(); }
+            }
+        }
+        if (v != ~0ull && first == RG_OK) {
+            char buf[160];
+            const uint32_t kk = k ? k : b->k;
+            snprintf(buf, sizeof buf, "not enough results: %u, expected: %u (query %u)", (unsigned)(v & 0xffffffffu), kk, (unsigned)(v >> 32));
+            first = RG_ERR_NOT_ENOUGH;
+            first_msg = buf;
+        }
+    }
+    {
+        std::lock_guard<std::mutex> lk(ix->mu);
+        for (Batch *b : todo) cx->spare.push_back(b);
+    }
+    if (first != RG_OK) return set_error(first, first_msg);
     return RG_OK;
 }
 
-static rg_status search_wait(rg_index *ix, hipStream_t s, uint32_t k) {
-    RG_HIP(hipMemcpyAsync(ix->h_status, ix->d_status, 8, hipMemcpyDeviceToHost, s));
-    if (ix->pending.active) {
-        RG_HIP(hipMemcpyAsync(ix->h_status + 1, ix->d_ovf, 4, hipMemcpyDeviceToHost, s));
-        RG_HIP(hipMemcpyAsync(ix->h_status + 2, ix->d_status + 1, 16, hipMemcpyDeviceToHost, s));
-    }
-    RG_HIP(hipStreamSynchronize(s));
-    const unsigned long long v = *ix->h_status;
-    float per_q = 0.0f;   // time per query of the batch just finished (adaptive default only)
-    if (ix->tune.timed) {
-        float ms = 0.0f;
-        if (hipEventElapsedTime(&ms, ix->tune.ev0, ix->tune.ev1) == hipSuccess && ix->tune.nq) per_q = ms / (float)ix->tune.nq;
-        ix->tune.timed = false;
-        if (ix->tune.mode == 0 && ix->tune.is_trial && per_q > 0.0f) {   // verdict of the trial
-            if (per_q < 0.97f * ix->tune.filter_per_q) ix->exact_from_L = std::min(ix->exact_from_L, ix->tune.L);
-            else ix->tune.filter_ok_upto = std::max(ix->tune.filter_ok_upto, ix->tune.L);
-            ix->tune.trial_L = 0;
-        }
-    }
-    if (ix->pending.active) {
-        ix->pending.active = false;
-        const unsigned long long performed = ix->h_status[2], distinct = ix->h_status[3];
-        if (distinct > 0 && (double)performed > 1.3 * (double)distinct && per_q > 0.0f && ix->pending.nq >= 1000 &&
-            ix->pending.L > ix->tune.filter_ok_upto && ix->pending.L < ix->exact_from_L) {
-            ix->tune.trial_L = ix->pending.L;      // next batch of this width: the exact words, timed
-            ix->tune.filter_per_q = per_q;
-        }
-        const uint32_t novf = (uint32_t)(ix->h_status[1] & 0xffffffffu);
-        if (novf > 0 && v == ~0ull) {
-            // logs that did not fit: recount those queries with the exact HBM visited words (only cmps is rewritten)
-            const auto &pd = ix->pending;
-            rg_status st = launch_k1(ix, 0, pd.q, novf, pd.qstride, pd.k, pd.L, pd.ids, pd.dists, pd.cmps, pd.hops, ix->d_ovf + 2, false, s);
-            if (st != RG_OK) return st;
-            RG_HIP(hipStreamSynchronize(s));
-        }
-    }
-    if (v != ~0ull) {
-        char buf[160];
-        if (k) snprintf(buf, sizeof buf, "not enough results: %u, expected: %u (query %u)", (unsigned)(v & 0xffffffffu), k, (unsigned)(v >> 32));
-        else snprintf(buf, sizeof buf, "not enough results: %u (query %u)", (unsigned)(v & 0xffffffffu), (unsigned)(v >> 32));
-        return set_error(RG_ERR_NOT_ENOUGH, buf);
-    }
+static rg_status check_search_args(const rg_index *ix, uint32_t qstride, uint32_t k, uint32_t L) {
+    if (!ix) return set_error(RG_ERR_ARG, "null index");
+    if (k > L) return set_error(RG_ERR_ARG, "L_pq must greater or equal than k");  // test_search_roargraph.cpp:192-195
+    if (k == 0 || L == 0) return set_error(RG_ERR_ARG, "k and L_pq must be positive");
+    if (qstride < ix->dim) return set_error(RG_ERR_ARG, "query stride smaller than the index dimension");
     return RG_OK;
 }
 
@@ -1114,11 +709,14 @@ rg_status build_search_dev(rg_index *ix, uint32_t node0, uint32_t n, uint32_t L,
     if (n == 0) return RG_OK;
     if ((uint64_t)node0 + n > ix->nd) return set_error(RG_ERR_ARG, "node range out of bounds");
     RG_HIP(hipSetDevice(ix->device));
-    RG_HIP(hipMemsetAsync(ix->d_status, 0xff, 8, (hipStream_t)stream));
+    // the build drives one stream from one thread: its context stays keyed to that stream for the life of the index
+    SearchCtx *cx = nullptr;
+    rg_status st = acquire_ctx(ix, (hipStream_t)stream, false, &cx);
+    if (st != RG_OK) return st;
     BuildOut bo{d_exp, exp_cap, node0, d_nexp};
     // queries are the base rows themselves; k = 1 (no top-k is written in build mode)
-    return launch_k1(ix, 1, ix->d_base + (size_t)node0 * ix->stride, n, ix->stride, 1, L, nullptr, nullptr, nullptr, nullptr,
-                     nullptr, false, (hipStream_t)stream, &bo);
+    return launch_k1(ix, cx, 1, ix->d_base + (size_t)node0 * ix->stride, n, ix->stride, 1, L, nullptr, nullptr, nullptr, nullptr,
+                     nullptr, false, cx->d_scratch_stat, (hipStream_t)stream, &bo);
 }
 
 rg_status build_index_create(const float *d_base, uint32_t nd, uint32_t dim, uint32_t stride, uint32_t ep, int metric,
@@ -1134,9 +732,6 @@ rg_status build_index_create(const float *d_base, uint32_t nd, uint32_t dim, uin
     ix->max_deg = ell_stride - 1;
     hipError_t e = hipMalloc(&ix->d_ell, (size_t)nd * ell_stride * 4);
     if (e == hipSuccess) e = hipMemset(ix->d_ell, 0, (size_t)nd * ell_stride * 4);
-    if (e == hipSuccess) e = hipMalloc(&ix->d_counter, 64);
-    if (e == hipSuccess) e = hipMalloc(&ix->d_status, 64);
-    if (e == hipSuccess) e = hipHostMalloc(&ix->h_status, 64);
     hipDeviceProp_t prop;
     if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
     if (e != hipSuccess) { rg_index_close(ix); return set_error(RG_ERR_DEVICE, hipGetErrorString(e)); }
@@ -1151,7 +746,61 @@ rg_status build_index_set_ell(rg_index *ix, const uint32_t *h_ell, void *stream)
     return RG_OK;
 }
 
+// host-form search in two halves (rg_search: one index; rg_search_sharded: one per replica, all in flight together)
+struct HostSearch {
+    rg_index *ix = nullptr;
+    SearchCtx *cx = nullptr;
+    uint32_t lo = 0, n = 0;
+};
+
+static rg_status host_search_begin(rg_index *ix, const float *hq, uint32_t n, uint32_t d, uint32_t k, uint32_t L, HostSearch *hs) {
+    hs->ix = ix; hs->n = n;
+    if (n == 0) return RG_OK;
+    RG_HIP(hipSetDevice(ix->device));
+    rg_status st = acquire_ctx(ix, nullptr, true, &hs->cx);
+    if (st != RG_OK) return st;
+    SearchCtx *cx = hs->cx;
+    const size_t qn = (size_t)n * d, rn = (size_t)n * k, cn = (size_t)n * 2;
+    if (cx->q_cap < qn) { if (cx->d_q) (void)hipFree(cx->d_q); cx->d_q = nullptr; cx->q_cap = 0; RG_HIP(hipMalloc(&cx->d_q, qn * 4)); cx->q_cap = qn; }
+    if (cx->res_cap < rn) {
+        if (cx->d_ids) (void)hipFree(cx->d_ids);
+        if (cx->d_dist) (void)hipFree(cx->d_dist);
+        cx->d_ids = nullptr; cx->d_dist = nullptr; cx->res_cap = 0;
+        RG_HIP(hipMalloc(&cx->d_ids, rn * 4));
+        RG_HIP(hipMalloc(&cx->d_dist, rn * 4));
+        cx->res_cap = rn;
+    }
+    if (cx->ch_cap < cn) { if (cx->d_ch) (void)hipFree(cx->d_ch); cx->d_ch = nullptr; cx->ch_cap = 0; RG_HIP(hipMalloc(&cx->d_ch, cn * 4)); cx->ch_cap = cn; }
+    hipStream_t s = cx->own;
+    RG_HIP(hipMemcpyAsync(cx->d_q, hq, qn * 4, hipMemcpyHostToDevice, s));
+    RG_HIP(hipMemsetAsync(cx->d_ids, 0, rn * 4, s));
+    RG_HIP(hipMemsetAsync(cx->d_dist, 0, rn * 4, s));
+    return search_dev(ix, cx, cx->d_q, n, d, k, L, cx->d_ids, cx->d_dist, cx->d_ch, cx->d_ch + n, s);
+}
+
+static rg_status host_search_end(HostSearch *hs, uint32_t k, uint32_t *out_ids, float *out_dists, uint32_t *out_cmps, uint32_t *out_hops) {
+    if (!hs->cx) return RG_OK;
+    rg_index *ix = hs->ix;
+    SearchCtx *cx = hs->cx;
+    (void)hipSetDevice(ix->device);
+    rg_status st = finish_batches(ix, cx, cx->own, k);
+    if (st == RG_OK || st == RG_ERR_NOT_ENOUGH) {
+        const std::string msg = st != RG_OK ? rg_last_error() : "";
+        const uint32_t n = hs->n;
+        (void)hipMemcpy(out_ids, cx->d_ids, (size_t)n * k * 4, hipMemcpyDeviceToHost);
+        (void)hipMemcpy(out_dists, cx->d_dist, (size_t)n * k * 4, hipMemcpyDeviceToHost);
+        if (out_cmps) (void)hipMemcpy(out_cmps, cx->d_ch, (size_t)n * 4, hipMemcpyDeviceToHost);
+        if (out_hops) (void)hipMemcpy(out_hops, cx->d_ch + n, (size_t)n * 4, hipMemcpyDeviceToHost);
+        if (st != RG_OK) set_error(st, msg);
+    }
+    release_ctx(ix, cx);
+    hs->cx = nullptr;
+    return st;
+}
+
 }  // namespace rg
+
+using rg::set_error;
 
 extern "C" {
 
@@ -1168,21 +817,13 @@ int rg_device_count(void) {
 void rg_index_close(rg_index *ix) {
     if (!ix) return;
     (void)hipSetDevice(ix->device);
+    (void)hipDeviceSynchronize();
+    for (rg::SearchCtx *cx : ix->ctxs) rg::free_ctx(cx);
     if (ix->own_base && ix->d_base) (void)hipFree(ix->d_base);
     if (ix->d_offsets) (void)hipFree(ix->d_offsets);
     if (ix->d_nbrs) (void)hipFree(ix->d_nbrs);
     if (ix->d_ell) (void)hipFree(ix->d_ell);
-    if (ix->d_visited) (void)hipFree(ix->d_visited);
-    if (ix->d_epoch) (void)hipFree(ix->d_epoch);
-    if (ix->d_qlog) (void)hipFree(ix->d_qlog);
-    if (ix->d_qlog_n) (void)hipFree(ix->d_qlog_n);
     if (ix->d_base_bf) (void)hipFree(ix->d_base_bf);
-    if (ix->d_ovf) (void)hipFree(ix->d_ovf);
-    if (ix->d_counter) (void)hipFree(ix->d_counter);
-    if (ix->d_status) (void)hipFree(ix->d_status);
-    if (ix->h_status) (void)hipHostFree(ix->h_status);
-    if (ix->tune.ev0) (void)hipEventDestroy(ix->tune.ev0);
-    if (ix->tune.ev1) (void)hipEventDestroy(ix->tune.ev1);
     delete ix;
 }
 
@@ -1283,6 +924,8 @@ rg_status rg_index_set(rg_index *ix, const char *name, int value) {
     else if (!strcmp(name, "log_budget_kb")) ix->log_budget_kb = value;
     else if (!strcmp(name, "query_in_lds")) ix->query_in_lds = value != 0;
     else if (!strcmp(name, "exact_filter")) ix->exact_filter = value != 0;
+    else if (!strcmp(name, "spec")) ix->spec = value;
+    else if (!strcmp(name, "multi_expand")) ix->multi_expand = value;
     else if (!strcmp(name, "fast_bf16")) {
         // opt-in, NOT parity (see rg.h): the bf16 copy of the base is made on first use
         if (value && !ix->d_base_bf) {
@@ -1304,44 +947,62 @@ rg_status rg_index_set(rg_index *ix, const char *name, int value) {
 
 rg_status rg_search_dev(rg_index *ix, const float *d_queries, uint32_t nq, uint32_t qstride, uint32_t k, uint32_t L_pq,
                         uint32_t *d_ids, float *d_dists, uint32_t *d_cmps, uint32_t *d_hops, void *stream) {
-    return rg::search_dev(ix, d_queries, nq, qstride, k, L_pq, d_ids, d_dists, d_cmps, d_hops, (hipStream_t)stream);
+    rg_status st = rg::check_search_args(ix, qstride, k, L_pq);
+    if (st != RG_OK) return st;
+    if (nq == 0) return RG_OK;
+    RG_HIP(hipSetDevice(ix->device));
+    rg::SearchCtx *cx = nullptr;
+    st = rg::acquire_ctx(ix, (hipStream_t)stream, false, &cx);
+    if (st != RG_OK) return st;
+    st = rg::search_dev(ix, cx, d_queries, nq, qstride, k, L_pq, d_ids, d_dists, d_cmps, d_hops, (hipStream_t)stream);
+    if (st != RG_OK) rg::release_ctx(ix, cx);
+    return st;
 }
 
 rg_status rg_search_wait(rg_index *ix, void *stream) {
     if (!ix) return set_error(RG_ERR_ARG, "null index");
-    return rg::search_wait(ix, (hipStream_t)stream, 0);
+    RG_HIP(hipSetDevice(ix->device));
+    rg::SearchCtx *cx = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(ix->mu);
+        for (rg::SearchCtx *c : ix->ctxs)
+            if (c->keyed && !c->reserved && c->key == (hipStream_t)stream) { cx = c; break; }
+    }
+    if (!cx) {   // nothing in flight on this stream
+        RG_HIP(hipStreamSynchronize((hipStream_t)stream));
+        return RG_OK;
+    }
+    rg_status st = rg::finish_batches(ix, cx, (hipStream_t)stream, 0);
+    const std::string msg = st != RG_OK ? rg_last_error() : "";
+    rg::release_ctx(ix, cx);
+    if (st != RG_OK) return set_error(st, msg);
+    return RG_OK;
+}
+
+// queries -> the index stride, zero padded; cosine queries normalised (test_search_roargraph.cpp:167-172)
+static void stage_queries(const rg_index *ix, const float *queries, uint32_t nq, uint32_t qstride, std::vector<float> &hq) {
+    const uint32_t d = ix->dim, use = std::min(qstride, d);
+    hq.assign((size_t)nq * d, 0.0f);
+    for (size_t i = 0; i < nq; ++i) std::memcpy(hq.data() + i * d, queries + i * (size_t)qstride, (size_t)use * 4);
+    if (ix->metric == RG_METRIC_COSINE) rg_normalize_rows(hq.data(), nq, d, d);
 }
 
 rg_status rg_search(rg_index *ix, const float *queries, uint32_t nq, uint32_t qstride, uint32_t k, uint32_t L_pq,
                     uint32_t *out_ids, float *out_dists, uint32_t *out_cmps, uint32_t *out_hops) {
     if (!ix || !queries || !out_ids || !out_dists) return set_error(RG_ERR_ARG, "null argument");
     if (k > L_pq) return set_error(RG_ERR_ARG, "L_pq must greater or equal than k");
+    if (k == 0) return set_error(RG_ERR_ARG, "k and L_pq must be positive");
     if (nq == 0) return RG_OK;
-    RG_HIP(hipSetDevice(ix->device));
-    // queries -> device at the index stride, zero padded; cosine queries normalised (test_search_roargraph.cpp:167-172)
-    const uint32_t d = ix->dim;
-    const uint32_t use = std::min(qstride, d);
-    std::vector<float> hq((size_t)nq * d, 0.0f);
-    for (size_t i = 0; i < nq; ++i) std::memcpy(hq.data() + i * d, queries + i * (size_t)qstride, (size_t)use * 4);
-    if (ix->metric == RG_METRIC_COSINE) rg_normalize_rows(hq.data(), nq, d, d);
-    rg::DevBuf<float> d_q, d_dist;
-    rg::DevBuf<uint32_t> d_ids, d_ch;
-    RG_HIP(d_q.alloc(hq.size()));
-    RG_HIP(d_ids.alloc((size_t)nq * k));
-    RG_HIP(d_dist.alloc((size_t)nq * k));
-    RG_HIP(d_ch.alloc((size_t)nq * 2));
-    RG_HIP(hipMemcpy(d_q.p, hq.data(), hq.size() * 4, hipMemcpyHostToDevice));
-    RG_HIP(hipMemset(d_ids.p, 0, (size_t)nq * k * 4));
-    RG_HIP(hipMemset(d_dist.p, 0, (size_t)nq * k * 4));
-    rg_status st = rg::search_dev(ix, d_q.p, nq, d, k, L_pq, d_ids.p, d_dist.p, d_ch.p, d_ch.p + nq, nullptr);
-    if (st == RG_OK) st = rg::search_wait(ix, nullptr, k);
-    if (st == RG_OK || st == RG_ERR_NOT_ENOUGH) {
-        (void)hipMemcpy(out_ids, d_ids.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost);
-        (void)hipMemcpy(out_dists, d_dist.p, (size_t)nq * k * 4, hipMemcpyDeviceToHost);
-        if (out_cmps) (void)hipMemcpy(out_cmps, d_ch.p, (size_t)nq * 4, hipMemcpyDeviceToHost);
-        if (out_hops) (void)hipMemcpy(out_hops, d_ch.p + nq, (size_t)nq * 4, hipMemcpyDeviceToHost);
+    std::vector<float> hq;
+    stage_queries(ix, queries, nq, qstride, hq);
+    rg::HostSearch hs;
+    rg_status st = rg::host_search_begin(ix, hq.data(), nq, ix->dim, k, L_pq, &hs);
+    if (st != RG_OK) {
+        const std::string msg = rg_last_error();
+        if (hs.cx) { (void)hipStreamSynchronize(hs.cx->own); rg::release_ctx(ix, hs.cx); }
+        return set_error(st, msg);
     }
-    return st;
+    return rg::host_search_end(&hs, k, out_ids, out_dists, out_cmps, out_hops);
 }
 
 rg_status rg_search_sharded(rg_index *const *replicas, int nrep, const float *queries, uint32_t nq, uint32_t qstride,
@@ -1354,61 +1015,41 @@ rg_status rg_search_sharded(rg_index *const *replicas, int nrep, const float *qu
             return set_error(RG_ERR_ARG, "replicas describe different indexes");
     }
     if (k > L_pq) return set_error(RG_ERR_ARG, "L_pq must greater or equal than k");
+    if (k == 0) return set_error(RG_ERR_ARG, "k and L_pq must be positive");
     if (nq == 0) return RG_OK;
-    const uint32_t d = replicas[0]->dim, use = std::min(qstride, d);
-    std::vector<float> hq((size_t)nq * d, 0.0f);
-    for (size_t i = 0; i < nq; ++i) std::memcpy(hq.data() + i * d, queries + i * (size_t)qstride, (size_t)use * 4);
-    if (replicas[0]->metric == RG_METRIC_COSINE) rg_normalize_rows(hq.data(), nq, d, d);
-    struct Shard {   // buffers and stream of one replica's slice, released on every exit path
-        int dev = 0;
-        uint32_t lo = 0, n = 0;
-        float *q = nullptr, *dist = nullptr;
-        uint32_t *ids = nullptr, *ch = nullptr;
-        hipStream_t s = nullptr;
-        ~Shard() {
-            if (!q && !dist && !ids && !ch && !s) return;
-            (void)hipSetDevice(dev);
-            if (s) (void)hipStreamSynchronize(s);
-            (void)hipFree(q); (void)hipFree(dist); (void)hipFree(ids); (void)hipFree(ch);
-            if (s) (void)hipStreamDestroy(s);
-        }
-    };
-    std::vector<Shard> S((size_t)nrep);
+    const uint32_t d = replicas[0]->dim;
+    std::vector<float> hq;
+    stage_queries(replicas[0], queries, nq, qstride, hq);
+    std::vector<rg::HostSearch> S((size_t)nrep);
     const uint32_t per = (nq + (uint32_t)nrep - 1) / (uint32_t)nrep;
-    rg_status st = RG_OK;
-    for (int r = 0; r < nrep && st == RG_OK; ++r) {
-        Shard &sh = S[(size_t)r];
-        rg_index *ix = replicas[r];
-        sh.dev = ix->device;
-        sh.lo = std::min(nq, (uint32_t)r * per);
-        sh.n = std::min(nq, sh.lo + per) - sh.lo;
-        if (sh.n == 0) continue;
-        RG_HIP(hipSetDevice(ix->device));
-        RG_HIP(hipStreamCreate(&sh.s));
-        RG_HIP(hipMalloc(&sh.q, (size_t)sh.n * d * 4));
-        RG_HIP(hipMalloc(&sh.ids, (size_t)sh.n * k * 4));
-        RG_HIP(hipMalloc(&sh.dist, (size_t)sh.n * k * 4));
-        RG_HIP(hipMalloc(&sh.ch, (size_t)sh.n * 2 * 4));
-        RG_HIP(hipMemcpyAsync(sh.q, hq.data() + (size_t)sh.lo * d, (size_t)sh.n * d * 4, hipMemcpyHostToDevice, sh.s));
-        RG_HIP(hipMemsetAsync(sh.ids, 0, (size_t)sh.n * k * 4, sh.s));
-        RG_HIP(hipMemsetAsync(sh.dist, 0, (size_t)sh.n * k * 4, sh.s));
-        st = rg::search_dev(ix, sh.q, sh.n, d, k, L_pq, sh.ids, sh.dist, sh.ch, sh.ch + sh.n, sh.s);
-    }
-    // every launched slice is waited for, whatever happened to the others; the first failure (in query order) is reported
-    rg_status first = st;
-    std::string first_msg = st != RG_OK ? rg_last_error() : "";
-    for (int r = 0; r < nrep; ++r) {
-        Shard &sh = S[(size_t)r];
-        if (!sh.s || sh.n == 0) continue;
-        (void)hipSetDevice(sh.dev);
-        rg_status w = rg::search_wait(replicas[r], sh.s, k);
-        if (w == RG_OK || w == RG_ERR_NOT_ENOUGH) {
-            (void)hipMemcpy(out_ids + (size_t)sh.lo * k, sh.ids, (size_t)sh.n * k * 4, hipMemcpyDeviceToHost);
-            (void)hipMemcpy(out_dists + (size_t)sh.lo * k, sh.dist, (size_t)sh.n * k * 4, hipMemcpyDeviceToHost);
-            if (out_cmps) (void)hipMemcpy(out_cmps + sh.lo, sh.ch, (size_t)sh.n * 4, hipMemcpyDeviceToHost);
-            if (out_hops) (void)hipMemcpy(out_hops + sh.lo, sh.ch + sh.n, (size_t)sh.n * 4, hipMemcpyDeviceToHost);
+    rg_status first = RG_OK;
+    std::string first_msg;
+    for (int r = 0; r < nrep && first == RG_OK; ++r) {
+        rg::HostSearch &hs = S[(size_t)r];
+        hs.lo = std::min(nq, (uint32_t)r * per);
+        const uint32_t n = std::min(nq, hs.lo + per) - hs.lo;
+        rg_status st = rg::host_search_begin(replicas[r], hq.data() + (size_t)hs.lo * d, n, d, k, L_pq, &hs);
+        if (st != RG_OK) {
+            first = st; first_msg = rg_last_error();
+            if (hs.cx) { (void)hipStreamSynchronize(hs.cx->own); rg::release_ctx(replicas[r], hs.cx); hs.cx = nullptr; }
         }
-        if (w != RG_OK && first == RG_OK) { first = w; first_msg = rg_last_error(); }
+    }
+    // every launched slice is waited for, whatever happened to the others; the first failure (in query order) is reported.
+    // A slice's "not enough results" names the query inside the slice: re-base it to the whole batch.
+    for (int r = 0; r < nrep; ++r) {
+        rg::HostSearch &hs = S[(size_t)r];
+        if (!hs.cx) continue;
+        rg_status w = rg::host_search_end(&hs, k, out_ids + (size_t)hs.lo * k, out_dists + (size_t)hs.lo * k,
+                                          out_cmps ? out_cmps + hs.lo : nullptr, out_hops ? out_hops + hs.lo : nullptr);
+        if (w != RG_OK && first == RG_OK) {
+            first = w; first_msg = rg_last_error();
+            unsigned got = 0, exp = 0, qq = 0;
+            if (w == RG_ERR_NOT_ENOUGH && sscanf(first_msg.c_str(), "not enough results: %u, expected: %u (query %u)", &got, &exp, &qq) == 3) {
+                char buf[160];
+                snprintf(buf, sizeof buf, "not enough results: %u, expected: %u (query %u)", got, exp, qq + hs.lo);
+                first_msg = buf;
+            }
+        }
     }
     if (first != RG_OK) return set_error(first, first_msg);
     return RG_OK;

@@ -72,7 +72,7 @@ def main():
     if prof:
         lib().rg_prof_buffer(C.c_void_p(pbuf.data_ptr()))
     rows = []
-    names = ["pop", "adj_wait", "filter", "gather_score", "merge", "other"]
+    names = ["pop", "adj_wait", "filter", "score_issue", "merge", "other", "gather_wait"]
     for L in [int(x) for x in args.Ls.split(",")]:
         ix.set("visited", 0); ix.search_dev(q, args.k, L, ids, ds, cm, hp, stream=st); ix.search_wait(st)
         distinct = float(cm.float().mean())
@@ -90,7 +90,7 @@ def main():
             if prof:
                 p = pbuf.cpu().numpy().astype(np.float64)
                 tot = p[:, :8].sum()
-                row["phase_share"] = {names[i]: round(float(p[:, i].sum() / tot), 4) for i in range(6)}
+                row["phase_share"] = {names[i]: round(float(p[:, i].sum() / tot), 4) for i in range(7)}
                 row["cycles_per_hop"] = float(tot / p[:, 10].sum()) if p[:, 10].sum() else None
                 c = p[:, 8:].sum(0)
                 row["chunks_per_hop"] = float(c[0] / max(hp.float().sum().item(), 1))
