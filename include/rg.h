@@ -97,6 +97,8 @@ rg_status rg_index_info(const rg_index *idx, uint32_t *nd, uint32_t *dim, uint32
 /* tuning knobs: "waves_per_cu", "rows_per_pass", "filter_log2", "log_cap", "log_budget_kb", "count_table_log2",
  * "count_full_ids", "query_in_lds", "exact_filter" never change results (0 = automatic where a knob has an automatic
  * choice: "rows_per_pass", "filter_log2", "waves_per_cu").
+ * "spec" = 1 turns on the speculative second expansion per hop (results are bit-identical either way, see
+ * rg_search_kernel.h); "rows_per_pass" = 4 * (passes of 4 rows a query keeps in flight).
  * "visited" selects how the visited set is kept:
  *   2 (default) LDS exact-match filter + per-query id log + exact distinct count: ids, dists, hops AND cmps bit-exact.
  *               Adaptive: once a batch shows the filter re-scoring > 30 % extra nodes at some L_pq (long searches on
@@ -109,7 +111,10 @@ rg_status rg_index_info(const rg_index *idx, uint32_t *nd, uint32_t *dim, uint32
  * default adjacency layout only, otherwise the knob has no effect), then every beam entry is re-scored with the exact
  * fp32 routine and the k best by exact (distance, id) are returned: out_dists are exact for the returned ids, the ids
  * can differ from the reference's (recall is reported separately by bench.py), cmps = evaluations performed.
- * It combines with "visited": 0 = exact HBM words (no repeated evaluations), 1 / 2 = LDS filter only. */
+ * It combines with "visited": 0 = exact HBM words (no repeated evaluations), 1 / 2 = LDS filter only.
+ * "multi_expand" = 1 is the second OPT-IN mode that is NOT parity (speculative multi-expansion): every hop
+ * also expands the runner-up -- the entry next in line after the pop -- in the same gather phase, whether or not it would
+ * have been the next pop; more fresh neighbours per latency chain, a slightly different visiting order. */
 rg_status rg_index_set(rg_index *idx, const char *name, int value);
 
 /* ----------------------------------------------------------------- operator
@@ -159,11 +164,35 @@ rg_status rg_gt_shard_dev(const float *d_base, uint32_t nb, uint32_t bstride, co
                           float *d_dists, int device, void *stream);
 rg_status rg_gt_merge_dev(const uint32_t *d_ids_in, const float *d_dists_in, uint32_t nlists, uint32_t nq, uint32_t K,
                           int metric, uint32_t *d_ids, float *d_dists, int device, void *stream);
-/* host-memory convenience: whole job on `ndev` GPUs of this process (base sharded by rows) */
+/* Multi-rank form (one rank per GPU; BASELINE configs[2]: base sharded over 8 GPUs + exchange of the per-shard top-K over
+ * xGMI).  A rank owns a contiguous row shard of the base, resident in its HBM; all ranks pass the same host query matrix.
+ * Queries are streamed in batches of `batch` (0 = 65,536): K2 over the shard, all-to-all of the per-shard K-lists on a
+ * second stream (RCCL ncclSend/ncclRecv, grouped) so that each rank receives the lists of the 1/world of the batch it
+ * owns, K3 merge, rows downloaded -- overlapped with the next batch's K2.  Host memory is O(batch).  Rank r writes the
+ * rows it owns (the r-th balanced contiguous slice of every batch) into out_ids / out_dists; the other rows are left
+ * alone, so ranks that are threads of one process can share the output arrays.
+ * rg_comm: RCCL communicator (librccl is dlopen'ed on first use) --
+ *   rg_comm_unique_id + rg_comm_init_rank  one process per GPU (the id travels by whatever the launcher offers:
+ *                                          torch.distributed broadcast, MPI, a file)
+ *   rg_comm_init_local                     all ranks in this process, one per entry of `devices` (out: nranks handles);
+ *                                          ranks that share a device, or a process without RCCL, move the lists with
+ *                                          peer-to-peer copies instead (rg_comm_uses_rccl tells which) */
+typedef struct rg_comm rg_comm;
+rg_status rg_comm_unique_id(void *id128);
+rg_status rg_comm_init_rank(const void *id128, int rank, int world, int device, rg_comm **out);
+rg_status rg_comm_init_local(const int *devices, int nranks, rg_comm **out);
+int rg_comm_uses_rccl(const rg_comm *comm);
+void rg_comm_destroy(rg_comm *comm);
+rg_status rg_groundtruth_rank(rg_comm *comm, const float *d_base_shard, uint32_t nb_shard, uint32_t bstride, uint32_t id_base,
+                              const float *queries, uint32_t nq, uint32_t qstride, uint32_t dim, int metric, uint32_t K,
+                              uint32_t batch, uint32_t *out_ids, float *out_dists);
+/* host-memory convenience: whole job on `ndev` GPUs of this process (base sharded by rows, one thread per GPU running the
+ * multi-rank form above; shards are uploaded through pinned chunks, no full-size staging copy) */
 rg_status rg_groundtruth_mem(const float *base, uint32_t nb, uint32_t bstride, const float *queries, uint32_t nq,
                              uint32_t qstride, uint32_t dim, int metric, uint32_t K, uint32_t *out_ids,
                              float *out_dists, const int *devices, int ndev);
-/* file form: the CLI twin's body */
+/* file form, the CLI twin's body: shards and query batches are read straight from the files and result rows written
+ * straight into the gt file -- host memory O(batch) for a 10M x 10M job */
 rg_status rg_groundtruth(const char *base_fbin, const char *query_fbin, const char *gt_out, int metric, uint32_t K,
                          const int *devices, int ndev);
 

@@ -888,124 +888,6 @@ rg_status rg_gt_merge_dev(const uint32_t *d_ids_in, const float *d_dists_in, uin
     return RG_OK;
 }
 
-rg_status rg_groundtruth_mem(const float *base, uint32_t nb, uint32_t bstride, const float *queries, uint32_t nq,
-                             uint32_t qstride, uint32_t dim, int metric, uint32_t K, uint32_t *out_ids,
-                             float *out_dists, const int *devices, int ndev) {
-    using namespace rg;
-    if (!base || !queries || !out_ids || !out_dists) return set_error(RG_ERR_ARG, "null argument");
-    if (K == 0 || K > nb) return set_error(RG_ERR_ARG, "K must be in [1, number of base rows]");
-    int visible = 0;
-    if (hipGetDeviceCount(&visible) != hipSuccess || visible <= 0)
-        return set_error(RG_ERR_DEVICE, "no HIP device visible: the gfx950 path cannot run (there is no CPU fallback)");
-    std::vector<int> devs;
-    if (devices && ndev > 0) devs.assign(devices, devices + ndev);
-    else devs.push_back(0);
-    while (devs.size() > 1 && nb / devs.size() < K) devs.pop_back();
-    const uint32_t nd = (uint32_t)devs.size();
-    const uint32_t ad = aligned_dim(dim);
-    // host staging at the aligned stride (zero padded), cosine rows normalised (compute_groundtruth's cosine mode)
-    auto stage = [&](const float *src, uint32_t n, uint32_t stride, std::vector<float> &dst) {
-        dst.assign((size_t)n * ad, 0.0f);
-        for (size_t i = 0; i < n; ++i) std::memcpy(dst.data() + i * ad, src + i * (size_t)stride, (size_t)dim * 4);
-        if (metric == RG_METRIC_COSINE) rg_normalize_rows(dst.data(), n, ad, dim);
-    };
-    std::vector<float> hq, hb;
-    stage(queries, nq, qstride, hq);
-    stage(base, nb, bstride, hb);
-    const int m = metric == RG_METRIC_COSINE ? RG_METRIC_IP : metric;
-    std::vector<uint32_t> all_ids((size_t)nd * nq * K);
-    std::vector<float> all_vals((size_t)nd * nq * K);
-    struct Dev {   // buffers and stream of one shard, released on every exit path
-        int dev = 0;
-        float *b = nullptr, *q = nullptr, *v = nullptr;
-        uint32_t *i = nullptr;
-        hipStream_t s = nullptr;
-        ~Dev() {
-            if (!b && !q && !v && !i && !s) return;
-            (void)hipSetDevice(dev);
-            if (s) (void)hipStreamSynchronize(s);
-            if (b) (void)hipFree(b);
-            if (q) (void)hipFree(q);
-            if (i) (void)hipFree(i);
-            if (v) (void)hipFree(v);
-            if (s) (void)hipStreamDestroy(s);
-        }
-    };
-    std::vector<Dev> D(nd);
-    for (uint32_t r = 0; r < nd; ++r) D[r].dev = devs[r];
-    rg_status st = RG_OK;
-    // balanced shards: floor(nb/nd) rows each, the first nb % nd shards one more (every shard holds >= K rows: the device
-    // list was trimmed to nb / nd >= K above)
-    const uint32_t per = nb / nd, extra = nb % nd;
-    for (uint32_t r = 0; r < nd && st == RG_OK; ++r) {
-        const uint32_t lo = r * per + std::min(r, extra), hi = lo + per + (r < extra ? 1u : 0u);
-        RG_HIP(hipSetDevice(devs[r]));
-        RG_HIP(hipStreamCreate(&D[r].s));
-        RG_HIP(hipMalloc(&D[r].b, std::max<size_t>((size_t)(hi - lo) * ad * 4, 16)));
-        RG_HIP(hipMalloc(&D[r].q, (size_t)nq * ad * 4));
-        RG_HIP(hipMalloc(&D[r].i, (size_t)nq * K * 4));
-        RG_HIP(hipMalloc(&D[r].v, (size_t)nq * K * 4));
-        RG_HIP(hipMemcpyAsync(D[r].b, hb.data() + (size_t)lo * ad, (size_t)(hi - lo) * ad * 4, hipMemcpyHostToDevice, D[r].s));
-        RG_HIP(hipMemcpyAsync(D[r].q, hq.data(), (size_t)nq * ad * 4, hipMemcpyHostToDevice, D[r].s));
-        st = rg_gt_shard_dev(D[r].b, hi - lo, ad, D[r].q, nq, ad, ad, m, K, lo, D[r].i, D[r].v, devs[r], D[r].s);
-        if (st == RG_OK) {
-            RG_HIP(hipMemcpyAsync(all_ids.data() + (size_t)r * nq * K, D[r].i, (size_t)nq * K * 4, hipMemcpyDeviceToHost, D[r].s));
-            RG_HIP(hipMemcpyAsync(all_vals.data() + (size_t)r * nq * K, D[r].v, (size_t)nq * K * 4, hipMemcpyDeviceToHost, D[r].s));
-        }
-    }
-    for (uint32_t r = 0; r < nd; ++r) {
-        if (!D[r].s) continue;
-        (void)hipSetDevice(devs[r]);
-        hipError_t e = hipStreamSynchronize(D[r].s);
-        if (e != hipSuccess && st == RG_OK) st = set_error(RG_ERR_DEVICE, hipGetErrorString(e));
-    }
-    if (st == RG_OK) {
-        if (nd == 1) {
-            std::memcpy(out_ids, all_ids.data(), (size_t)nq * K * 4);
-            std::memcpy(out_dists, all_vals.data(), (size_t)nq * K * 4);
-        } else {
-            // K3 on device 0 (single-process form; the one-process-per-GPU form exchanges these lists over RCCL)
-            (void)hipSetDevice(devs[0]);
-            struct Merge {
-                uint32_t *di = nullptr, *doi = nullptr;
-                float *dv = nullptr, *dov = nullptr;
-                ~Merge() { (void)hipFree(di); (void)hipFree(dv); (void)hipFree(doi); (void)hipFree(dov); }
-            } M;
-            uint32_t *&di = M.di, *&doi = M.doi;
-            float *&dv = M.dv, *&dov = M.dov;
-            RG_HIP(hipMalloc(&di, all_ids.size() * 4));
-            RG_HIP(hipMalloc(&dv, all_vals.size() * 4));
-            RG_HIP(hipMalloc(&doi, (size_t)nq * K * 4));
-            RG_HIP(hipMalloc(&dov, (size_t)nq * K * 4));
-            RG_HIP(hipMemcpy(di, all_ids.data(), all_ids.size() * 4, hipMemcpyHostToDevice));
-            RG_HIP(hipMemcpy(dv, all_vals.data(), all_vals.size() * 4, hipMemcpyHostToDevice));
-            st = rg_gt_merge_dev(di, dv, nd, nq, K, m, doi, dov, devs[0], nullptr);
-            if (st == RG_OK) {
-                RG_HIP(hipMemcpy(out_ids, doi, (size_t)nq * K * 4, hipMemcpyDeviceToHost));
-                RG_HIP(hipMemcpy(out_dists, dov, (size_t)nq * K * 4, hipMemcpyDeviceToHost));
-            }
-        }
-    }
-    return st;
-}
-
-rg_status rg_groundtruth(const char *base_fbin, const char *query_fbin, const char *gt_out, int metric, uint32_t K,
-                         const int *devices, int ndev) {
-    if (!base_fbin || !query_fbin || !gt_out) return set_error(RG_ERR_ARG, "null argument");
-    uint32_t nb = 0, bd = 0, bs = 0, nq = 0, qd = 0, qs = 0;
-    float *base = nullptr, *q = nullptr;
-    rg_status st = rg_fbin_load(base_fbin, &nb, &bd, &bs, &base);
-    if (st != RG_OK) return st;
-    st = rg_fbin_load(query_fbin, &nq, &qd, &qs, &q);
-    if (st != RG_OK) { rg_free(base); return st; }
-    if (bd != qd) { rg_free(base); rg_free(q); return set_error(RG_ERR_ARG, "base and query dimension mismatch"); }
-    std::vector<uint32_t> ids((size_t)nq * K);
-    std::vector<float> ds((size_t)nq * K);
-    st = rg_groundtruth_mem(base, nb, bs, q, nq, qs, bd, metric, K, ids.data(), ds.data(), devices, ndev);
-    rg_free(base);
-    rg_free(q);
-    if (st != RG_OK) return st;
-    return rg_gt_save(gt_out, ids.data(), ds.data(), nq, K);
-}
+/* rg_groundtruth_mem / rg_groundtruth (whole job, several GPUs of this process) live in rg_gt_dist.hip */
 
 }  // extern "C"

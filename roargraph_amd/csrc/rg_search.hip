@@ -396,10 +396,12 @@ static size_t stage_pass_floats(const rg_index *ix, bool bf) {
     return bf ? (size_t)((ix->dim + 127) / 128) * 256 : (size_t)((ix->dim + 63) / 64) * 256;
 }
 static size_t stage_total_floats(const rg_index *ix, int R, bool bf) {   // the fast mode's exact re-rank needs one fp32 pass
+    // register-staged instantiations (compile-time dimension, fp32): rows in flight live in VGPRs, one LDS bounce buffer
+    if (dimc_of(ix) && !bf) return (size_t)((ix->dim + 63) / 64) * 256;
     return std::max((size_t)R * stage_pass_floats(ix, bf), (size_t)((ix->dim + 63) / 64) * 256);
 }
 static size_t search_lds_bytes(const rg_index *ix, uint32_t L, int R, int mode, bool bf, int filter_auto) {
-    size_t b = stage_total_floats(ix, R, bf) * 4 + (dimc_of(ix) ? 0 : (size_t)ix->dim * 4) + kCand * 4 + kCand * 4 + (size_t)L * 8;
+    size_t b = stage_total_floats(ix, R, bf) * 4 + (dimc_of(ix) ? 0 : (size_t)ix->dim * 4) + kCand * 4 + kCand * 4 + 3 * kWave * 4 + (size_t)L * 8;
     if (mode != 0 || ix->exact_filter) b += 128 * 4 + std::max<size_t>(4, (size_t)2 << filter_log2_of(ix, filter_auto));
     return (b + 15) / 16 * 16;
 }
@@ -435,11 +437,17 @@ static rg_status launch_k1(rg_index *ix, SearchCtx *cx, int mode, const float *d
     // out-degree 40, -4 % at 16, where the extra staging only costs resident queries)
     // A batch that leaves most wave slots empty is latency bound per query: LDS is plentiful then, so each query keeps
     // 16 rows in flight (two hop-latency round trips instead of five to ten).
+    // The register-staged instantiations (d = 200 / 512) pay for rows in flight with VGPRs, not LDS: 16 rows (4 sets of 16
+    // registers) at d = 200, 8 rows (2 sets of 32) at d = 512.
     const int rpp = ix->rows_per_pass > 0 ? ix->rows_per_pass
+                    : (dimc_of(ix) == 200) ? 16
+                    : (dimc_of(ix) == 512) ? 8
                     : (nq <= (uint32_t)ix->num_cu * 6u && !bp) ? 16
                     : ((double)ix->n_edges >= 28.0 * ix->nd ? 8 : 4);
-    int R = std::max(1, std::min(4, rpp / 4));
+    int R = std::max(1, std::min(8, rpp / 4));
     if (R == 3) R = 2;
+    if (R > 4 && R < 8) R = 4;
+    if (R == 8 && !(dimc_of(ix) == 200)) R = 4;
     // opt-in fast mode: plain top-k searches only (never the logging / recount / build launches)
     const bool bf = ix->fast_bf16 && ix->d_base_bf && dimc_of(ix) && !with_log && !bp && !qlist;
     if (bf) R = std::min(R, 2);
@@ -455,10 +463,28 @@ static rg_status launch_k1(rg_index *ix, SearchCtx *cx, int mode, const float *d
     while (lds > ix->lds_per_cu && R > 1) { R >>= 1; lds = search_lds_bytes(ix, L, R, mode, bf, filter_auto); }
     if (lds > ix->lds_per_cu) return set_error(RG_ERR_ARG, "L_pq too large for the 160 KiB LDS of one CU");
     int wpc = (int)std::min<size_t>(ix->lds_per_cu / lds, 32);
+    // few resident queries (wide beams): each keeps 32 rows in flight (8 register sets, about 190 VGPRs: 8 waves per CU)
+    if (ix->rows_per_pass <= 0 && dimc_of(ix) == 200 && !bf && wpc <= 8) R = 8;
     if (ix->waves_per_cu > 0) wpc = std::min(wpc, ix->waves_per_cu);
     else wpc = std::min(wpc, 24);
     K1Launch c;
     c.R = R; c.vis = mode == 0 ? 0 : 1; c.dimc = dimc_of(ix); c.bf = bf; c.lds = lds;
+    const bool l2 = ix->metric == RG_METRIC_L2, ell = ix->d_ell != nullptr;
+    auto dispatch = [&](const SearchParams &sp) -> rg_status {
+        if (l2 && ell) return launch_search_l2_ell(sp, c, s);
+        if (l2) return launch_search_l2_csr(sp, c, s);
+        if (ell) return launch_search_ip_ell(sp, c, s);
+        return launch_search_ip_csr(sp, c, s);
+    };
+    {   // resident queries per CU: the smaller of what LDS and what the kernel's registers allow
+        int occ = 0;
+        c.occupancy = &occ;
+        SearchParams none{};
+        rg_status st = dispatch(none);
+        c.occupancy = nullptr;
+        if (st != RG_OK) return st;
+        if (occ > 0) wpc = std::min(wpc, occ);
+    }
     c.grid = (uint32_t)std::min<uint64_t>(nq, (uint64_t)ix->num_cu * wpc);
     if (mode == 0) {
         rg_status st = ensure_visited(ix, cx, c.grid);
@@ -482,17 +508,14 @@ static rg_status launch_k1(rg_index *ix, SearchCtx *cx, int mode, const float *d
     P.id_bits = id_bits_of(ix->nd);
     P.qlog = with_log ? cx->d_qlog : nullptr; P.logcap = cx->logcap; P.qlog_n = with_log ? cx->d_qlog_n : nullptr;
     P.qlist = qlist;
-    P.spec = 0;
+    // speculative second expansion (bit-exact either way; "spec" knob, off unless asked for)
+    P.spec = ix->multi_expand ? 2u : (ix->spec > 0 ? 1u : 0u);
 #ifdef RG_K1_PROF
     P.prof = (qlist || bp) ? nullptr : g_prof_buf;
 #endif
     P.out_exp = nullptr; P.exp_cap = 0; P.tgt_base = 0; P.out_nexp = nullptr;
     if (bp) { P.out_exp = reinterpret_cast<uint2 *>(bp->exp); P.exp_cap = bp->exp_cap; P.tgt_base = bp->node0; P.out_nexp = bp->nexp; }
-    const bool l2 = ix->metric == RG_METRIC_L2, ell = ix->d_ell != nullptr;
-    if (l2 && ell) return launch_search_l2_ell(P, c, s);
-    if (l2) return launch_search_l2_csr(P, c, s);
-    if (ell) return launch_search_ip_ell(P, c, s);
-    return launch_search_ip_csr(P, c, s);
+    return dispatch(P);
 }
 
 static rg_status ensure_qlog(rg_index *ix, SearchCtx *cx, uint32_t nq) {

@@ -54,6 +54,73 @@ def gt_merge_dev(ids_in_t, dists_in_t, nlists, nq, K, metric, ids_t, dists_t, st
                                 C.c_void_p(dists_t.data_ptr()), ids_in_t.device.index or 0, C.c_void_p(stream)))
 
 
+class Comm:
+    """rg_comm handles (include/rg.h): the transport of the native multi-rank ground truth.
+
+    Comm.local(devices)            all ranks in this process, one per entry (RCCL when the devices are distinct, peer copies
+                                   when ranks share a device); returns a list of Comm
+    Comm.from_torch_dist(device)   one process per GPU under torch.distributed: rank 0 makes the RCCL unique id, the
+                                   process group broadcasts it, every rank joins (ncclCommInitRank)"""
+
+    def __init__(self, handle, rank, world, device):
+        self.handle, self.rank, self.world, self.device = handle, rank, world, device
+
+    @classmethod
+    def local(cls, devices):
+        n = len(devices)
+        arr = (C.c_void_p * n)()
+        check(lib().rg_comm_init_local((C.c_int * n)(*devices), n, arr))
+        return [cls(C.c_void_p(arr[i]), i, n, devices[i]) for i in range(n)]
+
+    @classmethod
+    def from_torch_dist(cls, device, group=None):
+        import torch.distributed as dist
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        ident = [None]
+        if rank == 0 and world > 1:
+            buf = C.create_string_buffer(128)
+            check(lib().rg_comm_unique_id(buf))
+            ident = [buf.raw]
+        if world > 1:
+            dist.broadcast_object_list(ident, src=0, group=group)
+        h = C.c_void_p()
+        check(lib().rg_comm_init_rank(ident[0], rank, world, device, C.byref(h)))
+        return cls(h, rank, world, device)
+
+    def uses_rccl(self):
+        return bool(lib().rg_comm_uses_rccl(self.handle))
+
+    def destroy(self):
+        if self.handle:
+            lib().rg_comm_destroy(self.handle)
+            self.handle = None
+
+
+def groundtruth_rank(comm, base_shard_t, id_base, queries, metric, K, out_ids, out_dists, batch=0):
+    """rg_groundtruth_rank: this rank's part of the streamed multi-rank ground truth.  base_shard_t: torch CUDA tensor
+    (the rank's rows, resident in HBM); queries: host numpy [nq, dim] (same on every rank); out_ids / out_dists: host
+    numpy [nq, K] -- the rows this rank owns are written, the others left alone."""
+    queries = np.ascontiguousarray(queries, np.float32)
+    assert out_ids.dtype == np.uint32 and out_dists.dtype == np.float32 and out_ids.flags.c_contiguous and out_dists.flags.c_contiguous
+    check(lib().rg_groundtruth_rank(comm.handle, C.c_void_p(base_shard_t.data_ptr()), C.c_uint32(base_shard_t.shape[0]),
+                                    C.c_uint32(base_shard_t.stride(0)), C.c_uint32(id_base), _vp(queries), C.c_uint32(queries.shape[0]),
+                                    C.c_uint32(queries.shape[1]), C.c_uint32(queries.shape[1]), METRIC[metric], C.c_uint32(K),
+                                    C.c_uint32(batch), _vp(out_ids), _vp(out_dists)))
+
+
+def owned_rows(nq, world, rank, batch=0):
+    """Row indices of an nq-query job that rank `rank` owns under rg_groundtruth_rank's batching (the rank-th balanced
+    contiguous slice of every batch)."""
+    qb = min(nq, batch or 65536)
+    rows = []
+    for q0 in range(0, nq, qb):
+        n = min(qb, nq - q0)
+        per, extra = divmod(n, world)
+        lo = rank * per + min(rank, extra)
+        rows.extend(range(q0 + lo, q0 + lo + per + (1 if rank < extra else 0)))
+    return np.array(rows, np.int64)
+
+
 def query_ranges(nq, world):
     """Contiguous query ranges owned by each rank for the merge step."""
     per = (nq + world - 1) // world

@@ -86,7 +86,7 @@ def random_regular_csr(nd, deg, seed=11):
     return offsets, nbrs.reshape(-1)
 
 
-def make_device_set(dev, seed, nb, ntrain, nq, d, data="gaussian", rank=24, noise=0.05):
+def make_device_set(dev, seed, nb, ntrain, nq, d, data="gaussian", rank=24, noise=0.05, q_seed=None):
     """Base / training queries / test queries as torch tensors on `dev` (bench.py, scripts/e2e_pipeline.py).
 
     "gaussian": base ~ N(0,1)^d, queries ~ N(0.3, 0.5^2)^d -- the hardest case (no structure: a graph index cannot
@@ -95,6 +95,7 @@ def make_device_set(dev, seed, nb, ntrain, nq, d, data="gaussian", rank=24, nois
                 z ~ N(0, I_rank) for the base and z ~ N(0.3, 0.5^2 I_rank) for the queries (the same out-of-distribution
                 shift, in the latent space), A a fixed rank x d matrix with N(0, 1/rank) entries.  This is the set the
                 recall target (>= 0.9 recall@10) is demonstrated on.
+    q_seed: the test queries come from their own generator seeded with it (one batch per rank over the same base).
     Returns (base, train, queries, description)."""
     import torch
     g = torch.Generator(device=dev)
@@ -115,16 +116,23 @@ def make_device_set(dev, seed, nb, ntrain, nq, d, data="gaussian", rank=24, nois
                 out[s:s + m].add_(torch.empty((m, d), dtype=torch.float32, device=dev).normal_(generator=g), alpha=noise)
         return out
 
+    def queries(mix):
+        nonlocal g
+        if q_seed is not None:
+            g = torch.Generator(device=dev)
+            g.manual_seed(q_seed)
+        return fill(nq, 0.3, 0.5, mix)
+
     if data == "gaussian":
         base = fill(nb, 0.0, 1.0, None)
         train = fill(ntrain, 0.3, 0.5, None) if ntrain else None
-        q = fill(nq, 0.3, 0.5, None)
+        q = queries(None)
         desc = "base N(0,1) %dx%d, train/test queries N(0.3,0.5^2) (%d / %d)" % (nb, d, ntrain, nq)
     elif data == "lowrank":
         mix = torch.empty((rank, d), dtype=torch.float32, device=dev).normal_(generator=g) / float(rank) ** 0.5
         base = fill(nb, 0.0, 1.0, mix)
         train = fill(ntrain, 0.3, 0.5, mix) if ntrain else None
-        q = fill(nq, 0.3, 0.5, mix)
+        q = queries(mix)
         desc = ("low-rank embeddings %dx%d: x = zA + %.2f eps, latent rank %d, base z ~ N(0,1), train/test queries "
                 "z ~ N(0.3,0.5^2) (%d / %d)" % (nb, d, noise, rank, ntrain, nq))
     else:

@@ -68,7 +68,7 @@ def main():
         k_, v_ = kv.split("="); ix.set(k_, int(v_))
     ids = torch.zeros((args.nq, args.k), dtype=torch.int32, device=dev); ds = torch.zeros((args.nq, args.k), device=dev)
     cm = torch.zeros(args.nq, dtype=torch.int32, device=dev); hp = torch.zeros(args.nq, dtype=torch.int32, device=dev)
-    pbuf = torch.zeros((args.nq, 16), dtype=torch.int64, device=dev)
+    pbuf = torch.zeros((args.nq, 24), dtype=torch.int64, device=dev)
     if prof:
         lib().rg_prof_buffer(C.c_void_p(pbuf.data_ptr()))
     rows = []
@@ -91,12 +91,17 @@ def main():
                 p = pbuf.cpu().numpy().astype(np.float64)
                 tot = p[:, :8].sum()
                 row["phase_share"] = {names[i]: round(float(p[:, i].sum() / tot), 4) for i in range(7)}
-                row["cycles_per_hop"] = float(tot / p[:, 10].sum()) if p[:, 10].sum() else None
-                c = p[:, 8:].sum(0)
+                row["cycles_per_hop"] = float(tot / max(hp.float().sum().item(), 1))
+                c = p[:, 8:16].sum(0)
+                m = pbuf.cpu().numpy()[:, 16:20]
+                row["merge_split"] = {"search_dedup": round(float(m[:, 0].sum() / tot), 4), "rank_cursor": round(float(m[:, 1].sum() / tot), 4), "shift": round(float(m[:, 2].sum() / tot), 4)}
+                nm = max(float((m[:, 3] >> 32).sum()), 1.0)
+                row["valid_cands_per_hop"] = float((m[:, 3] >> 32).sum() / max(hp.float().sum().item(), 1))
+                row["chunks_moved_per_hop"] = float((m[:, 3] & 0xffffffff).sum() / max(hp.float().sum().item(), 1))
                 row["chunks_per_hop"] = float(c[0] / max(hp.float().sum().item(), 1))
                 row["fresh_per_hop"] = float(c[1] / max(hp.float().sum().item(), 1))
                 row["spec_hit_rate"] = float(c[3] / max(c[2], 1))
-                row["cursor_back_rate"] = float(c[4] / max(c[2], 1))
+                row["spec_tries_per_hop"] = float(c[2] / max(hp.float().sum().item(), 1))
                 row["deg_per_hop"] = float(c[5] / max(hp.float().sum().item(), 1))
             rows.append(row)
             print(json.dumps(row), flush=True)

@@ -136,7 +136,8 @@ def test_bench_multi_rank_control_flow_on_one_gpu():
         port = sk.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
-           "--backend", "gloo", "--nb", "200000", "--nq", "512", "--gt-nq", "4096", "--recall-nb", "0", "--cpu-seconds", "0"]
+           "--backend", "gloo", "--nb", "200000", "--nq", "512", "--gt-nq", "4096", "--cpu-seconds", "0", "--sweep", "20,100",
+           "--no-worstcase", "--no-fast", "--config1-nb", "0"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -144,3 +145,5 @@ def test_bench_multi_rank_control_flow_on_one_gpu():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
     assert d["gt_build"]["value"] > 0 and "sharded x2" in d["gt_build"]["metric"]
+    assert "genuine RoarGraph index" in d["config"]["workload"] and "on 2 GPU(s)" in d["config"]["workload"]
+    assert [p["L_pq"] for p in d["L_pq_sweep"]] == [20, 100, 500] and all(p["recall_at_10"] > 0.5 for p in d["L_pq_sweep"][1:])

@@ -1,0 +1,132 @@
+"""-m gpu: concurrent searches on ONE index.
+
+The reference calls SearchRoarGraph from many OpenMP threads against one index object
+(tests/test_search_roargraph.cpp:203-209); its only shared mutable state is the visited-list pool behind a mutex
+(include/visited_list_pool.h:47-65).  Here every launch-time buffer lives in a per-stream context handed out under the
+index mutex, so host threads on distinct streams -- and several batches in flight on one stream -- must all return
+the oracle's bits.
+"""
+import threading
+
+import numpy as np
+import pytest
+
+from helpers import bits, small_set
+
+pytestmark = pytest.mark.gpu
+
+
+def _same(got, want):
+    return ((got[0] == want[0]).all() and (bits(got[1]) == bits(want[1])).all() and (got[2] == want[2]).all()
+            and (got[3] == want[3]).all())
+
+
+@pytest.mark.parametrize("visited", [2, 0])
+def test_two_threads_two_streams_device_form(oracle, visited):
+    import torch
+    from roargraph_amd.index import IndexBipartite
+    base, q, off, nbrs, ep = small_set("ip", 4000, 200, nq=256)
+    dev = torch.device("cuda", 0)
+    ix = IndexBipartite.from_arrays(base, off, nbrs, ep, metric="ip")
+    ix.set("visited", visited)
+    ix.set("filter_log2", 6)          # forgetful filter: the id log / exact count path has work to do
+    jobs = [(q[:128], 10, 100), (q[128:], 10, 500)]
+    want = [oracle.search(base, "ip", off, nbrs, ep, qq, k, L, nthreads=4) for qq, k, L in jobs]
+    errors = []
+
+    def worker(t):
+        try:
+            qq, k, L = jobs[t]
+            with torch.cuda.device(dev):
+                s = torch.cuda.Stream(device=dev)
+                qt = torch.from_numpy(qq).to(dev)
+                nq = qq.shape[0]
+                for it in range(12):
+                    ids = torch.zeros((nq, k), dtype=torch.int32, device=dev); ds = torch.zeros((nq, k), device=dev)
+                    cm = torch.zeros(nq, dtype=torch.int32, device=dev); hp = torch.zeros(nq, dtype=torch.int32, device=dev)
+                    torch.cuda.synchronize()
+                    ix.search_dev(qt, k, L, ids, ds, cm, hp, stream=s.cuda_stream)
+                    ix.search_wait(s.cuda_stream)
+                    got = (ids.cpu().numpy().view(np.uint32), ds.cpu().numpy(), cm.cpu().numpy().view(np.uint32),
+                           hp.cpu().numpy().view(np.uint32))
+                    if not _same(got, want[t]):
+                        errors.append("thread %d iteration %d differs from the oracle" % (t, it))
+                        return
+        except Exception as e:  # noqa: BLE001
+            errors.append("thread %d: %r" % (t, e))
+
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    ix.close()
+    assert not errors, errors
+
+
+def test_many_threads_host_form(oracle):
+    """The reference's pattern: T host threads call the search on one index object, each with its own queries."""
+    from roargraph_amd.index import IndexBipartite
+    base, q, off, nbrs, ep = small_set("l2", 3000, 200, nq=240)
+    ix = IndexBipartite.from_arrays(base, off, nbrs, ep, metric="l2")
+    want = oracle.search(base, "l2", off, nbrs, ep, q, 10, 100, nthreads=4)
+    errors = []
+
+    def worker(t):
+        try:
+            sl = slice(30 * t, 30 * t + 30)
+            for _ in range(6):
+                got = ix.SearchRoarGraph(q[sl], 10, 100)
+                if not _same(got, tuple(w[sl] for w in want)):
+                    errors.append("thread %d differs from the oracle" % t)
+                    return
+        except Exception as e:  # noqa: BLE001
+            errors.append("thread %d: %r" % (t, e))
+
+    th = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    ix.close()
+    assert not errors, errors
+
+
+def test_batches_in_flight_on_one_stream(oracle):
+    """Five rg_search_dev calls (different beam widths, their own output buffers) before a single rg_search_wait: every
+    batch is finished by the wait -- including the exact recount of id logs that overflowed (log_cap 64 forces it) --
+    and a deferred "not enough results" of an early batch is still reported."""
+    import torch
+    from roargraph_amd._lib import RG_ERR_NOT_ENOUGH, RgError
+    from roargraph_amd.index import IndexBipartite
+    base, q, off, nbrs, ep = small_set("ip", 4000, 200, nq=96)
+    dev = torch.device("cuda", 0)
+    ix = IndexBipartite.from_arrays(base, off, nbrs, ep, metric="ip")
+    ix.set("filter_log2", 6)
+    ix.set("log_cap", 64)
+    qt = torch.from_numpy(q).to(dev)
+    outs = []
+    for L in (20, 100, 50, 200, 10):
+        ids = torch.zeros((96, 10), dtype=torch.int32, device=dev); ds = torch.zeros((96, 10), device=dev)
+        cm = torch.zeros(96, dtype=torch.int32, device=dev); hp = torch.zeros(96, dtype=torch.int32, device=dev)
+        ix.search_dev(qt, 10, L, ids, ds, cm, hp)
+        outs.append((L, ids, ds, cm, hp))
+    ix.search_wait()
+    for L, ids, ds, cm, hp in outs:
+        want = oracle.search(base, "ip", off, nbrs, ep, q, 10, L, nthreads=4)
+        got = (ids.cpu().numpy().view(np.uint32), ds.cpu().numpy(), cm.cpu().numpy().view(np.uint32), hp.cpu().numpy().view(np.uint32))
+        assert _same(got, want), L
+    ix.close()
+    # deferred error of the FIRST of three batches
+    lonely = np.random.default_rng(0).standard_normal((50, 16)).astype(np.float32)
+    ix = IndexBipartite.from_arrays(lonely, np.zeros(51, np.uint64), np.zeros(0, np.uint32), 3, metric="l2")
+    qt = torch.from_numpy(lonely[:4].copy()).to(dev)
+    bufs = [(torch.zeros((4, k), dtype=torch.int32, device=dev), torch.zeros((4, k), device=dev)) for k in (2, 1, 1)]
+    for (ids, ds), k in zip(bufs, (2, 1, 1)):
+        ix.search_dev(qt, k, 10, ids, ds)
+    with pytest.raises(RgError, match="not enough results: 1, expected: 2") as e:
+        ix.search_wait()
+    assert e.value.code == RG_ERR_NOT_ENOUGH
+    assert (bufs[1][0].cpu().numpy() == 3).all() and (bufs[2][0].cpu().numpy() == 3).all()
+    ix.search_wait()      # nothing pending any more
+    ix.close()

@@ -113,3 +113,66 @@ def test_single_process_multi_shard_path(oracle):
     l2_i, l2_d = groundtruth.compute_groundtruth(base, q, "l2", 10, devices=[0, 0])
     ref_i, _, ref_s = oracle.groundtruth_f64(base, q, "l2", 10, nthreads=8)
     check_gt(base, q, "l2", 10, l2_i, l2_d, ref_i, ref_s)
+
+
+@pytest.mark.parametrize("metric", ["ip", "l2", "cosine"])
+def test_streamed_batches_equal_one_shot(oracle, metric, monkeypatch):
+    """rg_groundtruth_mem streams the queries in batches (RG_GT_BATCH forces small ones: 7 batches here, the last one
+    short) through the double-buffered K2 / exchange / K3 / download pipeline; the result equals the one-batch run bit for
+    bit, on one rank and on three ranks sharing the GPU (in-process transport)."""
+    from roargraph_amd import groundtruth
+    base, q = synth.make_synth(61, 6000, 333, 200)
+    monkeypatch.delenv("RG_GT_BATCH", raising=False)
+    one_i, one_d = groundtruth.compute_groundtruth(base, q, metric, 64)
+    monkeypatch.setenv("RG_GT_BATCH", "50")
+    for devs in ([0], [0, 0, 0]):
+        got_i, got_d = groundtruth.compute_groundtruth(base, q, metric, 64, devices=devs)
+        assert (got_i == one_i).all() and (got_d.view(np.uint32) == one_d.view(np.uint32)).all(), devs
+    if metric != "cosine":
+        ref_i, _, ref_s = oracle.groundtruth_f64(base, q, metric, 64, nthreads=8)
+        check_gt(base, q, metric, 64, one_i, one_d, ref_i, ref_s)
+
+
+def test_rank_form_owned_rows_and_rccl_loopback(oracle, monkeypatch):
+    """rg_groundtruth_rank through its own handles: three in-process ranks (threads) fill disjoint rows of one output
+    array; and a single rank forced through RCCL (ncclCommInitAll on the one GPU, send/recv to itself) -- the dlopen'ed
+    library, the grouped send/recv and the stream/event hand-over are the ones a multi-GPU run uses."""
+    import threading
+    import torch
+    from roargraph_amd import groundtruth
+    base, q = synth.make_synth(62, 5000, 210, 200)
+    K, batch = 32, 64
+    want_i, want_d = groundtruth.compute_groundtruth(base, q, "ip", K)
+    dev = torch.device("cuda", 0)
+    comms = groundtruth.Comm.local([0, 0, 0])
+    assert not any(c.uses_rccl() for c in comms)            # ranks sharing a device: peer copies
+    out_i = np.zeros((210, K), np.uint32); out_d = np.zeros((210, K), np.float32)
+    shards = groundtruth.shard_rows(5000, 3)
+    errs = []
+
+    def work(r):
+        try:
+            lo, hi = shards[r]
+            bt = torch.from_numpy(base[lo:hi]).to(dev)
+            groundtruth.groundtruth_rank(comms[r], bt, lo, q, "ip", K, out_i, out_d, batch=batch)
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(3)]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    [c.destroy() for c in comms]
+    assert not errs, errs
+    assert (out_i == want_i).all() and (out_d.view(np.uint32) == want_d.view(np.uint32)).all()
+    rows = np.concatenate([groundtruth.owned_rows(210, 3, r, batch) for r in range(3)])
+    assert sorted(rows.tolist()) == list(range(210))          # the three ranks' rows partition the job
+    # one rank, RCCL transport
+    monkeypatch.setenv("RG_GT_FORCE_RCCL", "1")
+    (c,) = groundtruth.Comm.local([0])
+    if not c.uses_rccl():
+        c.destroy()
+        pytest.skip("librccl could not be loaded in this process")
+    out_i[:] = 0; out_d[:] = 0
+    groundtruth.groundtruth_rank(c, torch.from_numpy(base).to(dev), 0, q, "ip", K, out_i, out_d, batch=batch)
+    c.destroy()
+    assert (out_i == want_i).all() and (out_d.view(np.uint32) == want_d.view(np.uint32)).all()
