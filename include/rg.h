@@ -205,6 +205,12 @@ rg_status rg_groundtruth(const char *base_fbin, const char *query_fbin, const ch
 rg_status rg_build_roargraph(const float *base, uint32_t nb, uint32_t dim, uint32_t stride, const uint32_t *knn_ids,
                              uint32_t nq, uint32_t knn_k, int metric, uint32_t M_sq, uint32_t M_pjbp, uint32_t L_pjpq,
                              uint32_t num_threads, uint32_t *out_ep, uint64_t **out_offsets, uint32_t **out_nbrs);
+/* CalculateProjectionep (src/index_bipartite.cpp:2004-2041): the entry point, i.e. the base row nearest (squared L2) to the
+ * centroid, with the reference's arithmetic -- float sums over the rows in index order per dimension, j-order distance
+ * sums, the first of equal distances.  The device form gives the same bits (it keeps the serial order per dimension and
+ * gets its speed from owning 32 dimensions per workgroup); rg_build_roargraph_gpu uses it. */
+rg_status rg_projection_ep(const float *base, uint32_t nd, uint32_t dim, uint32_t stride, uint32_t *out_ep);
+rg_status rg_projection_ep_dev(const float *d_base, uint32_t nd, uint32_t dim, uint32_t stride, int device, uint32_t *out_ep);
 /* Same construction with phase 3 -- the n beam searches of the connectivity enhancement (index_bipartite.cpp:1192-1220,
  * 1279-1350), 85-93 % of the build time -- on the GPU (K1 in build mode), `batch` nodes at a time (0 = auto); pruning
  * and reverse-edge insertion stay on the host threads.  Nodes of a batch search the graph as it stood when the batch

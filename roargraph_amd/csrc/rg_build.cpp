@@ -133,6 +133,8 @@ struct Builder {
     bool l2, avx512;
     uint32_t M, L, Nq;  // M_pjbp, L_pjpq, M_sq
     uint32_t ep = 0;
+    bool ep_known = false;
+    float *d_base_pre = nullptr;   // GPU-assisted build: the base goes up once, for the entry point and for phase 3
     std::vector<std::vector<uint32_t>> proj, supply;
     std::vector<std::mutex> locks;
     int threads = 1;
@@ -396,9 +398,11 @@ struct Builder {
         uint32_t *h_nexp = nullptr;
         hipStream_t st = nullptr;
         hipEvent_t evA = nullptr, evB = nullptr;
-        bool ok = hipMalloc(&d_base, (size_t)nd * stride * 4) == hipSuccess &&
-                  hipMemcpy(d_base, base, (size_t)nd * stride * 4, hipMemcpyHostToDevice) == hipSuccess &&
-                  hipMalloc(&d_exp, (size_t)B * cap * 8) == hipSuccess && hipMalloc(&d_nexp, (size_t)B * 4) == hipSuccess &&
+        bool ok = true;
+        if (d_base_pre) { d_base = d_base_pre; d_base_pre = nullptr; }
+        else ok = hipMalloc(&d_base, (size_t)nd * stride * 4) == hipSuccess &&
+                  hipMemcpy(d_base, base, (size_t)nd * stride * 4, hipMemcpyHostToDevice) == hipSuccess;
+        ok = ok && hipMalloc(&d_exp, (size_t)B * cap * 8) == hipSuccess && hipMalloc(&d_nexp, (size_t)B * 4) == hipSuccess &&
                   hipHostMalloc(&h_exp, (size_t)B * cap * 8) == hipSuccess && hipHostMalloc(&h_nexp, (size_t)B * 4) == hipSuccess &&
                   hipStreamCreate(&st) == hipSuccess && hipEventCreate(&evA) == hipSuccess && hipEventCreate(&evB) == hipSuccess;
         if (ok) ok = build_index_create(d_base, nd, dim, (uint32_t)stride, ep, l2 ? RG_METRIC_L2 : RG_METRIC_IP, gpu_device, S, &ix) == RG_OK;
@@ -514,24 +518,16 @@ struct Builder {
         proj.assign(nd, {});
         supply.assign(nd, {});
         locks = std::vector<std::mutex>(nd);
-        // ---- entry point (:2004-2041): float sums in index order, plain (unfused) arithmetic
-        {
-            std::vector<float> center(dim, 0.0f);
-            for (size_t i = 0; i < nd; ++i)
-                for (unsigned d = 0; d < dim; ++d) center[d] += base[i * stride + d];
-            for (unsigned d = 0; d < dim; ++d) center[d] /= (float)nd;
-            uint32_t best = 0;
-            float bestd = 0.0f;
-            for (size_t i = 0; i < nd; ++i) {
-                float diff = 0.0f;
-                for (unsigned j = 0; j < dim; ++j) {
-                    const float t = center[j] - base[i * stride + j];
-                    diff += t * t;
-                }
-                if (i == 0 || diff < bestd) { best = (uint32_t)i; bestd = diff; }
-            }
-            ep = best;
+        // ---- entry point (:2004-2041): float sums in index order, plain (unfused) arithmetic -- on the build GPU when there
+        // is one (rg_projection_ep_dev: the same sums in the same order, checked bit for bit against this loop in the tests)
+        if (gpu_device >= 0 && dim % 4 == 0 && stride % 4 == 0 && hipSetDevice(gpu_device) == hipSuccess &&
+            hipMalloc(&d_base_pre, (size_t)nd * stride * 4) == hipSuccess) {
+            if (hipMemcpy(d_base_pre, base, (size_t)nd * stride * 4, hipMemcpyHostToDevice) == hipSuccess &&
+                rg_projection_ep_dev(d_base_pre, nd, dim, (uint32_t)stride, gpu_device, &ep) == RG_OK)
+                ep_known = true;
+            else { (void)hipFree(d_base_pre); d_base_pre = nullptr; }
         }
+        if (!ep_known) rg_projection_ep(base, nd, dim, (uint32_t)stride, &ep);
         lap("entry point");
         // ---- phase 1 (:1059-1097): every training query links its nearest base point to its other neighbours
         auto phase1_query = [&](uint32_t sq) {
@@ -679,6 +675,28 @@ static rg_status build_impl(const float *base, uint32_t nb, uint32_t dim, uint32
     *out_ep = b.ep;
     *out_offsets = off;
     *out_nbrs = nbr;
+    return RG_OK;
+}
+
+/* CalculateProjectionep (src/index_bipartite.cpp:2004-2041), host form: float sums in index order, plain (unfused)
+ * arithmetic, first of equal distances */
+extern "C" rg_status rg_projection_ep(const float *base, uint32_t nd, uint32_t dim, uint32_t stride, uint32_t *out_ep) {
+    if (!base || !out_ep || nd == 0 || stride < dim) return rg::set_error(RG_ERR_ARG, "bad argument");
+    std::vector<float> center(dim, 0.0f);
+    for (size_t i = 0; i < nd; ++i)
+        for (unsigned d = 0; d < dim; ++d) center[d] += base[i * stride + d];
+    for (unsigned d = 0; d < dim; ++d) center[d] /= (float)nd;
+    uint32_t best = 0;
+    float bestd = 0.0f;
+    for (size_t i = 0; i < nd; ++i) {
+        float diff = 0.0f;
+        for (unsigned j = 0; j < dim; ++j) {
+            const float t = center[j] - base[i * stride + j];
+            diff += t * t;
+        }
+        if (i == 0 || diff < bestd) { best = (uint32_t)i; bestd = diff; }
+    }
+    *out_ep = best;
     return RG_OK;
 }
 

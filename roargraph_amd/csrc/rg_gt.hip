@@ -14,6 +14,8 @@
 // fetched from HBM about once per XCD per generation of workgroups and otherwise served by L2 / Infinity Cache.
 #include <hip/hip_runtime.h>
 
+#include <mutex>
+
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
@@ -713,12 +715,23 @@ static int items_for(uint32_t n) {  // smallest ITEMS in {4,8,16} with 64*ITEMS 
 
 using rg::set_error;
 
-extern "C" {
+namespace rg {
 
-rg_status rg_gt_shard_dev(const float *d_base, uint32_t nb, uint32_t bstride, const float *d_queries, uint32_t nq,
-                          uint32_t qstride, uint32_t dim, int metric, uint32_t K, uint32_t id_base, uint32_t *d_ids,
-                          float *d_dists, int device, void *stream) {
-    using namespace rg;
+void gt_workspace_free(GtWorkspace *ws) {
+    if (!ws) return;
+    for (int i = 0; i < 7; ++i) {
+        if (ws->p[i]) (void)hipFree(ws->p[i]);
+        ws->p[i] = nullptr; ws->cap[i] = 0;
+    }
+}
+
+// K2 (+ K2b, segment merge) over one shard.  Scratch comes from the stream-ordered allocator, or -- ws != nullptr -- from a
+// caller-owned grow-only workspace: the multi-rank driver runs one host thread per rank on its own streams and keeps the
+// ranks' scratch apart (several threads allocating and freeing stream-ordered blocks of one device pool while their
+// kernels overlap handed a block to a second stream before the first one was done with it on this ROCm).
+rg_status gt_shard_ws(const float *d_base, uint32_t nb, uint32_t bstride, const float *d_queries, uint32_t nq,
+                      uint32_t qstride, uint32_t dim, int metric, uint32_t K, uint32_t id_base, uint32_t *d_ids,
+                      float *d_dists, int device, void *stream, GtWorkspace *ws) {
     hipStream_t s = (hipStream_t)stream;
     if (!d_base || !d_queries || !d_ids || !d_dists) return set_error(RG_ERR_ARG, "null argument");
     if (metric != RG_METRIC_L2 && metric != RG_METRIC_IP && metric != RG_METRIC_COSINE)
@@ -782,31 +795,44 @@ rg_status rg_gt_shard_dev(const float *d_base, uint32_t nb, uint32_t bstride, co
         if (nb - (nseg - 1) * seg_rows < K) nseg = 1, seg_rows = nb;   // the last segment must still hold K rows
     }
     const uint32_t grid = std::min<uint32_t>(nblocks * nseg, slots);
-    // stream-ordered scratch, released on every exit path
+    // scratch, released on every exit path (stream-ordered blocks) or kept for the next call (workspace)
     struct Scratch {
         hipStream_t s;
+        GtWorkspace *ws;
         void *p[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-        ~Scratch() { for (void *q : p) if (q) (void)hipFreeAsync(q, s); }
-    } scratch{s};
+        ~Scratch() { if (!ws) for (void *q : p) if (q) (void)hipFreeAsync(q, s); }
+        hipError_t get(int i, size_t bytes) {
+            bytes = std::max<size_t>(bytes, 64);
+            if (!ws) return hipMallocAsync(&p[i], bytes, s);
+            if (ws->cap[i] < bytes) {
+                if (ws->p[i]) { (void)hipStreamSynchronize(s); (void)hipFree(ws->p[i]); ws->p[i] = nullptr; ws->cap[i] = 0; }
+                hipError_t e = hipMalloc(&ws->p[i], bytes);
+                if (e != hipSuccess) return e;
+                ws->cap[i] = bytes;
+            }
+            p[i] = ws->p[i];
+            return hipSuccess;
+        }
+    } scratch{s, ws};
     float *bias = nullptr;
     u64 *cand = nullptr;
     uint32_t *counter = nullptr;
     float *vals = d_dists;
     uint32_t *ids_k2 = d_ids;            // where K2 (and the segment merge) leave their K-lists
     if (K != K_out) {                    // L2 with a margin: K2 writes K-wide scratch lists, the re-score writes the K_out-wide result
-        RG_HIP(hipMallocAsync(&scratch.p[5], (size_t)nq * K * 4, s));
-        RG_HIP(hipMallocAsync(&scratch.p[6], (size_t)nq * K * 4, s));
+        RG_HIP(scratch.get(5, (size_t)nq * K * 4));
+        RG_HIP(scratch.get(6, (size_t)nq * K * 4));
         ids_k2 = static_cast<uint32_t *>(scratch.p[5]);
         vals = static_cast<float *>(scratch.p[6]);
     }
     if (metric == RG_METRIC_L2) {
-        RG_HIP(hipMallocAsync(&scratch.p[0], (size_t)nb * 4, s));
+        RG_HIP(scratch.get(0, (size_t)nb * 4));
         bias = static_cast<float *>(scratch.p[0]);
         hipLaunchKernelGGL(rg_gt_bias_kernel, dim3((nb * 16 + 255) / 256), dim3(256), 0, s, d_base, nb, bstride, dim, bias);
     }
-    RG_HIP(hipMallocAsync(&scratch.p[1], (size_t)grid * mq * 64 * items * 8, s));
+    RG_HIP(scratch.get(1, (size_t)grid * mq * 64 * items * 8));
     cand = static_cast<u64 *>(scratch.p[1]);
-    RG_HIP(hipMallocAsync(&scratch.p[2], 64, s));
+    RG_HIP(scratch.get(2, 64));
     counter = static_cast<uint32_t *>(scratch.p[2]);
     RG_HIP(hipMemsetAsync(counter, 0, 4, s));
     GtParams P;
@@ -816,8 +842,8 @@ rg_status rg_gt_shard_dev(const float *d_base, uint32_t nb, uint32_t bstride, co
     P.diag = getenv("RG_GT_DIAG") ? (uint32_t)atoi(getenv("RG_GT_DIAG")) : 0u;
     P.nseg = nseg; P.seg_rows = seg_rows; P.seg_ids = nullptr; P.seg_vals = nullptr;
     if (nseg > 1) {
-        RG_HIP(hipMallocAsync(&scratch.p[3], (size_t)nseg * nq * K * 4, s));
-        RG_HIP(hipMallocAsync(&scratch.p[4], (size_t)nseg * nq * K * 4, s));
+        RG_HIP(scratch.get(3, (size_t)nseg * nq * K * 4));
+        RG_HIP(scratch.get(4, (size_t)nseg * nq * K * 4));
         P.seg_ids = static_cast<uint32_t *>(scratch.p[3]);
         P.seg_vals = static_cast<float *>(scratch.p[4]);
     }
@@ -863,6 +889,16 @@ rg_status rg_gt_shard_dev(const float *d_base, uint32_t nb, uint32_t bstride, co
     if (st != RG_OK) return st;
     RG_HIP(hipGetLastError());
     return RG_OK;
+}
+
+}  // namespace rg
+
+extern "C" {
+
+rg_status rg_gt_shard_dev(const float *d_base, uint32_t nb, uint32_t bstride, const float *d_queries, uint32_t nq,
+                          uint32_t qstride, uint32_t dim, int metric, uint32_t K, uint32_t id_base, uint32_t *d_ids,
+                          float *d_dists, int device, void *stream) {
+    return rg::gt_shard_ws(d_base, nb, bstride, d_queries, nq, qstride, dim, metric, K, id_base, d_ids, d_dists, device, stream, nullptr);
 }
 
 rg_status rg_gt_merge_dev(const uint32_t *d_ids_in, const float *d_dists_in, uint32_t nlists, uint32_t nq, uint32_t K,

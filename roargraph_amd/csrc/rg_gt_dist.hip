@@ -147,6 +147,7 @@ struct RankBufs {   // everything a rank allocates, released on every exit path
     float *h_q[2] = {nullptr, nullptr}, *d_q[2] = {nullptr, nullptr};
     uint32_t *d_ids[2] = {nullptr, nullptr}, *d_rids[2] = {nullptr, nullptr}, *d_oids[2] = {nullptr, nullptr}, *h_oids[2] = {nullptr, nullptr};
     float *d_vals[2] = {nullptr, nullptr}, *d_rvals[2] = {nullptr, nullptr}, *d_ovals[2] = {nullptr, nullptr}, *h_ovals[2] = {nullptr, nullptr};
+    GtWorkspace ws;   // K2's scratch, this rank's own
     ~RankBufs() {
         (void)hipSetDevice(device);
         if (s_comp) (void)hipStreamSynchronize(s_comp);
@@ -157,6 +158,7 @@ struct RankBufs {   // everything a rank allocates, released on every exit path
             for (void *d : {(void *)d_q[p], (void *)d_ids[p], (void *)d_rids[p], (void *)d_oids[p], (void *)d_vals[p], (void *)d_rvals[p], (void *)d_ovals[p]})
                 if (d) (void)hipFree(d);
         }
+        gt_workspace_free(&ws);
         if (s_comp) (void)hipStreamDestroy(s_comp);
         if (s_comm) (void)hipStreamDestroy(s_comm);
     }
@@ -222,7 +224,7 @@ static rg_status gt_rank_run(rg_comm *cm, const float *d_base, uint32_t nb_shard
         }
         RG_HIP(hipMemcpyAsync(B.d_q[p], B.h_q[p], (size_t)nqb * ad * 4, hipMemcpyHostToDevice, B.s_comp));
         RG_HIP(hipEventRecord(B.ev_q[p], B.s_comp));
-        st = rg_gt_shard_dev(d_base, nb_shard, bstride, B.d_q[p], nqb, ad, ad, m, K, id_base, B.d_ids[p], B.d_vals[p], cm->device, B.s_comp);
+        st = gt_shard_ws(d_base, nb_shard, bstride, B.d_q[p], nqb, ad, ad, m, K, id_base, B.d_ids[p], B.d_vals[p], cm->device, B.s_comp, &B.ws);
         if (st != RG_OK) return st;
         RG_HIP(hipEventRecord(B.ev_k2[p], B.s_comp));
         // ---- communication stream: all-to-all of the K-lists (rank j receives the rows of the range it owns), K3, download
@@ -278,6 +280,9 @@ static rg_status gt_rank_run(rg_comm *cm, const float *d_base, uint32_t nb_shard
     }
     RG_HIP(hipStreamSynchronize(B.s_comp));
     RG_HIP(hipStreamSynchronize(B.s_comm));
+    // in-process transport: peers copy straight out of this rank's K2 buffers, and their last copies may still be queued
+    // when this rank is done -- nobody releases anything before every rank has drained its own streams
+    if (lg && !lg->barrier()) return set_error(RG_ERR_DEVICE, "a peer rank failed");
     return RG_OK;
 }
 

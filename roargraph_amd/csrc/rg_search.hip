@@ -241,6 +241,77 @@ __global__ void rg_graph_stats_kernel(const uint64_t *offsets, const uint32_t *n
 }
 
 
+// ---- CalculateProjectionep (src/index_bipartite.cpp:2004-2041): entry point = the base row nearest (squared L2) to the
+// centroid.  The reference's centroid is a float sum over the rows IN INDEX ORDER per dimension (:2008-2012) and that order
+// fixes the bits, so the sum stays a serial chain per dimension; what the GPU adds is width: every workgroup owns 32
+// dimensions, all of its 256 threads stream the rows' 128-byte slices into a double-buffered LDS tile, and 32 threads walk
+// the tile row by row.  The distance pass is one thread per row with the reference's j-order sum, and the arg-min keeps
+// the first of equal distances (:2031-2035) through a 64-bit (distance bits, index) atomicMin.
+__global__ void __launch_bounds__(256) rg_centroid_sum_kernel(const float *__restrict__ base, uint32_t nd, uint32_t dim, uint32_t stride,
+                                                              float *__restrict__ sum) {
+    __shared__ float tile[2][256][33];
+    const int t = threadIdx.x;
+    const uint32_t d0 = blockIdx.x * 32u, nt = (nd + 255u) / 256u;
+    float4 r[8];
+    auto load = [&](uint32_t tl) {
+        const uint32_t row = tl * 256u + (uint32_t)t;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t c = d0 + 4u * (uint32_t)k;
+            r[k] = (row < nd && c < dim) ? *reinterpret_cast<const float4 *>(base + (size_t)row * stride + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+    };
+    auto store = [&](int buf) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            tile[buf][t][4 * k + 0] = r[k].x; tile[buf][t][4 * k + 1] = r[k].y;
+            tile[buf][t][4 * k + 2] = r[k].z; tile[buf][t][4 * k + 3] = r[k].w;
+        }
+    };
+    load(0);
+    store(0);
+    __syncthreads();
+    float acc = 0.0f;
+    for (uint32_t tl = 0; tl < nt; ++tl) {
+        if (tl + 1 < nt) load(tl + 1);                       // next tile's rows fly while this one is summed
+        if (t < 32) {
+            const uint32_t rows = min(256u, nd - tl * 256u);
+            for (uint32_t i = 0; i < rows; ++i) acc += tile[tl & 1u][i][t];
+        }
+        __syncthreads();
+        if (tl + 1 < nt) store((int)((tl + 1) & 1u));
+        __syncthreads();
+    }
+    if (t < 32 && d0 + (uint32_t)t < dim) sum[d0 + t] = acc;
+}
+
+__global__ void __launch_bounds__(256) rg_centroid_argmin_kernel(const float *__restrict__ base, uint32_t nd, uint32_t dim, uint32_t stride,
+                                                                 const float *__restrict__ center, unsigned long long *best) {
+    extern __shared__ float cen[];
+    for (uint32_t j = threadIdx.x; j < dim; j += blockDim.x) cen[j] = center[j];
+    __syncthreads();
+    unsigned long long mine = ~0ull;
+    for (uint32_t row = blockIdx.x * blockDim.x + threadIdx.x; row < nd; row += gridDim.x * blockDim.x) {
+        const float *x = base + (size_t)row * stride;
+        float diff = 0.0f;
+        for (uint32_t j = 0; j < dim; j += 4) {
+            const float4 v = *reinterpret_cast<const float4 *>(x + j);
+            float t0 = cen[j] - v.x; diff += t0 * t0;
+            t0 = cen[j + 1] - v.y; diff += t0 * t0;
+            t0 = cen[j + 2] - v.z; diff += t0 * t0;
+            t0 = cen[j + 3] - v.w; diff += t0 * t0;
+        }
+        const unsigned long long key = ((unsigned long long)__float_as_uint(diff) << 32) | row;   // diff >= 0: bits order like values
+        mine = min(mine, key);
+    }
+    for (int o = 32; o; o >>= 1) {
+        const unsigned long long other = ((unsigned long long)(uint32_t)__shfl_xor((int)(mine >> 32), o, 64) << 32) |
+                                         (uint32_t)__shfl_xor((int)(mine & 0xffffffffu), o, 64);
+        mine = min(mine, other);
+    }
+    if ((threadIdx.x & 63) == 0) atomicMin(best, mine);
+}
+
 // -------------------------------------------------------------------------------------------------- host
 static rg_status pick_device(int device) {
     int n = 0;
@@ -965,6 +1036,33 @@ rg_status rg_index_set(rg_index *ix, const char *name, int value) {
     else if (!strcmp(name, "count_table_log2")) ix->count_table_log2 = value;
     else if (!strcmp(name, "count_full_ids")) ix->count_full_ids = value != 0;
     else return set_error(RG_ERR_ARG, "unknown knob");
+    return RG_OK;
+}
+
+rg_status rg_projection_ep_dev(const float *d_base, uint32_t nd, uint32_t dim, uint32_t stride, int device, uint32_t *out_ep) {
+    if (!d_base || !out_ep || nd == 0) return set_error(RG_ERR_ARG, "null argument");
+    if (dim == 0 || dim % 4 || stride % 4 || stride < dim || ((uintptr_t)d_base & 15))
+        return set_error(RG_ERR_ARG, "device base must be 16-byte aligned with dim % 4 == 0 and stride % 4 == 0");
+    rg_status st = rg::pick_device(device);
+    if (st != RG_OK) return st;
+    rg::DevBuf<float> d_sum;
+    rg::DevBuf<unsigned long long> d_best;
+    RG_HIP(d_sum.alloc(dim));
+    RG_HIP(d_best.alloc(1));
+    hipLaunchKernelGGL(rg::rg_centroid_sum_kernel, dim3((dim + 31) / 32), dim3(256), 0, 0, d_base, nd, dim, stride, d_sum.p);
+    std::vector<float> center(dim);
+    RG_HIP(hipMemcpy(center.data(), d_sum.p, (size_t)dim * 4, hipMemcpyDeviceToHost));
+    for (uint32_t d = 0; d < dim; ++d) center[d] /= (float)nd;        // :2014-2016, on the host: the same division as the host form
+    RG_HIP(hipMemcpy(d_sum.p, center.data(), (size_t)dim * 4, hipMemcpyHostToDevice));
+    RG_HIP(hipMemset(d_best.p, 0xff, 8));
+    hipDeviceProp_t prop;
+    RG_HIP(hipGetDeviceProperties(&prop, device));
+    const uint32_t grid = std::min<uint32_t>((nd + 255) / 256, (uint32_t)prop.multiProcessorCount * 8u);
+    hipLaunchKernelGGL(rg::rg_centroid_argmin_kernel, dim3(grid), dim3(256), (size_t)dim * 4, 0, d_base, nd, dim, stride, d_sum.p, d_best.p);
+    unsigned long long best = 0;
+    RG_HIP(hipMemcpy(&best, d_best.p, 8, hipMemcpyDeviceToHost));
+    RG_HIP(hipGetLastError());
+    *out_ep = (uint32_t)(best & 0xffffffffu);
     return RG_OK;
 }
 

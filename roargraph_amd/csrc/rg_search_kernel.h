@@ -490,21 +490,20 @@ __global__ void __launch_bounds__(64) rg_search_kernel(SearchParams P) {
 #pragma unroll
                     for (int j = 0; j < R; ++j) {
                         const uint32_t c = 4 * (p0 + j) + g;
-                        rid[j] = c < n ? cand_id[c] : rid0;    // idle groups re-read a row that is being fetched anyway
+                        // idle groups and idle sets re-read a row that is being fetched anyway: every set is loaded
+                        // unconditionally so that the waits in front of the sets are exact counts (a set behind a branch
+                        // makes the compiler wait for ALL sets before the first one is scored: -10 % measured)
+                        rid[j] = c < n ? cand_id[c] : rid0;
                     }
 #pragma unroll
                     for (int j = 0; j < R; ++j) {
-                        // (sets beyond the last pass stay idle: a load nobody consumes would still be outstanding when
-                        // the merge reuses its registers, and the merge would wait a memory latency for it)
-                        if (p0 + j < npass) {
-                            const float *src = P.base + (size_t)rid[j] * P.stride + 4 * jsrc;
+                        const float *src = P.base + (size_t)rid[j] * P.stride + 4 * jsrc;
 #pragma unroll
-                            for (int b = 0; b < NFULL; ++b) rv[j][b] = *reinterpret_cast<const v4f *>(src + 64 * b);
-                            if constexpr (REM != 0) {
-                                v4f t = {0.0f, 0.0f, 0.0f, 0.0f};
-                                if (tail) t = *reinterpret_cast<const v4f *>(src + 64 * NFULL);
-                                rv[j][NFULL] = t;
-                            }
+                        for (int b = 0; b < NFULL; ++b) rv[j][b] = *reinterpret_cast<const v4f *>(src + 64 * b);
+                        if constexpr (REM != 0) {
+                            v4f t = {0.0f, 0.0f, 0.0f, 0.0f};
+                            if (tail) t = *reinterpret_cast<const v4f *>(src + 64 * NFULL);
+                            rv[j][NFULL] = t;
                         }
                     }
 #pragma unroll
@@ -706,7 +705,7 @@ __global__ void __launch_bounds__(64) rg_search_kernel(SearchParams P) {
                 lds_fence();
                 RG_PROF(3);
                 uint32_t none = 0xffffffffu;
-                if (ELL && c0 + kWave >= deg) {
+                if (ELL && c0 + kWave >= deg && !(P.diag & 4u)) {
                     // last chunk of the hop: once the ranks are known the next pop is known -- request its adjacency row
                     // now, its latency runs under the shifting and the pop
                     const MergePlan mp = merge_rank<VIS == 1>(bm, cd, cid, (uint32_t)lane < n, P.ep, lane, mscr, none RG_PROF_MERGE);

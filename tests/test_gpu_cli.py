@@ -147,3 +147,35 @@ def test_bench_multi_rank_control_flow_on_one_gpu():
     assert d["gt_build"]["value"] > 0 and "sharded x2" in d["gt_build"]["metric"]
     assert "genuine RoarGraph index" in d["config"]["workload"] and "on 2 GPU(s)" in d["config"]["workload"]
     assert [p["L_pq"] for p in d["L_pq_sweep"]] == [20, 100, 500] and all(p["recall_at_10"] > 0.5 for p in d["L_pq_sweep"][1:])
+
+
+@pytest.mark.parametrize("nd,d", [(1, 8), (300, 200), (4097, 200), (2500, 512), (70000, 24), (513, 104)])
+def test_projection_ep_kernel_equals_host_loop(nd, d):
+    """CalculateProjectionep (src/index_bipartite.cpp:2004-2041): the device form keeps the reference's summation orders
+    (rows in index order per dimension, j order per row) and so returns the host loop's entry point -- including on sets
+    with exactly tied distances (duplicated rows: the first index wins, :2031-2035) and with a large common offset, where
+    a re-associated sum would round differently."""
+    import ctypes as C
+    import torch
+    from roargraph_amd._lib import check, lib
+    rng = np.random.default_rng(nd + d)
+    base = (rng.standard_normal((nd, d)) * 3 + 100.0).astype(np.float32)
+    if nd > 10:
+        base[nd // 2:] = base[: nd - nd // 2]          # every row twice: ties everywhere
+    host = C.c_uint32()
+    check(lib().rg_projection_ep(base.ctypes.data_as(C.c_void_p), C.c_uint32(nd), C.c_uint32(d), C.c_uint32(d), C.byref(host)))
+    bt = torch.from_numpy(base).cuda()
+    devv = C.c_uint32()
+    check(lib().rg_projection_ep_dev(C.c_void_p(bt.data_ptr()), C.c_uint32(nd), C.c_uint32(d), C.c_uint32(d), 0, C.byref(devv)))
+    assert devv.value == host.value
+    # an independent restatement of the same arithmetic in numpy (float32 throughout, sequential accumulation)
+    if nd <= 5000:
+        c = np.zeros(d, np.float32)
+        for i in range(nd):
+            c = (c + base[i]).astype(np.float32)
+        c = (c / np.float32(nd)).astype(np.float32)
+        diff = np.zeros(nd, np.float32)
+        for j in range(d):
+            t = (c[j] - base[:, j]).astype(np.float32)
+            diff = (diff + (t * t).astype(np.float32)).astype(np.float32)
+        assert int(np.argmin(diff)) == host.value
