@@ -97,8 +97,7 @@ rg_status rg_index_info(const rg_index *idx, uint32_t *nd, uint32_t *dim, uint32
 /* tuning knobs: "waves_per_cu", "rows_per_pass", "filter_log2", "log_cap", "log_budget_kb", "count_table_log2",
  * "count_full_ids", "query_in_lds", "exact_filter" never change results (0 = automatic where a knob has an automatic
  * choice: "rows_per_pass", "filter_log2", "waves_per_cu").
- * "spec" = 1 turns on the speculative second expansion per hop (results are bit-identical either way, see
- * rg_search_kernel.h); "rows_per_pass" = 4 * (passes of 4 rows a query keeps in flight).
+ * "rows_per_pass" = 4 * (passes of 4 rows a query keeps in flight; 16 / 32 use register staging at d = 200).
  * "visited" selects how the visited set is kept:
  *   2 (default) LDS exact-match filter + per-query id log + exact distinct count: ids, dists, hops AND cmps bit-exact.
  *               Adaptive: once a batch shows the filter re-scoring > 30 % extra nodes at some L_pq (long searches on
@@ -112,9 +111,10 @@ rg_status rg_index_info(const rg_index *idx, uint32_t *nd, uint32_t *dim, uint32
  * fp32 routine and the k best by exact (distance, id) are returned: out_dists are exact for the returned ids, the ids
  * can differ from the reference's (recall is reported separately by bench.py), cmps = evaluations performed.
  * It combines with "visited": 0 = exact HBM words (no repeated evaluations), 1 / 2 = LDS filter only.
- * "multi_expand" = 1 is the second OPT-IN mode that is NOT parity (speculative multi-expansion): every hop
- * also expands the runner-up -- the entry next in line after the pop -- in the same gather phase, whether or not it would
- * have been the next pop; more fresh neighbours per latency chain, a slightly different visiting order. */
+ * "multi_expand" = 1 is the second OPT-IN mode that is NOT parity (speculative multi-expansion): every
+ * iteration pops the TWO closest unexpanded entries and expands both in one adjacency / visited / gather phase, whether or
+ * not the second would have been the reference's next pop; twice the fresh neighbours per latency chain, a slightly
+ * different visiting order (recall is reported beside it by bench.py). */
 rg_status rg_index_set(rg_index *idx, const char *name, int value);
 
 /* ----------------------------------------------------------------- operator

@@ -82,8 +82,7 @@ struct rg_index {
     int log_cap_knob = 0;       // 0 = auto; tests force small logs to exercise the exact fallback
     int count_table_log2 = 15;  // K4 LDS table: 2^15 words = 128 KiB
     bool fast_bf16 = false;      // opt-in non-parity mode: traverse a bf16 copy of the base, exact re-rank of the beam
-    int spec = -1;               // speculative second expansion per hop (bit-exact either way): -1 = auto, 0 = off, 1 = on
-    int multi_expand = 0;        // opt-in non-parity mode: the speculated expansion is merged unconditionally
+    int multi_expand = 0;        // opt-in non-parity mode: the two closest unexpanded entries are expanded per iteration
     uint16_t *d_base_bf = nullptr;
     uint32_t stride_bf = 0;
     bool exact_filter = true;    // mode 0: the LDS filter screens the exact HBM words (hits skip the atomics)

@@ -472,7 +472,7 @@ static size_t stage_total_floats(const rg_index *ix, int R, bool bf) {   // the 
     return std::max((size_t)R * stage_pass_floats(ix, bf), (size_t)((ix->dim + 63) / 64) * 256);
 }
 static size_t search_lds_bytes(const rg_index *ix, uint32_t L, int R, int mode, bool bf, int filter_auto) {
-    size_t b = stage_total_floats(ix, R, bf) * 4 + (dimc_of(ix) ? 0 : (size_t)ix->dim * 4) + kCand * 4 + kCand * 4 + 3 * kWave * 4 + (size_t)L * 8;
+    size_t b = stage_total_floats(ix, R, bf) * 4 + (dimc_of(ix) ? 0 : (size_t)ix->dim * 4) + kCand * 4 + kCand * 4 + 2 * kWave * 4 + (size_t)L * 8;
     if (mode != 0 || ix->exact_filter) b += 128 * 4 + std::max<size_t>(4, (size_t)2 << filter_log2_of(ix, filter_auto));
     return (b + 15) / 16 * 16;
 }
@@ -579,8 +579,9 @@ static rg_status launch_k1(rg_index *ix, SearchCtx *cx, int mode, const float *d
     P.id_bits = id_bits_of(ix->nd);
     P.qlog = with_log ? cx->d_qlog : nullptr; P.logcap = cx->logcap; P.qlog_n = with_log ? cx->d_qlog_n : nullptr;
     P.qlist = qlist;
-    // speculative second expansion (bit-exact either way; "spec" knob, off unless asked for)
-    P.spec = ix->multi_expand ? 2u : (ix->spec > 0 ? 1u : 0u);
+    // opt-in, NOT parity: two expansions per iteration (never in the build-mode searches, whose expansion lists must be the
+    // reference's)
+    P.spec = (ix->multi_expand && !bp) ? 2u : 0u;
 #ifdef RG_K1_PROF
     P.prof = (qlist || bp) ? nullptr : g_prof_buf;
 #endif
@@ -1018,7 +1019,6 @@ rg_status rg_index_set(rg_index *ix, const char *name, int value) {
     else if (!strcmp(name, "log_budget_kb")) ix->log_budget_kb = value;
     else if (!strcmp(name, "query_in_lds")) ix->query_in_lds = value != 0;
     else if (!strcmp(name, "exact_filter")) ix->exact_filter = value != 0;
-    else if (!strcmp(name, "spec")) ix->spec = value;
     else if (!strcmp(name, "multi_expand")) ix->multi_expand = value;
     else if (!strcmp(name, "fast_bf16")) {
         // opt-in, NOT parity (see rg.h): the bf16 copy of the base is made on first use

@@ -93,11 +93,25 @@ struct SearchParams {
 #define RG_PROF_CNT(i, v)
 #endif
 
-constexpr int kCand = 128;  // candidate ids / scores of one iteration held in LDS: up to 64 of the popped node + up to 63 speculated
+constexpr int kCand = 128;  // candidate ids / scores of one iteration held in LDS (two expansions of up to 63 neighbours in the multi_expand mode)
 
+// The beam == NeighborPriorityQueue (neighbor.h:138-223): the best `cap` of everything inserted so far under the total
+// order (distance, id), each entry with an "expanded" flag, popped closest-unexpanded first.  Two containers hold it:
+//   main     sorted array in LDS (x = distance bits, y = id | kFlagBit), `cur` = its first unflagged entry
+//   pending  up to 64 recent insertions, sorted, ONE PER LANE in registers (lane j < psize holds the j-th)
+// A hop inserts two or three entries on average (2.5 - 3 on a genuine index once the beam is full).  Into the sorted array
+// each of them would shift everything behind it -- six 64-entry chunks per hop at L_pq = 2000, a third of the hop's time --
+// so insertions go to the pending list (a few register operations) and the list is merged into the array in one pass when
+// it is full (every twenty-odd hops).  Every query the search loop asks is answered over BOTH containers: the worst entry
+// (tail test and eviction, neighbor.h:151-153, 168-170) is the worse of the two tails, the next pop (neighbor.h:185-192)
+// the better of the two first unflagged entries -- so the sequence of pops and the final contents are those of the single
+// sorted array.
 struct Beam {
-    uint2 *ent;  // LDS: x = distance bits, y = id | kFlagBit
+    uint2 *ent;
     uint32_t size, cur, cap;
+    float pd;          // pending entry of this lane
+    uint32_t pi;       // its id | kFlagBit
+    uint32_t psize;
 };
 
 // ordering point for LDS traffic inside a single-wave workgroup: the LDS unit executes one wave's DS instructions in
@@ -108,9 +122,25 @@ __device__ __forceinline__ void lds_fence() {
     __builtin_amdgcn_wave_barrier();
 }
 
-// closest_unexpanded (neighbor.h:185-192): flag the entry at cur, move cur to the next unflagged entry
+__device__ __forceinline__ bool beam_has_unexpanded(const Beam &bm, int lane) {
+    return bm.cur < bm.size || __ballot((uint32_t)lane < bm.psize && !(bm.pi & kFlagBit)) != 0ull;
+}
+
+// closest_unexpanded (neighbor.h:185-192) over both containers: flag the entry and return (distance bits, id)
 __device__ __forceinline__ uint2 beam_pop(Beam &bm, int lane) {
-    uint2 e = bm.ent[bm.cur];
+    const unsigned long long pm = __ballot((uint32_t)lane < bm.psize && !(bm.pi & kFlagBit));
+    const bool in_main = bm.cur < bm.size;
+    uint2 e = make_uint2(0u, 0u);
+    if (in_main) e = bm.ent[bm.cur];                         // unflagged by the cursor invariant
+    if (pm) {
+        const int j = __ffsll((long long)pm) - 1;            // sorted list: the first unflagged lane is the closest
+        const float d = readlane_f(bm.pd, j);
+        const uint32_t id = readlane_u(bm.pi, j);
+        if (!in_main || nb_less(d, id, __uint_as_float(e.x), e.y)) {
+            if (lane == j) bm.pi |= kFlagBit;
+            return make_uint2(__float_as_uint(d), id);
+        }
+    }
     if (lane == 0) bm.ent[bm.cur].y = e.y | kFlagBit;
     uint32_t c = bm.cur + 1;
     for (;;) {
@@ -123,45 +153,12 @@ __device__ __forceinline__ uint2 beam_pop(Beam &bm, int lane) {
     }
     bm.cur = c;
     lds_fence();
-    return make_uint2(e.x, e.y & ~kFlagBit);
+    return e;
 }
 
-// Insert the scored candidates (one per lane with have == true) -- the net effect of that many calls of
-// NeighborPriorityQueue::insert (neighbor.h:150-183).  The beam is the top-cap of everything inserted so far under the
-// total order (distance, id); candidates are distinct unvisited nodes, the only possible repeat is the entry point (never
-// marked visited, index_bipartite.cpp:2349), whose second insert the reference drops.
-//
-// The merge runs in two steps so that the caller can act between them:
-//   merge_rank   tail test, rank of every candidate among the beam entries and among each other, and from those the
-//                position of the cursor after the merge -- i.e. WHICH ENTRY IS POPPED NEXT is known here, before a single
-//                entry has moved (the hop loop requests that node's adjacency row at this point, so that the row's latency
-//                runs under the shifting)
-//   merge_apply  shifts the beam entries and writes the candidates in
-//   mscr   128 words of LDS scratch
-//   track  in: beam index of an entry to follow through the merge (or ~0u); out: its index afterwards, ~0u if it fell off
-struct MergePlan {
-    bool any;            // a candidate enters the beam
-    bool valid, keep;    // this lane's candidate is inserted / lands inside the capacity
-    uint32_t nc, fpos, slo, minq, ncur;
-    uint32_t s0, s1, s2, s3;   // insertion ranks of the first four candidates (wave-uniform; ~0u beyond nc)
-};
-
-template <bool DEDUP>
-__device__ __forceinline__ MergePlan merge_rank(const Beam &bm, float cd, uint32_t cid, bool have, uint32_t ep, int lane, uint32_t *mscr,
-                                                uint32_t &track RG_PROF_MERGE_ARG) {
-    RG_PROF_M0;
-    MergePlan mp;
-    mp.any = false; mp.valid = mp.keep = false; mp.nc = 0; mp.fpos = mp.slo = mp.minq = 0xffffffffu;
-    mp.s0 = mp.s1 = mp.s2 = mp.s3 = 0xffffffffu;
-    mp.ncur = bm.cur < bm.size ? bm.cur : 0xffffffffu;   // nothing enters: the cursor stays where it is
-    bool valid = have && cid != ep;
-    if (bm.size == bm.cap) {  // full: only candidates better than the current worst can enter (neighbor.h:151-153)
-        uint2 w = bm.ent[bm.cap - 1];
-        valid = valid && nb_less(cd, cid, __uint_as_float(w.x), w.y & ~kFlagBit);
-    }
-    if (!__any(valid)) { RG_PROF_M(0); return mp; }
-    // rank among the beam entries: lower bound under (distance, id)
-    uint32_t lo = 0, hi = valid ? bm.size : 0;
+// rank of this lane's key among the main array's entries: lower bound under (distance, id)
+__device__ __forceinline__ uint32_t beam_lower_bound(const Beam &bm, float cd, uint32_t cid, bool active) {
+    uint32_t lo = 0, hi = active ? bm.size : 0;
     while (__any(lo < hi)) {
         if (lo < hi) {
             const uint32_t mid = (lo + hi) >> 1;
@@ -170,16 +167,109 @@ __device__ __forceinline__ MergePlan merge_rank(const Beam &bm, float cd, uint32
             else hi = mid;
         }
     }
+    return lo;
+}
+
+// merge the pending list into the main array: one pass, top chunk first.  An entry of the array moves right by the number
+// of pending entries ranked at or before it; the pending entries carry their flags with them.
+__device__ __forceinline__ void beam_flush(Beam &bm, int lane, uint32_t *mscr) {
+    const uint32_t nc = bm.psize;
+    if (nc == 0) return;
+    const bool have = (uint32_t)lane < nc;
+    const uint32_t cid = bm.pi & ~kFlagBit;
+    const uint32_t lo = beam_lower_bound(bm, bm.pd, cid, have);       // rank among the array entries
+    const uint32_t fpos = lo + (uint32_t)lane;                        // the list is sorted: lane j is its j-th entry
+    // slo[j] = array rank of the j-th pending entry (non-decreasing in j): already one per lane
+    const uint32_t slo = have ? lo : 0xffffffffu;
+    const uint32_t minq = readlane_u(slo, 0);
+    // cursor afterwards: the old one, moved by the pending entries ranked at or before it, or the first unflagged newcomer
+    uint32_t ncur = 0xffffffffu;
+    if (bm.cur < bm.size) ncur = bm.cur + (uint32_t)__popcll(__ballot(have && slo <= bm.cur));
+    ncur = min(ncur, wave_min_u32(have && !(bm.pi & kFlagBit) ? fpos : 0xffffffffu));
+    (void)mscr;
+    constexpr int G = 4;
+    int jh = (int)nc;
+    for (int top = (int)bm.size - 1; top >= (int)minq; top -= kWave * G) {
+        uint2 e[G];
+        uint32_t sh[G];
+#pragma unroll
+        for (int g2 = 0; g2 < G; ++g2) {
+            const int i = top - kWave * g2 - lane;
+            e[g2] = i >= (int)minq ? bm.ent[i] : make_uint2(0, 0);
+            sh[g2] = 0;
+        }
+        // shift of an entry = pending entries ranked at or before it.  Walk down the sorted ranks: those above the group's
+        // top count for nobody (and for no later group either: jh only ever moves down), those at or below its bottom for
+        // everybody, the ones in between are compared lane by lane
+        const int gbot = top - kWave * G + 1;
+        while (jh > 0 && (int)readlane_u(slo, jh - 1) > top) --jh;
+        uint32_t all = 0;
+        for (int j = jh - 1; j >= 0; --j) {
+            const int l = (int)readlane_u(slo, j);
+            if (l <= gbot) { all = (uint32_t)j + 1u; break; }
+#pragma unroll
+            for (int g2 = 0; g2 < G; ++g2) sh[g2] += l <= top - kWave * g2 - lane ? 1u : 0u;
+        }
+        lds_fence();
+#pragma unroll
+        for (int g2 = 0; g2 < G; ++g2) {
+            const int i = top - kWave * g2 - lane;
+            if (i >= (int)minq) bm.ent[(uint32_t)i + sh[g2] + all] = e[g2];
+        }
+        lds_fence();
+    }
+    if (have) bm.ent[fpos] = make_uint2(__float_as_uint(bm.pd), bm.pi);
+    bm.size += nc;
+    bm.cur = ncur == 0xffffffffu ? bm.size : ncur;
+    bm.psize = 0;
+    lds_fence();
+}
+
+// Insert the scored candidates (one per lane with have == true) -- the net effect of that many calls of
+// NeighborPriorityQueue::insert (neighbor.h:150-183).  Candidates are distinct unvisited nodes, the only possible repeat
+// is the entry point (never marked visited, index_bipartite.cpp:2349), whose second insert the reference drops.
+//   mscr   128 words of LDS scratch
+// DEDUP: a node can reach the beam a second time (forgetful visited filter).  Its distance bits are the same, so it is
+// either still in the beam under exactly its key -- dropped like the reference's equal-id probe (neighbor.h:161) -- or it
+// was evicted / never got in, and then the tail test rejects it (the tail only improves).
+template <bool DEDUP>
+__device__ __forceinline__ void beam_insert(Beam &bm, float cd, uint32_t cid, bool have, uint32_t ep, int lane, uint32_t *mscr RG_PROF_MERGE_ARG) {
+    RG_PROF_M0;
+    bool valid = have && cid != ep;
+    if (bm.size + bm.psize == bm.cap) {   // full: only candidates better than the current worst can enter (neighbor.h:151-153)
+        float wd = 0.0f;
+        uint32_t wi = 0;
+        bool w_main = bm.size > 0;
+        if (w_main) { const uint2 w = bm.ent[bm.size - 1]; wd = __uint_as_float(w.x); wi = w.y & ~kFlagBit; }
+        if (bm.psize > 0) {
+            const float d2 = readlane_f(bm.pd, (int)bm.psize - 1);
+            const uint32_t i2 = readlane_u(bm.pi, (int)bm.psize - 1) & ~kFlagBit;
+            if (!w_main || nb_less(wd, wi, d2, i2)) { wd = d2; wi = i2; }
+        }
+        valid = valid && nb_less(cd, cid, wd, wi);
+    }
+    if (!__any(valid)) { RG_PROF_M(0); return; }
     if (DEDUP) {
-        // A node can reach the merge a second time (forgetful visited filter, or a speculated list that turns out to
-        // hold a visited node).  Its distance bits are the same, so the lower bound lands exactly on its beam entry if it
-        // is still there: drop it (the reference's equal-id rule, neighbor.h:161); if it was evicted or never got in the
-        // tail test above already rejected it (the tail only improves).
+        // still in the array?  the lower bound lands exactly on its entry
+        const uint32_t lo = beam_lower_bound(bm, cd, cid, valid);
         if (valid && lo < bm.size && (bm.ent[lo].y & ~kFlagBit) == cid) valid = false;
-        // The same id twice in one merge: one of them stays (they carry the same distance bits, so it does not matter
-        // which).  Election through a 64-slot table keyed by the id: every candidate writes its lane to its slot, the
-        // survivor of the slot keeps its candidate, a loser with the survivor's id is the duplicate and drops out, a loser
-        // with another id (slot collision) is settled by the exact pairwise loop below -- rare.
+        // still in the pending list?  (walk whichever side is shorter)
+        const unsigned long long vm0 = __ballot(valid);
+        if ((uint32_t)__popcll(vm0) <= bm.psize) {
+            for (unsigned long long m = vm0; m; m &= m - 1) {
+                const int s = __ffsll((long long)m) - 1;
+                const uint32_t oi = readlane_u(cid, s);
+                const bool hit = __ballot((uint32_t)lane < bm.psize && (bm.pi & ~kFlagBit) == oi) != 0ull;
+                if (hit && lane == s) valid = false;
+            }
+        } else {
+            for (uint32_t j = 0; j < bm.psize; ++j) valid = valid && (readlane_u(bm.pi, (int)j) & ~kFlagBit) != cid;
+        }
+        // The same id twice among the candidates: one of them stays (they carry the same distance bits, so it does not
+        // matter which).  Election through a 64-slot table keyed by the id: every candidate writes its lane to its slot,
+        // the survivor of the slot keeps its candidate, a loser with the survivor's id is the duplicate and drops out, a
+        // loser with another id (slot collision) is undecided.  A twin of an undecided lane lost the same slot the same
+        // way, so twins are looked for among the undecided lanes only; the lowest lane of a set of twins stays.
         const uint32_t slot = (cid * 0x9E3779B1u) >> 26;
         if (valid) mscr[slot] = (uint32_t)lane;
         lds_fence();
@@ -188,8 +278,6 @@ __device__ __forceinline__ MergePlan merge_rank(const Beam &bm, float cd, uint32
         const uint32_t wid = (uint32_t)__shfl((int)cid, (int)wl, 64);     // the slot survivor's id
         const bool won = valid && wl == (uint32_t)lane;
         if (valid && !won && wid == cid) valid = false;
-        // undecided: lost the slot to ANOTHER id.  A twin of such a lane lost the same slot the same way, so twins are
-        // looked for among the undecided lanes only; the lowest lane of a set of twins stays
         const bool unsure = valid && !won;
         const unsigned long long mu = __ballot(unsure);
         bool dup = false;
@@ -201,101 +289,47 @@ __device__ __forceinline__ MergePlan merge_rank(const Beam &bm, float cd, uint32
     }
     const unsigned long long vmask = __ballot(valid);
     RG_PROF_M(0);
-    if (!vmask) return mp;
+    if (!vmask) return;
     const uint32_t nc = __popcll(vmask);
-    // rank among the candidates
-    uint32_t crank = 0;
+    if (bm.psize + nc > (uint32_t)kWave) { beam_flush(bm, lane, mscr); RG_PROF_M(2); }
+#ifdef RG_K1_PROF
+    pf_m[3] += ((unsigned long long)nc << 32) | 1u;
+#endif
+    // new places in the pending list: a pending entry moves up by the candidates ranked before it; a candidate lands
+    // behind the pending entries and the candidates ranked before it
+    const bool plane = (uint32_t)lane < bm.psize;
+    const uint32_t pid = bm.pi & ~kFlagBit;
+    uint32_t up = 0, crank = 0, prank = 0;
     for (unsigned long long m = vmask; m; m &= m - 1) {
         const int s = __ffsll((long long)m) - 1;
         const float od = readlane_f(cd, s);
         const uint32_t oi = readlane_u(cid, s);
+        const bool before_me = plane && nb_less(od, oi, bm.pd, pid);
+        up += before_me ? 1u : 0u;
         crank += nb_less(od, oi, cd, cid) ? 1u : 0u;
+        const uint32_t behind = bm.psize - (uint32_t)__popcll(__ballot(before_me));   // pending entries ranked before candidate s
+        if (lane == s) prank = behind;
     }
-    mp.any = true; mp.valid = valid; mp.nc = nc;
-    mp.fpos = lo + crank;
-    mp.keep = valid && mp.fpos < bm.cap;
-    // insertion ranks in candidate order: lane j <- the beam rank of the candidate of rank j (non-decreasing in j)
-    if (valid) mscr[crank] = lo;
+    uint2 *slots = reinterpret_cast<uint2 *>(mscr);
+    if (plane) slots[(uint32_t)lane + up] = make_uint2(__float_as_uint(bm.pd), bm.pi);
+    if (valid) slots[prank + crank] = make_uint2(__float_as_uint(cd), cid);
     lds_fence();
-    mp.slo = (uint32_t)lane < nc ? mscr[lane] : 0xffffffffu;
+    bm.psize += nc;
+    if ((uint32_t)lane < bm.psize) { const uint2 t = slots[lane]; bm.pd = __uint_as_float(t.x); bm.pi = t.y; }
     lds_fence();
-    mp.s0 = readlane_u(mp.slo, 0); mp.s1 = readlane_u(mp.slo, 1); mp.s2 = readlane_u(mp.slo, 2); mp.s3 = readlane_u(mp.slo, 3);
-    mp.minq = mp.s0;                                    // first beam index that moves
-    // new cursor: first unflagged entry after the merge
-    uint32_t ncur = 0xffffffffu;
-    if (bm.cur < bm.size) {
-        const uint32_t sh = __popcll(__ballot((uint32_t)lane < nc && mp.slo <= bm.cur));
-        if (bm.cur + sh < bm.cap) ncur = bm.cur + sh;
-    }
-    mp.ncur = min(ncur, wave_min_u32(mp.keep ? mp.fpos : 0xffffffffu));
-    if (track != 0xffffffffu) {
-        const uint32_t sh = __popcll(__ballot((uint32_t)lane < nc && mp.slo <= track));
-        track = track + sh < bm.cap ? track + sh : 0xffffffffu;
+    // eviction (neighbor.h:168-170): the worst entries beyond the capacity fall off, from whichever container holds them
+    while (bm.size + bm.psize > bm.cap) {
+        bool drop_pending = bm.size == 0;
+        if (!drop_pending && bm.psize > 0) {
+            const uint2 w = bm.ent[bm.size - 1];
+            const float d2 = readlane_f(bm.pd, (int)bm.psize - 1);
+            const uint32_t i2 = readlane_u(bm.pi, (int)bm.psize - 1) & ~kFlagBit;
+            drop_pending = nb_less(__uint_as_float(w.x), w.y & ~kFlagBit, d2, i2);
+        }
+        if (drop_pending) --bm.psize;
+        else { --bm.size; bm.cur = min(bm.cur, bm.size); }
     }
     RG_PROF_M(1);
-    return mp;
-}
-
-// (distance bits, id) of the entry the cursor will point at once the plan is applied: an old entry that only shifts, or
-// one of the candidates; valid when mp.ncur != ~0u.  Wave-uniform.
-__device__ __forceinline__ uint2 merge_next_entry(const Beam &bm, const MergePlan &mp, float cd, uint32_t cid, int lane) {
-    const unsigned long long from_cand = __ballot(mp.keep && mp.fpos == mp.ncur);
-    if (from_cand) {
-        const int s = __ffsll((long long)from_cand) - 1;
-        return make_uint2(__float_as_uint(readlane_f(cd, s)), readlane_u(cid, s));
-    }
-    const uint2 e = bm.ent[bm.cur];     // the old cursor entry, moved right by the candidates ranked at or before it
-    return make_uint2(e.x, e.y & ~kFlagBit);
-}
-
-__device__ __forceinline__ void merge_apply(Beam &bm, const MergePlan &mp, float cd, uint32_t cid, int lane RG_PROF_MERGE_ARG) {
-    if (!mp.any) return;
-    RG_PROF_M0;
-#ifdef RG_K1_PROF
-    pf_m[3] += ((unsigned long long)mp.nc << 32) | ((bm.size - mp.minq + 63) >> 6);
-#endif
-    // shift entries [minq, size) right by the number of candidates ranked at or before them.  Done in place, top group
-    // first; a group is up to G chunks of 64 entries held in registers, so its reads all complete before its writes
-    // (which only land on indices >= the ones read, i.e. inside the group or in groups already moved).  Hardly ever more
-    // than four candidates enter per hop (2.5 - 3 on a genuine index once the beam is full): their ranks sit in scalar
-    // registers and an entry's shift is four compares; further candidates are walked one by one.
-    constexpr int G = 4;
-    const int minq = (int)mp.minq;
-    for (int top = (int)bm.size - 1; top >= minq; top -= kWave * G) {
-        uint2 e[G];
-        uint32_t sh[G];
-#pragma unroll
-        for (int g2 = 0; g2 < G; ++g2) {
-            const int i = top - kWave * g2 - lane;
-            e[g2] = i >= minq ? bm.ent[i] : make_uint2(0, 0);
-            const uint32_t ui = (uint32_t)max(i, 0);
-            sh[g2] = (mp.s0 <= ui ? 1u : 0u) + (mp.s1 <= ui ? 1u : 0u) + (mp.s2 <= ui ? 1u : 0u) + (mp.s3 <= ui ? 1u : 0u);
-        }
-        for (uint32_t j = 4; j < mp.nc; ++j) {
-            const uint32_t l = readlane_u(mp.slo, (int)j);
-#pragma unroll
-            for (int g2 = 0; g2 < G; ++g2) sh[g2] += (int)l <= top - kWave * g2 - lane ? 1u : 0u;
-        }
-        lds_fence();
-#pragma unroll
-        for (int g2 = 0; g2 < G; ++g2) {
-            const int i = top - kWave * g2 - lane;
-            if (i >= minq && (uint32_t)i + sh[g2] < bm.cap) bm.ent[(uint32_t)i + sh[g2]] = e[g2];
-        }
-        lds_fence();
-    }
-    if (mp.keep) bm.ent[mp.fpos] = make_uint2(__float_as_uint(cd), cid);
-    bm.size = min(bm.cap, bm.size + mp.nc);
-    bm.cur = mp.ncur == 0xffffffffu ? bm.size : mp.ncur;
-    lds_fence();
-    RG_PROF_M(2);
-}
-
-template <bool DEDUP>
-__device__ __forceinline__ void beam_merge(Beam &bm, float cd, uint32_t cid, bool have, uint32_t ep, int lane, uint32_t *mscr,
-                                           uint32_t &track RG_PROF_MERGE_ARG) {
-    const MergePlan mp = merge_rank<DEDUP>(bm, cd, cid, have, ep, lane, mscr, track RG_PROF_MERGE);
-    merge_apply(bm, mp, cd, cid, lane RG_PROF_MERGE);
 }
 
 // DIMC: 0 = any dimension (query staged in LDS), else the compile-time dimension (query in registers)
@@ -303,15 +337,10 @@ __device__ __forceinline__ void beam_merge(Beam &bm, float cd, uint32_t cid, boo
 //       lines per d = 200 evaluation); at the end the whole beam is re-scored with the exact fp32 routine and the k best
 //       by exact (distance, id) are returned, so the reported distances are exact for the returned ids.
 //
-// Speculative second expansion (P.spec, ELL adjacency): together with the popped node's adjacency row the kernel fetches
-// the row of the entry that is NEXT in line (the closest unexpanded entry after the pop), screens its neighbours against
-// the visited set WITHOUT marking them, and gathers + scores them in the same passes as the popped node's.  After the
-// popped node's candidates are merged, the next pop is known: if it is the speculated node (about 90 % of the hops on a
-// genuine index at L_pq >= 500) its candidates are marked visited, counted and merged right away -- two hops on one
-// adjacency / visited / gather latency chain.  If not, the speculated scores are dropped and nothing else happened: no
-// visited mark, no count, no beam change.  Results are therefore bit-identical with and without speculation; a miss
-// costs the row reads of the dropped candidates.  P.spec == 2 (opt-in, NOT parity) expands the speculated node even on
-// a miss, as long as it is still in the beam.
+// P.spec == 2 ("multi_expand", opt-in, NOT parity -- SURVEY 8(f-4), speculative multi-expansion): every iteration pops
+// the TWO closest unexpanded entries and expands both in one adjacency / visited / gather phase.  The second one is not
+// necessarily the node the reference would expand next (a neighbour of the first may have been closer), so the visiting
+// order -- and with it, occasionally, the result -- differs; twice the fresh neighbours share one latency chain.
 template <bool L2, bool ELL, int R, int VIS, int DIMC, bool BF>
 __global__ void __launch_bounds__(64) rg_search_kernel(SearchParams P) {
     static_assert(!BF || (DIMC != 0 && ELL), "fast mode: compile-time dimension, ELL adjacency");
@@ -328,8 +357,7 @@ __global__ void __launch_bounds__(64) rg_search_kernel(SearchParams P) {
     float *cand_d = reinterpret_cast<float *>(cand_id + kCand);           // kCand
     uint32_t *mscr = reinterpret_cast<uint32_t *>(cand_d + kCand);        // 128: merge scratch
     Beam bm;
-    uint32_t *adjbuf = mscr + 2 * kWave;                                  // 64: prefetched adjacency row (LDS-DMA)
-    bm.ent = reinterpret_cast<uint2 *>(adjbuf + kWave);                   // L
+    bm.ent = reinterpret_cast<uint2 *>(mscr + 2 * kWave);                 // L
     bm.cap = P.L;
     // VIS=1: lossy exact-match visited filter (direct mapped, 16-bit remainders of a bijective id hash)
     // id-log staging: ids are appended here and flushed to HBM 64 at a time (256-B aligned full-line stores; small
@@ -400,7 +428,7 @@ __global__ void __launch_bounds__(64) rg_search_kernel(SearchParams P) {
             bool fresh = false;
             if (VIS == 1) {
                 // exact-match lookup: a hit proves "visited"; a miss is treated as fresh (may re-score a node whose
-                // entry was overwritten -- harmless for the beam, see beam_merge<true>)
+                // entry was overwritten -- harmless for the beam, see beam_insert<true>)
                 if (have) {
                     uint32_t slot; uint16_t rem;
                     vf_hash(id, slot, rem);
@@ -432,19 +460,6 @@ __global__ void __launch_bounds__(64) rg_search_kernel(SearchParams P) {
                 }
             }
             return fresh;
-        };
-        // the same test WITHOUT the set (speculated list).  A stale answer can only err towards "fresh": the list is
-        // screened again, with the set, when (if) it is consumed.
-        auto visit_peek = [&](uint32_t id, bool have) __attribute__((always_inline)) -> bool {
-            if (!have) return false;
-            if (VIS == 1 || P.vf_front) {
-                uint32_t slot; uint16_t rem;
-                vf_hash(id, slot, rem);
-                if (vtab[slot] == rem) return false;
-                if (VIS == 1) return true;
-            }
-            const uint32_t w = __hip_atomic_load(&vmap[id >> 4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            return !((w >> 16) == epoch && (w & (1u << (id & 15u))));
         };
         // id log (VIS = 1): n ids from cand_id[off ..) join the LDS line buffer; a full 64-id line leaves as one aligned
         // 256-B store.  The store is issued where no gather is outstanding: in front of gathers it would sit at the head
@@ -559,38 +574,19 @@ __global__ void __launch_bounds__(64) rg_search_kernel(SearchParams P) {
         if (lane == 0) bm.ent[0] = make_uint2(__float_as_uint(epd), P.ep);
         bm.size = 1;
         bm.cur = 0;
+        bm.psize = 0;
+        bm.pd = 0.0f;
+        bm.pi = 0u;
         wave_sync();
 
         uint32_t cmps = 0, hops = 0;
-        // adjacency row of the node that will be popped next, requested as soon as the merge knows which one it is
-        uint32_t pre_node = 0xffffffffu;
-        RG_PROF(5);
-        while (bm.cur < bm.size) {                                         // has_unexpanded_node, :2356
-            const uint2 popped = beam_pop(bm, lane);                       // :2358
-            const uint32_t node = popped.y;
-            if (build && lane == 0 && hops < P.exp_cap) P.out_exp[(size_t)qi * P.exp_cap + hops] = popped;   // full_retset, :1319
-            ++hops;                                                        // :2366
-            RG_PROF(0);
-            // adjacency of `node`, 64 words at a time; with it (ELL) the row of the entry that is now next in line
-            uint32_t deg, first = 0, first2 = 0, node2 = 0xffffffffu, pos2 = 0xffffffffu;
+        // one expansion (:2368-2399): neighbours of `node` 64 at a time -- visited test-and-set, gather + score, insert
+        auto expand = [&](uint32_t node, uint32_t first) __attribute__((always_inline)) {
+            uint32_t deg;
             const uint32_t *list;
             if (ELL) {
-                const uint32_t *row = P.ell + (size_t)node * P.ell_stride;
-                if (pre_node == node) {                                    // requested during the previous hop's merge
-                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    first = (uint32_t)lane < P.ell_stride ? adjbuf[lane] : 0u;
-                } else {
-                    first = (uint32_t)lane < P.ell_stride ? row[lane] : 0u;
-                }
-                pre_node = 0xffffffffu;
-                if (P.spec && !P.diag && bm.cur < bm.size) {
-                    pos2 = bm.cur;
-                    node2 = bm.ent[pos2].y;                                // unflagged by the cursor invariant
-                    const uint32_t *row2 = P.ell + (size_t)node2 * P.ell_stride;
-                    first2 = (uint32_t)lane < P.ell_stride ? row2[lane] : 0u;
-                }
                 deg = readlane_u(first, 0);
-                list = row + 1;
+                list = P.ell + (size_t)node * P.ell_stride + 1;
             } else {
                 const uint64_t o0 = P.offsets[node], o1 = P.offsets[node + 1];
                 deg = (uint32_t)(o1 - o0);
@@ -601,79 +597,6 @@ __global__ void __launch_bounds__(64) rg_search_kernel(SearchParams P) {
 #endif
             RG_PROF(1);
             RG_PROF_CNT(5, deg);
-            uint32_t deg2 = 0;
-            if (ELL && node2 != 0xffffffffu) {
-                deg2 = readlane_u(first2, 0);
-                if (deg > 63u || deg2 > 63u || deg2 == 0u) node2 = 0xffffffffu;   // wide or empty rows take the plain path
-            }
-            if (ELL && node2 != 0xffffffffu) {
-                // ---- pair path: candidates of `node` (A) and, speculatively, of `node2` (B) share one gather phase
-                uint32_t idA = (uint32_t)__shfl_down((int)first, 1, 64), idB = (uint32_t)__shfl_down((int)first2, 1, 64);
-                bool haveA = (uint32_t)lane < deg, haveB = (uint32_t)lane < deg2;
-                if (build) { haveA = haveA && idA != tgt; haveB = haveB && idB != tgt; }
-                const bool freshA = visit_set(idA, haveA);
-                const bool freshB = visit_peek(idB, haveB);      // after A's marks: common neighbours are not gathered twice
-                const unsigned long long fmA = __ballot(freshA), fmB = __ballot(freshB);
-                const uint32_t nA = __popcll(fmA), nB = __popcll(fmB);
-                const unsigned long long below = (1ull << lane) - 1ull;
-                if (freshA) cand_id[__popcll(fmA & below)] = idA;
-                if (freshB) cand_id[nA + __popcll(fmB & below)] = idB;
-                lds_fence();
-                log_append(0, nA);
-                cmps += nA;                                                // :2397
-                RG_PROF_CNT(0, 1); RG_PROF_CNT(1, nA); RG_PROF_CNT(2, 1);
-                RG_PROF(2);
-                if (nA + nB) gather_list(nA + nB);
-                log_flush();
-                // queue inserts of A (:2398)
-                {
-                    const float cd = (uint32_t)lane < nA ? cand_d[lane] : 0.0f;
-                    const uint32_t cid = (uint32_t)lane < nA ? cand_id[lane] : 0u;
-                    lds_fence();
-                    RG_PROF(3);
-                    if (nA) beam_merge<VIS == 1>(bm, cd, cid, (uint32_t)lane < nA, P.ep, lane, mscr, pos2 RG_PROF_MERGE);
-                    RG_PROF(4);
-                }
-                // the next pop is known now: is it the speculated node?
-                const bool hit = bm.cur < bm.size && pos2 == bm.cur;
-                RG_PROF_CNT(3, hit ? 1 : 0);
-                if (hit || (P.spec == 2u && pos2 != 0xffffffffu)) {
-                    uint2 e2;
-                    if (hit) e2 = beam_pop(bm, lane);                      // :2358 of the second hop
-                    else {                                                 // multi_expand, miss: expanded out of order (NOT parity)
-                        e2 = bm.ent[pos2];
-                        if (lane == 0) bm.ent[pos2].y = e2.y | kFlagBit;
-                        lds_fence();
-                    }
-                    if (build && lane == 0 && hops < P.exp_cap) P.out_exp[(size_t)qi * P.exp_cap + hops] = make_uint2(e2.x, e2.y & ~kFlagBit);
-                    ++hops;
-                    RG_PROF(0);
-                    // B becomes the expansion of node2: mark, count, log, merge
-                    const float cd = (uint32_t)lane < nB ? cand_d[nA + lane] : 0.0f;
-                    const uint32_t cid = (uint32_t)lane < nB ? cand_id[nA + lane] : 0u;
-                    bool validB = (uint32_t)lane < nB;
-                    uint32_t cntB = nB;
-                    if (VIS == 1) {
-                        if (validB) { uint32_t slot; uint16_t rem; vf_hash(cid, slot, rem); vtab[slot] = rem; }
-                        log_append(nA, nB);
-                    } else {
-                        // authoritative test-and-set; a candidate that turns out visited (stale peek, repeated edge) is
-                        // not counted, and the merge's de-duplication drops it
-                        const bool fr = visit_set(cid, validB);
-                        cntB = __popcll(__ballot(fr));
-                        validB = fr;
-                    }
-                    cmps += cntB;
-                    RG_PROF_CNT(0, 1); RG_PROF_CNT(1, cntB);
-                    lds_fence();
-                    log_flush();
-                    RG_PROF(2);
-                    uint32_t none = 0xffffffffu;
-                    if (nB) beam_merge<true>(bm, cd, cid, validB, P.ep, lane, mscr, none RG_PROF_MERGE);
-                    RG_PROF(4);
-                }
-                continue;
-            }
             for (uint32_t c0 = 0; c0 < deg; c0 += kWave) {                 // neighbour loop, :2368
                 uint32_t id = 0;
                 bool have;
@@ -704,30 +627,67 @@ __global__ void __launch_bounds__(64) rg_search_kernel(SearchParams P) {
                 const uint32_t cid = (uint32_t)lane < n ? cand_id[lane] : 0u;
                 lds_fence();
                 RG_PROF(3);
-                uint32_t none = 0xffffffffu;
-                if (ELL && c0 + kWave >= deg && !(P.diag & 4u)) {
-                    // last chunk of the hop: once the ranks are known the next pop is known -- request its adjacency row
-                    // now, its latency runs under the shifting and the pop
-                    const MergePlan mp = merge_rank<VIS == 1>(bm, cd, cid, (uint32_t)lane < n, P.ep, lane, mscr, none RG_PROF_MERGE);
-                    if (mp.ncur != 0xffffffffu) {
-                        // LDS-DMA through inline asm: the row has no register destination the compiler could want to wait
-                        // for (it parked an s_waitcnt vmcnt(0) at the top of the shift loop when this was a plain load);
-                        // it is waited for explicitly where the next hop picks it up
-                        pre_node = merge_next_entry(bm, mp, cd, cid, lane).y;
-                        const uint32_t *src = P.ell + (size_t)pre_node * P.ell_stride + lane;
-                        const uint32_t lds_addr = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(lds_ptr_t *)adjbuf);
-                        if ((uint32_t)lane < P.ell_stride)
-                            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off" :: "s"(lds_addr), "v"(src) : "memory");
-                    }
-                    merge_apply(bm, mp, cd, cid, lane RG_PROF_MERGE);
-                } else {
-                    beam_merge<VIS == 1>(bm, cd, cid, (uint32_t)lane < n, P.ep, lane, mscr, none RG_PROF_MERGE);
-                }
+                beam_insert<VIS == 1>(bm, cd, cid, (uint32_t)lane < n, P.ep, lane, mscr RG_PROF_MERGE);
                 RG_PROF(4);
             }
+        };
+        RG_PROF(5);
+        while (beam_has_unexpanded(bm, lane)) {                            // has_unexpanded_node, :2356
+            const uint2 popped = beam_pop(bm, lane);                       // :2358
+            const uint32_t node = popped.y;
+            if (build && lane == 0 && hops < P.exp_cap) P.out_exp[(size_t)qi * P.exp_cap + hops] = popped;   // full_retset, :1319
+            ++hops;                                                        // :2366
+            uint32_t first = 0;
+            if (ELL) first = (uint32_t)lane < P.ell_stride ? P.ell[(size_t)node * P.ell_stride + lane] : 0u;
+            if (ELL && P.spec == 2u && beam_has_unexpanded(bm, lane)) {
+                // ---- multi_expand (opt-in, NOT parity): the runner-up is expanded in the same phase
+                const uint2 popped2 = beam_pop(bm, lane);
+                const uint32_t node2 = popped2.y;
+                ++hops;
+                const uint32_t first2 = (uint32_t)lane < P.ell_stride ? P.ell[(size_t)node2 * P.ell_stride + lane] : 0u;
+                RG_PROF(0);
+                const uint32_t deg = readlane_u(first, 0), deg2 = readlane_u(first2, 0);
+                if (deg <= 63u && deg2 <= 63u) {
+                    const uint32_t idA = (uint32_t)__shfl_down((int)first, 1, 64), idB = (uint32_t)__shfl_down((int)first2, 1, 64);
+#ifdef RG_K1_PROF
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+                    RG_PROF(1);
+                    const bool freshA = visit_set(idA, (uint32_t)lane < deg);
+                    const bool freshB = visit_set(idB, (uint32_t)lane < deg2);     // after A's marks: a common neighbour counts once
+                    const unsigned long long fmA = __ballot(freshA), fmB = __ballot(freshB);
+                    const uint32_t nA = __popcll(fmA), nB = __popcll(fmB);
+                    const unsigned long long below = (1ull << lane) - 1ull;
+                    if (freshA) cand_id[__popcll(fmA & below)] = idA;
+                    if (freshB) cand_id[nA + __popcll(fmB & below)] = idB;
+                    lds_fence();
+                    log_append(0, nA);
+                    log_flush();
+                    log_append(nA, nB);
+                    cmps += nA + nB;
+                    RG_PROF_CNT(0, 2); RG_PROF_CNT(1, nA + nB);
+                    RG_PROF(2);
+                    if (nA + nB) gather_list(nA + nB);
+                    log_flush();
+                    const float cdA = (uint32_t)lane < nA ? cand_d[lane] : 0.0f, cdB = (uint32_t)lane < nB ? cand_d[nA + lane] : 0.0f;
+                    const uint32_t ciA = (uint32_t)lane < nA ? cand_id[lane] : 0u, ciB = (uint32_t)lane < nB ? cand_id[nA + lane] : 0u;
+                    lds_fence();
+                    RG_PROF(3);
+                    if (nA) beam_insert<true>(bm, cdA, ciA, (uint32_t)lane < nA, P.ep, lane, mscr RG_PROF_MERGE);
+                    if (nB) beam_insert<true>(bm, cdB, ciB, (uint32_t)lane < nB, P.ep, lane, mscr RG_PROF_MERGE);
+                    RG_PROF(4);
+                } else {
+                    expand(node, first);
+                    expand(node2, first2);
+                }
+                continue;
+            }
+            RG_PROF(0);
+            expand(node, first);
         }
 
-        // results (:2408-2418)
+        // results (:2408-2418): the first k entries of the merged beam
+        beam_flush(bm, lane, mscr);
         wave_sync();
         if (cmps_only || build) {
             if (build && lane == 0) P.out_nexp[qi] = hops;

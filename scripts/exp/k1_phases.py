@@ -100,7 +100,7 @@ def main():
                 row["chunks_moved_per_hop"] = float((m[:, 3] & 0xffffffff).sum() / max(hp.float().sum().item(), 1))
                 row["chunks_per_hop"] = float(c[0] / max(hp.float().sum().item(), 1))
                 row["fresh_per_hop"] = float(c[1] / max(hp.float().sum().item(), 1))
-                row["spec_hit_rate"] = float(c[3] / max(c[2], 1))
+                row["spec_hit_rate"] = 0.0
                 row["spec_tries_per_hop"] = float(c[2] / max(hp.float().sum().item(), 1))
                 row["deg_per_hop"] = float(c[5] / max(hp.float().sum().item(), 1))
             rows.append(row)

@@ -56,3 +56,38 @@ def test_fast_mode_is_a_no_op_where_it_does_not_apply(rg, oracle):
     want = oracle.search(base, "l2", off, nbrs, ep, q, 10, 100, nthreads=4)
     assert (got[0] == want[0]).all() and (bits(got[1]) == bits(want[1])).all() and (got[2] == want[2]).all()
     ix.close()
+
+
+@pytest.mark.parametrize("metric,d,nb", [("ip", 200, 4000), ("l2", 512, 2000), ("l2", 24, 3000)])
+@pytest.mark.parametrize("L,k", [(100, 10), (500, 100), (16, 1)])
+@pytest.mark.parametrize("visited", [2, 1, 0])
+def test_multi_expand_properties(rg, oracle, metric, d, nb, L, k, visited):
+    """rg_index_set "multi_expand" (opt-in, NOT parity): two expansions per iteration.  The traversal
+    differs from the reference's, so the checks are properties: exact distances of the returned ids, (distance, id)
+    order without repeats, determinism, every query expands at least as many nodes as its beam is wide, high overlap
+    with the exact search, and the knob off restores parity bit for bit."""
+    base, q, off, nbrs, ep = small_set(metric, nb, d)
+    ix = rg.IndexBipartite.from_arrays(base, off, nbrs, ep, metric=metric)
+    exact = ix.SearchRoarGraph(q, k, L)
+    ix.set("visited", visited)
+    ix.set("multi_expand", 1)
+    ids, dists, cmps, hops = ix.SearchRoarGraph(q, k, L)
+    ids2, dists2, cmps2, hops2 = ix.SearchRoarGraph(q, k, L)
+    assert (ids == ids2).all() and (bits(dists) == bits(dists2)).all() and (hops == hops2).all(), "not deterministic"
+    if visited != 1:
+        assert (cmps == cmps2).all()
+    overlap = 0
+    for i in range(q.shape[0]):
+        assert len(set(ids[i].tolist())) == k, "repeated id"
+        want = ix.score_batch(q[i], ids[i])
+        assert (bits(dists[i]) == bits(want)).all(), "returned distances are not the exact fp32 distances of the ids"
+        key = list(zip(dists[i].tolist(), ids[i].tolist()))
+        assert key == sorted(key), "not ordered by (distance, id)"
+        overlap += len(set(ids[i].tolist()) & set(exact[0][i].tolist()))
+    assert overlap / (q.shape[0] * k) >= 0.9
+    assert (hops >= np.minimum(L, exact[3])).all() and (cmps > 0).all()
+    ix.set("multi_expand", 0)
+    ix.set("visited", 2)
+    back = ix.SearchRoarGraph(q, k, L)
+    assert (back[0] == exact[0]).all() and (bits(back[1]) == bits(exact[1])).all() and (back[2] == exact[2]).all() and (back[3] == exact[3]).all()
+    ix.close()
