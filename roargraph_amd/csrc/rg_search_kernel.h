@@ -337,12 +337,15 @@ __device__ __forceinline__ void beam_insert(Beam &bm, float cd, uint32_t cid, bo
 //       lines per d = 200 evaluation); at the end the whole beam is re-scored with the exact fp32 routine and the k best
 //       by exact (distance, id) are returned, so the reported distances are exact for the returned ids.
 //
+// Register budget (amdgpu_waves_per_eu): the register-staged gather wants many VGPRs, LDS leaves room for 12 - 16 resident
+// queries per CU at L_pq <= 500 -- four waves per SIMD (128 VGPRs) up to four register sets at d = 200, three (170) for the
+// two sets of d = 512, two (256) for the eight-set form that wide beams use.
 // P.spec == 2 ("multi_expand", opt-in, NOT parity -- SURVEY 8(f-4), speculative multi-expansion): every iteration pops
 // the TWO closest unexpanded entries and expands both in one adjacency / visited / gather phase.  The second one is not
 // necessarily the node the reference would expand next (a neighbour of the first may have been closer), so the visiting
 // order -- and with it, occasionally, the result -- differs; twice the fresh neighbours share one latency chain.
 template <bool L2, bool ELL, int R, int VIS, int DIMC, bool BF>
-__global__ void __launch_bounds__(64) rg_search_kernel(SearchParams P) {
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC == 512 ? (R <= 1 ? 4 : R <= 2 ? 3 : 2) : (R <= 4 ? 4 : 2)))) rg_search_kernel(SearchParams P) {
     static_assert(!BF || (DIMC != 0 && ELL), "fast mode: compile-time dimension, ELL adjacency");
     constexpr int NB = (DIMC + 127) / 128;                                // fast mode: LDS-DMA instructions per bf16 row
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
