@@ -80,7 +80,8 @@ struct rg_index {
     int visited_mode = 2;
     int log_budget_kb = 16 << 20;  // HBM budget of the id logs per context (KiB, default 16 GiB = 32768 queries): larger batches are searched in sub-batches
     int log_cap_knob = 0;       // 0 = auto; tests force small logs to exercise the exact fallback
-    int count_table_log2 = 15;  // K4 LDS table: 2^15 words = 128 KiB
+    int count_table_log2 = 15;  // K4 LDS table: at most 2^15 words = 128 KiB
+    bool count_table_auto = true;   // sized per launch from L_pq (knob "count_table_log2" <= 0) or fixed by the knob
     bool fast_bf16 = false;      // opt-in non-parity mode: traverse a bf16 copy of the base, exact re-rank of the beam
     int multi_expand = 0;        // opt-in non-parity mode: the two closest unexpanded entries are expanded per iteration
     uint16_t *d_base_bf = nullptr;

@@ -682,8 +682,13 @@ static rg_status search_dev(rg_index *ix, SearchCtx *cx, const float *d_q, uint3
     st = ensure_qlog(ix, cx, nq);
     if (st != RG_OK) return fail(st);
     if (hipMemsetAsync(b->d_ovf, 0, 8, s) != hipSuccess) return fail(set_error(RG_ERR_DEVICE, "hipMemsetAsync failed"));
-    // default table: 2^15 words = 128 KiB of LDS (+ 16 KiB side table in the half-word form)
-    const uint32_t tbits = (uint32_t)std::max(6, std::min(15, ix->count_table_log2));
+    // table: up to 2^15 words = 128 KiB of LDS (+ 16 KiB side table in the half-word form).  Narrow beams log a few
+    // thousand ids per query; a table sized for them (L_pq x 64 ids) is cleared in a fraction of the time -- clearing is
+    // what K4 costs at small L_pq (a tenth of the whole step at L_pq = 50 with the full table) -- and two workgroups fit
+    // a CU.  A log that outgrows its table is counted in hash partitions, as before.
+    uint32_t tbits = (uint32_t)std::max(6, std::min(15, ix->count_table_log2));
+    if (ix->count_table_auto)
+        while (tbits > 11 && (uint64_t)((1u << (tbits - 1)) / 4u) * 5u >= (uint64_t)L * 64u) --tbits;
     const uint32_t bbits = tbits - 2u;
     const uint32_t id_bits = std::max(id_bits_of(ix->nd), bbits + 1u);
     const bool half = id_bits - bbits <= 15u && !ix->count_full_ids;
@@ -695,7 +700,8 @@ static rg_status search_dev(rg_index *ix, SearchCtx *cx, const float *d_q, uint3
                        d_dists ? d_dists + (size_t)q0 * k : nullptr, d_cmps + q0, d_hops ? d_hops + q0 : nullptr, nullptr, true,
                        b->d_stat, s, nullptr, q0);
         if (st != RG_OK) return fail(st);
-        const dim3 grid(std::min<uint32_t>(nqc, (uint32_t)ix->num_cu));
+        const uint32_t k4_per_cu = lds * 2 + 4096 <= ix->lds_per_cu ? 2u : 1u;   // 1024 threads each: two per CU at most
+        const dim3 grid(std::min<uint32_t>(nqc, (uint32_t)ix->num_cu * k4_per_cu));
         if (half) {
             auto kern = rg_distinct_kernel<true>;
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1033,7 +1039,7 @@ rg_status rg_index_set(rg_index *ix, const char *name, int value) {
         }
         ix->fast_bf16 = value != 0;
     }
-    else if (!strcmp(name, "count_table_log2")) ix->count_table_log2 = value;
+    else if (!strcmp(name, "count_table_log2")) { ix->count_table_log2 = value > 0 ? value : 15; ix->count_table_auto = value <= 0; }
     else if (!strcmp(name, "count_full_ids")) ix->count_full_ids = value != 0;
     else return set_error(RG_ERR_ARG, "unknown knob");
     return RG_OK;
