@@ -20,6 +20,8 @@ run() {  # name, bench args (quoted), rocprof args...
   rm -rf /tmp/rp_$name
   grep -v "simple_timer\|SQLite3" $OUT/$name.log | tail -12 > $OUT/$name.log.tail; rm -f $OUT/$name.log
 }
+# the index is built once, outside the profiler (its phase-3 searches run K1 in build mode and would pollute the kernel stats)
+python $R/bench.py $COMMON --index-cache /tmp/bench_ix.npz --L ${L_STAR:-50} > $OUT/build_run.log 2>&1
 for W in head:"--index-cache /tmp/bench_ix.npz --L ${L_STAR:-50}" L500:"--index-cache /tmp/bench_ix.npz --L 500" L2000:"--index-cache /tmp/bench_ix.npz --L 2000" worst:"--graph random --L 500"; do
   N=${W%%:*}; A=${W#*:}
   run ${N}_trace "$A" --kernel-trace --stats

@@ -91,3 +91,17 @@ def test_partition_helpers():
             r = groundtruth.shard_rows(n, w)
             assert r[0][0] == 0 and r[-1][1] == n and all(a[1] == b[0] for a, b in zip(r, r[1:]))
             assert [rgdist.query_slice(n, i, w) for i in range(w)] == groundtruth.query_ranges(n, w)
+
+
+def test_row_shards_are_balanced_and_owned_rows_partition_the_job():
+    """shard_rows: floor(n/w) rows each, the first n % w one more -- no shard shorter than K or empty when n is not a
+    multiple of w (810 rows over 8 ranks with K = 100 used to leave 96 in the last one).  owned_rows mirrors the batching
+    of rg_groundtruth_rank: per batch, rank r owns the r-th balanced slice; together the ranks own every row once."""
+    import numpy as np
+    from roargraph_amd import groundtruth
+    for n, w in ((810, 8), (9, 4), (10_000_000, 8), (5, 5), (1000, 3)):
+        sizes = [hi - lo for lo, hi in groundtruth.shard_rows(n, w)]
+        assert sum(sizes) == n and max(sizes) - min(sizes) <= 1 and min(sizes) == n // w
+    for nq, w, batch in ((210, 3, 64), (65536 * 2 + 5, 8, 0), (7, 2, 100), (64, 4, 64)):
+        rows = np.concatenate([groundtruth.owned_rows(nq, w, r, batch) for r in range(w)])
+        assert rows.shape[0] == nq and (np.sort(rows) == np.arange(nq)).all()

@@ -179,3 +179,26 @@ def test_projection_ep_kernel_equals_host_loop(nd, d):
             t = (c[j] - base[:, j]).astype(np.float32)
             diff = (diff + (t * t).astype(np.float32)).astype(np.float32)
         assert int(np.argmin(diff)) == host.value
+
+
+@pytest.mark.parametrize("dist_fn,metric,d", [("mips", "ip", 200), ("l2", "l2", 100)])
+def test_compute_groundtruth_cli_multi_rank_leg(bins, oracle, tmp_path, dist_fn, metric, d):
+    """`compute_groundtruth --devices 0,0,0`: the C++ CLI runs the multi-rank ground truth natively -- three ranks (threads)
+    over row shards read straight from the .fbin file, query batches streamed (RG_GT_BATCH keeps them small), per-shard
+    K-lists exchanged device to device, K3, rows written straight into the gt file.  d = 100 also exercises the zero
+    padding of rows to the aligned stride on the way up."""
+    from test_gpu_groundtruth import check_gt
+    from roargraph_amd import synth
+    base, q = synth.make_synth(88, 5003, 301, d)
+    bf, qf, g1, g3 = (str(tmp_path / x) for x in ("b.fbin", "q.fbin", "gt1.bin", "gt3.bin"))
+    io.write_fbin(bf, base); io.write_fbin(qf, q)
+    env = dict(os.environ, RG_GT_BATCH="64")
+    for devs, out in (("0", g1), ("0,0,0", g3)):
+        r = subprocess.run([os.path.join(bins, "compute_groundtruth"), "--data_type", "float", "--dist_fn", dist_fn, "--base_file", bf,
+                            "--query_file", qf, "--gt_file", out, "--K", "50", "--devices", devs], capture_output=True, text=True, env=env)
+        assert r.returncode == 0, r.stdout + r.stderr
+    i1, d1 = oracle.gt_load(g1)
+    i3, d3 = oracle.gt_load(g3)
+    assert (i1 == i3).all() and (d1.view(np.uint32) == d3.view(np.uint32)).all()
+    ref_ids, _, ref_s = oracle.groundtruth_f64(base, q, metric, 50, nthreads=8)
+    check_gt(base, q, metric, 50, i3, d3, ref_ids, ref_s)
