@@ -700,17 +700,20 @@ static rg_status search_dev(rg_index *ix, SearchCtx *cx, const float *d_q, uint3
                        d_dists ? d_dists + (size_t)q0 * k : nullptr, d_cmps + q0, d_hops ? d_hops + q0 : nullptr, nullptr, true,
                        b->d_stat, s, nullptr, q0);
         if (st != RG_OK) return fail(st);
-        const uint32_t k4_per_cu = lds * 2 + 4096 <= ix->lds_per_cu ? 2u : 1u;   // 1024 threads each: two per CU at most
+        // workgroup width by table size: a few thousand ids per query want many small workgroups per CU (a 1024-thread
+        // group spends its time in barriers), the full table wants the 16 waves that cover its LDS latency
+        const uint32_t k4_threads = tbits <= 13u ? 256u : 1024u;
+        const uint32_t k4_per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(2048u / k4_threads, ix->lds_per_cu / (lds + 2048)));
         const dim3 grid(std::min<uint32_t>(nqc, (uint32_t)ix->num_cu * k4_per_cu));
         if (half) {
             auto kern = rg_distinct_kernel<true>;
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(kern, grid, dim3(1024), lds, s, cx->d_qlog, cx->logcap, cx->d_qlog_n, nqc, d_cmps + q0, b->d_ovf + 2,
+            hipLaunchKernelGGL(kern, grid, dim3(k4_threads), lds, s, cx->d_qlog, cx->logcap, cx->d_qlog_n, nqc, d_cmps + q0, b->d_ovf + 2,
                                b->d_ovf, b->d_ovf + 1, tbits, id_bits, q0, b->d_stat + 1);
         } else {
             auto kern = rg_distinct_kernel<false>;
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            hipLaunchKernelGGL(kern, grid, dim3(1024), lds, s, cx->d_qlog, cx->logcap, cx->d_qlog_n, nqc, d_cmps + q0, b->d_ovf + 2,
+            hipLaunchKernelGGL(kern, grid, dim3(k4_threads), lds, s, cx->d_qlog, cx->logcap, cx->d_qlog_n, nqc, d_cmps + q0, b->d_ovf + 2,
                                b->d_ovf, b->d_ovf + 1, tbits, id_bits, q0, b->d_stat + 1);
         }
     }
