@@ -477,6 +477,8 @@ def main():
         del gi, gv, gq
 
     traffic, traffic_src = pmc_traffic(wl_key) if rank == 0 else (None, None)
+    shape_name = {(10_000_000, 200, "ip"): "t2i-10M-shaped", (10_000_000, 512, "l2"): "laion-10M-shaped",
+                  (2_500_000, 512, "ip"): "webvid-2.5M-shaped"}.get((args.nb, args.dim, args.metric), "%dx%d" % (args.nb, args.dim))
     if rank == 0:
         if cpu and cpu.get("value"):
             # x CPU for the sweep: the CPU baseline is measured at the headline L_pq only (bounded run time); its cost per
@@ -486,13 +488,13 @@ def main():
                 p["x_cpu_16_threads_est"] = p["qps"] * p["mean_evals"] * per_eval
             cpu["gpu_over_cpu"] = qps / cpu["value"]
         line = {
-            "metric": "QPS @ recall@10 >= %.2f, t2i-10M-shaped d=%d %s (search, top-%d, smallest L_pq reaching it: %d)"
-                      % (args.target_recall, args.dim, args.metric.upper(), args.k, L_star),
+            "metric": "QPS @ recall@10 >= %.2f, %s d=%d %s (search, top-%d, smallest L_pq reaching it: %d)"
+                      % (args.target_recall, shape_name, args.dim, args.metric.upper(), args.k, L_star),
             "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "t2i-10M-shaped: base %dx%d fp32 %s, %d queries/GPU/step, top-%d, L_pq=%d, %s, %s (replicated per GPU)"
-                                   % (args.nb, args.dim, args.metric, args.nq, args.k, L_star, data_desc, graph_desc),
+            "config": {"workload": "%s: base %dx%d fp32 %s, %d queries/GPU/step, top-%d, L_pq=%d, %s, %s (replicated per GPU)"
+                                   % (shape_name, args.nb, args.dim, args.metric, args.nq, args.k, L_star, data_desc, graph_desc),
                        "parallelism": "query-sharded x%d, index replicated" % world,
                        "L_pq": L_star, "recall_at_10": head["recall_at_10"], "target_recall": args.target_recall,
                        "visited": {2: "default: lds-filter + id log + exact distinct count, adaptive to the exact HBM words where a timed "

@@ -222,6 +222,68 @@ __device__ __forceinline__ float gather_score_q(const float *stage, const float 
     return L2 ? acc : -acc;
 }
 
+// The same value again for a pass that sits in REGISTERS (rg_search_kernel's register-staged gather): rv[b] is the 16 bytes
+// this lane fetched of 64-element block b of its group's row -- elements 64b + 4*((p - 4g) & 15) .. +3, the slot LDS-DMA
+// would have filled.  Block by block the wave drops its 1 KiB into ONE 1-KiB LDS buffer and reads it back transposed
+// (lane a gets elements a, a+16, a+32, a+48 of its row's block).  The LDS unit executes a wave's DS instructions in issue
+// order, so block b+1 may be written behind the reads of block b without waiting for their data; only the FMAs wait.
+// One KiB per in-flight query instead of ceil(dim/64): at wide beams LDS is what limits resident queries.
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+template <bool L2, int DIMC>
+__device__ __forceinline__ float bounce_score_q(float *stage1k, const v4f_t (&rv)[(DIMC + 63) / 64], const float (&qr)[(DIMC + 15) / 16],
+                                                int lane) {
+    static_assert(DIMC % 8 == 0 && DIMC > 0, "dimension");
+    constexpr int nfull = DIMC >> 6, rem = DIMC & 63, nt = rem >> 4;
+    const int g = lane >> 4, a = lane & 15;
+    const int o0 = 64 * g + a + 16 * ((0 + g) & 3);
+    const int o1 = 64 * g + a + 16 * ((1 + g) & 3);
+    const int o2 = 64 * g + a + 16 * ((2 + g) & 3);
+    const int o3 = 64 * g + a + 16 * ((3 + g) & 3);
+    float acc = 0.0f;
+#define RG_STEPB(v_, q_)                                   \
+    {                                                      \
+        const float v = (v_), q = (q_);                    \
+        if (L2) { const float t = v - q; acc = __builtin_fmaf(t, t, acc); } \
+        else acc = __builtin_fmaf(v, q, acc);              \
+    }
+#pragma unroll
+    for (int b = 0; b < nfull; ++b) {
+        *reinterpret_cast<v4f_t *>(stage1k + 4 * lane) = rv[b];
+        asm volatile("" ::: "memory");
+        const float v0 = stage1k[o0], v1 = stage1k[o1], v2 = stage1k[o2], v3 = stage1k[o3];
+        asm volatile("" ::: "memory");
+        RG_STEPB(v0, qr[4 * b + 0]);
+        RG_STEPB(v1, qr[4 * b + 1]);
+        RG_STEPB(v2, qr[4 * b + 2]);
+        RG_STEPB(v3, qr[4 * b + 3]);
+    }
+    if constexpr (rem != 0) {
+        *reinterpret_cast<v4f_t *>(stage1k + 4 * lane) = rv[nfull];
+        asm volatile("" ::: "memory");
+        float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f, t8 = 0.0f;
+        if constexpr (nt > 0) t0 = stage1k[o0];
+        if constexpr (nt > 1) t1 = stage1k[o1];
+        if constexpr (nt > 2) t2 = stage1k[o2];
+        if constexpr ((rem & 8) != 0) {
+            const int x = 16 * nt + (a & 7);
+            t8 = stage1k[64 * g + ((x + 16 * g) & 63)];
+        }
+        asm volatile("" ::: "memory");
+        if constexpr (nt > 0) RG_STEPB(t0, qr[4 * nfull + 0]);
+        if constexpr (nt > 1) RG_STEPB(t1, qr[4 * nfull + 1]);
+        if constexpr (nt > 2) RG_STEPB(t2, qr[4 * nfull + 2]);
+        acc = acc + dpp_f<0x128>(acc);                   // 16 -> 8
+        if constexpr ((rem & 8) != 0) RG_STEPB(t8, qr[(DIMC + 15) / 16 - 1]);   // 8-wide tail on the folded sum
+    } else {
+        acc = acc + dpp_f<0x128>(acc);
+    }
+#undef RG_STEPB
+    acc = acc + dpp_f<0x124>(acc);
+    acc = acc + dpp_f<0xB1>(acc);
+    acc = acc + dpp_f<0x4E>(acc);
+    return L2 ? acc : -acc;
+}
+
 // ---- opt-in fast mode (NOT parity): traversal over a bf16 copy of the base ---------------------------
 // Rows of the copy are padded with zeros to a multiple of 128 elements (256 B: whole LDS-DMA instructions, whole
 // 128-B lines: 512 B per d = 200 row instead of the 7 lines = 896 B of the fp32 row).  One 16-lane group per row as in

@@ -475,7 +475,7 @@ static size_t stage_pass_floats(const rg_index *ix, bool bf) {
 }
 static size_t stage_total_floats(const rg_index *ix, int R, bool bf) {   // the fast mode's exact re-rank needs one fp32 pass
     // register-staged instantiations (compile-time dimension, fp32): rows in flight live in VGPRs, one LDS bounce buffer
-    if (dimc_of(ix) && !bf) return (size_t)((ix->dim + 63) / 64) * 256;
+    if (dimc_of(ix) && !bf) return 256;   // one 1-KiB block at a time (bounce_score_q)
     return std::max((size_t)R * stage_pass_floats(ix, bf), (size_t)((ix->dim + 63) / 64) * 256);
 }
 static size_t search_lds_bytes(const rg_index *ix, uint32_t L, int R, int mode, bool bf, int filter_auto) {

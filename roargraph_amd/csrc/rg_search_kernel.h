@@ -489,7 +489,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
         // gather + score (:2387) of cand_id[0 .. n) into cand_d, 4 rows per pass.
         //  * compile-time dimension (the BASELINE shapes): REGISTER-STAGED.  A batch of R passes (4R rows) is fetched with
         //    plain global_load_dwordx4 into R register sets -- all of them in flight together, one HBM latency per batch --
-        //    and each set is then bounced through ONE LDS buffer in the slot layout the scoring routine reads (the layout
+        //    and each set is then bounced, 64-element block by block, through ONE 1-KiB LDS buffer in the slot layout the scoring routine reads (the layout
         //    the LDS-DMA path produces: lane l's 16 bytes at 16 l inside each 1-KiB block).  Rows in flight cost VGPRs, of
         //    which a latency-bound wave has plenty, instead of LDS, which is what limits resident queries at large L_pq.
         //  * otherwise (any dimension, or the bf16 fast mode): LDS-DMA into a ring of R staging buffers; pass p is consumed
@@ -497,7 +497,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
         auto gather_list = [&](uint32_t n) __attribute__((always_inline)) {
             const uint32_t npass = (n + 3u) >> 2;
             if constexpr (DIMC != 0 && !BF) {
-                typedef float v4f __attribute__((ext_vector_type(4)));
+                typedef v4f_t v4f;
                 constexpr int NBLK = (DIMC + 63) / 64, NFULL = DIMC / 64, REM = DIMC & 63;
                 const int jsrc = ((lane & 15) - 4 * g) & 15;
                 const bool tail = 4 * jsrc < REM;
@@ -527,11 +527,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
 #pragma unroll
                     for (int j = 0; j < R; ++j) {
                         if (p0 + j < npass) {
-#pragma unroll
-                            for (int b = 0; b < NBLK; ++b) *reinterpret_cast<v4f *>(stage + 256 * b + 4 * lane) = rv[j][b];
                             RG_PROF(6);
-                            lds_fence();
-                            const float d = score(stage);
+                            const float d = bounce_score_q<L2, DIMC>(stage, rv[j], qr, lane);
                             const uint32_t c = 4 * (p0 + j) + g;
                             if (c < n && (lane & 15) == 0) cand_d[c] = d;
                             lds_fence();
@@ -571,9 +568,18 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
         };
 
         // entry point: scored and queued, not marked visited (index_bipartite.cpp:2338-2352)
-        issue(P.ep, g == 0, stage);
-        gather_wait(0);
-        const float epd = score(stage);
+        float epd;
+        if constexpr (DIMC != 0 && !BF) {
+            if (lane == 0) cand_id[0] = P.ep;
+            lds_fence();
+            gather_list(1);
+            epd = cand_d[0];
+            lds_fence();
+        } else {
+            issue(P.ep, g == 0, stage);
+            gather_wait(0);
+            epd = score(stage);
+        }
         if (lane == 0) bm.ent[0] = make_uint2(__float_as_uint(epd), P.ep);
         bm.size = 1;
         bm.cur = 0;
