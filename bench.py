@@ -185,7 +185,7 @@ class Searcher:
     def wait(self):
         self.ix.search_wait(self.stream)
 
-    def timed(self, L, reps=3, settle=2):
+    def timed(self, L, reps=3, settle=3):
         """Average milliseconds per batch over `reps` launches (HIP events on the launch stream), after `settle` untimed
         batches (that is where the adaptive default decides between its two exact forms)."""
         t = self.t

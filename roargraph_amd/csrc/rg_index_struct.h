@@ -33,6 +33,7 @@ struct Batch {
     bool counted = false;   // filter + id log + K4 ran: logs that overflowed are recounted in rg_search_wait
     bool timed = false;     // adaptive default: ev0/ev1 bracket the batch
     bool is_trial = false;
+    bool cold = false;      // a buffer was (re)allocated while the batch was enqueued: its event pair spans the allocation
     int mode = 2;           // the exact form the batch ran in (0 = HBM words, 2 = filter + log + K4)
 };
 
@@ -48,6 +49,7 @@ struct SearchCtx {
     uint32_t slots = 0, vwords = 0;
     uint32_t *d_qlog = nullptr, *d_qlog_n = nullptr;
     uint32_t qlog_nq = 0, logcap = 0, qlog_chunk = 0;
+    uint32_t allocs = 0;         // bumped by every (re)allocation of the buffers above
     std::vector<Batch *> pending, spare;
     // host-form staging (rg_search): queries up, results down
     float *d_q = nullptr, *d_dist = nullptr;

@@ -448,7 +448,7 @@ static rg_status take_batch(SearchCtx *cx, uint32_t nq, Batch **out) {
         if (e == hipSuccess) b->ovf_cap = nq + 2;
     }
     if (e != hipSuccess) { free_batch(b); return set_error(RG_ERR_DEVICE, hipGetErrorString(e)); }
-    b->counted = b->timed = b->is_trial = false;
+    b->counted = b->timed = b->is_trial = b->cold = false;
     b->mode = 2;
     *out = b;
     return RG_OK;
@@ -492,6 +492,7 @@ static rg_status ensure_visited(rg_index *ix, SearchCtx *cx, uint32_t slots) {
     cx->d_visited = nullptr;
     cx->d_epoch = nullptr;
     cx->slots = 0;
+    ++cx->allocs;
     RG_HIP(hipMalloc(&cx->d_visited, (size_t)slots * vwords * 4));
     RG_HIP(hipMemset(cx->d_visited, 0, (size_t)slots * vwords * 4));
     RG_HIP(hipMalloc(&cx->d_epoch, (size_t)slots * 4));
@@ -609,6 +610,7 @@ static rg_status ensure_qlog(rg_index *ix, SearchCtx *cx, uint32_t nq) {
     if (cx->d_qlog_n) (void)hipFree(cx->d_qlog_n);
     cx->d_qlog = cx->d_qlog_n = nullptr;
     cx->qlog_nq = 0;
+    ++cx->allocs;
     RG_HIP(hipMalloc(&cx->d_qlog, (size_t)chunk * cap * 4));
     RG_HIP(hipMalloc(&cx->d_qlog_n, (size_t)chunk * 4));
     cx->qlog_nq = chunk;
@@ -643,8 +645,10 @@ static rg_status search_dev(rg_index *ix, SearchCtx *cx, const float *d_q, uint3
         exact_from_L = ix->exact_from_L;
         trial_L = ix->trial_L;
     }
+    const uint32_t allocs0 = cx->allocs;
     auto done = [&]() -> rg_status {
         b->h_stat[3] = 0;
+        b->cold = cx->allocs != allocs0;
         if (hipMemcpyAsync(b->h_stat, b->d_stat, 24, hipMemcpyDeviceToHost, s) != hipSuccess)
             return fail(set_error(RG_ERR_DEVICE, "hipMemcpyAsync failed"));
         if (b->counted && hipMemcpyAsync(b->h_stat + 3, b->d_ovf, 4, hipMemcpyDeviceToHost, s) != hipSuccess)
@@ -746,7 +750,9 @@ static rg_status finish_batches(rg_index *ix, SearchCtx *cx, hipStream_t s, uint
         float per_q = 0.0f;   // time per query of the batch (adaptive default only)
         if (b->timed) {
             float ms = 0.0f;
-            if (hipEventElapsedTime(&ms, b->ev0, b->ev1) == hipSuccess && b->nq) per_q = ms / (float)b->nq;
+            // a cold batch (its enqueue allocated the id logs or the visited words between the two events) is not a
+            // measurement: no verdict, no trial request; the next batch of this width decides
+            if (!b->cold && hipEventElapsedTime(&ms, b->ev0, b->ev1) == hipSuccess && b->nq) per_q = ms / (float)b->nq;
             std::lock_guard<std::mutex> lk(ix->mu);
             if (b->mode == 0 && b->is_trial && per_q > 0.0f) {   // verdict of the trial
                 if (per_q < 0.97f * ix->filter_per_q) ix->exact_from_L = std::min(ix->exact_from_L, b->L);
