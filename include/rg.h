@@ -95,8 +95,12 @@ void rg_index_close(rg_index *idx);
 rg_status rg_index_info(const rg_index *idx, uint32_t *nd, uint32_t *dim, uint32_t *stride, uint32_t *ep,
                         float *avg_degree, uint32_t *max_degree, int *device);
 /* tuning knobs: "waves_per_cu", "rows_per_pass", "filter_log2", "log_cap", "log_budget_kb", "count_table_log2",
- * "count_full_ids", "query_in_lds", "exact_filter" never change results (0 = automatic where a knob has an automatic
- * choice: "rows_per_pass", "filter_log2", "waves_per_cu").
+ * "count_full_ids", "query_in_lds", "exact_filter", "split_rows" never change results (0 = automatic where a knob has an
+ * automatic choice: "rows_per_pass", "filter_log2", "waves_per_cu").
+ * "split_rows" (default 1; d = 200 with the default adjacency layout): searches read a split copy of the base made at
+ * open -- the first 192 elements of every row at a 768-byte stride (six whole 128-byte lines instead of the seven an
+ * 800-byte row spans) and the 8-element tails once per edge in adjacency order, so one hop's tails come from
+ * ceil(degree/4) lines; costs nd * 768 + (edges + 1) * 32 bytes of HBM (environment RG_SPLIT_ROWS=0: never built).
  * "rows_per_pass" = 4 * (passes of 4 rows a query keeps in flight; 16 / 32 use register staging at d = 200).
  * "visited" selects how the visited set is kept:
  *   2 (default) LDS exact-match filter + per-query id log + exact distinct count: ids, dists, hops AND cmps bit-exact.

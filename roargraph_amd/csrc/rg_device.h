@@ -229,11 +229,15 @@ __device__ __forceinline__ float gather_score_q(const float *stage, const float 
 // order, so block b+1 may be written behind the reads of block b without waiting for their data; only the FMAs wait.
 // One KiB per in-flight query instead of ceil(dim/64): at wide beams LDS is what limits resident queries.
 typedef float v4f_t __attribute__((ext_vector_type(4)));
+// The 8-element remainder of a d = 200 row needs no bounce: after the 16 -> 8 fold lane a applies element 192 + (a & 7)
+// (distance.h:194-201), so every lane fetches that one float itself (`t8`; from behind the row or, with split rows, from the
+// per-edge tail array).
 template <bool L2, int DIMC>
-__device__ __forceinline__ float bounce_score_q(float *stage1k, const v4f_t (&rv)[(DIMC + 63) / 64], const float (&qr)[(DIMC + 15) / 16],
+__device__ __forceinline__ float bounce_score_q(float *stage1k, const v4f_t (&rv)[DIMC / 64], float t8, const float (&qr)[(DIMC + 15) / 16],
                                                 int lane) {
     static_assert(DIMC % 8 == 0 && DIMC > 0, "dimension");
-    constexpr int nfull = DIMC >> 6, rem = DIMC & 63, nt = rem >> 4;
+    constexpr int nfull = DIMC >> 6, rem = DIMC & 63;
+    static_assert(rem == 0 || rem == 8, "register-staged gather: whole 64-element blocks plus at most the 8-wide tail");
     const int g = lane >> 4, a = lane & 15;
     const int o0 = 64 * g + a + 16 * ((0 + g) & 3);
     const int o1 = 64 * g + a + 16 * ((1 + g) & 3);
@@ -257,26 +261,8 @@ __device__ __forceinline__ float bounce_score_q(float *stage1k, const v4f_t (&rv
         RG_STEPB(v2, qr[4 * b + 2]);
         RG_STEPB(v3, qr[4 * b + 3]);
     }
-    if constexpr (rem != 0) {
-        *reinterpret_cast<v4f_t *>(stage1k + 4 * lane) = rv[nfull];
-        asm volatile("" ::: "memory");
-        float t0 = 0.0f, t1 = 0.0f, t2 = 0.0f, t8 = 0.0f;
-        if constexpr (nt > 0) t0 = stage1k[o0];
-        if constexpr (nt > 1) t1 = stage1k[o1];
-        if constexpr (nt > 2) t2 = stage1k[o2];
-        if constexpr ((rem & 8) != 0) {
-            const int x = 16 * nt + (a & 7);
-            t8 = stage1k[64 * g + ((x + 16 * g) & 63)];
-        }
-        asm volatile("" ::: "memory");
-        if constexpr (nt > 0) RG_STEPB(t0, qr[4 * nfull + 0]);
-        if constexpr (nt > 1) RG_STEPB(t1, qr[4 * nfull + 1]);
-        if constexpr (nt > 2) RG_STEPB(t2, qr[4 * nfull + 2]);
-        acc = acc + dpp_f<0x128>(acc);                   // 16 -> 8
-        if constexpr ((rem & 8) != 0) RG_STEPB(t8, qr[(DIMC + 15) / 16 - 1]);   // 8-wide tail on the folded sum
-    } else {
-        acc = acc + dpp_f<0x128>(acc);
-    }
+    acc = acc + dpp_f<0x128>(acc);                       // 16 -> 8
+    if constexpr (rem == 8) RG_STEPB(t8, qr[(DIMC + 15) / 16 - 1]);   // 8-wide tail on the folded sum
 #undef RG_STEPB
     acc = acc + dpp_f<0x124>(acc);
     acc = acc + dpp_f<0xB1>(acc);

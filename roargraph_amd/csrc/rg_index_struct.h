@@ -88,6 +88,12 @@ struct rg_index {
     int multi_expand = 0;        // opt-in non-parity mode: the two closest unexpanded entries are expanded per iteration
     uint16_t *d_base_bf = nullptr;
     uint32_t stride_bf = 0;
+    // split rows (d = 200 with ELL adjacency): the first 192 elements of every row at a 768-B stride, the
+    // 8-element tails once per edge in adjacency order (+ one slot for the entry point), first edge of every node
+    float *d_main = nullptr, *d_etail = nullptr;
+    uint32_t *d_tail_off = nullptr;
+    uint32_t main_dim = 0, tail_dim = 0;
+    bool split_rows = true;      // knob: use them (when they exist)
     bool exact_filter = true;    // mode 0: the LDS filter screens the exact HBM words (hits skip the atomics)
     bool query_in_lds = false;   // K1: force the generic (query staged in LDS) instantiation for d = 200 / 512
     bool count_full_ids = false; // K4: force the full-id bucket form (the half-word form is used when the remainder fits)

@@ -319,6 +319,33 @@ __global__ void __launch_bounds__(256) rg_centroid_argmin_kernel(const float *__
     if ((threadIdx.x & 63) == 0) atomicMin(best, mine);
 }
 
+// split rows: main part of every row at a whole-line stride / per-edge tails in adjacency order (slot ne = entry point) /
+// first edge of every node
+__global__ void __launch_bounds__(256) rg_split_main_kernel(const float *__restrict__ base, uint32_t nd, uint32_t stride, uint32_t main_dim,
+                                                            float *__restrict__ out) {
+    const uint32_t per = main_dim / 4u;
+    const size_t total = (size_t)nd * per;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t row = i / per;
+        const uint32_t c = (uint32_t)(i - row * per);
+        reinterpret_cast<float4 *>(out)[i] = *reinterpret_cast<const float4 *>(base + row * stride + 4u * c);
+    }
+}
+__global__ void __launch_bounds__(256) rg_split_tail_kernel(const float *__restrict__ base, uint32_t stride, uint32_t main_dim, uint32_t tail_dim,
+                                                            const uint32_t *__restrict__ nbrs, uint64_t ne, uint32_t ep, float *__restrict__ etail) {
+    const uint32_t per = tail_dim / 4u;
+    const size_t total = (size_t)(ne + 1) * per;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t e = i / per;
+        const uint32_t c = (uint32_t)(i - e * per);
+        const uint32_t row = e < ne ? nbrs[e] : ep;
+        reinterpret_cast<float4 *>(etail)[i] = *reinterpret_cast<const float4 *>(base + (size_t)row * stride + main_dim + 4u * c);
+    }
+}
+__global__ void __launch_bounds__(256) rg_tail_off_kernel(const uint64_t *__restrict__ off, uint32_t nd, uint32_t *__restrict__ out) {
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < nd; i += gridDim.x * blockDim.x) out[i] = (uint32_t)off[i];
+}
+
 // -------------------------------------------------------------------------------------------------- host
 static rg_status pick_device(int device) {
     int n = 0;
@@ -355,6 +382,22 @@ static rg_status finish_graph(rg_index *ix, const uint64_t *d_off, const uint32_
         RG_HIP(hipMalloc(&ix->d_ell, (size_t)ix->nd * es * 4));
         hipLaunchKernelGGL(rg_csr_to_ell_kernel, dim3(4096), dim3(256), 0, 0, d_off, d_nb, ix->nd, ix->d_ell, es);
         RG_HIP(hipDeviceSynchronize());
+        // split rows: an 800-B row (d = 200) spans seven 128-B lines wherever it starts; its first 192 elements at a 768-B
+        // stride span six, and the 8-element tails, stored per edge in adjacency order, are read from ceil(deg/4) lines
+        // per hop instead of one more line per fresh neighbour.  7.7 GB + 32 B per edge at 10M rows.
+        const char *env = getenv("RG_SPLIT_ROWS");
+        if (ix->dim == 200 && ne + 1 < 0xffffffffull && !(env && atoi(env) == 0)) {
+            ix->main_dim = 192; ix->tail_dim = 8;
+            RG_HIP(hipMalloc(&ix->d_main, (size_t)ix->nd * ix->main_dim * 4));
+            RG_HIP(hipMalloc(&ix->d_etail, (size_t)(ne + 1) * ix->tail_dim * 4));
+            RG_HIP(hipMalloc(&ix->d_tail_off, (size_t)ix->nd * 4));
+            hipLaunchKernelGGL(rg_split_main_kernel, dim3(8192), dim3(256), 0, 0, ix->d_base, ix->nd, ix->stride, ix->main_dim, ix->d_main);
+            hipLaunchKernelGGL(rg_split_tail_kernel, dim3(8192), dim3(256), 0, 0, ix->d_base, ix->stride, ix->main_dim, ix->tail_dim, d_nb,
+                               (uint64_t)ne, ix->ep, ix->d_etail);
+            hipLaunchKernelGGL(rg_tail_off_kernel, dim3(2048), dim3(256), 0, 0, d_off, ix->nd, ix->d_tail_off);
+            RG_HIP(hipGetLastError());
+            RG_HIP(hipDeviceSynchronize());
+        }
     } else {
         RG_HIP(hipMalloc(&ix->d_offsets, ((size_t)ix->nd + 1) * 8));
         RG_HIP(hipMalloc(&ix->d_nbrs, std::max<size_t>(ne * 4, 4)));
@@ -580,6 +623,13 @@ static rg_status launch_k1(rg_index *ix, SearchCtx *cx, int mode, const float *d
     P.stage_floats = (uint32_t)stage_pass_floats(ix, bf);
     P.stage_total = (uint32_t)stage_total_floats(ix, R, bf);
     P.base_bf = bf ? ix->d_base_bf : nullptr; P.stride_bf = ix->stride_bf;
+    // remainder block of a row in the register-staged gather (d = 200: elements 192..199): behind the row, or -- split
+    // rows -- in the per-edge tail array
+    P.tail_base = ix->d_base + (ix->dim / 64u) * 64u; P.tail_stride = ix->stride; P.tail_off = nullptr; P.ep_tail = ix->ep;
+    if (ix->d_tail_off && ix->split_rows && ix->d_ell && !bp && !bf && dimc_of(ix) == 200) {
+        P.base = ix->d_main; P.stride = ix->main_dim;
+        P.tail_base = ix->d_etail; P.tail_stride = ix->tail_dim; P.tail_off = ix->d_tail_off; P.ep_tail = (uint32_t)ix->n_edges;
+    }
     P.diag = (uint32_t)ix->diag;
     P.qbase = qbase;
     P.vf_slots_log2 = filter_log2_of(ix, filter_auto);
@@ -941,6 +991,9 @@ void rg_index_close(rg_index *ix) {
     if (ix->d_nbrs) (void)hipFree(ix->d_nbrs);
     if (ix->d_ell) (void)hipFree(ix->d_ell);
     if (ix->d_base_bf) (void)hipFree(ix->d_base_bf);
+    if (ix->d_main) (void)hipFree(ix->d_main);
+    if (ix->d_etail) (void)hipFree(ix->d_etail);
+    if (ix->d_tail_off) (void)hipFree(ix->d_tail_off);
     delete ix;
 }
 
@@ -1042,6 +1095,7 @@ rg_status rg_index_set(rg_index *ix, const char *name, int value) {
     else if (!strcmp(name, "query_in_lds")) ix->query_in_lds = value != 0;
     else if (!strcmp(name, "exact_filter")) ix->exact_filter = value != 0;
     else if (!strcmp(name, "multi_expand")) ix->multi_expand = value;
+    else if (!strcmp(name, "split_rows")) ix->split_rows = value != 0;
     else if (!strcmp(name, "fast_bf16")) {
         // opt-in, NOT parity (see rg.h): the bf16 copy of the base is made on first use
         if (value && !ix->d_base_bf) {

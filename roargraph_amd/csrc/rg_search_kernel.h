@@ -68,6 +68,14 @@ struct SearchParams {
     uint32_t id_bits;         // VIS=1: ceil(log2(nd))
     const uint16_t *base_bf;  // fast mode (BF): bf16 copy of the base, rows padded to stride_bf elements (multiple of 128)
     uint32_t stride_bf;
+    // split rows (d = 200, ELL): `base` is then a copy of the first 192 elements of every row at a 768-B stride (six
+    // whole 128-B lines), and the 8-element tails live once per EDGE, in adjacency order: the tails of one node's
+    // neighbours are contiguous (tail_off[node] + position in the row), so a hop reads them from ceil(deg/4) lines
+    // instead of a seventh line per fresh row.  Not split: tail_base = base + 192, tail_stride = stride, index = row id.
+    const float *tail_base;
+    uint32_t tail_stride;
+    const uint32_t *tail_off; // [nd] first edge of the node (null = rows are not split)
+    uint32_t ep_tail;         // tail slot of the entry point (it is scored without an edge leading to it)
     uint32_t spec;            // 1 = speculative second expansion per hop (bit-exact), 2 = merged unconditionally (opt-in, NOT parity)
 #ifdef RG_K1_PROF
     unsigned long long *prof; // instrumented build only: [nq][16] per-phase cycle sums and event counts
@@ -357,8 +365,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
     uint32_t *cand_id = reinterpret_cast<uint32_t *>(qv + (DIMC ? 0u : P.dim));   // kCand
     float qr[DIMC ? (DIMC + 15) / 16 : 1];
     float qb[BF ? 8 * NB : 1];
-    float *cand_d = reinterpret_cast<float *>(cand_id + kCand);           // kCand
-    uint32_t *mscr = reinterpret_cast<uint32_t *>(cand_d + kCand);        // 128: merge scratch
+    // kCand words: candidate c's tail slot (split rows) until its row is requested, then its distance bits
+    uint32_t *cand_x = cand_id + kCand;
+    uint32_t *mscr = cand_x + kCand;                                      // 128: merge scratch
     Beam bm;
     bm.ent = reinterpret_cast<uint2 *>(mscr + 2 * kWave);                 // L
     bm.cap = P.L;
@@ -498,13 +507,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
             const uint32_t npass = (n + 3u) >> 2;
             if constexpr (DIMC != 0 && !BF) {
                 typedef v4f_t v4f;
-                constexpr int NBLK = (DIMC + 63) / 64, NFULL = DIMC / 64, REM = DIMC & 63;
+                constexpr int NFULL = DIMC / 64, REM = DIMC & 63;
                 const int jsrc = ((lane & 15) - 4 * g) & 15;
-                const bool tail = 4 * jsrc < REM;
                 const uint32_t rid0 = cand_id[0];
+                const bool split = REM != 0 && P.tail_off != nullptr;
+                const uint32_t tix0 = split ? cand_x[0] : rid0;
                 for (uint32_t p0 = 0; p0 < npass; p0 += R) {
-                    v4f rv[R][NBLK];
-                    uint32_t rid[R];
+                    v4f rv[R][NFULL];
+                    float t8[R];
+                    uint32_t rid[R], tix[R];
 #pragma unroll
                     for (int j = 0; j < R; ++j) {
                         const uint32_t c = 4 * (p0 + j) + g;
@@ -512,25 +523,24 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
                         // unconditionally so that the waits in front of the sets are exact counts (a set behind a branch
                         // makes the compiler wait for ALL sets before the first one is scored: -10 % measured)
                         rid[j] = c < n ? cand_id[c] : rid0;
+                        if constexpr (REM != 0) tix[j] = split ? (c < n ? cand_x[c] : tix0) : rid[j];
                     }
 #pragma unroll
                     for (int j = 0; j < R; ++j) {
                         const float *src = P.base + (size_t)rid[j] * P.stride + 4 * jsrc;
 #pragma unroll
                         for (int b = 0; b < NFULL; ++b) rv[j][b] = *reinterpret_cast<const v4f *>(src + 64 * b);
-                        if constexpr (REM != 0) {
-                            v4f t = {0.0f, 0.0f, 0.0f, 0.0f};
-                            if (tail) t = *reinterpret_cast<const v4f *>(src + 64 * NFULL);
-                            rv[j][NFULL] = t;
-                        }
+                        // the 8-wide tail: lane a's own element 192 + (a & 7), straight into the register that scores it
+                        if constexpr (REM != 0) t8[j] = P.tail_base[(size_t)tix[j] * P.tail_stride + (lane & 7)];
+                        else t8[j] = 0.0f;
                     }
 #pragma unroll
                     for (int j = 0; j < R; ++j) {
                         if (p0 + j < npass) {
                             RG_PROF(6);
-                            const float d = bounce_score_q<L2, DIMC>(stage, rv[j], qr, lane);
+                            const float d = bounce_score_q<L2, DIMC>(stage, rv[j], t8[j], qr, lane);
                             const uint32_t c = 4 * (p0 + j) + g;
-                            if (c < n && (lane & 15) == 0) cand_d[c] = d;
+                            if (c < n && (lane & 15) == 0) cand_x[c] = __float_as_uint(d);
                             lds_fence();
                             RG_PROF(3);
                         }
@@ -555,7 +565,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
                     float *buf = stage + (size_t)(p & (R - 1)) * P.stage_floats;
                     const uint32_t c = 4 * p + g;
                     const float d = score(buf);
-                    if (c < n && (lane & 15) == 0) cand_d[c] = d;
+                    if (c < n && (lane & 15) == 0) cand_x[c] = __float_as_uint(d);
                     lds_sync();
                     if (p + R < npass) {
                         const uint32_t c2 = 4 * (p + R) + g;
@@ -570,10 +580,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
         // entry point: scored and queued, not marked visited (index_bipartite.cpp:2338-2352)
         float epd;
         if constexpr (DIMC != 0 && !BF) {
-            if (lane == 0) cand_id[0] = P.ep;
+            if (lane == 0) { cand_id[0] = P.ep; cand_x[0] = P.ep_tail; }
             lds_fence();
             gather_list(1);
-            epd = cand_d[0];
+            epd = __uint_as_float(cand_x[0]);
             lds_fence();
         } else {
             issue(P.ep, g == 0, stage);
@@ -590,7 +600,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
 
         uint32_t cmps = 0, hops = 0;
         // one expansion (:2368-2399): neighbours of `node` 64 at a time -- visited test-and-set, gather + score, insert
-        auto expand = [&](uint32_t node, uint32_t first) __attribute__((always_inline)) {
+        auto expand = [&](uint32_t node, uint32_t first, uint32_t toff) __attribute__((always_inline)) {
             uint32_t deg;
             const uint32_t *list;
             if (ELL) {
@@ -624,7 +634,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
                 const uint32_t n = __popcll(fm);
                 RG_PROF_CNT(0, 1); RG_PROF_CNT(1, n);
                 if (n == 0) { RG_PROF(2); continue; }
-                if (fresh) cand_id[__popcll(fm & ((1ull << lane) - 1ull))] = id;
+                if (fresh) {
+                    const uint32_t pos = __popcll(fm & ((1ull << lane) - 1ull));
+                    cand_id[pos] = id;
+                    if (P.tail_off) cand_x[pos] = toff + c0 + lane;        // the neighbour's place in the adjacency order
+                }
                 lds_fence();
                 log_append(0, n);
                 cmps += n;                                                 // :2397
@@ -632,7 +646,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
                 gather_list(n);
                 log_flush();
                 // queue inserts (:2398)
-                const float cd = (uint32_t)lane < n ? cand_d[lane] : 0.0f;
+                const float cd = (uint32_t)lane < n ? __uint_as_float(cand_x[lane]) : 0.0f;
                 const uint32_t cid = (uint32_t)lane < n ? cand_id[lane] : 0u;
                 lds_fence();
                 RG_PROF(3);
@@ -648,12 +662,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
             ++hops;                                                        // :2366
             uint32_t first = 0;
             if (ELL) first = (uint32_t)lane < P.ell_stride ? P.ell[(size_t)node * P.ell_stride + lane] : 0u;
+            uint32_t toff = 0;
+            if (ELL && P.tail_off) toff = P.tail_off[node];
             if (ELL && P.spec == 2u && beam_has_unexpanded(bm, lane)) {
                 // ---- multi_expand (opt-in, NOT parity): the runner-up is expanded in the same phase
                 const uint2 popped2 = beam_pop(bm, lane);
                 const uint32_t node2 = popped2.y;
                 ++hops;
                 const uint32_t first2 = (uint32_t)lane < P.ell_stride ? P.ell[(size_t)node2 * P.ell_stride + lane] : 0u;
+                const uint32_t toff2 = P.tail_off ? P.tail_off[node2] : 0u;
                 RG_PROF(0);
                 const uint32_t deg = readlane_u(first, 0), deg2 = readlane_u(first2, 0);
                 if (deg <= 63u && deg2 <= 63u) {
@@ -667,8 +684,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
                     const unsigned long long fmA = __ballot(freshA), fmB = __ballot(freshB);
                     const uint32_t nA = __popcll(fmA), nB = __popcll(fmB);
                     const unsigned long long below = (1ull << lane) - 1ull;
-                    if (freshA) cand_id[__popcll(fmA & below)] = idA;
-                    if (freshB) cand_id[nA + __popcll(fmB & below)] = idB;
+                    if (freshA) { const uint32_t pos = __popcll(fmA & below); cand_id[pos] = idA; if (P.tail_off) cand_x[pos] = toff + lane; }
+                    if (freshB) { const uint32_t pos = nA + __popcll(fmB & below); cand_id[pos] = idB; if (P.tail_off) cand_x[pos] = toff2 + lane; }
                     lds_fence();
                     log_append(0, nA);
                     log_flush();
@@ -678,7 +695,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
                     RG_PROF(2);
                     if (nA + nB) gather_list(nA + nB);
                     log_flush();
-                    const float cdA = (uint32_t)lane < nA ? cand_d[lane] : 0.0f, cdB = (uint32_t)lane < nB ? cand_d[nA + lane] : 0.0f;
+                    const float cdA = (uint32_t)lane < nA ? __uint_as_float(cand_x[lane]) : 0.0f, cdB = (uint32_t)lane < nB ? __uint_as_float(cand_x[nA + lane]) : 0.0f;
                     const uint32_t ciA = (uint32_t)lane < nA ? cand_id[lane] : 0u, ciB = (uint32_t)lane < nB ? cand_id[nA + lane] : 0u;
                     lds_fence();
                     RG_PROF(3);
@@ -686,13 +703,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
                     if (nB) beam_insert<true>(bm, cdB, ciB, (uint32_t)lane < nB, P.ep, lane, mscr RG_PROF_MERGE);
                     RG_PROF(4);
                 } else {
-                    expand(node, first);
-                    expand(node2, first2);
+                    expand(node, first, toff);
+                    expand(node2, first2, toff2);
                 }
                 continue;
             }
             RG_PROF(0);
-            expand(node, first);
+            expand(node, first, toff);
         }
 
         // results (:2408-2418): the first k entries of the merged beam

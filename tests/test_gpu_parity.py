@@ -152,6 +152,47 @@ def test_default_mode_stays_exact_when_it_switches_to_the_exact_words(rg, oracle
     ix.close()
 
 
+@pytest.mark.parametrize("metric", ["ip", "l2"])
+def test_split_rows_equal_plain_rows(rg, oracle, metric, monkeypatch):
+    """d = 200 with ELL adjacency searches a split copy of the base by default (first 192 elements of a row at a whole-line
+    stride, the 8-element tail once per edge in adjacency order).  Same values, same order of operations: the outputs must
+    be the oracle's with the copy, with the knob off, and with the copy never built (RG_SPLIT_ROWS=0) -- on a graph with
+    degrees 0 ... 150 (tails beyond the first 64-word adjacency read), repeated edges, and in all three visited modes."""
+    rng = np.random.default_rng(23)
+    nb, d = 3000, 200
+    base = rng.standard_normal((nb, d)).astype(np.float32)
+    q = (rng.standard_normal((64, d)) * 0.5 + 0.3).astype(np.float32)
+    deg = rng.integers(0, 151, nb)
+    deg[0] = 150
+    off = np.zeros(nb + 1, np.uint64); off[1:] = np.cumsum(deg)
+    nbrs = np.concatenate([rng.choice(nb, int(k), replace=True) for k in deg]).astype(np.uint32)   # repeats inside a row
+    want = {L: oracle.search(base, metric, off, nbrs, 0, q, 10, L, nthreads=4) for L in (20, 500)}
+
+    def check(ix, what):
+        for vis in (2, 0, 1):
+            ix.set("visited", vis)
+            for L, w in want.items():
+                got = ix.SearchRoarGraph(q, 10, L)
+                assert (got[0] == w[0]).all() and (bits(got[1]) == bits(w[1])).all(), (what, vis, L)
+                assert (got[3] == w[3]).all(), (what, vis, L)
+                if vis != 1:
+                    assert (got[2] == w[2]).all(), (what, vis, L)
+
+    ix = rg.IndexBipartite.from_arrays(base, off, nbrs, 0, metric=metric)
+    check(ix, "split")
+    ix.set("split_rows", 0)
+    check(ix, "knob off")
+    ix.set("split_rows", 1)
+    ix.set("multi_expand", 1)                   # opt-in mode over the split copy: still a valid search
+    got = ix.SearchRoarGraph(q, 10, 500)
+    assert (np.sort(got[1], axis=1) == got[1]).all() and (got[0] < nb).all()
+    ix.close()
+    monkeypatch.setenv("RG_SPLIT_ROWS", "0")
+    ix = rg.IndexBipartite.from_arrays(base, off, nbrs, 0, metric=metric)
+    check(ix, "never built")
+    ix.close()
+
+
 @pytest.mark.parametrize("layout", ["ell", "csr"])
 def test_wide_and_empty_adjacency_rows(rg, oracle, layout, monkeypatch):
     """Adjacency rows wider than one 64-word read (degrees up to 150) and rows of degree 0, both layouts."""
