@@ -371,6 +371,21 @@ def main():
     wl_key = {"nb": args.nb, "dim": args.dim, "nq": args.nq, "k": args.k, "metric": args.metric, "data": args.data,
               "graph": "roargraph" if roar else "random", "L": L_star, "visited": args.visited}
 
+    # ---- the boundary's host form (rg_search: host buffers in, host buffers out -- PCIe inclusive; never `value`) --------
+    host_form = None
+    if rank == 0 and world == 1:
+        qh = q.cpu().numpy()
+        index.SearchRoarGraph(qh, args.k, L_star)
+        t1 = time.perf_counter()
+        for _ in range(5):
+            hres = index.SearchRoarGraph(qh, args.k, L_star)
+        dt = (time.perf_counter() - t1) / 5
+        assert (hres[0] == ids_head).all(), "host form and device form disagree"
+        host_form = {"what": "rg_search with pageable host buffers (queries up, ids/dists/cmps/hops down, one synchronous call per "
+                             "%d-query batch), L_pq=%d" % (args.nq, L_star),
+                     "qps": args.nq / dt, "ms_per_batch": dt * 1e3, "vs_device_resident": args.nq / dt / qps}
+        del qh
+
     # ---- opt-in NON-parity modes, reported separately, never as `value` -----------------------------------------------
     fast = None
     if rank == 0 and not args.no_fast and args.dim in (200, 512):
@@ -514,6 +529,7 @@ def main():
             "L_pq_500": next((p for p in sweep if p["L_pq"] == 500), None),
             "L_pq_sweep": sweep,
             "roofline_worstcase": worst,
+            "host_form_pcie_inclusive": host_form,
             "non_parity_modes": fast,
             "gt_build": gt,
         }
