@@ -74,6 +74,13 @@ def parse():
     ap.add_argument("--gt-nq", type=int, default=65536, help="queries of the ground-truth (K2) leg; 0 = skip")
     ap.add_argument("--gt-K", type=int, default=100)
     ap.add_argument("--config1-nb", type=int, default=100_000, help="rows of the BASELINE configs[0] subset (0 = skip)")
+    ap.add_argument("--data-root", default="", help="directory with the reference's files (README.md:93-117): base.10M.fbin, "
+                    "query.10k.fbin and, optionally, t2i_10M_roar.index (else query.train.10M.fbin to build one from). Overrides the "
+                    "synthetic set; --nb / --dim / --nq are taken from the files. Names: --base-file / --query-file / --train-file / --index-file")
+    ap.add_argument("--base-file", default="base.10M.fbin")
+    ap.add_argument("--query-file", default="query.10k.fbin")
+    ap.add_argument("--train-file", default="query.train.10M.fbin")
+    ap.add_argument("--index-file", default="t2i_10M_roar.index")
     ap.add_argument("--index-cache", default="", help="file the built graph is kept in (profiling: the rocprofv3 passes of one box "
                     "re-use the index the first pass built; the data set is seeded, so it is the same base)")
     return ap.parse_args()
@@ -242,10 +249,48 @@ def main():
 
     # ---- synthetic t2i-10M-shaped inputs: the same base (and index) on every rank, one query batch per rank ---------
     ntrain = (args.train or args.nb // 5) if roar else 0
-    base, train, q, data_desc = synth.make_device_set(dev, 1234, args.nb, ntrain, args.nq, args.dim, data=args.data, rank=args.rank,
-                                                      q_seed=99 + rank)
+    file_index = None
+    if args.data_root:
+        # the reference's own files: every rank reads the base; rank r takes the r-th slice of the query file, wrapped
+        from roargraph_amd import index as ixmod
+
+        def read_fbin(path):     # the library's loader (load_data + data_align, util.h:179-211, 37-75)
+            arr, d = ixmod.fbin_load(path)
+            return arr if arr.shape[1] == d else np.ascontiguousarray(arr[:, :d])
+        fp = lambda name: os.path.join(args.data_root, name)
+        for need in (args.base_file, args.query_file):
+            if not os.path.exists(fp(need)):
+                raise SystemExit("--data-root: %s not found" % fp(need))
+        hb = read_fbin(fp(args.base_file))
+        hq = read_fbin(fp(args.query_file))
+        args.nb, args.dim = int(hb.shape[0]), int(hb.shape[1])
+        args.nq = min(args.nq, int(hq.shape[0]))
+        sel = (np.arange(args.nq) + rank * args.nq) % hq.shape[0]
+        base = torch.from_numpy(hb).to(dev); q = torch.from_numpy(np.ascontiguousarray(hq[sel])).to(dev)
+        del hb, hq
+        train = None
+        if roar and os.path.exists(fp(args.index_file)):
+            file_index = ixmod.graph_load(fp(args.index_file))
+        elif roar:
+            if not os.path.exists(fp(args.train_file)):
+                raise SystemExit("--data-root: neither %s nor %s found" % (fp(args.index_file), fp(args.train_file)))
+            ht = read_fbin(fp(args.train_file))
+            ntrain = min(args.train or int(ht.shape[0]), int(ht.shape[0]))
+            train = torch.from_numpy(np.ascontiguousarray(ht[:ntrain])).to(dev)
+            del ht
+        data_desc = "files of %s (%s, %s)" % (args.data_root, args.base_file, args.query_file)
+        args.data = "files"
+    else:
+        base, train, q, data_desc = synth.make_device_set(dev, 1234, args.nb, ntrain, args.nq, args.dim, data=args.data, rank=args.rank,
+                                                          q_seed=99 + rank)
     t_gt = t_build = 0.0
-    if roar:
+    if file_index is not None:
+        h_off, h_nbrs, ep = file_index
+        off = torch.from_numpy(np.ascontiguousarray(h_off).view(np.int64)).to(dev)
+        nbrs = torch.from_numpy(np.ascontiguousarray(h_nbrs).view(np.int32)).to(dev)
+        graph_desc = "index file %s (avg degree %.1f)" % (args.index_file, float(nbrs.numel()) / args.nb)
+        del file_index
+    elif roar:
         # training-query ground truth: base rows sharded over the ranks, one all-to-all, K3 (the multi-GPU form of K2)
         t0 = time.perf_counter()
         lo, hi = groundtruth.shard_rows(args.nb, world)[rank]
@@ -507,7 +552,7 @@ def main():
                       % (args.target_recall, shape_name, args.dim, args.metric.upper(), args.k, L_star),
             "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": "f32", "data": "files" if args.data_root else "synthetic",
             "config": {"workload": "%s: base %dx%d fp32 %s, %d queries/GPU/step, top-%d, L_pq=%d, %s, %s (replicated per GPU)"
                                    % (shape_name, args.nb, args.dim, args.metric, args.nq, args.k, L_star, data_desc, graph_desc),
                        "parallelism": "query-sharded x%d, index replicated" % world,

@@ -573,13 +573,19 @@ static rg_status launch_k1(rg_index *ix, SearchCtx *cx, int mode, const float *d
     // opt-in fast mode: plain top-k searches only (never the logging / recount / build launches)
     const bool bf = ix->fast_bf16 && ix->d_base_bf && dimc_of(ix) && !with_log && !bp && !qlist;
     if (bf) R = std::min(R, 2);
-    // LDS visited filter, automatic size: the largest of 2^12 .. 2^9 entries that still leaves 14 resident queries per
-    // CU (on genuine indexes a forgetful filter re-scores up to 50 % more nodes; past that point the lost residency
-    // costs more than the repeats -- scripts/exp/filter_real.py)
+    // LDS visited filter, automatic size: the largest of 2^12 .. 2^9 entries that still leaves enough resident queries per
+    // CU.  A forgetful filter re-scores nodes (1.37x the distinct ones at L_pq = 500 on the 10M bench index with 2^11
+    // entries, 1.28x with 2^12), and every re-scored row is HBM traffic in a kernel that is bandwidth bound.  The
+    // register-staged forms keep 16 - 32 rows in flight per query, so eight resident queries still cover the latency:
+    // measured on that index (scripts/exp/filter_size_10m.sh, % of 8 TB/s, 2^11 -> 2^12 entries): 81 -> 83.5 at
+    // L_pq = 100, 70 -> 75 at 300, 65 -> 70 at 500, 53 -> 56 at 1000; 2^13 loses everywhere (too few queries left).
+    // The LDS-DMA ring forms (4 - 8 rows in flight) and the exact-words form (the filter only screens the atomics, whose
+    // round trip more resident queries hide) keep the older bound of 14.
+    const int min_wpc = (dimc_of(ix) && !bf && mode != 0) ? 8 : 14;
     int filter_auto = 9;
     for (int f = 12; f >= 9; --f) {
         filter_auto = f;
-        if (f == 9 || ix->lds_per_cu / search_lds_bytes(ix, L, R, mode, bf, f) >= 14) break;
+        if (f == 9 || (int)(ix->lds_per_cu / search_lds_bytes(ix, L, R, mode, bf, f)) >= min_wpc) break;
     }
     size_t lds = search_lds_bytes(ix, L, R, mode, bf, filter_auto);
     while (lds > ix->lds_per_cu && R > 1) { R >>= 1; lds = search_lds_bytes(ix, L, R, mode, bf, filter_auto); }

@@ -149,6 +149,38 @@ def test_bench_multi_rank_control_flow_on_one_gpu():
     assert [p["L_pq"] for p in d["L_pq_sweep"]] == [20, 100, 500] and all(p["recall_at_10"] > 0.5 for p in d["L_pq_sweep"][1:])
 
 
+def test_bench_on_the_reference_file_layout(tmp_path):
+    """bench.py --data-root: the reference's own file names (README.md:93-117).  First run: base + queries + training queries
+    -> the index is built in the run; second run: an index file beside them is searched as it is.  Same base and queries, so
+    both runs must report a sensible recall, and the second must say it used the file."""
+    import json
+    import sys
+    from roargraph_amd import io, build, synth
+    rng = np.random.default_rng(5)
+    nb, d = 60000, 200
+    A = (rng.standard_normal((16, d)) / 4.0).astype(np.float32)
+    base = (rng.standard_normal((nb, 16)).astype(np.float32) @ A + 0.05 * rng.standard_normal((nb, d)).astype(np.float32))
+    mk = lambda n: ((0.3 + 0.5 * rng.standard_normal((n, 16))).astype(np.float32) @ A
+                    + 0.05 * rng.standard_normal((n, d)).astype(np.float32))
+    io.write_fbin(str(tmp_path / "base.10M.fbin"), base)
+    io.write_fbin(str(tmp_path / "query.10k.fbin"), mk(700))
+    io.write_fbin(str(tmp_path / "query.train.10M.fbin"), mk(20000))
+    common = [sys.executable, os.path.join(ROOT, "bench.py"), "--data-root", str(tmp_path), "--steps", "2", "--warmup", "1", "--nq", "512",
+              "--gt-nq", "0", "--cpu-seconds", "0", "--sweep", "20,100", "--no-worstcase", "--no-fast", "--config1-nb", "0"]
+    r = subprocess.run(common + ["--index-cache", str(tmp_path / "g.npz")], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    d1 = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d1["data"] == "files" and "genuine RoarGraph index built in the run" in d1["config"]["workload"]
+    assert d1["L_pq_sweep"][-1]["recall_at_10"] > 0.9
+    z = np.load(str(tmp_path / "g.npz"))
+    io.write_index(str(tmp_path / "t2i_10M_roar.index"), z["off"], z["nbrs"], int(z["ep"]))
+    r = subprocess.run(common, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    d2 = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert "index file t2i_10M_roar.index" in d2["config"]["workload"]
+    assert [p["recall_at_10"] for p in d2["L_pq_sweep"]] == [p["recall_at_10"] for p in d1["L_pq_sweep"]]
+
+
 @pytest.mark.parametrize("nd,d", [(1, 8), (300, 200), (4097, 200), (2500, 512), (70000, 24), (513, 104)])
 def test_projection_ep_kernel_equals_host_loop(nd, d):
     """CalculateProjectionep (src/index_bipartite.cpp:2004-2041): the device form keeps the reference's summation orders
