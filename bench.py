@@ -318,7 +318,7 @@ def main():
             meta[0], meta[1] = int(h_nbrs.size), int(ep)
         elif rank == 0:
             h_off, h_nbrs, ep = build.build_roargraph(base.cpu().numpy(), ti.cpu().numpy().view(np.uint32), args.metric, 100, 35, 500,
-                                                      num_threads=min(128, os.cpu_count() or 1), device=local)
+                                                      num_threads=int(os.environ.get("RG_BENCH_BUILD_THREADS", min(128, os.cpu_count() or 1))), device=local)
             off = torch.from_numpy(h_off.view(np.int64)).to(dev)
             nbrs = torch.from_numpy(h_nbrs.view(np.int32)).to(dev)
             meta[0], meta[1] = int(h_nbrs.size), int(ep)

@@ -388,15 +388,25 @@ static rg_status finish_graph(rg_index *ix, const uint64_t *d_off, const uint32_
         const char *env = getenv("RG_SPLIT_ROWS");
         if (ix->dim == 200 && ne + 1 < 0xffffffffull && !(env && atoi(env) == 0)) {
             ix->main_dim = 192; ix->tail_dim = 8;
-            RG_HIP(hipMalloc(&ix->d_main, (size_t)ix->nd * ix->main_dim * 4));
-            RG_HIP(hipMalloc(&ix->d_etail, (size_t)(ne + 1) * ix->tail_dim * 4));
-            RG_HIP(hipMalloc(&ix->d_tail_off, (size_t)ix->nd * 4));
-            hipLaunchKernelGGL(rg_split_main_kernel, dim3(8192), dim3(256), 0, 0, ix->d_base, ix->nd, ix->stride, ix->main_dim, ix->d_main);
-            hipLaunchKernelGGL(rg_split_tail_kernel, dim3(8192), dim3(256), 0, 0, ix->d_base, ix->stride, ix->main_dim, ix->tail_dim, d_nb,
-                               (uint64_t)ne, ix->ep, ix->d_etail);
-            hipLaunchKernelGGL(rg_tail_off_kernel, dim3(2048), dim3(256), 0, 0, d_off, ix->nd, ix->d_tail_off);
-            RG_HIP(hipGetLastError());
-            RG_HIP(hipDeviceSynchronize());
+            // optional: an index that cannot afford the copy (or whose kernels fail) searches the base itself
+            bool ok = hipMalloc(&ix->d_main, (size_t)ix->nd * ix->main_dim * 4) == hipSuccess &&
+                      hipMalloc(&ix->d_etail, (size_t)(ne + 1) * ix->tail_dim * 4) == hipSuccess &&
+                      hipMalloc(&ix->d_tail_off, (size_t)ix->nd * 4) == hipSuccess;
+            if (ok) {
+                hipLaunchKernelGGL(rg_split_main_kernel, dim3(8192), dim3(256), 0, 0, ix->d_base, ix->nd, ix->stride, ix->main_dim, ix->d_main);
+                hipLaunchKernelGGL(rg_split_tail_kernel, dim3(8192), dim3(256), 0, 0, ix->d_base, ix->stride, ix->main_dim, ix->tail_dim, d_nb,
+                                   (uint64_t)ne, ix->ep, ix->d_etail);
+                hipLaunchKernelGGL(rg_tail_off_kernel, dim3(2048), dim3(256), 0, 0, d_off, ix->nd, ix->d_tail_off);
+                ok = hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess;
+            }
+            if (!ok) {
+                (void)hipGetLastError();
+                if (ix->d_main) (void)hipFree(ix->d_main);
+                if (ix->d_etail) (void)hipFree(ix->d_etail);
+                if (ix->d_tail_off) (void)hipFree(ix->d_tail_off);
+                ix->d_main = ix->d_etail = nullptr;
+                ix->d_tail_off = nullptr;
+            }
         }
     } else {
         RG_HIP(hipMalloc(&ix->d_offsets, ((size_t)ix->nd + 1) * 8));

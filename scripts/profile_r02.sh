@@ -22,12 +22,12 @@ run() {  # name, bench args (quoted), rocprof args...
 }
 # the index is built once, outside the profiler (its phase-3 searches run K1 in build mode and would pollute the kernel stats)
 python $R/bench.py $COMMON --index-cache /tmp/bench_ix.npz --L ${L_STAR:-50} > $OUT/build_run.log 2>&1
-for W in head:"--index-cache /tmp/bench_ix.npz --L ${L_STAR:-50}" L500:"--index-cache /tmp/bench_ix.npz --L 500" L2000:"--index-cache /tmp/bench_ix.npz --L 2000" worst:"--graph random --L 500"; do
+for W in head:"--index-cache /tmp/bench_ix.npz --L ${L_STAR:-50}" L500:"--index-cache /tmp/bench_ix.npz --L 500" L1000:"--index-cache /tmp/bench_ix.npz --L 1000" L2000:"--index-cache /tmp/bench_ix.npz --L 2000" worst:"--graph random --L 500"; do
   N=${W%%:*}; A=${W#*:}
   run ${N}_trace "$A" --kernel-trace --stats
   run ${N}_fetch "$A" --pmc FETCH_SIZE
   run ${N}_write "$A" --pmc WRITE_SIZE
   run ${N}_sq "$A" --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM
 done
-python $R/scripts/make_traffic_json.py $OUT/head $OUT/L500 $OUT/L2000 $OUT/worst > $OUT/search_traffic.json 2> $OUT/make_traffic.err
+python $R/scripts/make_traffic_json.py $OUT/head $OUT/L500 $OUT/L1000 $OUT/L2000 $OUT/worst > $OUT/search_traffic.json 2> $OUT/make_traffic.err
 ls -la $OUT
