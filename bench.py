@@ -71,6 +71,8 @@ def parse():
     ap.add_argument("--set", default="", help="comma list of knob=value passed to rg_index_set (tuning experiments)")
     ap.add_argument("--no-worstcase", action="store_true", help="skip the random-graph block")
     ap.add_argument("--no-fast", action="store_true", help="skip the opt-in non-parity modes")
+    ap.add_argument("--no-two-streams", action="store_true", help="skip the two-stream block (profiling: its overlapped launches would "
+                    "blur the per-launch kernel durations of the trace)")
     ap.add_argument("--gt-nq", type=int, default=65536, help="queries of the ground-truth (K2) leg; 0 = skip")
     ap.add_argument("--gt-K", type=int, default=100)
     ap.add_argument("--config1-nb", type=int, default=100_000, help="rows of the BASELINE configs[0] subset (0 = skip)")
@@ -435,7 +437,7 @@ def main():
     # queries fill the wave slots the previous batch's tail leaves idle.  Reported beside `value`, never as it: `value` and
     # the roofline keep the one-stream form whose per-launch duration rocprofv3 can be held against.
     two_streams = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_two_streams:
         s2 = torch.cuda.Stream(device=dev)
         S2 = Searcher(torch, index, q, args.k, args.dim, s2.cuda_stream, None)
         for _ in range(2):

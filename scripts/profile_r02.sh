@@ -9,7 +9,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/prof_r02
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-COMMON="--steps 5 --warmup 2 --cpu-seconds 0 --gt-nq 0 --no-fast --no-worstcase --config1-nb 0 --sweep= ${BENCH_ARGS}"
+COMMON="--steps 5 --warmup 2 --cpu-seconds 0 --gt-nq 0 --no-fast --no-two-streams --no-worstcase --config1-nb 0 --sweep= ${BENCH_ARGS}"
 run() {  # name, bench args (quoted), rocprof args...
   local name=$1; local bargs=$2; shift; shift
   rm -rf /tmp/rp_$name
