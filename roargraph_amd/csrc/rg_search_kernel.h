@@ -76,7 +76,7 @@ struct SearchParams {
     uint32_t tail_stride;
     const uint32_t *tail_off; // [nd] first edge of the node (null = rows are not split)
     uint32_t ep_tail;         // tail slot of the entry point (it is scored without an edge leading to it)
-    uint32_t spec;            // 1 = speculative second expansion per hop (bit-exact), 2 = merged unconditionally (opt-in, NOT parity)
+    uint32_t spec;            // 2 = "multi_expand": two expansions per iteration (opt-in, NOT parity); 0 = the reference's order
 #ifdef RG_K1_PROF
     unsigned long long *prof; // instrumented build only: [nq][16] per-phase cycle sums and event counts
 #endif

@@ -58,13 +58,15 @@ def make_case(seed):
              "exact_filter": int(rng.random() < 0.7),
              "query_in_lds": int(rng.random() < 0.2),
              "log_cap": int(rng.choice([0, 0, 64, 1024]))}
+    knobs["_csr"] = int(rng.random() < 0.2)     # adjacency layout (read from the environment at open)
     return base, q, off, nbrs, ep, metric, k, L, knobs
 
 
 @pytest.mark.parametrize("seed", range(60))
-def test_random_case_matches_the_oracle(oracle, seed):
+def test_random_case_matches_the_oracle(oracle, seed, monkeypatch):
     from roargraph_amd import index as rg
     base, q, off, nbrs, ep, metric, k, L, knobs = make_case(seed)
+    monkeypatch.setenv("RG_FORCE_CSR", str(knobs.pop("_csr")))
     try:
         want = oracle.search(base, metric, off, nbrs, ep, q, k, L, nthreads=2)
     except RuntimeError as e:           # "not enough results": the HIP path must refuse the same batch the same way
