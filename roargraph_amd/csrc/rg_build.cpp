@@ -174,6 +174,11 @@ struct Builder {
         for (size_t o = 0; o < (size_t)dim * 4; o += 64) __builtin_prefetch(r + o, 0, 3);
     }
 
+    // Monotone: `result` only grows, so a candidate found occluded once stays occluded, and a candidate already in
+    // `result` is "occluded" by itself (the id test).  The reference's second sweeps (:1662-1676, :1576-1590, :1496-1510,
+    // :1912-1926) walk candidates the first sweep has already decided -- each iteration re-derives "occluded" and adds
+    // nothing.  Those iterations are skipped below; the lists produced are the same (checked at one thread against the
+    // sweeps written out, scripts/exp/build_t1_hashes.py), the distance evaluations are halved.
     bool occluded(const Nb &p, const std::vector<uint32_t> &result) const {
         for (uint32_t r : result) {
             if (p.id == r) return true;
@@ -202,12 +207,8 @@ struct Builder {
             const Nb &p = bp[start];
             if (!occluded(p, result) && p.id != tgt) result.push_back(p.id);
         }
-        start = 0;
-        while (result.size() < M && (++start) < pool.size()) {   // second sweep walks the UNSORTED pool (:1662)
-            const Nb &p = pool[start];
-            if (has(result, p.id)) continue;
-            if (!occluded(p, result) && p.id != tgt && !has(result, p.id)) result.push_back(p.id);
-        }
+        // second sweep over the unsorted pool (:1662-1676): every pool entry is the target, or bp[0] (in `result`), or was
+        // decided by the first sweep, which ran to the end of bp if `result` is still short -- a no-op, skipped
         for (size_t i = 1; i < bp.size() && result.size() < M; ++i)
             if (!has(result, bp[i].id) && bp[i].id != tgt) result.push_back(bp[i].id);
         out = result;
@@ -236,11 +237,7 @@ struct Builder {
             const Nb &p = pq[start];
             if (!occluded(p, result) && p.id != src) result.push_back(p.id);
         }
-        start = 0;
-        while (result.size() < M && (++start) < pq.size()) {
-            const Nb &p = pq[start];
-            if (!occluded(p, result) && p.id != src && !has(result, p.id)) result.push_back(p.id);
-        }
+        // second sweep (:1576-1590 / :1496-1510) over pq[1 ..): all of them in `result` or decided by the first sweep -- skipped
         if (!phantoms)   // :1594-1598 top-up in the original list order
             for (size_t i = 0; i < list.size() && result.size() < M; ++i)
                 if (!has(result, list[i])) result.push_back(list[i]);
@@ -285,6 +282,7 @@ struct Builder {
         const std::vector<uint32_t> &have = proj[node];
         while (start < pool.size() && has(have, pool[start].id)) ++start;
         if (start >= pool.size()) { out = result; return; }
+        const uint32_t first = start;
         result.push_back(pool[start].id);
         for (uint32_t j = start + 1; j < pool.size() && j <= start + 6; ++j) prefetch_row(pool[j].id);
         while (result.size() < M && (++start) < pool.size()) {
@@ -292,10 +290,11 @@ struct Builder {
             if (start + 6 < pool.size()) prefetch_row(pool[start + 6].id);
             if (!occluded(p, result) && p.id != node) result.push_back(p.id);
         }
+        // second sweep (:1912-1926): only the entries in front of the first sweep's starting point are still undecided
+        // (the ones skipped because the projection list holds them already); index 0 is never visited (++start first)
         start = 0;
-        while (result.size() < M && (++start) < pool.size()) {
+        while (result.size() < M && (++start) < first) {
             const Nb &p = pool[start];
-            if (start + 6 < pool.size()) prefetch_row(pool[start + 6].id);
             if (!occluded(p, result) && p.id != node && !has(result, p.id)) result.push_back(p.id);
         }
         out = result;
@@ -362,7 +361,9 @@ struct Builder {
         }
     }
     // rest of the per-node work of phase 3 (:1203-1215)
+    std::atomic<long long> ns_prune{0}, ns_reverse{0};   // RG_BUILD_TIMING: thread time inside the two halves of the linking
     void link_from_search(uint32_t node, std::vector<Nb> &expanded) {
+        const auto t0 = timing ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
         expanded.erase(std::remove_if(expanded.begin(), expanded.end(), [&](const Nb &x) { return x.id == node; }), expanded.end());
         std::vector<uint32_t> pruned;
         prune_search(expanded, node, pruned);
@@ -370,7 +371,13 @@ struct Builder {
             std::lock_guard<std::mutex> guard(locks[node]);
             supply[node] = pruned;
         }
+        const auto t1 = timing ? std::chrono::steady_clock::now() : t0;
         add_reverse(supply, node, 2 * M, true);
+        if (timing) {
+            const auto t2 = std::chrono::steady_clock::now();
+            ns_prune += std::chrono::duration_cast<std::chrono::nanoseconds>(t1 - t0).count();
+            ns_reverse += std::chrono::duration_cast<std::chrono::nanoseconds>(t2 - t1).count();
+        }
     }
 
     // Phase 3 with the n beam searches on the GPU (K1 in build mode), in batches: every node of a batch searches the
@@ -598,6 +605,8 @@ struct Builder {
             });
         }
         lap("phase 3");
+        if (timing) fprintf(stderr, "[rg_build]   linking, thread-seconds: prune of the expansion list %.1f, reverse edges %.1f\n",
+                            ns_prune.load() * 1e-9, ns_reverse.load() * 1e-9);
         // ---- phase 4 (:1224-1248)
         parallel_for(nd, 2048, [&](uint32_t node, int) {
             if (supply[node].size() <= M) return;
