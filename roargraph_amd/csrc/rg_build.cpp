@@ -1,6 +1,9 @@
-// rg_build.cpp -- CPU restatement of RoarGraph's graph construction (a "next" row; the
-// reference keeps construction on the CPU and so does this).  It consumes the ground truth produced by K2 and emits
-// the .index the search path loads, which closes the pipeline  GT (GPU) -> build (CPU) -> search (GPU).
+// rg_build.cpp -- RoarGraph's graph construction (a "next" row).  It consumes the ground truth
+// produced by K2 and emits the .index the search path loads, which closes the pipeline  GT (GPU) -> build -> search (GPU).
+// rg_build_roargraph is the all-CPU restatement (one thread = the reference's sequence); rg_build_roargraph_gpu moves what
+// dominates the reference's build time to the GPU: the entry point, the n beam searches of phase 3 (K1 in build mode) and
+// the occlusion pruning of their expansion lists (rg_build_prune.hip) -- the host threads keep phases 1, 2, 4, 5 and the
+// reverse-edge insertion of phase 3.
 //
 // Follows IndexBipartite::BuildRoarGraph (src/index_bipartite.cpp:143-233):
 //   CalculateProjectionep                       :2004-2041   entry point = base row nearest to the centroid
@@ -380,10 +383,23 @@ struct Builder {
         }
     }
 
+    // a node's pruned list (from the GPU) takes the place of prune_search's result; the reverse edges follow as usual
+    void link_pruned(uint32_t node, const uint32_t *ids, uint32_t n) {
+        const auto t0 = timing ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
+        {
+            std::lock_guard<std::mutex> guard(locks[node]);
+            supply[node].assign(ids, ids + n);
+        }
+        add_reverse(supply, node, 2 * M, true);
+        if (timing) ns_reverse += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+    }
+
     // Phase 3 with the n beam searches on the GPU (K1 in build mode), in batches: every node of a batch searches the
     // supply graph as it stood when the batch started (the reference's multi-threaded build sees a similarly racy
     // graph; at one thread it sees every earlier node's links -- so this variant is NOT the T=1 result, it is a valid
-    // scheduling of the same algorithm).  Pruning and reverse-edge insertion stay on the host threads.
+    // scheduling of the same algorithm).  The occlusion pruning of the expansion lists follows the searches on the GPU
+    // (rg_build_prune.hip: the same lists prune_search returns, checked under RG_BUILD_VERIFY; RG_BUILD_HOST_PRUNE=1 keeps
+    // it on the host threads, as do shapes the kernel does not take); reverse-edge insertion stays on the host threads.
     int gpu_device = -1;
     uint32_t gpu_batch = 0;
     bool gpu_verify = false;
@@ -403,6 +419,8 @@ struct Builder {
         std::vector<uint32_t> h_ell((size_t)nd * S);
         uint2_pod *h_exp = nullptr;     // pinned: the downloads of one half overlap the search of the other
         uint32_t *h_nexp = nullptr;
+        const uint32_t hs = 72;         // row stride of the projection lists handed to the pruning kernel (length + <= 64 ids)
+        uint32_t *d_have = nullptr, *h_have = nullptr, *d_out = nullptr, *h_out = nullptr;
         hipStream_t st = nullptr;
         hipEvent_t evA = nullptr, evB = nullptr;
         bool ok = true;
@@ -413,7 +431,12 @@ struct Builder {
                   hipHostMalloc(&h_exp, (size_t)B * cap * 8) == hipSuccess && hipHostMalloc(&h_nexp, (size_t)B * 4) == hipSuccess &&
                   hipStreamCreate(&st) == hipSuccess && hipEventCreate(&evA) == hipSuccess && hipEventCreate(&evB) == hipSuccess;
         if (ok) ok = build_index_create(d_base, nd, dim, (uint32_t)stride, ep, l2 ? RG_METRIC_L2 : RG_METRIC_IP, gpu_device, S, &ix) == RG_OK;
-        std::atomic<uint32_t> mismatches(0);
+        const bool gpu_prune = ok && !getenv("RG_BUILD_HOST_PRUNE") && build_prune_supported(ix, M);
+        if (gpu_prune)
+            ok = hipMalloc(&d_have, (size_t)B * hs * 4) == hipSuccess && hipHostMalloc(&h_have, (size_t)B * hs * 4) == hipSuccess &&
+                 hipMalloc(&d_out, (size_t)B * (M + 1) * 4) == hipSuccess && hipHostMalloc(&h_out, (size_t)B * (M + 1) * 4) == hipSuccess;
+        const bool want_exp = !gpu_prune || gpu_verify;   // the expansion lists come down only if the host needs them
+        std::atomic<uint32_t> mismatches(0), prune_mismatches(0);
         std::vector<std::vector<uint32_t>> stamp(std::max(1, threads));
         std::vector<uint32_t> serial(std::max(1, threads), 0);
         // The projection graph is barely connected before phase 3 (searches from the entry point expand a handful of
@@ -444,16 +467,30 @@ struct Builder {
             // the batch goes to the GPU in two halves over the same snapshot: the host links the first half while the
             // GPU searches the second (same semantics as one launch: every node of the batch searched the snapshot)
             const uint32_t nA = n >= 4096 ? n / 2 : n, nB = n - nA;
-            ok = build_index_set_ell(ix, h_ell.data(), nullptr) == RG_OK &&
-                 build_search_dev(ix, b0, nA, L, d_exp, cap, d_nexp, st) == RG_OK &&
-                 hipMemcpyAsync(h_nexp, d_nexp, (size_t)nA * 4, hipMemcpyDeviceToHost, st) == hipSuccess &&
-                 hipMemcpyAsync(h_exp, d_exp, (size_t)nA * cap * 8, hipMemcpyDeviceToHost, st) == hipSuccess &&
-                 hipEventRecord(evA, st) == hipSuccess;
-            if (ok && nB)
-                ok = build_search_dev(ix, b0 + nA, nB, L, d_exp + (size_t)nA * cap, cap, d_nexp + nA, st) == RG_OK &&
-                     hipMemcpyAsync(h_nexp + nA, d_nexp + nA, (size_t)nB * 4, hipMemcpyDeviceToHost, st) == hipSuccess &&
-                     hipMemcpyAsync(h_exp + (size_t)nA * cap, d_exp + (size_t)nA * cap, (size_t)nB * cap * 8, hipMemcpyDeviceToHost, st) == hipSuccess &&
-                     hipEventRecord(evB, st) == hipSuccess;
+            if (gpu_prune) {   // projection lists of the batch's nodes (constant during phase 3)
+                parallel_for(n, 4096, [&](uint32_t i, int) {
+                    uint32_t *row = h_have + (size_t)i * hs;
+                    const std::vector<uint32_t> &l = proj[b0 + i];
+                    row[0] = (uint32_t)l.size();                       // > 64: the kernel leaves the node to the host
+                    std::memcpy(row + 1, l.data(), std::min<size_t>(l.size(), hs - 1) * 4);
+                });
+                ok = hipMemcpyAsync(d_have, h_have, (size_t)n * hs * 4, hipMemcpyHostToDevice, st) == hipSuccess;
+            }
+            // one half: searches, pruning, downloads, event
+            auto enqueue = [&](uint32_t h0, uint32_t hn, hipEvent_t ev) {
+                bool good = build_search_dev(ix, b0 + h0, hn, L, d_exp + (size_t)h0 * cap, cap, d_nexp + h0, st) == RG_OK &&
+                            hipMemcpyAsync(h_nexp + h0, d_nexp + h0, (size_t)hn * 4, hipMemcpyDeviceToHost, st) == hipSuccess;
+                if (good && gpu_prune)
+                    good = build_prune_dev(ix, b0 + h0, hn, M, d_exp + (size_t)h0 * cap, cap, d_nexp + h0, d_have + (size_t)h0 * hs, hs,
+                                           d_out + (size_t)h0 * (M + 1), st) == RG_OK &&
+                           hipMemcpyAsync(h_out + (size_t)h0 * (M + 1), d_out + (size_t)h0 * (M + 1), (size_t)hn * (M + 1) * 4,
+                                          hipMemcpyDeviceToHost, st) == hipSuccess;
+                if (good && want_exp)
+                    good = hipMemcpyAsync(h_exp + (size_t)h0 * cap, d_exp + (size_t)h0 * cap, (size_t)hn * cap * 8, hipMemcpyDeviceToHost, st) == hipSuccess;
+                return good && hipEventRecord(ev, st) == hipSuccess;
+            };
+            ok = ok && build_index_set_ell(ix, h_ell.data(), nullptr) == RG_OK && enqueue(0, nA, evA);
+            if (ok && nB) ok = enqueue(nA, nB, evB);
             if (ok) ok = hipEventSynchronize(evA) == hipSuccess;
             if (!ok) break;
             t_gpu += since(t_b); t_b = std::chrono::steady_clock::now();
@@ -470,8 +507,13 @@ struct Builder {
                 const uint32_t i = h0 + ii;
                 const uint32_t node = b0 + i;
                 std::vector<Nb> expanded;
-                if (h_nexp[i] > cap) {
-                    search_snapshot(node, h_ell.data(), S, stamp[t], serial[t], expanded);   // expansion list did not fit
+                const uint32_t *po = gpu_prune ? h_out + (size_t)i * (M + 1) : nullptr;
+                if (po && po[0] != 0xffffffffu && !gpu_verify) {
+                    link_pruned(node, po + 1, po[0]);
+                    return;
+                }
+                if (h_nexp[i] > cap || (po && po[0] == 0xffffffffu && !want_exp)) {
+                    search_snapshot(node, h_ell.data(), S, stamp[t], serial[t], expanded);   // list did not fit / left to the host
                 } else {
                     expanded.resize(h_nexp[i]);
                     const uint2_pod *e = h_exp + (size_t)i * cap;
@@ -487,6 +529,13 @@ struct Builder {
                         for (size_t j = 0; same && j < ref.size(); ++j)
                             same = ref[j].id == expanded[j].id && std::memcmp(&ref[j].dist, &expanded[j].dist, 4) == 0;
                         if (!same) mismatches.fetch_add(1);
+                        if (po && po[0] != 0xffffffffu) {   // the GPU's pruned list against prune_search on the same expansion list
+                            std::vector<Nb> pool = expanded;
+                            pool.erase(std::remove_if(pool.begin(), pool.end(), [&](const Nb &x) { return x.id == node; }), pool.end());
+                            std::vector<uint32_t> want;
+                            prune_search(pool, node, want);
+                            if (want.size() != po[0] || !std::equal(want.begin(), want.end(), po + 1)) prune_mismatches.fetch_add(1);
+                        }
                     }
                 }
                 link_from_search(node, expanded);
@@ -494,8 +543,8 @@ struct Builder {
             }
         }
         t_link += since(t_b);
-        if (timing) fprintf(stderr, "[rg_build]   phase 3: %u batches, snapshot %.2f s, upload + GPU search + download %.2f s, host linking %.2f s\n",
-                            nbatches, t_snap, t_gpu, t_link);
+        if (timing) fprintf(stderr, "[rg_build]   phase 3: %u batches, snapshot %.2f s, upload + GPU search%s + download %.2f s, host linking %.2f s\n",
+                            nbatches, t_snap, gpu_prune ? " + GPU pruning" : "", t_gpu, t_link);
         if (ix) rg_index_close(ix);
         if (d_base) (void)hipFree(d_base);
         if (d_exp) (void)hipFree(d_exp);
@@ -503,11 +552,16 @@ struct Builder {
         if (st) (void)hipStreamSynchronize(st);
         if (h_exp) (void)hipHostFree(h_exp);
         if (h_nexp) (void)hipHostFree(h_nexp);
+        if (d_have) (void)hipFree(d_have);
+        if (d_out) (void)hipFree(d_out);
+        if (h_have) (void)hipHostFree(h_have);
+        if (h_out) (void)hipHostFree(h_out);
         if (evA) (void)hipEventDestroy(evA);
         if (evB) (void)hipEventDestroy(evB);
         if (st) (void)hipStreamDestroy(st);
         if (!ok) return fail(std::string("GPU phase 3 failed: ") + rg_last_error());
         if (mismatches.load()) return fail("GPU phase 3: " + std::to_string(mismatches.load()) + " expansion lists differ from the host search");
+        if (prune_mismatches.load()) return fail("GPU phase 3: " + std::to_string(prune_mismatches.load()) + " pruned lists differ from the host pruning");
         return true;
     }
 

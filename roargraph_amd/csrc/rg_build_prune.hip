@@ -1,0 +1,219 @@
+// rg_build_prune.hip -- PruneProjectionBaseSearchCandidates (src/index_bipartite.cpp:1846-1940) on the GPU: the occlusion
+// pruning of a node's phase-3 expansion list, one wave per node.  Host counterpart: Builder::prune_search (rg_build.cpp),
+// which this kernel reproduces bit for bit -- same (distance, id) order, same distance routine (rg_device.h: the
+// reference's compare()), same greedy scan -- so the GPU-assisted build produces the lists the host pruning would
+// (RG_BUILD_VERIFY=1 compares them node by node).
+//
+// Why here: on a 10M-row build the host spent 80 s in these scans (every distance between two base rows is a DRAM miss
+// on the host), four times the GPU's time for the searches that produce the lists; the scan is the same gather-score
+// pattern as K1, and the expansion lists are already in HBM.
+//
+// Per node (all state wave-private, in LDS):
+//   keys   u64[1024]   (orderable distance bits << 32 | id), bitonic-sorted: the pool in the reference's order
+//   rows   the chosen neighbours' base rows, staged 4 per pass in the layout gather_score reads (filled by LDS-DMA)
+//   qv     the candidate's row, double buffered: the next candidate's row is in flight while this one is scored
+// occluded(p) = some chosen r has compare(p, r) < dist(p) (or r == p): the chosen rows are scored four per pass against
+// the candidate, stopping at the first pass that holds an occluder (the answer does not depend on which one is found).
+// The reference's second sweep only matters for the entries in front of the first sweep's start (rg_build.cpp).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <string>
+
+#include "rg.h"
+#include "rg_device.h"
+#include "rg_index_struct.h"
+#include "rg_internal.h"
+
+namespace rg {
+
+struct PruneParams {
+    const float *base;
+    uint32_t stride, dim;
+    const uint2 *exp;        // [n][cap] expanded (distance bits, id) in pop order
+    uint32_t cap;
+    const uint32_t *nexp;    // [n]
+    const uint32_t *have;    // [n][hs]: word 0 = length of the node's projection list, then its ids
+    uint32_t hs;
+    uint32_t node0, n, M;
+    uint32_t *out;           // [n][M + 1]: word 0 = length (0xffffffff: left to the host), then the pruned list
+    uint32_t stage_floats;   // floats of one 4-row pass: ceil(dim / 64) * 256
+    uint32_t qv_floats;      // floats of one candidate buffer (dim rounded up to 64)
+};
+
+constexpr uint32_t kPruneKeys = 1024;
+constexpr int kQChunks = 4;   // candidate row in registers while in flight: up to 4 x 64 lanes x 16 B = dim <= 1024
+
+template <bool L2>
+__global__ void __launch_bounds__(64) rg_prune_search_kernel(PruneParams P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x;
+    const int g = lane >> 4;
+    unsigned long long *keys = reinterpret_cast<unsigned long long *>(smem);                 // kPruneKeys
+    uint32_t *res_id = reinterpret_cast<uint32_t *>(keys + kPruneKeys);                      // 64
+    uint32_t *have_l = res_id + 64;                                                          // 64
+    float *qv = reinterpret_cast<float *>(have_l + 64);                                      // 2 * qv_floats
+    float *rows = qv + 2 * P.qv_floats;                                                      // passes * stage_floats
+    const uint32_t nq4 = P.dim / 4;                                                          // float4 pieces of a row
+
+    for (uint32_t i = blockIdx.x; i < P.n; i += gridDim.x) {
+        const uint32_t node = P.node0 + i;
+        uint32_t *out = P.out + (size_t)i * (P.M + 1);
+        const uint32_t ne = P.nexp[i];
+        const uint32_t nh = P.have[(size_t)i * P.hs];
+        if (ne > P.cap || ne > kPruneKeys || nh + 1 > P.hs || nh > 64) {   // the host prunes this one
+            if (lane == 0) out[0] = 0xffffffffu;
+            continue;
+        }
+        // ---- the pool: expansion list without the node itself (:1203), as sortable keys
+        const uint2 *e = P.exp + (size_t)i * P.cap;
+        uint32_t n = 0;
+        for (uint32_t j0 = 0; j0 < ne; j0 += kWave) {
+            const uint32_t j = j0 + lane;
+            uint2 v = make_uint2(0u, 0u);
+            bool keep = false;
+            if (j < ne) { v = e[j]; keep = v.y != node; }
+            const unsigned long long m = __ballot(keep);
+            if (keep) {
+                uint32_t b = v.x;
+                if (b == 0x80000000u) b = 0u;                                    // -0.0 == +0.0 in the reference's order
+                const uint32_t ord = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
+                keys[n + __popcll(m & ((1ull << lane) - 1ull))] = ((unsigned long long)ord << 32) | v.y;
+            }
+            n += __popcll(m);
+        }
+        if (lane < (int)nh) have_l[lane] = P.have[(size_t)i * P.hs + 1 + lane];
+        uint32_t N = 64;
+        while (N < n) N <<= 1;
+        for (uint32_t j = n + lane; j < N; j += kWave) keys[j] = ~0ull;
+        lds_sync();
+        // ---- std::sort by (distance, id) (:1863): bitonic network over N keys
+        for (uint32_t k = 2; k <= N; k <<= 1)
+            for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+                for (uint32_t t = lane; t < N / 2; t += kWave) {
+                    const uint32_t lo = ((t & ~(j - 1u)) << 1) | (t & (j - 1u)), hi = lo | j;
+                    const unsigned long long a = keys[lo], b = keys[hi];
+                    const bool up = (lo & k) == 0u;
+                    if ((a > b) == up) { keys[lo] = b; keys[hi] = a; }
+                }
+                lds_sync();
+            }
+        auto pool_id = [&](uint32_t j) { return (uint32_t)(keys[j] & 0xffffffffull); };
+        auto pool_dist = [&](uint32_t j) {
+            const uint32_t ord = (uint32_t)(keys[j] >> 32);
+            return __uint_as_float((ord & 0x80000000u) ? (ord & 0x7fffffffu) : ~ord);
+        };
+        // ---- first entry the projection list does not hold already (:1866-1871)
+        uint32_t first = n;
+        for (uint32_t j0 = 0; j0 < n && first == n; j0 += kWave) {
+            const uint32_t j = j0 + lane;
+            bool fresh = false;
+            if (j < n) {
+                const uint32_t id = pool_id(j);
+                fresh = true;
+                for (uint32_t x = 0; x < nh; ++x) fresh = fresh && have_l[x] != id;
+            }
+            const unsigned long long m = __ballot(fresh);
+            if (m) first = j0 + (uint32_t)__builtin_ctzll(m);
+        }
+        uint32_t cnt = 0;
+        // chosen neighbour: id + its base row into the staged passes (LDS-DMA; the scoring layout of rg_device.h)
+        auto append = [&](uint32_t id) {
+            if (lane == 0) res_id[cnt] = id;
+            gather_issue(P.base + (size_t)id * P.stride, P.dim, g == (int)(cnt & 3u), rows + (size_t)(cnt >> 2) * P.stage_floats, lane);
+            gather_wait(0);
+            lds_sync();
+            ++cnt;
+        };
+        // occluded(p, result): compare() of p against the chosen rows, four per pass
+        auto occluded = [&](const float *q, uint32_t pid, float pd) -> bool {
+            for (uint32_t ps = 0; 4u * ps < cnt; ++ps) {
+                const float d = gather_score<L2>(rows + (size_t)ps * P.stage_floats, q, P.dim, lane);
+                const uint32_t c = 4u * ps + (uint32_t)g;
+                const bool hit = c < cnt && (res_id[c] == pid || d < pd);
+                if (__ballot(hit)) return true;
+            }
+            return false;
+        };
+        float4 nx[kQChunks];
+        auto fetch = [&](uint32_t id) {            // candidate row -> registers (in flight)
+            const float4 *src = reinterpret_cast<const float4 *>(P.base + (size_t)id * P.stride);
+#pragma unroll
+            for (int c = 0; c < kQChunks; ++c)
+                if ((uint32_t)(c * kWave + lane) < nq4) nx[c] = src[c * kWave + lane];
+        };
+        auto park = [&](float *q) {                // registers -> the candidate buffer
+#pragma unroll
+            for (int c = 0; c < kQChunks; ++c)
+                if ((uint32_t)(c * kWave + lane) < nq4) reinterpret_cast<float4 *>(q)[c * kWave + lane] = nx[c];
+            lds_sync();
+        };
+        if (first < n) {
+            append(pool_id(first));
+            // ---- first sweep (:1874-1907)
+            uint32_t j = first + 1, buf = 0;
+            if (j < n) fetch(pool_id(j));
+            while (cnt < P.M && j < n) {
+                float *q = qv + (size_t)buf * P.qv_floats;
+                park(q);
+                if (j + 1 < n) fetch(pool_id(j + 1));
+                const uint32_t pid = pool_id(j);
+                const float pd = pool_dist(j);
+                if (!occluded(q, pid, pd) && pid != node) append(pid);
+                ++j;
+                buf ^= 1u;
+            }
+            // ---- second sweep (:1912-1926): only the entries in front of `first` are still undecided
+            for (uint32_t j2 = 1; j2 < first && cnt < P.M; ++j2) {
+                const uint32_t pid = pool_id(j2);
+                const float pd = pool_dist(j2);
+                fetch(pid);
+                float *q = qv;
+                park(q);
+                if (!occluded(q, pid, pd) && pid != node) append(pid);
+            }
+        }
+        lds_sync();
+        if (lane == 0) out[0] = cnt;
+        if ((uint32_t)lane < cnt) out[1 + lane] = res_id[lane];
+        lds_sync();
+    }
+}
+
+// LDS bytes of one workgroup, 0 if the shape does not fit (then the host prunes)
+static size_t prune_lds_bytes(uint32_t dim, uint32_t M, size_t lds_per_cu) {
+    if (dim % 8 || dim > (uint32_t)kQChunks * kWave * 4 || M > 64) return 0;
+    const size_t stage = (size_t)((dim + 63) / 64) * 256, qvf = (size_t)(dim + 63) / 64 * 64;
+    const size_t b = (size_t)kPruneKeys * 8 + 64 * 4 + 64 * 4 + 2 * qvf * 4 + (size_t)((M + 3) / 4) * stage * 4;
+    return b <= lds_per_cu ? (b + 15) / 16 * 16 : 0;
+}
+
+bool build_prune_supported(const rg_index *ix, uint32_t M) { return prune_lds_bytes(ix->dim, M, ix->lds_per_cu) != 0; }
+
+rg_status build_prune_dev(rg_index *ix, uint32_t node0, uint32_t n, uint32_t M, const uint2_pod *d_exp, uint32_t exp_cap,
+                          const uint32_t *d_nexp, const uint32_t *d_have, uint32_t hs, uint32_t *d_out, void *stream) {
+    if (!ix || !d_exp || !d_nexp || !d_have || !d_out) return set_error(RG_ERR_ARG, "null argument");
+    if (n == 0) return RG_OK;
+    const size_t lds = prune_lds_bytes(ix->dim, M, ix->lds_per_cu);
+    if (!lds) return set_error(RG_ERR_ARG, "pruning kernel: shape not supported");
+    if (hipSetDevice(ix->device) != hipSuccess) return set_error(RG_ERR_DEVICE, "cannot select the index device");
+    PruneParams P;
+    P.base = ix->d_base; P.stride = ix->stride; P.dim = ix->dim;
+    P.exp = reinterpret_cast<const uint2 *>(d_exp); P.cap = exp_cap; P.nexp = d_nexp;
+    P.have = d_have; P.hs = hs; P.node0 = node0; P.n = n; P.M = M; P.out = d_out;
+    P.stage_floats = (uint32_t)((ix->dim + 63) / 64) * 256u;
+    P.qv_floats = (ix->dim + 63u) / 64u * 64u;
+    const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(16, ix->lds_per_cu / lds));
+    const dim3 grid(std::min<uint32_t>(n, (uint32_t)ix->num_cu * per_cu));
+    const bool l2 = ix->metric == RG_METRIC_L2;
+    const void *fn = l2 ? reinterpret_cast<const void *>(rg_prune_search_kernel<true>) : reinterpret_cast<const void *>(rg_prune_search_kernel<false>);
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        return set_error(RG_ERR_DEVICE, "pruning kernel: cannot reserve its LDS");
+    if (l2) hipLaunchKernelGGL(rg_prune_search_kernel<true>, grid, dim3(kWave), lds, (hipStream_t)stream, P);
+    else hipLaunchKernelGGL(rg_prune_search_kernel<false>, grid, dim3(kWave), lds, (hipStream_t)stream, P);
+    if (hipGetLastError() != hipSuccess) return set_error(RG_ERR_DEVICE, "pruning kernel launch failed");
+    return RG_OK;
+}
+
+}  // namespace rg

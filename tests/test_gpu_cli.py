@@ -124,6 +124,31 @@ def test_gpu_assisted_build(oracle, monkeypatch):
         assert rg_ > rc - 0.03, (metric, rc, rg_)
 
 
+@pytest.mark.parametrize("metric,d,M,L", [("ip", 200, 35, 500), ("l2", 512, 24, 150), ("ip", 104, 12, 100), ("l2", 200, 35, 300)])
+def test_gpu_pruning_equals_host_pruning(oracle, monkeypatch, metric, d, M, L):
+    """The occlusion pruning of the phase-3 expansion lists (PruneProjectionBaseSearchCandidates, :1846-1940) on the GPU
+    against Builder::prune_search on the host.  (i) RG_BUILD_VERIFY: every pruned list coming back from the GPU is compared
+    with the host rule applied to the same expansion list (a difference fails the build).  (ii) With one host thread the
+    whole GPU-assisted build is deterministic, so the index built with the GPU pruning must equal, edge for edge, the one
+    built with RG_BUILD_HOST_PRUNE=1.  Structured data with repeated rows: ties in distance, heavy occlusion."""
+    from roargraph_amd import build
+    rng = np.random.default_rng(7 + d)
+    nb, r = 6000, 8
+    A = (rng.standard_normal((r, d)) / np.sqrt(r)).astype(np.float32)
+    base = (rng.standard_normal((nb, r)).astype(np.float32) @ A + 0.05 * rng.standard_normal((nb, d)).astype(np.float32))
+    base[rng.integers(0, nb, 300)] = base[rng.integers(0, nb, 300)]          # exact duplicates
+    train = ((0.3 + 0.5 * rng.standard_normal((3000, r))).astype(np.float32) @ A).astype(np.float32)
+    knn, _, _ = oracle.groundtruth_f64(base, train, metric, 100, nthreads=16)
+    monkeypatch.setenv("RG_BUILD_VERIFY", "1")
+    build.build_roargraph(base, knn, metric, 100, M, L, num_threads=8, device=0, batch=900)      # (i): raises on a mismatch
+    monkeypatch.delenv("RG_BUILD_VERIFY")
+    got = build.build_roargraph(base, knn, metric, 100, M, L, num_threads=1, device=0, batch=900)
+    monkeypatch.setenv("RG_BUILD_HOST_PRUNE", "1")
+    want = build.build_roargraph(base, knn, metric, 100, M, L, num_threads=1, device=0, batch=900)
+    assert got[2] == want[2] and (got[0] == want[0]).all() and (got[1] == want[1]).all()
+    assert np.diff(got[0].astype(np.int64)).max() <= 3 * M
+
+
 def test_bench_multi_rank_control_flow_on_one_gpu():
     """bench.py as the driver launches it for N > 1 (torch.distributed.run, one process per rank), here with two ranks on
     the one visible GPU and the gloo backend: rank/LOCAL_RANK handling, barriers, max-over-ranks timing, the sharded
