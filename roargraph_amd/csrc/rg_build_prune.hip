@@ -11,7 +11,9 @@
 // Per node (all state wave-private, in LDS):
 //   keys   u64[1024]   (orderable distance bits << 32 | id), bitonic-sorted: the pool in the reference's order
 //   rows   the chosen neighbours' base rows, staged 4 per pass in the layout gather_score reads (filled by LDS-DMA)
-//   qv     the candidate's row, double buffered: the next candidate's row is in flight while this one is scored
+//   qv     a ring of D candidate rows filled by LDS-DMA: the rows of the next D candidates of the sorted pool are in
+//          flight while one is scored (a random 800-B row is 2 us away, scoring a candidate takes a fraction of that);
+//          every fill is issued unconditionally, so the wait in front of a slot is an exact vmcnt
 // occluded(p) = some chosen r has compare(p, r) < dist(p) (or r == p): the chosen rows are scored four per pass against
 // the candidate, stopping at the first pass that holds an occluder (the answer does not depend on which one is found).
 // The reference's second sweep only matters for the entries in front of the first sweep's start (rg_build.cpp).
@@ -43,18 +45,22 @@ struct PruneParams {
 };
 
 constexpr uint32_t kPruneKeys = 1024;
-constexpr int kQChunks = 4;   // candidate row in registers while in flight: up to 4 x 64 lanes x 16 B = dim <= 1024
+constexpr int kQChunksMax = 4;   // candidate row in registers while in flight: up to 4 x 64 lanes x 16 B = dim <= 1024
 
-template <bool L2>
+constexpr int kPruneRing = 4;     // candidate rows in flight
+
+// QC: 1-KiB chunks (64 lanes x 16 B) of a candidate row: dim <= 256 QC
+template <bool L2, int QC>
 __global__ void __launch_bounds__(64) rg_prune_search_kernel(PruneParams P) {
+    constexpr int D = kPruneRing;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
     const int g = lane >> 4;
     unsigned long long *keys = reinterpret_cast<unsigned long long *>(smem);                 // kPruneKeys
     uint32_t *res_id = reinterpret_cast<uint32_t *>(keys + kPruneKeys);                      // 64
     uint32_t *have_l = res_id + 64;                                                          // 64
-    float *qv = reinterpret_cast<float *>(have_l + 64);                                      // 2 * qv_floats
-    float *rows = qv + 2 * P.qv_floats;                                                      // passes * stage_floats
+    float *qv = reinterpret_cast<float *>(have_l + 64);                                      // D slots of QC * 256 floats
+    float *rows = qv + D * QC * 256;                                                         // passes * stage_floats
     const uint32_t nq4 = P.dim / 4;                                                          // float4 pieces of a row
 
     for (uint32_t i = blockIdx.x; i < P.n; i += gridDim.x) {
@@ -136,44 +142,54 @@ __global__ void __launch_bounds__(64) rg_prune_search_kernel(PruneParams P) {
             }
             return false;
         };
-        float4 nx[kQChunks];
-        auto fetch = [&](uint32_t id) {            // candidate row -> registers (in flight)
-            const float4 *src = reinterpret_cast<const float4 *>(P.base + (size_t)id * P.stride);
+        // candidate rows in flight: slot s of the ring holds the candidate that is D ahead of the one last taken from it.
+        // Every fill is issued unconditionally (lanes beyond the row re-read its start into the slot's padding, indices
+        // beyond the pool re-read its last entry): QC loads per fill, so "at most (D - 1) QC outstanding" means slot s is in
+        uint32_t xoff[QC];
 #pragma unroll
-            for (int c = 0; c < kQChunks; ++c)
-                if ((uint32_t)(c * kWave + lane) < nq4) nx[c] = src[c * kWave + lane];
-        };
-        auto park = [&](float *q) {                // registers -> the candidate buffer
-#pragma unroll
-            for (int c = 0; c < kQChunks; ++c)
-                if ((uint32_t)(c * kWave + lane) < nq4) reinterpret_cast<float4 *>(q)[c * kWave + lane] = nx[c];
-            lds_sync();
-        };
+        for (int c = 0; c < QC; ++c) { const uint32_t x = (uint32_t)(c * kWave + lane); xoff[c] = 4u * (x < nq4 ? x : 0u); }
+#define RG_FETCH(s_, id_)                                                                  \
+    {                                                                                      \
+        const float *src_ = P.base + (size_t)(id_) * P.stride;                             \
+        _Pragma("unroll") for (int c_ = 0; c_ < QC; ++c_)                                  \
+            __builtin_amdgcn_global_load_lds((glb_ptr_t *)(src_ + xoff[c_]), (lds_ptr_t *)(qv + ((s_) * QC + c_) * 256), 16, 0, 0); \
+    }
+#define RG_ARRIVED(n_) { asm volatile("s_waitcnt vmcnt(%0)" :: "n"(n_) : "memory"); __builtin_amdgcn_wave_barrier(); }
         if (first < n) {
             append(pool_id(first));
             // ---- first sweep (:1874-1907)
-            uint32_t j = first + 1, buf = 0;
-            if (j < n) fetch(pool_id(j));
-            while (cnt < P.M && j < n) {
-                float *q = qv + (size_t)buf * P.qv_floats;
-                park(q);
-                if (j + 1 < n) fetch(pool_id(j + 1));
-                const uint32_t pid = pool_id(j);
-                const float pd = pool_dist(j);
-                if (!occluded(q, pid, pd) && pid != node) append(pid);
-                ++j;
-                buf ^= 1u;
+            const uint32_t j0 = first + 1;
+#pragma unroll
+            for (int s = 0; s < D; ++s) RG_FETCH(s, pool_id(min(j0 + (uint32_t)s, n - 1u)));
+            bool more = j0 < n;
+            for (uint32_t jb = j0; more; jb += D) {
+#pragma unroll
+                for (int s = 0; s < D; ++s) {
+                    const uint32_t j = jb + (uint32_t)s;
+                    if (more && (j >= n || cnt >= P.M)) more = false;
+                    if (more) {
+                        RG_ARRIVED((D - 1) * QC);
+                        const uint32_t pid = pool_id(j);
+                        const float pd = pool_dist(j);
+                        const bool occ = occluded(qv + s * QC * 256, pid, pd);
+                        lds_sync();                                        // the slot has been read: refill it
+                        RG_FETCH(s, pool_id(min(j + (uint32_t)D, n - 1u)));
+                        if (!occ && pid != node) append(pid);
+                    }
+                }
             }
             // ---- second sweep (:1912-1926): only the entries in front of `first` are still undecided
             for (uint32_t j2 = 1; j2 < first && cnt < P.M; ++j2) {
                 const uint32_t pid = pool_id(j2);
                 const float pd = pool_dist(j2);
-                fetch(pid);
-                float *q = qv;
-                park(q);
-                if (!occluded(q, pid, pd) && pid != node) append(pid);
+                lds_sync();
+                RG_FETCH(0, pid);
+                RG_ARRIVED(0);
+                if (!occluded(qv, pid, pd) && pid != node) append(pid);
             }
         }
+#undef RG_FETCH
+#undef RG_ARRIVED
         lds_sync();
         if (lane == 0) out[0] = cnt;
         if ((uint32_t)lane < cnt) out[1 + lane] = res_id[lane];
@@ -183,9 +199,11 @@ __global__ void __launch_bounds__(64) rg_prune_search_kernel(PruneParams P) {
 
 // LDS bytes of one workgroup, 0 if the shape does not fit (then the host prunes)
 static size_t prune_lds_bytes(uint32_t dim, uint32_t M, size_t lds_per_cu) {
-    if (dim % 8 || dim > (uint32_t)kQChunks * kWave * 4 || M > 64) return 0;
+    if (dim % 8 || dim > (uint32_t)kQChunksMax * kWave * 4 || M > 64) return 0;
     const size_t stage = (size_t)((dim + 63) / 64) * 256, qvf = (size_t)(dim + 63) / 64 * 64;
-    const size_t b = (size_t)kPruneKeys * 8 + 64 * 4 + 64 * 4 + 2 * qvf * 4 + (size_t)((M + 3) / 4) * stage * 4;
+    const size_t qc = dim <= 256 ? 1 : dim <= 512 ? 2 : 4;
+    (void)qvf;
+    const size_t b = (size_t)kPruneKeys * 8 + 64 * 4 + 64 * 4 + (size_t)kPruneRing * qc * 1024 + (size_t)((M + 3) / 4) * stage * 4;
     return b <= lds_per_cu ? (b + 15) / 16 * 16 : 0;
 }
 
@@ -207,11 +225,17 @@ rg_status build_prune_dev(rg_index *ix, uint32_t node0, uint32_t n, uint32_t M, 
     const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(16, ix->lds_per_cu / lds));
     const dim3 grid(std::min<uint32_t>(n, (uint32_t)ix->num_cu * per_cu));
     const bool l2 = ix->metric == RG_METRIC_L2;
-    const void *fn = l2 ? reinterpret_cast<const void *>(rg_prune_search_kernel<true>) : reinterpret_cast<const void *>(rg_prune_search_kernel<false>);
-    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-        return set_error(RG_ERR_DEVICE, "pruning kernel: cannot reserve its LDS");
-    if (l2) hipLaunchKernelGGL(rg_prune_search_kernel<true>, grid, dim3(kWave), lds, (hipStream_t)stream, P);
-    else hipLaunchKernelGGL(rg_prune_search_kernel<false>, grid, dim3(kWave), lds, (hipStream_t)stream, P);
+    const int qc = ix->dim <= 256 ? 1 : ix->dim <= 512 ? 2 : 4;
+#define RG_PRUNE_LAUNCH(L2_, QC_)                                                                                              \
+    do {                                                                                                                       \
+        auto kern = rg_prune_search_kernel<L2_, QC_>;                                                                          \
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
+            return set_error(RG_ERR_DEVICE, "pruning kernel: cannot reserve its LDS");                                         \
+        hipLaunchKernelGGL(kern, grid, dim3(kWave), lds, (hipStream_t)stream, P);                                              \
+    } while (0)
+    if (l2) { if (qc == 1) RG_PRUNE_LAUNCH(true, 1); else if (qc == 2) RG_PRUNE_LAUNCH(true, 2); else RG_PRUNE_LAUNCH(true, 4); }
+    else { if (qc == 1) RG_PRUNE_LAUNCH(false, 1); else if (qc == 2) RG_PRUNE_LAUNCH(false, 2); else RG_PRUNE_LAUNCH(false, 4); }
+#undef RG_PRUNE_LAUNCH
     if (hipGetLastError() != hipSuccess) return set_error(RG_ERR_DEVICE, "pruning kernel launch failed");
     return RG_OK;
 }
