@@ -152,6 +152,24 @@ def test_default_mode_stays_exact_when_it_switches_to_the_exact_words(rg, oracle
     ix.close()
 
 
+def test_empty_batch_and_single_query(rg, oracle):
+    """An empty query batch is a no-op (host and device forms); a batch of one query is searched like any other."""
+    import torch
+    base, q, off, nbrs, ep = small_set("ip", 4000, 200)
+    ix = rg.IndexBipartite.from_arrays(base, off, nbrs, ep, metric="ip")
+    got = ix.SearchRoarGraph(np.zeros((0, 200), np.float32), 10, 50)
+    assert got[0].shape == (0, 10) and got[2].shape == (0,)
+    dev = torch.device("cuda", 0)
+    e = torch.zeros((0, 200), device=dev)
+    ix.search_dev(e, 10, 50, torch.zeros((0, 10), dtype=torch.int32, device=dev), torch.zeros((0, 10), device=dev),
+                  torch.zeros(0, dtype=torch.int32, device=dev), torch.zeros(0, dtype=torch.int32, device=dev))
+    ix.search_wait()
+    got = ix.SearchRoarGraph(q[:1], 10, 50)
+    want = oracle.search(base, "ip", off, nbrs, ep, q[:1], 10, 50)
+    assert (got[0] == want[0]).all() and (bits(got[1]) == bits(want[1])).all() and (got[2] == want[2]).all()
+    ix.close()
+
+
 @pytest.mark.parametrize("metric", ["ip", "l2"])
 def test_split_rows_equal_plain_rows(rg, oracle, metric, monkeypatch):
     """d = 200 with ELL adjacency searches a split copy of the base by default (first 192 elements of a row at a whole-line
