@@ -589,9 +589,10 @@ static rg_status launch_k1(rg_index *ix, SearchCtx *cx, int mode, const float *d
     // register-staged forms keep 16 - 32 rows in flight per query, so eight resident queries still cover the latency:
     // measured on that index (scripts/exp/filter_size_10m.sh, % of 8 TB/s, 2^11 -> 2^12 entries): 81 -> 83.5 at
     // L_pq = 100, 70 -> 75 at 300, 65 -> 70 at 500, 53 -> 56 at 1000; 2^13 loses everywhere (too few queries left).
-    // The LDS-DMA ring forms (4 - 8 rows in flight) and the exact-words form (the filter only screens the atomics, whose
-    // round trip more resident queries hide) keep the older bound of 14.
-    const int min_wpc = (dimc_of(ix) && !bf && mode != 0) ? 8 : 14;
+    // The same holds where the filter only screens the atomics of the exact words (scripts/exp/filter_size_mode0_10m.sh:
+    // 60 -> 64 % at L_pq = 500, 54 -> 55 % at 1000 with 2^12 entries).  The LDS-DMA ring forms (4 - 8 rows in flight) keep
+    // the older bound of 14.
+    const int min_wpc = (dimc_of(ix) && !bf) ? 8 : 14;
     int filter_auto = 9;
     for (int f = 12; f >= 9; --f) {
         filter_auto = f;
