@@ -821,10 +821,17 @@ static rg_status finish_batches(rg_index *ix, SearchCtx *cx, hipStream_t s, uint
             // measurement: no verdict, no trial request; the next batch of this width decides
             if (!b->cold && hipEventElapsedTime(&ms, b->ev0, b->ev1) == hipSuccess && b->nq) per_q = ms / (float)b->nq;
             std::lock_guard<std::mutex> lk(ix->mu);
+            static const bool trace = getenv("RG_TRACE_ADAPTIVE") != nullptr;   // decisions of the adaptive default on stderr
+            if (trace)
+                fprintf(stderr, "[rg_search] batch L=%u nq=%u form=%s%s%s: %.3f us/query\n", b->L, b->nq, b->mode == 0 ? "exact words" : "filter+log",
+                        b->is_trial ? " (trial)" : "", b->cold ? " (cold: not a measurement)" : "", per_q * 1e3f);
             if (b->mode == 0 && b->is_trial && per_q > 0.0f) {   // verdict of the trial
                 if (per_q < 0.97f * ix->filter_per_q) ix->exact_from_L = std::min(ix->exact_from_L, b->L);
                 else ix->filter_ok_upto = std::max(ix->filter_ok_upto, b->L);
                 if (ix->trial_L == b->L) ix->trial_L = 0;
+                if (trace)
+                    fprintf(stderr, "[rg_search]   verdict at L=%u: exact words %.3f vs filter+log %.3f us/query -> exact from L=%u, filter kept up to L=%u\n",
+                            b->L, per_q * 1e3f, ix->filter_per_q * 1e3f, ix->exact_from_L, ix->filter_ok_upto);
             }
         }
         if (b->counted) {
