@@ -538,7 +538,10 @@ def main():
         g = torch.Generator(device=dev); g.manual_seed(4242)
         gq = torch.empty((args.gt_nq, args.dim), dtype=torch.float32, device=dev).normal_(generator=g) * 0.5 + 0.3
         shard = base[lo:hi]
-        groundtruth.groundtruth_distributed(shard[: min(hi - lo, 65536)], lo, gq[:2048], args.metric, args.gt_K)  # warm-up
+        # warm-up: a small call (allocations, module load), then one of the timed size -- the leg follows half a minute of
+        # CPU-only baselines, and on some boxes the first two seconds of MFMA work after that idle ran at 70 % of the rate
+        groundtruth.groundtruth_distributed(shard[: min(hi - lo, 65536)], lo, gq[:2048], args.metric, args.gt_K)
+        groundtruth.groundtruth_distributed(shard, lo, gq, args.metric, args.gt_K)
         sync_all()
         tg0 = time.perf_counter()
         gi, gv = groundtruth.groundtruth_distributed(shard, lo, gq, args.metric, args.gt_K)
