@@ -431,7 +431,7 @@ struct Builder {
                   hipHostMalloc(&h_exp, (size_t)B * cap * 8) == hipSuccess && hipHostMalloc(&h_nexp, (size_t)B * 4) == hipSuccess &&
                   hipStreamCreate(&st) == hipSuccess && hipEventCreate(&evA) == hipSuccess && hipEventCreate(&evB) == hipSuccess;
         if (ok) ok = build_index_create(d_base, nd, dim, (uint32_t)stride, ep, l2 ? RG_METRIC_L2 : RG_METRIC_IP, gpu_device, S, &ix) == RG_OK;
-        const bool gpu_prune = ok && !getenv("RG_BUILD_HOST_PRUNE") && build_prune_supported(ix, M);
+        const bool gpu_prune = ok && !getenv("RG_BUILD_HOST_PRUNE") && build_prune_supported(ix, M, cap);
         if (gpu_prune)
             ok = hipMalloc(&d_have, (size_t)B * hs * 4) == hipSuccess && hipHostMalloc(&h_have, (size_t)B * hs * 4) == hipSuccess &&
                  hipMalloc(&d_out, (size_t)B * (M + 1) * 4) == hipSuccess && hipHostMalloc(&h_out, (size_t)B * (M + 1) * 4) == hipSuccess;

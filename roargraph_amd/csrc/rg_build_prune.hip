@@ -207,7 +207,9 @@ static size_t prune_lds_bytes(uint32_t dim, uint32_t M, size_t lds_per_cu) {
     return b <= lds_per_cu ? (b + 15) / 16 * 16 : 0;
 }
 
-bool build_prune_supported(const rg_index *ix, uint32_t M) { return prune_lds_bytes(ix->dim, M, ix->lds_per_cu) != 0; }
+bool build_prune_supported(const rg_index *ix, uint32_t M, uint32_t exp_cap) {
+    return exp_cap <= kPruneKeys && prune_lds_bytes(ix->dim, M, ix->lds_per_cu) != 0;   // longer lists: the host prunes
+}
 
 rg_status build_prune_dev(rg_index *ix, uint32_t node0, uint32_t n, uint32_t M, const uint2_pod *d_exp, uint32_t exp_cap,
                           const uint32_t *d_nexp, const uint32_t *d_have, uint32_t hs, uint32_t *d_out, void *stream) {

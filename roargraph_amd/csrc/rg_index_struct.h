@@ -122,7 +122,7 @@ rg_status build_index_set_ell(rg_index *ix, const uint32_t *h_ell, void *stream)
 // PruneProjectionBaseSearchCandidates (:1846-1940) of n expansion lists on the GPU (rg_build_prune.hip): d_have[i] = length +
 // ids of node i's projection list (row stride hs words), d_out[i] = length + pruned ids (row stride M + 1; length
 // 0xffffffff = left to the host).  Bit-identical to Builder::prune_search.
-bool build_prune_supported(const rg_index *ix, uint32_t M);
+bool build_prune_supported(const rg_index *ix, uint32_t M, uint32_t exp_cap);
 rg_status build_prune_dev(rg_index *ix, uint32_t node0, uint32_t n, uint32_t M, const uint2_pod *d_exp, uint32_t exp_cap,
                           const uint32_t *d_nexp, const uint32_t *d_have, uint32_t hs, uint32_t *d_out, void *stream);
 }  // namespace rg
