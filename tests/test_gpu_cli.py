@@ -124,7 +124,8 @@ def test_gpu_assisted_build(oracle, monkeypatch):
         assert rg_ > rc - 0.03, (metric, rc, rg_)
 
 
-@pytest.mark.parametrize("metric,d,M,L", [("ip", 200, 35, 500), ("l2", 512, 24, 150), ("ip", 104, 12, 100), ("l2", 200, 35, 300)])
+@pytest.mark.parametrize("metric,d,M,L", [("ip", 200, 35, 500), ("l2", 512, 24, 150), ("ip", 104, 12, 100), ("l2", 200, 35, 300),
+                                          ("ip", 200, 24, 600)])   # the last: lists longer than the kernel sorts -> host pruning
 def test_gpu_pruning_equals_host_pruning(oracle, monkeypatch, metric, d, M, L):
     """The occlusion pruning of the phase-3 expansion lists (PruneProjectionBaseSearchCandidates, :1846-1940) on the GPU
     against Builder::prune_search on the host.  (i) RG_BUILD_VERIFY: every pruned list coming back from the GPU is compared
