@@ -41,7 +41,6 @@ struct PruneParams {
     uint32_t node0, n, M;
     uint32_t *out;           // [n][M + 1]: word 0 = length (0xffffffff: left to the host), then the pruned list
     uint32_t stage_floats;   // floats of one 4-row pass: ceil(dim / 64) * 256
-    uint32_t qv_floats;      // floats of one candidate buffer (dim rounded up to 64)
 };
 
 constexpr uint32_t kPruneKeys = 1024;
@@ -200,9 +199,8 @@ __global__ void __launch_bounds__(64) rg_prune_search_kernel(PruneParams P) {
 // LDS bytes of one workgroup, 0 if the shape does not fit (then the host prunes)
 static size_t prune_lds_bytes(uint32_t dim, uint32_t M, size_t lds_per_cu) {
     if (dim % 8 || dim > (uint32_t)kQChunksMax * kWave * 4 || M > 64) return 0;
-    const size_t stage = (size_t)((dim + 63) / 64) * 256, qvf = (size_t)(dim + 63) / 64 * 64;
-    const size_t qc = dim <= 256 ? 1 : dim <= 512 ? 2 : 4;
-    (void)qvf;
+    const size_t stage = (size_t)((dim + 63) / 64) * 256;
+    const size_t qc = dim <= 256 ? 1 : dim <= 512 ? 2 : 4;   // 1-KiB chunks of a candidate slot
     const size_t b = (size_t)kPruneKeys * 8 + 64 * 4 + 64 * 4 + (size_t)kPruneRing * qc * 1024 + (size_t)((M + 3) / 4) * stage * 4;
     return b <= lds_per_cu ? (b + 15) / 16 * 16 : 0;
 }
@@ -223,7 +221,6 @@ rg_status build_prune_dev(rg_index *ix, uint32_t node0, uint32_t n, uint32_t M, 
     P.exp = reinterpret_cast<const uint2 *>(d_exp); P.cap = exp_cap; P.nexp = d_nexp;
     P.have = d_have; P.hs = hs; P.node0 = node0; P.n = n; P.M = M; P.out = d_out;
     P.stage_floats = (uint32_t)((ix->dim + 63) / 64) * 256u;
-    P.qv_floats = (ix->dim + 63u) / 64u * 64u;
     const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(16, ix->lds_per_cu / lds));
     const dim3 grid(std::min<uint32_t>(n, (uint32_t)ix->num_cu * per_cu));
     const bool l2 = ix->metric == RG_METRIC_L2;
