@@ -634,6 +634,7 @@ struct Builder {
         lap("phase 1");
         // ---- phase 2 (:1100-1136)
         parallel_for(nd, 100, [&](uint32_t node, int) { add_reverse(proj, node, M, false); });
+        lap("phase 2 reverse edges");
         parallel_for(nd, 2048, [&](uint32_t node, int) {
             if (proj[node].size() <= M) return;
             std::vector<Nb> full;
@@ -644,8 +645,9 @@ struct Builder {
             std::lock_guard<std::mutex> guard(locks[node]);
             proj[node] = pruned;
         });
-        for (uint32_t i = 0; i < nd; ++i) supply[i] = proj[i];   // :1183-1188
-        lap("phase 2 + supply copy");
+        lap("phase 2 pruning");
+        parallel_for(nd, 8192, [&](uint32_t i, int) { supply[i] = proj[i]; });   // :1183-1188
+        lap("supply copy");
         // ---- phase 3 (:1192-1220): connectivity enhancement -- beam search from the entry point towards every node
         if (gpu_device >= 0) {
             if (!phase3_gpu()) return false;
