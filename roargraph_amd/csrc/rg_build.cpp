@@ -627,9 +627,16 @@ struct Builder {
             std::stable_sort(groups.begin(), groups.end(), [](const std::pair<uint32_t, uint32_t> &a, const std::pair<uint32_t, uint32_t> &b) {
                 return a.second - a.first > b.second - b.first;
             });
+            std::atomic<long long> ns_big{0};
             parallel_for((uint32_t)groups.size(), 4, [&](uint32_t gi, int) {
+                const auto t0 = (timing && gi == 0) ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
                 for (uint32_t i = groups[gi].first; i < groups[gi].second; ++i) phase1_query(order[i]);
+                if (timing && gi == 0) ns_big = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
             });
+            if (timing && !groups.empty())
+                fprintf(stderr, "[rg_build]   phase 1: %zu base points are somebody's nearest, the most popular one of %u queries (%.2f s on its thread), "
+                                "10th %u, 100th %u\n", groups.size(), groups[0].second - groups[0].first, ns_big.load() * 1e-9,
+                        groups.size() > 9 ? groups[9].second - groups[9].first : 0u, groups.size() > 99 ? groups[99].second - groups[99].first : 0u);
         }
         lap("phase 1");
         // ---- phase 2 (:1100-1136)
