@@ -85,6 +85,36 @@ def score_batch(base, metric, query, ids):
     return out
 
 
+def normalize_rows(a):
+    """In place: normalize<float> (util.h:214-225) over the rows of a C-contiguous float32 matrix."""
+    assert a.dtype == np.float32 and a.flags.c_contiguous and a.ndim == 2
+    lib().rgo_normalize_rows(_p(a), C.c_size_t(a.shape[0]), C.c_size_t(a.shape[1]), C.c_uint(a.shape[1]))
+    return a
+
+
+def projection_ep(base, dim=None):
+    """CalculateProjectionep (src/index_bipartite.cpp:2004-2041)."""
+    base = np.ascontiguousarray(base, np.float32)
+    lib().rgo_projection_ep.restype = C.c_uint32
+    return int(lib().rgo_projection_ep(_p(base), C.c_size_t(base.shape[1]), C.c_uint32(base.shape[0]),
+                                       C.c_uint(dim if dim is not None else base.shape[1])))
+
+
+def ref_projection_ep(base):
+    """The same loops compiled with the reference's Release flags (oracle/_ref/rg_ref ep)."""
+    base = np.ascontiguousarray(base, np.float32)
+    with tempfile.TemporaryDirectory() as td:
+        fin = os.path.join(td, "b.fbin")
+        with open(fin, "wb") as f:
+            f.write(np.array(base.shape, np.uint32).tobytes())
+            f.write(base.tobytes())
+        r = ref_run("ep", fin)
+    for line in r.stdout.splitlines():
+        if line.startswith("EP "):
+            return int(line.split()[1])
+    raise RuntimeError("rg_ref ep: no answer: " + r.stdout[-200:])
+
+
 def queue_trace(cap, ops, ids, dists):
     ops = np.ascontiguousarray(ops, np.uint8)
     ids = np.ascontiguousarray(ids, np.uint32)
@@ -258,10 +288,11 @@ def ref_queue(cap, ops, ids, dists):
     return dict(size=int(size), cur=int(cur), ids=rid, dists=rd, flags=rf, pops=pops)
 
 
-def ref_search(base_fbin, index_path, query_fbin, metric, k, L, threads=1, repeat=1):
+def ref_search(base_fbin, index_path, query_fbin, metric, k, L, threads=1, repeat=1, prefetch=True):
+    """oracle/_ref/rg_ref search; prefetch=True issues the reference's software prefetches (index_bipartite.cpp:2324, 2374-2375)."""
     with tempfile.TemporaryDirectory() as td:
         fout = os.path.join(td, "out")
-        r = ref_run("search", base_fbin, index_path, query_fbin, metric, k, L, threads, fout, repeat, check=False)
+        r = ref_run("search", base_fbin, index_path, query_fbin, metric, k, L, threads, fout, repeat, 1 if prefetch else 0, check=False)
         if r.returncode != 0:
             raise RuntimeError((r.stdout + r.stderr).strip().splitlines()[-1])
         raw = open(fout, "rb").read()

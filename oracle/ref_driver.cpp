@@ -124,8 +124,14 @@ static Graph read_index(const char *path) {  // layout of index_bipartite.cpp:20
     return g;
 }
 
-// search base.fbin graph.index query.fbin <l2|ip|cosine> k L T out.bin [repeat]
-// out = u32 nq, u32 k, ids[nq][k], dists[nq][k], cmps[nq], hops[nq]; prints "QPS <v> threads <T>"
+// search base.fbin graph.index query.fbin <l2|ip|cosine> k L T out.bin [repeat] [prefetch]
+// out = u32 nq, u32 k, ids[nq][k], dists[nq][k], cmps[nq], hops[nq]; prints "QPS <v> threads <T> ms <ms> prefetch <0|1>"
+// prefetch (default 1): the loop issues the software prefetches SearchRoarGraph issues -- prefetch_vector of the entry
+// point's row (:2324, util.h:77-80, with the reference's own byte count: `dimension_` BYTES of the row) and, on every
+// neighbour iteration, _MM_HINT_T0 of the NEXT neighbour's visited tag and of the first line of its base row
+// (:2374-2375).  The reference reads cur_nbrs[j + 1] one past the end of the list on the last iteration; here the last
+// iteration prefetches nothing (a prefetch changes no result, only the time).  prefetch = 0 is the loop without them
+// (what the round-2 baseline timed): both rates are reported by bench.py.
 static int cmd_search(int argc, char **argv) {
     if (argc < 10) return 2;
     const char *base_f = argv[2], *index_f = argv[3], *query_f = argv[4];
@@ -133,6 +139,7 @@ static int cmd_search(int argc, char **argv) {
     uint32_t k = (uint32_t)atoi(argv[6]), L = (uint32_t)atoi(argv[7]);
     int T = atoi(argv[8]);
     int repeat = argc > 10 ? atoi(argv[10]) : 1;
+    const bool prefetch = argc > 11 ? atoi(argv[11]) != 0 : true;
     // the loader sequence of tests/test_search_roargraph.cpp:119-132 and LoadVectorData (:2664-2695)
     uint32_t nb, bd, nq, qd;
     efanna2e::load_meta<float>(base_f, nb, bd);
@@ -165,12 +172,20 @@ static int cmd_search(int argc, char **argv) {
             vl_type *seen = vl->mass;
             const vl_type stamp = vl->curV;
             // entry point goes into the beam unmarked
+            if (prefetch) efanna2e::prefetch_vector((const char *)(base + (size_t)g.ep * dim), dim);   // :2324
             beam.insert(Neighbor(g.ep, dist->compare(base + (size_t)g.ep * dim, q, (unsigned)dim), false));
             uint32_t ncmp = 0, nhop = 0;
             while (beam.has_unexpanded_node()) {
                 const unsigned node = beam.closest_unexpanded().id;
+                const uint32_t *nbrs = g.adj[node].data();
+                const size_t deg = g.adj[node].size();
                 ++nhop;
-                for (uint32_t nb_id : g.adj[node]) {
+                for (size_t j = 0; j < deg; ++j) {
+                    const uint32_t nb_id = nbrs[j];
+                    if (prefetch && j + 1 < deg) {                                                      // :2374-2375
+                        _mm_prefetch((const char *)(seen + nbrs[j + 1]), _MM_HINT_T0);
+                        _mm_prefetch((const char *)(base + (size_t)nbrs[j + 1] * dim), _MM_HINT_T0);
+                    }
                     if (seen[nb_id] == stamp) continue;
                     seen[nb_id] = stamp;
                     const float dd = dist->compare(base + (size_t)nb_id * dim, q, (unsigned)dim);
@@ -206,7 +221,7 @@ static int cmd_search(int argc, char **argv) {
     out.write((char *)dists.data(), dists.size() * 4);
     out.write((char *)cmps.data(), cmps.size() * 4);
     out.write((char *)hops.data(), hops.size() * 4);
-    std::cout << "QPS " << (nq / (best_ms / 1000.0)) << " threads " << T << " ms " << best_ms << std::endl;
+    std::cout << "QPS " << (nq / (best_ms / 1000.0)) << " threads " << T << " ms " << best_ms << " prefetch " << (prefetch ? 1 : 0) << std::endl;
     return 0;
 }
 
@@ -250,8 +265,40 @@ static int cmd_fbinload(int argc, char **argv) {
     return 0;
 }
 
+// ep base.fbin : the loops of IndexBipartite::CalculateProjectionep (src/index_bipartite.cpp:2004-2041) -- the TU itself
+// cannot be compiled here (see the header), so its four plain loops are restated and compiled with the reference's flags
+// (-Ofast: the compiler is free to vectorise the j loop, as it is in the reference's build); prints "EP <row>"
+static int cmd_ep(int argc, char **argv) {
+    if (argc < 3) return 2;
+    uint32_t n = 0, d = 0;
+    float *data = nullptr;
+    efanna2e::load_meta<float>(argv[2], n, d);
+    efanna2e::load_data<float>(argv[2], n, d, data);
+    data = efanna2e::data_align(data, n, d);
+    const size_t nd_ = n, dimension_ = d;
+    float *center = new float[dimension_]();
+    for (size_t i = 0; i < nd_; ++i)
+        for (size_t dd = 0; dd < dimension_; ++dd) center[dd] += data[i * dimension_ + dd];
+    for (size_t dd = 0; dd < dimension_; ++dd) center[dd] /= (float)nd_;
+    float *distances = new float[nd_]();
+#pragma omp parallel for
+    for (size_t i = 0; i < nd_; ++i) {
+        const float *cur_data = data + i * dimension_;
+        float diff = 0;
+        for (size_t j = 0; j < dimension_; ++j) diff += ((center[j] - cur_data[j]) * (center[j] - cur_data[j]));
+        distances[i] = diff;
+    }
+    uint32_t closest = 0;
+    for (size_t i = 1; i < nd_; ++i)
+        if (distances[i] < distances[closest]) closest = static_cast<uint32_t>(i);
+    std::cout << "EP " << closest << std::endl;
+    delete[] center;
+    delete[] distances;
+    return 0;
+}
+
 int main(int argc, char **argv) {
-    if (argc < 2) { std::cerr << "usage: rg_ref <dist|queue|search|meta|gtload|fbinload> ..." << std::endl; return 2; }
+    if (argc < 2) { std::cerr << "usage: rg_ref <dist|queue|search|meta|gtload|fbinload|ep> ..." << std::endl; return 2; }
     std::string c = argv[1];
     try {
         if (c == "dist") return cmd_dist(argc, argv);
@@ -260,6 +307,7 @@ int main(int argc, char **argv) {
         if (c == "meta") return cmd_meta(argc, argv);
         if (c == "gtload") return cmd_gtload(argc, argv);
         if (c == "fbinload") return cmd_fbinload(argc, argv);
+        if (c == "ep") return cmd_ep(argc, argv);
     } catch (const std::exception &e) {
         std::cout << "EXC: " << e.what() << std::endl;
         return 3;

@@ -421,6 +421,30 @@ void rgo_normalize_rows(float *data, size_t n, size_t stride, unsigned d) {
     }
 }
 
+/* f-2: IndexBipartite::CalculateProjectionep (src/index_bipartite.cpp:2004-2041): the entry point of the projection
+ * graph = the base row nearest (squared L2) to the centroid.  Plain float loops in the reference's statement order:
+ * centroid = per-dimension sum over the rows in index order (:2008-2012), divided by (float)nd (:2014-2016); distance of
+ * a row = sum over j of (c[j] - x[j])^2 in j order (:2022-2028); the first of equal minima wins (:2031-2035, strict <).
+ * A SECOND RESTATEMENT, not a pin: index_bipartite.cpp cannot be compiled in this image, and under the reference's
+ * -Ofast the j loop may be vectorised with re-associated partial sums (`rg_ref ep` compiles these same loops with the
+ * reference's flags; tests/test_oracle_vs_ref.py compares the entry points, not the distance bits). */
+uint32_t rgo_projection_ep(const float *base, size_t stride, uint32_t nd, unsigned d) {
+    float *center = (float *)calloc(d ? d : 1, sizeof(float));
+    for (size_t i = 0; i < nd; ++i)
+        for (unsigned j = 0; j < d; ++j) center[j] += base[i * stride + j];
+    for (unsigned j = 0; j < d; ++j) center[j] /= (float)nd;
+    uint32_t closest = 0;
+    float best = 0.0f;
+    for (size_t i = 0; i < nd; ++i) {
+        const float *x = base + i * stride;
+        float diff = 0.0f;
+        for (unsigned j = 0; j < d; ++j) diff += (center[j] - x[j]) * (center[j] - x[j]);
+        if (i == 0 || diff < best) { closest = (uint32_t)i; best = diff; }
+    }
+    free(center);
+    return closest;
+}
+
 /* ------------------------------------------------------------ a10 GT (fp64) */
 typedef struct { double s; uint32_t id; } gt_item;
 /* "a ranks before b": mips score desc / l2 dist asc, then id asc */

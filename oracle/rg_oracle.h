@@ -93,6 +93,9 @@ void rgo_graph_free(rgo_graph *g);
 void rgo_free(void *p);
 void rgo_normalize_rows(float *data, size_t n, size_t stride, unsigned d);   /* util.h:214-225 */
 
+/* f-2: CalculateProjectionep (src/index_bipartite.cpp:2004-2041): argmin squared L2 to the float centroid */
+uint32_t rgo_projection_ep(const float *base, size_t stride, uint32_t nd, unsigned d);
+
 /* a10: exact top-K ground truth (DiskANN compute_groundtruth; source absent, README.md:62-75).
  * fp64 accumulation; order: mips = score desc then id asc, l2 = dist asc then id asc.
  * dists written as +inner product for mips (test_search_bipartite.cpp:46-48), squared L2 for l2. */

@@ -12,7 +12,7 @@ can check both the oracle and the HIP path against them.
                               (genuine queue + visited pool + distance, loop restated -- see oracle/ref_driver.cpp)
   G4 formats.npz              bytes of small .fbin / gt files (good and truncated) + what util.h's loaders said
 
-usage: python scripts/make_golden.py
+usage: python scripts/make_golden.py [g1 g2 g3 g3c g4]   (default: all)
 """
 import os
 import subprocess
@@ -89,6 +89,36 @@ def g3():
             np.savez_compressed(os.path.join(OUT, "search_%s.npz" % name), **out)
 
 
+def g3_cosine():
+    """G3c search_cos200.npz: `rg_ref search ... cosine` -- the reference's normalize<float> (util.h:214-225) over base
+    rows (LoadVectorData, index_bipartite.cpp:2679-2684) and queries (test_search_roargraph.cpp:167-172), then the IP
+    kernel.  The fixture holds the RAW rows; the expectations are what the reference build of this container returned.
+    normalize compiles (GCC 11.4, -Ofast) to a 16-lane sum of squares, vrsqrtss + one Newton step, and a multiply: the
+    vrsqrtss estimate differs between CPU vendors, so these bits are those of THIS machine's reference build and the
+    tests compare with the float tolerance of the north star, not bit for bit (tests/test_gpu_golden.py)."""
+    nb, d, nq = 1500, 200, 40
+    base, q = synth.make_synth(777, nb, nq, d)
+    base = (base * np.linspace(0.5, 3.0, nb, dtype=np.float32)[:, None]).astype(np.float32)   # norms that matter
+    nbase = base / np.linalg.norm(base.astype(np.float64), axis=1)[:, None].astype(np.float32)
+    tq = synth.make_synth(778, nb, 400, d)[1]
+    lists, ep = synth.knn_graph(nbase.astype(np.float32), "ip", M=10, train_queries=tq)
+    off, nbrs = io.lists_to_csr(lists)
+    with tempfile.TemporaryDirectory() as td:
+        bf, qf, gf = (os.path.join(td, x) for x in ("b.fbin", "q.fbin", "g.index"))
+        io.write_fbin(bf, base)
+        io.write_fbin(qf, q)
+        io.write_index(gf, off, nbrs, ep)
+        out = dict(base=base, queries=q, offsets=off, nbrs=nbrs, ep=ep, metric="cosine")
+        cfgs = []
+        for L, k in ((10, 10), (50, 10), (100, 100), (300, 10)):
+            ids, ds, cmps, hops, _ = po.ref_search(bf, gf, qf, "cosine", k, L, threads=2)
+            tag = "L%d_k%d" % (L, k)
+            cfgs.append(tag)
+            out.update({tag + "_ids": ids, tag + "_dist_bits": ds.view(np.uint32), tag + "_cmps": cmps, tag + "_hops": hops})
+        out["configs"] = np.array(cfgs)
+        np.savez_compressed(os.path.join(OUT, "search_cos200.npz"), **out)
+
+
 def g4():
     out = {}
     rng = np.random.default_rng(3)
@@ -136,6 +166,9 @@ if __name__ == "__main__":
     if not po.have_ref():
         sys.exit("oracle/_ref/rg_ref is not available (needs /root/reference and an AVX-512 host)")
     os.makedirs(OUT, exist_ok=True)
-    g1(); g2(); g3(); g4()
+    only = sys.argv[1:]
+    for name, fn in (("g1", g1), ("g2", g2), ("g3", g3), ("g3c", g3_cosine), ("g4", g4)):
+        if not only or name in only:
+            fn()
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))
     print("golden fixtures written to", OUT, "(%.2f MB)" % (tot / 1e6))

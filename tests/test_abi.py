@@ -125,6 +125,21 @@ def test_recall_matches_oracle(rg, oracle):
     assert rg.recall(wide, gt, 10) == oracle.recall(res, gt, 10)
 
 
+@pytest.mark.parametrize("nd,d,stride", [(1, 8, 8), (300, 200, 200), (4097, 200, 208), (700, 24, 24)])
+def test_projection_ep_host_loop_matches_oracle(rg, oracle, nd, d, stride):
+    """rg_projection_ep (host loop, no device needed) == the oracle's CalculateProjectionep, ties included (every row
+    twice: the first index wins, index_bipartite.cpp:2031-2035)."""
+    from roargraph_amd._lib import check, lib
+    rng = np.random.default_rng(nd + d)
+    base = np.zeros((nd, stride), np.float32)
+    base[:, :d] = (rng.standard_normal((nd, d)) * 3 + 50.0).astype(np.float32)
+    if nd > 10:
+        base[nd // 2:] = base[: nd - nd // 2]
+    got = C.c_uint32()
+    check(lib().rg_projection_ep(base.ctypes.data_as(C.c_void_p), C.c_uint32(nd), C.c_uint32(d), C.c_uint32(stride), C.byref(got)))
+    assert got.value == oracle.projection_ep(base, dim=d)
+
+
 def test_normalize_matches_oracle(rg, oracle):
     from roargraph_amd._lib import lib
     a = np.random.default_rng(3).standard_normal((20, 24)).astype(np.float32)

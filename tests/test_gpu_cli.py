@@ -208,7 +208,7 @@ def test_bench_on_the_reference_file_layout(tmp_path):
 
 
 @pytest.mark.parametrize("nd,d", [(1, 8), (300, 200), (4097, 200), (2500, 512), (70000, 24), (513, 104)])
-def test_projection_ep_kernel_equals_host_loop(nd, d):
+def test_projection_ep_kernel_equals_host_loop(nd, d, oracle):
     """CalculateProjectionep (src/index_bipartite.cpp:2004-2041): the device form keeps the reference's summation orders
     (rows in index order per dimension, j order per row) and so returns the host loop's entry point -- including on sets
     with exactly tied distances (duplicated rows: the first index wins, :2031-2035) and with a large common offset, where
@@ -225,6 +225,7 @@ def test_projection_ep_kernel_equals_host_loop(nd, d):
     bt = torch.from_numpy(base).cuda()
     devv = C.c_uint32()
     check(lib().rg_projection_ep_dev(C.c_void_p(bt.data_ptr()), C.c_uint32(nd), C.c_uint32(d), C.c_uint32(d), 0, C.byref(devv)))
+    assert devv.value == oracle.projection_ep(base), "device entry point differs from the oracle's CalculateProjectionep"
     assert devv.value == host.value
     # an independent restatement of the same arithmetic in numpy (float32 throughout, sequential accumulation)
     if nd <= 5000:

@@ -56,6 +56,30 @@ def test_search_goldens_on_gpu(name, layout, monkeypatch):
     ix.close()
 
 
+@pytest.mark.parametrize("layout", ["ell", "csr"])
+def test_search_golden_cosine_on_gpu(layout, monkeypatch, oracle):
+    """a3 on the HIP path: rg_index_open_mem(metric = RG_METRIC_COSINE) normalises the base rows, rg_search the queries
+    (test_search_roargraph.cpp:141-153, 167-172; index_bipartite.cpp:2679-2684), then the IP kernel.  Against the golden of
+    the reference build (tolerance rule: tests/test_oracle_golden.py::cosine_close) and, bit for bit, against the oracle."""
+    from test_oracle_golden import cosine_close
+    from roargraph_amd.index import IndexBipartite
+    monkeypatch.setenv("RG_FORCE_CSR", "1" if layout == "csr" else "0")
+    z = np.load(os.path.join(GOLD, "search_cos200.npz"))
+    ix = IndexBipartite.from_arrays(z["base"], z["offsets"], z["nbrs"], int(z["ep"]), metric="cosine")
+    b, q = z["base"].copy(), z["queries"].copy()
+    oracle.normalize_rows(b)
+    oracle.normalize_rows(q)
+    for tag in z["configs"]:
+        L, k = (int(x[1:]) for x in str(tag).split("_"))
+        for visited in (2, 0):
+            ix.set("visited", visited)
+            ids, ds, cmps, hops = ix.SearchRoarGraph(z["queries"], k, L)
+            cosine_close(ids, ds, cmps, hops, z, tag)
+            want = oracle.search(b, "ip", z["offsets"], z["nbrs"], int(z["ep"]), q, k, L, nthreads=2)
+            assert (ids == want[0]).all() and (bits(ds) == bits(want[1])).all() and (cmps == want[2]).all() and (hops == want[3]).all()
+    ix.close()
+
+
 def test_not_enough_results_and_arg_errors():
     from roargraph_amd._lib import RG_ERR_ARG, RG_ERR_NOT_ENOUGH, RgError
     from roargraph_amd.index import IndexBipartite

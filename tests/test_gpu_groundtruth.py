@@ -128,7 +128,13 @@ def test_streamed_batches_equal_one_shot(oracle, metric, monkeypatch):
     for devs in ([0], [0, 0, 0]):
         got_i, got_d = groundtruth.compute_groundtruth(base, q, metric, 64, devices=devs)
         assert (got_i == one_i).all() and (got_d.view(np.uint32) == one_d.view(np.uint32)).all(), devs
-    if metric != "cosine":
+    if metric == "cosine":   # fp64 truth of the normalised rows (compute_groundtruth --dist_fn cosine: IP on unit vectors)
+        nb_, nq_ = base.copy(), q.copy()
+        oracle.normalize_rows(nb_)
+        oracle.normalize_rows(nq_)
+        ref_i, _, ref_s = oracle.groundtruth_f64(nb_, nq_, "ip", 64, nthreads=8)
+        check_gt(nb_, nq_, "ip", 64, one_i, one_d, ref_i, ref_s)
+    else:
         ref_i, _, ref_s = oracle.groundtruth_f64(base, q, metric, 64, nthreads=8)
         check_gt(base, q, metric, 64, one_i, one_d, ref_i, ref_s)
 

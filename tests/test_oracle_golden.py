@@ -47,6 +47,29 @@ def test_search_goldens(oracle, name):
         assert (cmps == z[tag + "_cmps"]).all() and (hops == z[tag + "_hops"]).all(), tag
 
 
+def cosine_close(ids, ds, cmps, hops, z, tag):
+    """Cosine against the reference build's golden (scripts/make_golden.py g3c).  The reference's normalize<float>
+    compiles to vrsqrtss + one Newton step (an estimate whose bits differ between CPU vendors), so its cosine results are
+    not a bit-level contract: ids / cmps / hops must be equal (the fixture's rank gaps are far above the rounding), the
+    distances within the north star's 1e-4 relative -- in fact within 4 ulp."""
+    assert (ids == z[tag + "_ids"]).all() and (cmps == z[tag + "_cmps"]).all() and (hops == z[tag + "_hops"]).all(), tag
+    want = z[tag + "_dist_bits"].view(np.float32)
+    assert np.abs((ds - want) / want).max() <= 2e-6, tag
+
+
+def test_search_golden_cosine(oracle):
+    """a3: COSINE = normalize<float> over base rows and queries (util.h:214-225; index_bipartite.cpp:2679-2684;
+    test_search_roargraph.cpp:167-172), then the IP kernel (index.cpp:8-26)."""
+    z = np.load(os.path.join(GOLD, "search_cos200.npz"))
+    b, q = z["base"].copy(), z["queries"].copy()
+    oracle.normalize_rows(b)
+    oracle.normalize_rows(q)
+    for tag in z["configs"]:
+        L, k = (int(x[1:]) for x in str(tag).split("_"))
+        ids, ds, cmps, hops = oracle.search(b, "ip", z["offsets"], z["nbrs"], int(z["ep"]), q, k, L, nthreads=2)
+        cosine_close(ids, ds, cmps, hops, z, tag)
+
+
 def test_format_goldens(oracle, tmp_path):
     z = np.load(os.path.join(GOLD, "formats.npz"))
     p = str(tmp_path / "f.bin")

@@ -50,6 +50,29 @@ def test_search_live(tmp_path, metric, d, nb):
         assert (r[2] == o[2]).all() and (r[3] == o[3]).all()
 
 
+def test_prefetching_loop_returns_the_same_bits(tmp_path):
+    """rg_ref search with the reference's software prefetches (index_bipartite.cpp:2324, 2374-2375; the form bench.py times
+    as cpu_baseline) and without them: prefetches change the time, never a result."""
+    base, q, off, nbrs, ep = small_set("ip", 3000, 200, nq=40)
+    bf, qf, gf = (str(tmp_path / x) for x in ("b.fbin", "q.fbin", "g.index"))
+    io.write_fbin(bf, base); io.write_fbin(qf, q); io.write_index(gf, off, nbrs, ep)
+    a = po.ref_search(bf, gf, qf, "ip", 10, 120, threads=2, prefetch=True)
+    b = po.ref_search(bf, gf, qf, "ip", 10, 120, threads=2, prefetch=False)
+    o = po.search(base, "ip", off, nbrs, ep, q, 10, 120, nthreads=2)
+    for x, y in ((a, b), (a, o)):
+        assert (x[0] == y[0]).all() and (bits(x[1]) == bits(y[1])).all() and (x[2] == y[2]).all() and (x[3] == y[3]).all()
+
+
+@pytest.mark.parametrize("nd,d,offset", [(1, 8, 0.0), (300, 200, 0.0), (4097, 200, 100.0), (2500, 512, 0.0), (20000, 24, 3.0), (513, 104, 0.0)])
+def test_projection_ep_restatement_vs_reference_flags(nd, d, offset):
+    """CalculateProjectionep (src/index_bipartite.cpp:2004-2041): the oracle's index-order loops against the same loops
+    compiled with the reference's -Ofast (rg_ref ep), where the compiler may re-associate the j sum.  The rows here are in
+    general position (no exact ties), so both must name the same row."""
+    rng = np.random.default_rng(nd * 7 + d)
+    base = (rng.standard_normal((nd, d)) * 3 + offset).astype(np.float32)
+    assert po.projection_ep(base) == po.ref_projection_ep(base)
+
+
 def test_not_enough_results_message(tmp_path):
     base = np.random.default_rng(0).standard_normal((50, 16)).astype(np.float32)
     bf, qf, gf = (str(tmp_path / x) for x in ("b.fbin", "q.fbin", "g.index"))
