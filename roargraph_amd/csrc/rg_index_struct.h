@@ -95,6 +95,8 @@ struct rg_index {
     uint32_t main_dim = 0, tail_dim = 0;
     bool split_rows = true;      // knob: use them (when they exist)
     bool exact_filter = true;    // mode 0: the LDS filter screens the exact HBM words (hits skip the atomics)
+    bool lookahead = true;       // mode 0: the look-ahead form of K1 where it applies (knob "lookahead"; same results either way)
+    bool adj_dups = false;       // some adjacency list names a node twice (found at open): the look-ahead form is not used
     bool query_in_lds = false;   // K1: force the generic (query staged in LDS) instantiation for d = 200 / 512
     bool count_full_ids = false; // K4: force the full-id bucket form (the half-word form is used when the remainder fits)
     int filter_log2 = 0;    // VIS=1: log2 of the LDS filter's 16-bit entries; 0 = automatic (per launch)

@@ -215,9 +215,12 @@ __global__ void rg_base_to_bf16_kernel(const float *__restrict__ base, uint32_t 
     }
 }
 
-// CSR -> ELL ([deg, ids...] per node at a fixed stride), one wave per node
+// CSR -> ELL ([deg, ids...] per node at a fixed stride), one wave per node.  *dups is set when a list of at most 63
+// neighbours names a node twice (the file format does not forbid it, index_bipartite.cpp:2097-2117; the reference's own
+// builds never produce it): the look-ahead form of K1 tests a hop's neighbours against the visited words in one step
+// and would score such a node twice, so those indexes keep the returning-atomic form, which orders the two tests.
 __global__ void rg_csr_to_ell_kernel(const uint64_t *offsets, const uint32_t *nbrs, uint32_t nd, uint32_t *ell,
-                                     uint32_t ell_stride) {
+                                     uint32_t ell_stride, uint32_t *dups) {
     const int lane = threadIdx.x & 63;
     const uint32_t wpb = blockDim.x / 64;
     for (uint32_t node = blockIdx.x * wpb + threadIdx.x / 64; node < nd; node += gridDim.x * wpb) {
@@ -226,6 +229,12 @@ __global__ void rg_csr_to_ell_kernel(const uint64_t *offsets, const uint32_t *nb
         uint32_t *row = ell + (size_t)node * ell_stride;
         if (lane == 0) row[0] = deg;
         for (uint32_t j = lane; j < ell_stride - 1; j += 64) row[1 + j] = j < deg ? nbrs[o0 + j] : 0u;
+        if (deg <= 63u && deg > 1u) {
+            const uint32_t mine = (uint32_t)lane < deg ? nbrs[o0 + lane] : 0xffffffffu;
+            bool twice = false;
+            for (uint32_t j = 0; j < deg; ++j) twice = twice || ((uint32_t)lane > j && readlane_u(mine, (int)j) == mine);
+            if (__ballot(twice) != 0ull && lane == 0) atomicOr(dups, 1u);
+        }
     }
 }
 
@@ -380,8 +389,12 @@ static rg_status finish_graph(rg_index *ix, const uint64_t *d_off, const uint32_
     if (!ix->force_csr && (ell_bytes <= 2.5 * csr_bytes + (64 << 20) || ell_bytes <= 16.0 * (1ull << 30))) {
         ix->ell_stride = es;
         RG_HIP(hipMalloc(&ix->d_ell, (size_t)ix->nd * es * 4));
-        hipLaunchKernelGGL(rg_csr_to_ell_kernel, dim3(4096), dim3(256), 0, 0, d_off, d_nb, ix->nd, ix->d_ell, es);
+        RG_HIP(hipMemset(d_stat, 0, 4));
+        hipLaunchKernelGGL(rg_csr_to_ell_kernel, dim3(4096), dim3(256), 0, 0, d_off, d_nb, ix->nd, ix->d_ell, es, d_stat);
         RG_HIP(hipDeviceSynchronize());
+        uint32_t dups = 0;
+        RG_HIP(hipMemcpy(&dups, d_stat, 4, hipMemcpyDeviceToHost));
+        ix->adj_dups = dups != 0;
         // split rows: an 800-B row (d = 200) spans seven 128-B lines wherever it starts; its first 192 elements at a 768-B
         // stride span six, and the 8-element tails, stored per edge in adjacency order, are read from ceil(deg/4) lines
         // per hop instead of one more line per fresh neighbour.  7.7 GB + 32 B per edge at 10M rows.
@@ -608,6 +621,11 @@ static rg_status launch_k1(rg_index *ix, SearchCtx *cx, int mode, const float *d
     else wpc = std::min(wpc, 24);
     K1Launch c;
     c.R = R; c.vis = mode == 0 ? 0 : 1; c.dimc = dimc_of(ix); c.bf = bf; c.lds = lds;
+    // exact words, look-ahead form (rg_search_kernel.h, VIS = 2): the register-staged instantiations over ELL rows that
+    // name no node twice; never with the opt-in second expansion, whose two lists share one test phase
+    if (mode == 0 && ix->lookahead && !ix->adj_dups && !ix->multi_expand && !bf && !bp && ix->diag == 0 &&
+        ((c.dimc == 200 && R >= 2) || (c.dimc == 512 && (R == 2 || R == 4))))
+        c.vis = 2;
     const bool l2 = ix->metric == RG_METRIC_L2, ell = ix->d_ell != nullptr;
     auto dispatch = [&](const SearchParams &sp) -> rg_status {
         if (l2 && ell) return launch_search_l2_ell(sp, c, s);
@@ -1118,6 +1136,7 @@ rg_status rg_index_set(rg_index *ix, const char *name, int value) {
     else if (!strcmp(name, "log_budget_kb")) ix->log_budget_kb = value;
     else if (!strcmp(name, "query_in_lds")) ix->query_in_lds = value != 0;
     else if (!strcmp(name, "exact_filter")) ix->exact_filter = value != 0;
+    else if (!strcmp(name, "lookahead")) ix->lookahead = value != 0;
     else if (!strcmp(name, "multi_expand")) ix->multi_expand = value;
     else if (!strcmp(name, "split_rows")) ix->split_rows = value != 0;
     else if (!strcmp(name, "fast_bf16")) {

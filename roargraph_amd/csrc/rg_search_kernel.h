@@ -17,6 +17,7 @@
 
 #include <cstdint>
 #include <string>
+#include <type_traits>
 
 #include "rg.h"
 #include "rg_device.h"
@@ -162,6 +163,24 @@ __device__ __forceinline__ uint2 beam_pop(Beam &bm, int lane) {
     bm.cur = c;
     lds_fence();
     return e;
+}
+
+// the entry the next beam_pop would return if nothing were inserted before it (no state changes): the prediction of the
+// look-ahead form (VIS = 2)
+__device__ __forceinline__ bool beam_peek(const Beam &bm, int lane, uint32_t &id) {
+    const unsigned long long pm = __ballot((uint32_t)lane < bm.psize && !(bm.pi & kFlagBit));
+    const bool in_main = bm.cur < bm.size;
+    if (!in_main && !pm) return false;
+    uint2 e = make_uint2(0u, 0u);
+    if (in_main) e = bm.ent[bm.cur];
+    id = e.y;
+    if (pm) {
+        const int j = __ffsll((long long)pm) - 1;
+        const float d = readlane_f(bm.pd, j);
+        const uint32_t i = readlane_u(bm.pi, j);
+        if (!in_main || nb_less(d, i, __uint_as_float(e.x), e.y)) id = i;
+    }
+    return true;
 }
 
 // rank of this lane's key among the main array's entries: lower bound under (distance, id)
@@ -352,9 +371,26 @@ __device__ __forceinline__ void beam_insert(Beam &bm, float cd, uint32_t cid, bo
 // the TWO closest unexpanded entries and expands both in one adjacency / visited / gather phase.  The second one is not
 // necessarily the node the reference would expand next (a neighbour of the first may have been closer), so the visiting
 // order -- and with it, occasionally, the result -- differs; twice the fresh neighbours share one latency chain.
+//
+// VIS: how the visited set (VisitedList, visited_list_pool.h:8-29) is kept
+//   0  exact epoch-tagged words in HBM, test-and-set with one returning atomic per neighbour (a dependent round trip per hop)
+//   1  lossy exact-match filter in LDS (+ id log -> K4 for the exact cmps)
+//   2  LOOK-AHEAD over the same exact words (round 3; d = 200 / 512, ELL rows without repeated ids): the test is a plain
+//      load of the word, the mark a fire-and-forget atomic issued only for fresh neighbours -- so testing has no side
+//      effect and can be done EARLY: while the rows of the node being expanded are in flight, the adjacency row of the
+//      entry that would be popped next (beam_peek: right in ~90 % of the hops) and the visited words of its neighbours
+//      are fetched too.  When the next pop is that node, its fresh list is ready after a few register operations and the
+//      hop's dependent chain is ONE memory latency (the row gather) instead of three (adjacency -> visited -> rows).
+//      A wrong prediction costs one small wasted read and takes the two-latency path (adjacency -> words).
+//      Exactness: the words read early can miss only the marks of the hop during which they were read (everything older
+//      has been acknowledged: the row loads issued after those marks were waited for), and exactly those ids are at hand
+//      -- the previous hop's fresh list -- so every early-tested neighbour is checked against them.
 template <bool L2, bool ELL, int R, int VIS, int DIMC, bool BF>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC == 512 ? (R <= 1 ? 4 : R <= 2 ? 3 : 2) : (R <= 4 ? 4 : 2)))) rg_search_kernel(SearchParams P) {
     static_assert(!BF || (DIMC != 0 && ELL), "fast mode: compile-time dimension, ELL adjacency");
+    static_assert(VIS != 2 || (DIMC != 0 && ELL && !BF), "look-ahead form: register-staged gather over ELL rows");
+    constexpr bool EXACT = VIS != 1;   // visited words in HBM
+    constexpr bool LOOK = VIS == 2;
     constexpr int NB = (DIMC + 127) / 128;                                // fast mode: LDS-DMA instructions per bf16 row
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
@@ -381,7 +417,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
     const uint32_t vf_rem_mask = (1u << vf_rem_bits) - 1u;
 
     uint32_t *vmap = P.visited + (size_t)blockIdx.x * P.vwords;
-    uint32_t epoch = VIS == 0 ? P.slot_epoch[blockIdx.x] : 0u;
+    uint32_t epoch = EXACT ? P.slot_epoch[blockIdx.x] : 0u;
 
     for (;;) {
         uint32_t qi = 0;
@@ -401,7 +437,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
         if constexpr (BF) load_query_regs_bf<DIMC>(query, qb, lane);
         // new visited epoch (VisitedList::reset, visited_list_pool.h:20-26: ++curV, wipe on wrap)
         uint32_t etag = 0;
-        if (VIS == 0) {
+        if (EXACT) {
             if (++epoch == 0x10000u) {
                 for (uint32_t w = lane; w < P.vwords; w += kWave) vmap[w] = 0u;
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -503,7 +539,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
         //    which a latency-bound wave has plenty, instead of LDS, which is what limits resident queries at large L_pq.
         //  * otherwise (any dimension, or the bf16 fast mode): LDS-DMA into a ring of R staging buffers; pass p is consumed
         //    once only the loads of the passes issued after it are still outstanding.
-        auto gather_list = [&](uint32_t n) __attribute__((always_inline)) {
+        // `hook` runs once, right behind the load instructions of the first batch (the look-ahead form issues its early
+        // visited-word loads there: behind the rows in the memory queue, ahead of the first wait)
+        auto gather_list = [&](uint32_t n, auto hook) __attribute__((always_inline)) {
             const uint32_t npass = (n + 3u) >> 2;
             if constexpr (DIMC != 0 && !BF) {
                 typedef v4f_t v4f;
@@ -512,7 +550,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
                 const uint32_t rid0 = cand_id[0];
                 const bool split = REM != 0 && P.tail_off != nullptr;
                 const uint32_t tix0 = split ? cand_x[0] : rid0;
-                for (uint32_t p0 = 0; p0 < npass; p0 += R) {
+                auto batch = [&](uint32_t p0, auto first_batch) __attribute__((always_inline)) {
                     v4f rv[R][NFULL];
                     float t8[R];
                     uint32_t rid[R], tix[R];
@@ -534,6 +572,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
                         if constexpr (REM != 0) t8[j] = P.tail_base[(size_t)tix[j] * P.tail_stride + (lane & 7)];
                         else t8[j] = 0.0f;
                     }
+                    if constexpr (decltype(first_batch)::value) hook();
 #pragma unroll
                     for (int j = 0; j < R; ++j) {
                         if (p0 + j < npass) {
@@ -545,6 +584,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
                             RG_PROF(3);
                         }
                     }
+                };
+                if constexpr (LOOK) {
+                    batch(0u, std::true_type{});
+                    for (uint32_t p0 = R; p0 < npass; p0 += R) batch(p0, std::false_type{});
+                } else {
+                    for (uint32_t p0 = 0; p0 < npass; p0 += R) batch(p0, std::false_type{});
                 }
             } else {
                 const uint32_t lpp = BF ? (uint32_t)NB : loads_per_pass(P.dim);
@@ -577,12 +622,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
             }
         };
 
+        auto no_hook = []() __attribute__((always_inline)) {};
         // entry point: scored and queued, not marked visited (index_bipartite.cpp:2338-2352)
         float epd;
         if constexpr (DIMC != 0 && !BF) {
             if (lane == 0) { cand_id[0] = P.ep; cand_x[0] = P.ep_tail; }
             lds_fence();
-            gather_list(1);
+            gather_list(1, no_hook);
             epd = __uint_as_float(cand_x[0]);
             lds_fence();
         } else {
@@ -643,7 +689,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
                 log_append(0, n);
                 cmps += n;                                                 // :2397
                 RG_PROF(2);
-                gather_list(n);
+                gather_list(n, no_hook);
                 log_flush();
                 // queue inserts (:2398)
                 const float cd = (uint32_t)lane < n ? __uint_as_float(cand_x[lane]) : 0.0f;
@@ -655,6 +701,90 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
             }
         };
         RG_PROF(5);
+        if constexpr (LOOK) {
+            // ---- look-ahead form over the exact visited words (see the template's comment)
+            uint32_t la_node = 0xffffffffu;      // the node whose adjacency row / visited words were fetched early
+            uint32_t la_first = 0, la_word = 0, la_toff = 0;
+            uint32_t prev_id = 0xffffffffu;      // fresh ids of the previous hop, the j-th in lane j: the only marks an early
+            uint32_t prev_n = 0;                 // read of the words can have missed
+            while (beam_has_unexpanded(bm, lane)) {                        // has_unexpanded_node, :2356
+                const uint2 popped = beam_pop(bm, lane);                   // :2358
+                const uint32_t node = popped.y;
+                ++hops;                                                    // :2366
+                const bool hit = node == la_node;
+                uint32_t first, toff = 0, word = 0;
+                if (hit) { first = la_first; toff = la_toff; word = la_word; }
+                else {
+                    first = (uint32_t)lane < P.ell_stride ? P.ell[(size_t)node * P.ell_stride + lane] : 0u;
+                    if (P.tail_off) toff = P.tail_off[node];
+                }
+                RG_PROF(0);
+                const uint32_t deg = readlane_u(first, 0);
+                if (deg > 63u) {                 // a row longer than one read: the general path (returning atomics)
+                    expand(node, first, toff);
+                    la_node = 0xffffffffu;
+                    prev_n = 0;
+                    continue;
+                }
+                const uint32_t id = (uint32_t)__shfl_down((int)first, 1, 64);
+                const bool have = (uint32_t)lane < deg;
+                if (!hit) word = __hip_atomic_load(&vmap[(have ? id : 0u) >> 4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef RG_K1_PROF
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+                RG_PROF(1);
+                RG_PROF_CNT(5, deg); RG_PROF_CNT(6, hit ? 1 : 0);
+                bool known = false;              // the LDS filter in front of the words: a hit proves "visited"
+                if (P.vf_front && have) {
+                    uint32_t slot; uint16_t rem;
+                    vf_hash(id, slot, rem);
+                    known = vtab[slot] == rem;
+                    if (!known) vtab[slot] = rem;
+                }
+                const uint32_t bit = 1u << (id & 15u);
+                bool fresh = have && !known && !((word >> 16) == epoch && (word & bit));   // :2378
+                if (hit)                         // words read during the previous hop: its marks may not have landed yet
+                    for (uint32_t j = 0; j < prev_n; ++j) fresh = fresh && readlane_u(prev_id, (int)j) != id;
+                if (fresh) {                     // :2385, fire and forget
+                    uint32_t *w = &vmap[id >> 4];
+                    (void)__hip_atomic_fetch_max(w, etag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // stale epoch -> (epoch, no bits)
+                    (void)__hip_atomic_fetch_or(w, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // same address: behind the max
+                }
+                const unsigned long long fm = __ballot(fresh);
+                const uint32_t n = __popcll(fm);
+                RG_PROF_CNT(0, 1); RG_PROF_CNT(1, n);
+                if (fresh) {
+                    const uint32_t pos = __popcll(fm & ((1ull << lane) - 1ull));
+                    cand_id[pos] = id;
+                    if (P.tail_off) cand_x[pos] = toff + lane;
+                }
+                lds_fence();
+                prev_id = (uint32_t)lane < n ? cand_id[lane] : 0xffffffffu;
+                prev_n = n;
+                cmps += n;                                                 // :2397
+                // the prediction: what the next pop returns unless one of this hop's candidates is closer
+                uint32_t pn = node;
+                const bool pv = beam_peek(bm, lane, pn);
+                la_node = pv ? pn : 0xffffffffu;
+                la_first = (uint32_t)lane < P.ell_stride ? P.ell[(size_t)pn * P.ell_stride + lane] : 0u;
+                la_toff = P.tail_off ? P.tail_off[pn] : 0u;
+                auto early_words = [&]() __attribute__((always_inline)) {
+                    const uint32_t ldeg = readlane_u(la_first, 0);
+                    const uint32_t lid = (uint32_t)__shfl_down((int)la_first, 1, 64);
+                    const bool lhave = (uint32_t)lane < min(ldeg, 63u);
+                    la_word = __hip_atomic_load(&vmap[(lhave ? lid : 0u) >> 4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                };
+                RG_PROF(2);
+                if (n) gather_list(n, early_words);
+                else early_words();
+                const float cd = (uint32_t)lane < n ? __uint_as_float(cand_x[lane]) : 0.0f;
+                const uint32_t cid = (uint32_t)lane < n ? cand_id[lane] : 0u;
+                lds_fence();
+                RG_PROF(3);
+                if (n) beam_insert<false>(bm, cd, cid, (uint32_t)lane < n, P.ep, lane, mscr RG_PROF_MERGE);
+                RG_PROF(4);
+            }
+        } else
         while (beam_has_unexpanded(bm, lane)) {                            // has_unexpanded_node, :2356
             const uint2 popped = beam_pop(bm, lane);                       // :2358
             const uint32_t node = popped.y;
@@ -693,7 +823,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
                     cmps += nA + nB;
                     RG_PROF_CNT(0, 2); RG_PROF_CNT(1, nA + nB);
                     RG_PROF(2);
-                    if (nA + nB) gather_list(nA + nB);
+                    if (nA + nB) gather_list(nA + nB, no_hook);
                     log_flush();
                     const float cdA = (uint32_t)lane < nA ? __uint_as_float(cand_x[lane]) : 0.0f, cdB = (uint32_t)lane < nB ? __uint_as_float(cand_x[nA + lane]) : 0.0f;
                     const uint32_t ciA = (uint32_t)lane < nA ? cand_id[lane] : 0u, ciB = (uint32_t)lane < nB ? cand_id[nA + lane] : 0u;
@@ -776,14 +906,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
         }
         wave_sync();
     }
-    if (VIS == 0 && lane == 0) P.slot_epoch[blockIdx.x] = epoch;
+    if (EXACT && lane == 0) P.slot_epoch[blockIdx.x] = epoch;
 }
 
 // ------------------------------------------------------------------------------------------ launch plumbing
 // what the host decided for one launch (rg_search.hip: plan_k1)
 struct K1Launch {
     int R = 1;        // staging ring depth (passes of 4 rows in flight)
-    int vis = 1;      // 0 = exact HBM visited words, 1 = LDS filter
+    int vis = 1;      // 0 = exact HBM visited words, 1 = LDS filter, 2 = exact words, look-ahead form
     int dimc = 0;     // compile-time dimension instantiation (0 = generic)
     bool bf = false;  // opt-in bf16 traversal
     uint32_t grid = 0;
@@ -817,8 +947,19 @@ static rg_status launch_search_v(const SearchParams &P, const K1Launch &c, hipSt
     return launch_search_d<L2, ELL, R, VIS, 0>(P, c, s);
 }
 
+// the look-ahead form exists for the register-staged instantiations only (k1_look_ok, rg_search.hip, asks for nothing else)
+template <bool L2, bool ELL, int R>
+static rg_status launch_search_look(const SearchParams &P, const K1Launch &c, hipStream_t s) {
+    if constexpr (ELL && R >= 2) {
+        if (c.dimc == 200) return launch_search_d<L2, ELL, R, 2, 200>(P, c, s);
+        if (c.dimc == 512 && R <= 4) return launch_search_d<L2, ELL, R, 2, 512>(P, c, s);
+    }
+    return set_error(RG_ERR_ARG, "internal: look-ahead form requested for a launch that has no such instantiation");
+}
+
 template <bool L2, bool ELL, int R>
 static rg_status launch_search_t(const SearchParams &P, const K1Launch &c, hipStream_t s) {
+    if (c.vis == 2) return launch_search_look<L2, ELL, R>(P, c, s);
     return c.vis == 1 ? launch_search_v<L2, ELL, R, 1>(P, c, s) : launch_search_v<L2, ELL, R, 0>(P, c, s);
 }
 
@@ -826,8 +967,10 @@ static rg_status launch_search_t(const SearchParams &P, const K1Launch &c, hipSt
 template <bool L2, bool ELL>
 static rg_status launch_search_family(const SearchParams &P, const K1Launch &c, hipStream_t s) {
     if constexpr (ELL) {   // eight register sets (32 rows in flight): d = 200 only, for launches with few resident queries
-        if (c.R == 8 && c.dimc == 200 && !c.bf)
+        if (c.R == 8 && c.dimc == 200 && !c.bf) {
+            if (c.vis == 2) return launch_search_d<L2, ELL, 8, 2, 200>(P, c, s);
             return c.vis == 1 ? launch_search_d<L2, ELL, 8, 1, 200>(P, c, s) : launch_search_d<L2, ELL, 8, 0, 200>(P, c, s);
+        }
     }
     switch (c.R) {
         case 1: return launch_search_t<L2, ELL, 1>(P, c, s);

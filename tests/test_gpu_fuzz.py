@@ -14,7 +14,7 @@ DIMS = [200, 200, 200, 512, 512, 8, 24, 64, 96, 104, 136, 256, 264]
 
 def make_case(seed):
     rng = np.random.default_rng(1000 + seed)
-    d = DIMS[seed % len(DIMS)]
+    d = DIMS[seed % len(DIMS)] if seed < 60 else (200, 512, 200)[seed % 3]
     nb = int(rng.integers(300, 4000))
     metric = "ip" if rng.random() < 0.5 else "l2"
     structured = rng.random() < 0.5
@@ -59,10 +59,24 @@ def make_case(seed):
              "query_in_lds": int(rng.random() < 0.2),
              "log_cap": int(rng.choice([0, 0, 64, 1024]))}
     knobs["_csr"] = int(rng.random() < 0.2)     # adjacency layout (read from the environment at open)
+    knobs["lookahead"] = int(rng.random() < 0.7)
+    # lists without repeated ids (what every real index has): the look-ahead form of the exact words applies to them.
+    # Cases 60+ aim at it: register-staged dimensions, exact words, ELL rows, beams wide enough to run for a while
+    if seed >= 60 or rng.random() < 0.5:
+        rows = []
+        for i in range(nb):
+            r = nbrs[int(off[i]):int(off[i + 1])]
+            _, first = np.unique(r, return_index=True)
+            rows.append(r[np.sort(first)])
+        deg = np.array([len(r) for r in rows])
+        off = np.zeros(nb + 1, np.uint64); off[1:] = np.cumsum(deg)
+        nbrs = np.concatenate(rows).astype(np.uint32) if nb else nbrs
+    if seed >= 60:
+        knobs.update(visited=0, lookahead=1, _csr=0, query_in_lds=0, rows_per_pass=int(rng.choice([0, 8, 16, 32])))
     return base, q, off, nbrs, ep, metric, k, L, knobs
 
 
-@pytest.mark.parametrize("seed", range(60))
+@pytest.mark.parametrize("seed", range(100))
 def test_random_case_matches_the_oracle(oracle, seed, monkeypatch):
     from roargraph_amd import index as rg
     base, q, off, nbrs, ep, metric, k, L, knobs = make_case(seed)

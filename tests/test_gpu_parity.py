@@ -69,6 +69,56 @@ def test_search_lds_filter_mode(rg, oracle, metric, d, nb, L, k, flt):
     ix.close()
 
 
+@pytest.mark.parametrize("metric,d,nb", [("ip", 200, 4000), ("l2", 512, 2000), ("l2", 200, 3000), ("ip", 512, 1500)])
+@pytest.mark.parametrize("lookahead,exact_filter", [(1, 1), (1, 0), (0, 1), (0, 0)])
+def test_exact_words_forms(rg, oracle, metric, d, nb, lookahead, exact_filter):
+    """visited=0, the reference's tag array (visited_list_pool.h:8-29) as epoch-tagged words in HBM, in both kernel forms:
+    look-ahead (plain-load test, fire-and-forget marks, the next pop's adjacency row and words fetched early) and
+    returning atomics; with and without the LDS filter in front; every register-set depth.  All four outputs bit-exact."""
+    base, q, off, nbrs, ep = small_set(metric, nb, d)
+    ix = rg.IndexBipartite.from_arrays(base, off, nbrs, ep, metric=metric)
+    ix.set("visited", 0)
+    ix.set("lookahead", lookahead)
+    ix.set("exact_filter", exact_filter)
+    for L, k in ((10, 10), (100, 100), (700, 10), (2000, 10)):
+        want = oracle.search(base, metric, off, nbrs, ep, q, k, L, nthreads=4)
+        for rpp in ((8, 16, 32) if d == 200 else (8, 16)):
+            ix.set("rows_per_pass", rpp)
+            for rep in range(2):        # the second call re-uses the slots' visited words under the next epochs
+                got = ix.SearchRoarGraph(q, k, L)
+                assert (got[2] == want[2]).all(), ("cmps", L, rpp, rep)
+                assert (got[3] == want[3]).all() and (got[0] == want[0]).all() and (bits(got[1]) == bits(want[1])).all(), (L, rpp, rep)
+    ix.close()
+
+
+@pytest.mark.parametrize("lookahead", [1, 0])
+def test_exact_words_on_rows_with_repeats_and_long_rows(rg, oracle, lookahead):
+    """The file format allows a list to name a node twice (SURVEY C-10): the second occurrence must not be scored.  An
+    index with such a list is detected at open and keeps the returning-atomic form whatever the knob says; lists longer
+    than one 63-neighbour read take the general path inside the look-ahead form."""
+    from roargraph_amd import io
+    base, q, off, nbrs, ep = small_set("ip", 4000, 200)
+    lists = [nbrs[int(off[i]):int(off[i + 1])].copy() for i in range(base.shape[0])]
+    long_rows = dict((i, np.unique(np.concatenate([lists[i], np.arange(i + 1, i + 120, dtype=np.uint32) % 4000]))) for i in (ep, 17, 900))
+    for with_repeats in (False, True):
+        ls = list(lists)
+        for i, row in long_rows.items():
+            ls[i] = row.astype(np.uint32)
+        if with_repeats:
+            ls[3] = np.concatenate([ls[3], ls[3][:2]]).astype(np.uint32)
+            ls[int(ls[ep][0])] = np.concatenate([ls[int(ls[ep][0])][:5], ls[int(ls[ep][0])][:5]]).astype(np.uint32)
+        o2, n2 = io.lists_to_csr(ls)
+        ix = rg.IndexBipartite.from_arrays(base, o2, n2, ep, metric="ip")
+        ix.set("visited", 0)
+        ix.set("lookahead", lookahead)
+        for L, k in ((20, 10), (300, 10)):
+            got = ix.SearchRoarGraph(q, k, L)
+            want = oracle.search(base, "ip", o2, n2, ep, q, k, L, nthreads=4)
+            assert (got[2] == want[2]).all(), ("cmps", with_repeats, L)
+            assert (got[3] == want[3]).all() and (got[0] == want[0]).all() and (bits(got[1]) == bits(want[1])).all()
+        ix.close()
+
+
 @pytest.mark.parametrize("full_ids", [0, 1])
 @pytest.mark.parametrize("log_cap,table", [(0, 15), (64, 15), (100000, 7), (700, 8), (100000, 6), (100000, 11)])
 def test_default_mode_exact_cmps_paths(rg, oracle, log_cap, table, full_ids):
