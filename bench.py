@@ -19,8 +19,14 @@ graph construction with the reference's parameters (M_sq=100, M_pjbp=35, L_pjpq=
   * `cpu_baseline_config1`: BASELINE configs[0], a 100K-row subset with its own index, L_pq = 50, ONE CPU thread;
   * `gt_build`: K2 over 65,536 queries x the 10M base (sharded over the ranks + all-to-all + K3), distances/s.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python bench.py [--gpus N] [--steps K] [--warmup W]        (N > 1 without a launcher: re-executes itself under
+                                                              torch.distributed.run, one rank per GPU, 127.0.0.1)
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Every step searches a DIFFERENT seeded batch of 10,000 queries (steps + warm-ups distinct batches, rotated): no launch
+replays the rows the previous one left in the L2 / Infinity Cache.  Hub rows near the entry point are shared by every
+query of every batch -- that reuse is the workload's own -- and `roofline.distinct_rows_frac` says how much of a
+launch's evaluations are first touches of a row (the share that HBM itself must serve).
 
 Multi-GPU: the index is replicated, every rank searches its own batch of queries (independent units, no data-path
 collective); value = total queries / max-over-ranks time; scaling = weak.  The index is built once (training-query
@@ -125,11 +131,17 @@ def cpu_search_baseline(base_np, off, nbrs, ep, q_np, ids_gpu, metric, k, L, thr
             n = max(threads, n - n % threads)
             if use_ref:
                 io.write_fbin(qf, q_np[:n])
-                ids, _, cmps, _, qps = po.ref_search(bf, gf, qf, metric, k, L, threads=threads)
+                # the reference's loop issues two software prefetches per neighbour (index_bipartite.cpp:2374-2375) and one
+                # prefetch_vector of the entry point (:2324): that form is `value`; the loop without them (what round 2
+                # timed) is recorded beside it
+                ids, _, cmps, _, qps = po.ref_search(bf, gf, qf, metric, k, L, threads=threads, prefetch=True)
                 assert (ids == ids_gpu[:n]).all(), "reference-header driver and GPU disagree on the bench workload (L_pq=%d)" % L
-                out.update(value=qps, kind="reference", mean_evals=float(np.mean(cmps)),
+                ids_np, _, _, _, qps_np = po.ref_search(bf, gf, qf, metric, k, L, threads=threads, prefetch=False)
+                assert (ids_np == ids).all()
+                out.update(value=qps, value_without_prefetch=qps_np, kind="reference", mean_evals=float(np.mean(cmps)),
                            sample="%d queries, %d OpenMP thread(s), oracle/_ref/rg_ref (reference distance.h/neighbor.h/"
-                                  "visited_list_pool.h, search loop restated), ids equal the GPU's" % (n, threads))
+                                  "visited_list_pool.h; search loop restated with the reference's software prefetches, "
+                                  "index_bipartite.cpp:2324,2374-2375), ids equal the GPU's" % (n, threads))
             else:
                 t0 = time.time()
                 r = po.search(base_np, metric, off, nbrs, ep, q_np[:n], k, L, nthreads=threads)
@@ -147,7 +159,7 @@ def gt_cpu_baseline(base, gq, args):
     shape of the reference's compute_groundtruth) on a bounded sample of the same workload."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import gt_numpy
-    nbs, nqs = min(args.nb, 1_000_000), min(args.gt_nq, 2048)
+    nbs, nqs = min(args.nb, 1_000_000), min(int(gq.shape[0]), 2048)
     hb = base[:nbs].cpu().numpy()
     hq = gq[:nqs].cpu().numpy()
     gt_numpy.groundtruth_blocked(hb[:65536], hq[:64], args.metric, args.gt_K)   # warm the BLAS threads
@@ -178,47 +190,82 @@ def pmc_traffic(key):
 
 
 class Searcher:
-    """One index + its device buffers; timing helpers."""
+    """One index + B distinct query batches, each with its own result buffers; timing helpers.  run() without a batch
+    number takes the next one in rotation, so consecutive launches never search the same queries."""
 
-    def __init__(self, torch, index, q, k, dim, stream, gt_np):
-        self.t, self.ix, self.q, self.k, self.dim, self.stream, self.gt = torch, index, q, k, dim, stream, gt_np
-        dev, nq = q.device, q.shape[0]
-        self.ids = torch.zeros((nq, k), dtype=torch.int32, device=dev)
-        self.dists = torch.zeros((nq, k), dtype=torch.float32, device=dev)
-        self.cmps = torch.zeros(nq, dtype=torch.int32, device=dev)
-        self.hops = torch.zeros(nq, dtype=torch.int32, device=dev)
+    def __init__(self, torch, index, qs, k, dim, stream, gts):
+        self.t, self.ix, self.qs, self.k, self.dim, self.stream = torch, index, list(qs), k, dim, stream
+        self.gts = list(gts) if gts is not None else [None] * len(self.qs)
+        dev, nq = self.qs[0].device, self.qs[0].shape[0]
+        self.nq = nq
+        self.out = [dict(ids=torch.zeros((nq, k), dtype=torch.int32, device=dev), dists=torch.zeros((nq, k), dtype=torch.float32, device=dev),
+                         cmps=torch.zeros(nq, dtype=torch.int32, device=dev), hops=torch.zeros(nq, dtype=torch.int32, device=dev)) for _ in self.qs]
+        self.cursor = 0
 
-    def run(self, L):
-        self.ix.search_dev(self.q, self.k, L, self.ids, self.dists, self.cmps, self.hops, stream=self.stream)
+    def run(self, L, b=None):
+        if b is None:
+            b = self.cursor
+            self.cursor = (self.cursor + 1) % len(self.qs)
+        o = self.out[b]
+        self.ix.search_dev(self.qs[b], self.k, L, o["ids"], o["dists"], o["cmps"], o["hops"], stream=self.stream)
+        return b
 
     def wait(self):
         self.ix.search_wait(self.stream)
 
     def timed(self, L, reps=3, settle=3):
-        """Average milliseconds per batch over `reps` launches (HIP events on the launch stream), after `settle` untimed
-        batches (that is where the adaptive default decides between its two exact forms)."""
+        """(average milliseconds per batch, batches timed) over `reps` launches (HIP events on the launch stream), after
+        `settle` untimed batches (that is where the adaptive default decides between its two exact forms)."""
         t = self.t
         for _ in range(settle):
             self.run(L); self.wait()
         ev = [(t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)) for _ in range(reps)]
+        used = []
         for a, b in ev:
-            a.record(); self.run(L); b.record()
+            a.record(); used.append(self.run(L)); b.record()
         self.wait()
-        return float(np.mean([a.elapsed_time(b) for a, b in ev]))
+        return float(np.mean([a.elapsed_time(b) for a, b in ev])), used
 
-    def point(self, L, ms, exact_cmps=None):
+    def point(self, L, ms, used):
+        """One row of the report: `used` = the batches the timing ran (their buffers hold the results at this L)."""
         from roargraph_amd import index as ixmod
-        nq = self.q.shape[0]
-        mc = float(self.cmps.float().mean().item()) if exact_cmps is None else exact_cmps
-        gbps = nq * mc * 4 * self.dim / (ms / 1e3) / 1e9
-        return {"L_pq": L, "qps": nq / (ms / 1e3), "ms_per_batch": ms,
-                "recall_at_10": ixmod.recall(self.ids.cpu().numpy().view(np.uint32), self.gt, 10) if self.k >= 10 and self.gt is not None else None,
-                "mean_evals": mc, "mean_hops": float(self.hops.float().mean().item()),
-                "GBps": gbps, "pct_of_8000": 100.0 * gbps / 8000.0, "pct_of_6290": 100.0 * gbps / 6290.0}
+        used = sorted(set(used))
+        mc = float(np.mean([self.out[b]["cmps"].float().mean().item() for b in used]))
+        mh = float(np.mean([self.out[b]["hops"].float().mean().item() for b in used]))
+        rec = None
+        if self.k >= 10 and all(self.gts[b] is not None for b in used):
+            rec = float(np.mean([ixmod.recall(self.out[b]["ids"].cpu().numpy().view(np.uint32), self.gts[b], 10) for b in used]))
+        gbps = self.nq * mc * 4 * self.dim / (ms / 1e3) / 1e9
+        return {"L_pq": L, "qps": self.nq / (ms / 1e3), "ms_per_batch": ms, "recall_at_10": rec, "mean_evals": mc, "mean_hops": mh,
+                "distinct_batches": len(used), "GBps": gbps, "pct_of_8000": 100.0 * gbps / 8000.0, "pct_of_6290": 100.0 * gbps / 6290.0}
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with no launcher around it: N ranks of this script under torch.distributed.run, one per
+    GPU, rendezvous on 127.0.0.1 (the container's hostname may not resolve)."""
+    import socket
+    import subprocess
+    from roargraph_amd._lib import lib
+    ndev = lib().rg_device_count()
+    if ndev < 1:
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    if args.backend == "nccl" and ndev < args.gpus:
+        raise SystemExit("bench.py --gpus %d: only %d device(s) visible (RCCL needs one GPU per rank; --backend gloo runs "
+                         "several ranks on one GPU to exercise the control flow only)" % (args.gpus, ndev))
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=%d" % args.gpus,
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    raise SystemExit(subprocess.call(cmd, env=env))
 
 
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)
     import torch
     import torch.distributed as dist
     from roargraph_amd import build, groundtruth, synth
@@ -230,6 +277,10 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if lib().rg_device_count() < 1:
         raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    if world != args.gpus:
+        raise SystemExit("bench.py --gpus %d was started with WORLD_SIZE=%d: launch as many ranks as --gpus says" % (args.gpus, world))
+    if args.backend == "nccl" and torch.cuda.device_count() < world:
+        raise SystemExit("bench.py --gpus %d: only %d device(s) visible" % (world, torch.cuda.device_count()))
     local = local % torch.cuda.device_count()   # (control-flow tests run several ranks on one GPU with --backend gloo)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -356,20 +407,27 @@ def main():
         index.set(kname, int(kval))
     index.set("visited", args.visited)
 
-    # exact truth of this rank's test queries (K2)
+    # distinct query batches of this rank: one per timed step and warm-up (at most 32), every one with its exact truth (K2)
+    nbatch = max(1, min(32, args.steps + args.warmup)) if not args.data_root else 1
+    qs = [q]
+    for b in range(1, nbatch):
+        qs.append(synth.make_device_set(dev, 1234, 1024, 0, args.nq, args.dim, data=args.data, rank=args.rank,
+                                        q_seed=99 + rank + 7919 * b)[2])
+    gts = []
     ti_q = torch.zeros((args.nq, 100), dtype=torch.int32, device=dev); tv_q = torch.zeros((args.nq, 100), device=dev)
-    groundtruth.gt_shard_dev(base, q, args.metric, 100, 0, ti_q, tv_q, stream=stream); torch.cuda.synchronize()
-    gt_np = ti_q.cpu().numpy().view(np.uint32)
+    for qb in qs:
+        groundtruth.gt_shard_dev(base, qb, args.metric, 100, 0, ti_q, tv_q, stream=stream); torch.cuda.synchronize()
+        gts.append(ti_q.cpu().numpy().view(np.uint32).copy())
     del ti_q, tv_q
-    S = Searcher(torch, index, q, args.k, args.dim, stream, gt_np)
+    S = Searcher(torch, index, qs, args.k, args.dim, stream, gts)
 
     # ---- L_pq sweep (every rank runs it: it also settles the adaptive default; rank 0 reports) -------------------------
     sweep_Ls = sorted({int(x) for x in args.sweep.split(",") if x} | {500}) if args.sweep else []
     sweep_Ls = [L for L in sweep_Ls if L >= args.k]
     sweep = []
     for L in sweep_Ls:
-        ms = S.timed(L, reps=3 if L <= 500 else 2)
-        sweep.append(S.point(L, ms))
+        ms, used = S.timed(L, reps=3 if L <= 500 else 2)
+        sweep.append(S.point(L, ms, used))
     if args.L > 0:
         L_star = args.L
     else:
@@ -380,16 +438,18 @@ def main():
         dist.broadcast(t, 0)
         L_star = int(t.item())
 
-    # ---- the timed headline: exactly --steps batches at L_star between barriers, the wait included ---------------------
+    # ---- the timed headline: exactly --steps batches at L_star between barriers, the wait included; every warm-up and
+    # every step searches another batch (rotation over `nbatch` distinct ones)
     for _ in range(args.warmup):
         S.run(L_star)
     S.wait()
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    used = []
     sync_all()
     t0 = time.perf_counter()
     for a, b in evs:
         a.record()
-        S.run(L_star)
+        used.append(S.run(L_star))
         b.record()
     S.wait()
     sync_all()
@@ -400,17 +460,40 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     qps = args.nq * args.steps * world / elapsed
-    head = S.point(L_star, float(np.mean(kernel_ms)))
-    ids_head = S.ids.cpu().numpy().view(np.uint32).copy()
+    head = S.point(L_star, float(np.mean(kernel_ms)), used)
+    # what the same launch gains when it REPLAYS one batch (round 2's protocol: the rows of the previous launch are still
+    # in the Infinity Cache) -- reported, never `value`
+    for _ in range(3):
+        S.run(L_star, 0)
+    S.wait()
+    ev_r = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(min(10, args.steps))]
+    for a, b in ev_r:
+        a.record(); S.run(L_star, 0); b.record()
+    S.wait()
+    replay_ms = float(np.mean([a.elapsed_time(b) for a, b in ev_r]))
+    replay_alg = float(S.out[0]["cmps"].float().sum().item()) * 4.0 * args.dim
+    # first touches: distinct base rows among the evaluations of one launch (the id logs of the default visited mode)
+    reuse = None
+    if args.visited == 2:
+        try:
+            ev_n, dr_n = index.reuse_stats(stream)
+            reuse = {"evaluations_performed": ev_n, "distinct_rows": dr_n, "distinct_rows_frac": dr_n / max(ev_n, 1)}
+        except Exception as e:  # noqa: BLE001  (the launch ran on the exact words: no logs)
+            reuse = {"unavailable": str(e)}
+    ids_head = S.out[0]["ids"].cpu().numpy().view(np.uint32).copy()
     # the exact HBM-visited form returns the same bits (parity between the two exact forms, checked every run)
     if args.visited != 0:
-        keep = [x.clone() for x in (S.ids, S.dists, S.cmps, S.hops)]
+        o = S.out[0]
+        keep = [o[x].clone() for x in ("ids", "dists", "cmps", "hops")]
         index.set("visited", 0)
-        S.run(L_star); S.wait()
-        assert torch.equal(S.ids, keep[0]) and torch.equal(S.hops, keep[3]), "visited modes disagree on ids/hops"
-        assert torch.equal(S.dists.view(torch.int32), keep[1].view(torch.int32)), "visited modes disagree on distances"
-        if args.visited == 2:
-            assert torch.equal(S.cmps, keep[2]), "cmps differ from the exact visited mode"
+        for look in (1, 0):      # both kernel forms of the exact words
+            index.set("lookahead", look)
+            S.run(L_star, 0); S.wait()
+            assert torch.equal(o["ids"], keep[0]) and torch.equal(o["hops"], keep[3]), "visited modes disagree on ids/hops"
+            assert torch.equal(o["dists"].view(torch.int32), keep[1].view(torch.int32)), "visited modes disagree on distances"
+            if args.visited == 2:
+                assert torch.equal(o["cmps"], keep[2]), "cmps differ from the exact visited mode"
+        index.set("lookahead", 1)
         index.set("visited", args.visited)
     kavg = float(np.mean(kernel_ms)) / 1e3
     alg_bytes = head["mean_evals"] * args.nq * 4.0 * args.dim
@@ -421,7 +504,7 @@ def main():
     # ---- the boundary's host form (rg_search: host buffers in, host buffers out -- PCIe inclusive; never `value`) --------
     host_form = None
     if rank == 0 and world == 1:
-        qh = q.cpu().numpy()
+        qh = qs[0].cpu().numpy()
         index.SearchRoarGraph(qh, args.k, L_star)
         t1 = time.perf_counter()
         for _ in range(5):
@@ -439,7 +522,8 @@ def main():
     two_streams = None
     if rank == 0 and world == 1 and not args.no_two_streams:
         s2 = torch.cuda.Stream(device=dev)
-        S2 = Searcher(torch, index, q, args.k, args.dim, s2.cuda_stream, None)
+        S2 = Searcher(torch, index, qs, args.k, args.dim, s2.cuda_stream, None)
+        S2.cursor = len(qs) // 2
         for _ in range(2):
             S.run(L_star); S2.run(L_star)
         S.wait(); S2.wait()
@@ -450,8 +534,9 @@ def main():
         S.wait(); S2.wait()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t1
-        assert torch.equal(S2.ids, S.ids) and torch.equal(S2.cmps, S.cmps), "the two streams disagree"
-        two_streams = {"what": "%d batches of %d queries alternating over two streams of one index, L_pq=%d" % (args.steps, args.nq, L_star),
+        S.run(L_star, 0); S2.run(L_star, 0); S.wait(); S2.wait()
+        assert torch.equal(S2.out[0]["ids"], S.out[0]["ids"]) and torch.equal(S2.out[0]["cmps"], S.out[0]["cmps"]), "the two streams disagree"
+        two_streams = {"what": "%d batches of %d queries (distinct, rotated) alternating over two streams of one index, L_pq=%d" % (args.steps, args.nq, L_star),
                        "qps": args.nq * args.steps / dt, "vs_one_stream": args.nq * args.steps / dt / qps}
         del S2
 
@@ -465,8 +550,8 @@ def main():
                 index.set(knob, 1)
                 rows = []
                 for L in sorted({L_star, 500}):
-                    ms = S.timed(L, reps=2, settle=1)
-                    p = S.point(L, ms)
+                    ms, used_f = S.timed(L, reps=2, settle=1)
+                    p = S.point(L, ms, used_f)
                     rows.append({"L_pq": L, "qps": p["qps"], "recall_at_10": p["recall_at_10"], "mean_evals_performed": p["mean_evals"]})
                 fast.append({"mode": name + " -- opt-in, NOT parity", "points": rows})
             except Exception as e:  # noqa: BLE001
@@ -479,7 +564,7 @@ def main():
         base_np = base.cpu().numpy()
         h_off_np = off.cpu().numpy().view(np.uint64)
         h_nbrs_np = nbrs.cpu().numpy().view(np.uint32)
-        q_np = q.cpu().numpy()
+        q_np = qs[0].cpu().numpy()
         try:
             cpu, cpu1 = cpu_search_baseline(base_np, h_off_np, h_nbrs_np, ep, q_np, ids_head, args.metric, args.k, L_star,
                                             [min(16, os.cpu_count() or 1), 1], args.cpu_seconds)   # README.md:110 evaluates with 16 threads
@@ -500,10 +585,10 @@ def main():
                                              metric=args.metric)
             g1i = torch.zeros((2000, 100), dtype=torch.int32, device=dev); g1v = torch.zeros((2000, 100), device=dev)
             groundtruth.gt_shard_dev(b1, q1, args.metric, 100, 0, g1i, g1v, stream=stream); torch.cuda.synchronize()
-            S1 = Searcher(torch, ix1, q1, args.k, args.dim, stream, g1i.cpu().numpy().view(np.uint32))
-            ms1 = S1.timed(50)
-            p1 = S1.point(50, ms1)
-            cpu_cfg1 = cpu_search_baseline(b1.cpu().numpy(), o1, n1, e1, q1.cpu().numpy(), S1.ids.cpu().numpy().view(np.uint32), args.metric,
+            S1 = Searcher(torch, ix1, [q1], args.k, args.dim, stream, [g1i.cpu().numpy().view(np.uint32)])
+            ms1, u1 = S1.timed(50)
+            p1 = S1.point(50, ms1, u1)
+            cpu_cfg1 = cpu_search_baseline(b1.cpu().numpy(), o1, n1, e1, q1.cpu().numpy(), S1.out[0]["ids"].cpu().numpy().view(np.uint32), args.metric,
                                            args.k, 50, [1], args.cpu_seconds / 2)[0]
             cpu_cfg1.update(workload="%d-row subset, own RoarGraph index, 2000 queries, top-%d, L_pq=50" % (nb1, args.k),
                             recall_at_10=p1["recall_at_10"], gpu_qps_same_inputs=p1["qps"])
@@ -517,9 +602,9 @@ def main():
         rn = torch.randint(0, args.nb, (args.nb * args.deg,), dtype=torch.int32, device=dev, generator=g)
         ro = torch.arange(0, args.nb + 1, dtype=torch.int64, device=dev) * args.deg
         ixr = IndexBipartite.from_device(base, ro, rn, 0, metric=args.metric)
-        Sr = Searcher(torch, ixr, q, args.k, args.dim, stream, None)
-        msr = Sr.timed(500, reps=min(5, args.steps), settle=2)
-        pr = Sr.point(500, msr)
+        Sr = Searcher(torch, ixr, qs, args.k, args.dim, stream, None)
+        msr, ur = Sr.timed(500, reps=min(5, args.steps), settle=2)
+        pr = Sr.point(500, msr, ur)
         tr_, trs = pmc_traffic({"nb": args.nb, "dim": args.dim, "nq": args.nq, "k": args.k, "metric": args.metric, "data": args.data,
                                 "graph": "random", "L": 500, "visited": 2})
         worst = {"workload": "same base, random out-degree-%d graph, %d queries, top-%d, L_pq=500 (every neighbour fresh: pure random "
@@ -530,38 +615,77 @@ def main():
         ixr.close()
         del rn, ro, Sr
 
-    # ---- second BASELINE metric: ground-truth build, distances/s.  Base rows sharded over the ranks (each rank scores
-    # ALL gt queries against its rows), per-shard top-K exchanged with one all-to-all over RCCL, merged by K3.
+    # ---- second BASELINE metric: ground-truth build, distances/s, through the NATIVE multi-rank path the CLI twin ships
+    # (rg_comm + rg_groundtruth_rank, csrc/rg_gt_dist.hip): base rows sharded over the ranks and resident in HBM, the
+    # queries streamed from host memory in batches of 65,536 (>= 4 batches, so that K2 of batch b+1 runs under the
+    # exchange of batch b), per-shard top-K lists exchanged with grouped RCCL send/recv on a side stream, K3, rows written
+    # to the owner's host array.  Ranks that share a GPU (--backend gloo, control-flow tests) cannot form an RCCL
+    # communicator: they take the torch.distributed form (one all_to_all) instead.
     gt = None
     if args.gt_nq > 0:
         lo, hi = groundtruth.shard_rows(args.nb, world)[rank]
         g = torch.Generator(device=dev); g.manual_seed(4242)
-        gq = torch.empty((args.gt_nq, args.dim), dtype=torch.float32, device=dev).normal_(generator=g) * 0.5 + 0.3
         shard = base[lo:hi]
-        # warm-up: a small call (allocations, module load), then one of the timed size -- the leg follows half a minute of
-        # CPU-only baselines, and on some boxes the first two seconds of MFMA work after that idle ran at 70 % of the rate
-        groundtruth.groundtruth_distributed(shard[: min(hi - lo, 65536)], lo, gq[:2048], args.metric, args.gt_K)
-        groundtruth.groundtruth_distributed(shard, lo, gq, args.metric, args.gt_K)
-        sync_all()
-        tg0 = time.perf_counter()
-        gi, gv = groundtruth.groundtruth_distributed(shard, lo, gq, args.metric, args.gt_K)
-        sync_all()
-        tg = time.perf_counter() - tg0
+        native = world == 1 or args.backend == "nccl"
+        gt_batch = 65536
+        if native:
+            nq_gt = max(args.gt_nq, 4 * gt_batch) if args.gt_nq >= gt_batch else args.gt_nq
+            gq_h = (torch.empty((nq_gt, args.dim), dtype=torch.float32, device=dev).normal_(generator=g) * 0.5 + 0.3).cpu().numpy()
+            out_i = np.zeros((nq_gt, args.gt_K), np.uint32); out_d = np.zeros((nq_gt, args.gt_K), np.float32)
+            comm = groundtruth.Comm.from_torch_dist(local) if world > 1 else groundtruth.Comm.local([local])[0]
+            # warm-up: a small call (allocations, module load, communicator), then one batch of the timed size -- the leg
+            # follows half a minute of CPU-only baselines, and the first seconds of MFMA work after that idle run slower
+            groundtruth.groundtruth_rank(comm, shard, lo, gq_h[:4096], args.metric, args.gt_K, out_i[:4096], out_d[:4096], batch=2048)
+            groundtruth.groundtruth_rank(comm, shard, lo, gq_h[:gt_batch], args.metric, args.gt_K, out_i[:gt_batch], out_d[:gt_batch], batch=gt_batch)
+            sync_all()
+            tg0 = time.perf_counter()
+            groundtruth.groundtruth_rank(comm, shard, lo, gq_h, args.metric, args.gt_K, out_i, out_d, batch=gt_batch)
+            sync_all()
+            tg = time.perf_counter() - tg0
+            form = ("rg_groundtruth_rank over %s: %d query batches of %d streamed from host memory, per-shard K-lists exchanged on a "
+                    "side stream under the next batch's K2" % ("RCCL (ncclSend/ncclRecv, xGMI)" if comm.uses_rccl() else "the in-process transport",
+                                                              (nq_gt + gt_batch - 1) // gt_batch, gt_batch))
+            comm.destroy()
+            del out_i, out_d
+        else:
+            nq_gt = args.gt_nq
+            gq = torch.empty((nq_gt, args.dim), dtype=torch.float32, device=dev).normal_(generator=g) * 0.5 + 0.3
+            groundtruth.groundtruth_distributed(shard[: min(hi - lo, 65536)], lo, gq[:2048], args.metric, args.gt_K)
+            groundtruth.groundtruth_distributed(shard, lo, gq, args.metric, args.gt_K)
+            sync_all()
+            tg0 = time.perf_counter()
+            gi, gv = groundtruth.groundtruth_distributed(shard, lo, gq, args.metric, args.gt_K)
+            sync_all()
+            tg = time.perf_counter() - tg0
+            form = "torch.distributed form (K2 per rank, one all_to_all, K3): ranks share a GPU, no RCCL communicator possible"
+            gq_h = gq.cpu().numpy()
+            del gi, gv, gq
         if world > 1:
             t = torch.tensor([tg], dtype=torch.float64, device=cdev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             tg = float(t.item())
-        dps = float(args.gt_nq) * float(args.nb) / tg
-        gt = {"metric": "GT-build distances/sec (K=%d, %d queries x %d base rows, base sharded x%d)" % (args.gt_K, args.gt_nq, args.nb, world),
-              "value": dps, "seconds": tg, "TFLOPs_fp32_mfma": 2.0 * args.dim * dps / 1e12,
+        dps = float(nq_gt) * float(args.nb) / tg
+        gt = {"metric": "GT-build distances/sec (K=%d, %d queries x %d base rows, base sharded x%d)" % (args.gt_K, nq_gt, args.nb, world),
+              "value": dps, "seconds": tg, "form": form, "TFLOPs_fp32_mfma": 2.0 * args.dim * dps / 1e12,
               "roofline": {"bound": "mfma", "achieved": 2.0 * args.dim * dps / 1e12, "peak": 157.3 * world, "unit": "TFLOP/s",
                            "frac": 2.0 * args.dim * dps / 1e12 / (157.3 * world)}}
-        if rank == 0 and world == 1 and args.cpu_seconds > 0:
-            try:
-                gt["cpu_baseline"] = gt_cpu_baseline(base, gq, args)
-            except Exception as e:  # noqa: BLE001
-                gt["cpu_baseline"] = {"value": None, "unit": "distances/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
-        del gi, gv, gq
+        if rank == 0 and world == 1:
+            # the kernel alone, queries and results resident in HBM (one K2 launch over 65,536 queries): what profiles/*/gt_* profile
+            gq = torch.from_numpy(gq_h[: min(nq_gt, gt_batch)]).to(dev)
+            groundtruth.groundtruth_distributed(shard, lo, gq, args.metric, args.gt_K)
+            torch.cuda.synchronize()
+            tk0 = time.perf_counter()
+            groundtruth.groundtruth_distributed(shard, lo, gq, args.metric, args.gt_K)
+            torch.cuda.synchronize()
+            tk = time.perf_counter() - tk0
+            gt["k2_device_resident"] = {"queries": int(gq.shape[0]), "seconds": tk, "value": float(gq.shape[0]) * float(args.nb) / tk,
+                                        "frac_of_mfma_peak": 2.0 * args.dim * float(gq.shape[0]) * float(args.nb) / tk / 1e12 / 157.3}
+            if args.cpu_seconds > 0:
+                try:
+                    gt["cpu_baseline"] = gt_cpu_baseline(base, gq, args)
+                except Exception as e:  # noqa: BLE001
+                    gt["cpu_baseline"] = {"value": None, "unit": "distances/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
+            del gq
 
     traffic, traffic_src = pmc_traffic(wl_key) if rank == 0 else (None, None)
     shape_name = {(10_000_000, 200, "ip"): "t2i-10M-shaped", (10_000_000, 512, "l2"): "laion-10M-shaped",
@@ -580,9 +704,10 @@ def main():
             "value": qps, "unit": "queries/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "files" if args.data_root else "synthetic",
-            "config": {"workload": "%s: base %dx%d fp32 %s, %d queries/GPU/step, top-%d, L_pq=%d, %s, %s (replicated per GPU)"
+            "config": {"workload": "%s: base %dx%d fp32 %s, %d queries/GPU/step (a different seeded batch every step), top-%d, L_pq=%d, %s, %s (replicated per GPU)"
                                    % (shape_name, args.nb, args.dim, args.metric, args.nq, args.k, L_star, data_desc, graph_desc),
                        "parallelism": "query-sharded x%d, index replicated" % world,
+                       "distinct_query_batches": len(qs),
                        "L_pq": L_star, "recall_at_10": head["recall_at_10"], "target_recall": args.target_recall,
                        "visited": {2: "default: lds-filter + id log + exact distinct count, adaptive to the exact HBM words where a timed "
                                       "trial finds them faster (ids/dists/hops/cmps bit-exact vs the HBM-visited mode, checked in this run)",
@@ -594,7 +719,20 @@ def main():
                          "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "rg_search_kernel (+ rg_distinct_kernel in visited mode 2)", "kernel_ms_avg": kavg * 1e3,
                          "algorithmic_bytes_per_launch": alg_bytes,
-                         "frac_of_measured_stream_ceiling_6290": achieved / 6290.0},
+                         "frac_of_measured_stream_ceiling_6290": achieved / 6290.0,
+                         # how much of `achieved` HBM itself had to serve: the share of a launch's row reads that are FIRST
+                         # touches of a row within the launch (rg_search_reuse_stats over the id logs); the rest re-reads rows
+                         # other queries of the same launch read moments earlier (the neighbourhood of the entry point)
+                         # and can come from the L2s / Infinity Cache.  hbm_frac_floor = frac x that share; the cache
+                         # counters of the same command are in profiles/r03/ (TCC hit rate, FETCH_SIZE calibration).
+                         "distinct_rows_frac": reuse.get("distinct_rows_frac") if reuse else None,
+                         "cache_served_frac_ceiling": (1.0 - reuse["distinct_rows_frac"]) if reuse and "distinct_rows_frac" in reuse else None,
+                         "hbm_frac_floor": (achieved / 8000.0 * reuse["distinct_rows_frac"]) if reuse and "distinct_rows_frac" in reuse else None,
+                         "reuse": reuse,
+                         "replay_same_batch": {"what": "the same launch replaying ONE batch back to back (round 2's protocol): the rows of "
+                                                       "the previous launch are still in the Infinity Cache; not `value`",
+                                               "kernel_ms_avg": replay_ms, "frac": replay_alg / (replay_ms / 1e3) / 1e9 / 8000.0
+                                               if replay_ms > 0 else None}},
             "cpu_baseline": cpu,
             "cpu_baseline_1_thread": cpu1,
             "cpu_baseline_config1": cpu_cfg1,

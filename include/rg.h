@@ -153,6 +153,12 @@ rg_status rg_search_dev(rg_index *idx, const float *d_queries, uint32_t nq, uint
                         uint32_t L_pq, uint32_t *d_ids, float *d_dists, uint32_t *d_cmps, uint32_t *d_hops,
                         void *stream);
 rg_status rg_search_wait(rg_index *idx, void *stream);
+/* Measurement aid (bench.py's roofline block; no counterpart in the reference): over the id logs the last batch on
+ * `stream` left behind -- it must have run in the default visited mode in one piece and have been waited for --
+ * the number of distance evaluations the launch performed (re-scored rows included: each is a row read) and the number
+ * of DISTINCT base rows among them.  distinct / evaluations is the share of a launch's row reads that are first touches,
+ * i.e. that no cache can have served from an earlier read of the same launch. */
+rg_status rg_search_reuse_stats(rg_index *idx, void *stream, uint64_t *evaluations, uint64_t *distinct_rows);
 
 /* ------------------------------------------------------------- ground truth
  * Replaces: the external `compute_groundtruth --data_type float --dist_fn {l2,mips,cosine} --base_file F

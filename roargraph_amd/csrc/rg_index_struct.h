@@ -11,6 +11,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <mutex>
+#include <string>
 #include <vector>
 
 #include "rg.h"
@@ -49,6 +50,9 @@ struct SearchCtx {
     uint32_t slots = 0, vwords = 0;
     uint32_t *d_qlog = nullptr, *d_qlog_n = nullptr;
     uint32_t qlog_nq = 0, logcap = 0, qlog_chunk = 0;
+    uint32_t log_holds = 0;      // queries whose logs the last filter+log batch left in d_qlog (0: searched in sub-batches)
+    rg_status deferred = RG_OK;  // "not enough results" of batches that were collected before the caller waited
+    std::string deferred_msg;
     uint32_t allocs = 0;         // bumped by every (re)allocation of the buffers above
     std::vector<Batch *> pending, spare;
     // host-form staging (rg_search): queries up, results down

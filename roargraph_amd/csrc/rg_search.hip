@@ -200,6 +200,28 @@ __global__ void __launch_bounds__(64) rg_score_kernel(const float *__restrict__ 
     }
 }
 
+// rg_search_reuse_stats: mark every row id of the id logs in a bitmap / count the marks
+__global__ void rg_log_mark_kernel(const uint32_t *__restrict__ qlog, uint32_t logcap, const uint32_t *__restrict__ qlog_n, uint32_t nq,
+                                   uint32_t *__restrict__ bitmap, unsigned long long *__restrict__ total) {
+    unsigned long long mine = 0;
+    for (uint32_t q = blockIdx.x; q < nq; q += gridDim.x) {
+        const uint32_t n = min(qlog_n[q], logcap);
+        const uint32_t *log = qlog + (size_t)q * logcap;
+        for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
+            const uint32_t id = log[i];
+            atomicOr(&bitmap[id >> 5], 1u << (id & 31u));
+        }
+        if (threadIdx.x == 0) mine += n;
+    }
+    if (threadIdx.x == 0 && mine) atomicAdd(total, mine);
+}
+__global__ void rg_bitmap_count_kernel(const uint32_t *__restrict__ bitmap, size_t words, unsigned long long *__restrict__ total) {
+    unsigned long long mine = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (size_t)gridDim.x * blockDim.x) mine += __popc(bitmap[i]);
+    for (int o = 32; o; o >>= 1) mine += __shfl_xor(mine, o, 64);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(total, mine);
+}
+
 // fp32 base -> bf16 copy (round to nearest even), rows zero-padded to stride_bf elements
 __global__ void rg_base_to_bf16_kernel(const float *__restrict__ base, uint32_t nd, uint32_t dim, uint32_t stride,
                                        uint16_t *__restrict__ out, uint32_t stride_bf) {
@@ -713,10 +735,15 @@ static rg_status search_dev(rg_index *ix, SearchCtx *cx, const float *d_q, uint3
     if (cx->pending.size() >= 32) {
         rg_status st = finish_batches(ix, cx, s, 0);
         if (st != RG_OK && st != RG_ERR_NOT_ENOUGH) return st;
+        if (st == RG_ERR_NOT_ENOUGH && cx->deferred == RG_OK) {   // reported by the next rg_search_wait on this stream
+            cx->deferred = st;
+            cx->deferred_msg = rg_last_error();
+        }
     }
     Batch *b = nullptr;
     rg_status st = take_batch(cx, nq, &b);
     if (st != RG_OK) return st;
+    cx->log_holds = 0;
     auto fail = [&](rg_status e) { cx->spare.push_back(b); return e; };
     b->q = d_q; b->nq = nq; b->qstride = qstride; b->k = k; b->L = L;
     b->ids = d_ids; b->dists = d_dists; b->cmps = d_cmps; b->hops = d_hops;
@@ -815,6 +842,7 @@ static rg_status search_dev(rg_index *ix, SearchCtx *cx, const float *d_q, uint3
     }
     if (hipGetLastError() != hipSuccess) return fail(set_error(RG_ERR_DEVICE, "K4 launch failed"));
     if (b->timed) (void)hipEventRecord(b->ev1, s);
+    cx->log_holds = nq <= cx->qlog_chunk ? nq : 0;   // rg_search_reuse_stats: the logs of a batch searched in one piece
     b->counted = true;
     return done();
 }
@@ -1199,6 +1227,35 @@ rg_status rg_search_dev(rg_index *ix, const float *d_queries, uint32_t nq, uint3
     return st;
 }
 
+rg_status rg_search_reuse_stats(rg_index *ix, void *stream, uint64_t *evaluations, uint64_t *distinct_rows) {
+    if (!ix || !evaluations || !distinct_rows) return set_error(RG_ERR_ARG, "null argument");
+    RG_HIP(hipSetDevice(ix->device));
+    rg::SearchCtx *cx = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(ix->mu);
+        for (rg::SearchCtx *c : ix->ctxs)
+            if (c->key == (hipStream_t)stream && c->pending.empty() && c->d_qlog && c->log_holds) { cx = c; break; }
+    }
+    if (!cx) return set_error(RG_ERR_ARG, "no id logs for this stream: the last batch on it must have run in the default visited mode "
+                                          "(filter + log), in one piece, and have been waited for");
+    RG_HIP(hipStreamSynchronize((hipStream_t)stream));
+    const size_t words = ((size_t)ix->nd + 31) / 32;
+    rg::DevBuf<uint32_t> bm;
+    rg::DevBuf<unsigned long long> tot;
+    RG_HIP(bm.alloc(words));
+    RG_HIP(tot.alloc(2));
+    RG_HIP(hipMemset(bm.p, 0, words * 4));
+    RG_HIP(hipMemset(tot.p, 0, 16));
+    hipLaunchKernelGGL(rg::rg_log_mark_kernel, dim3(std::min<uint32_t>(cx->log_holds, 4096u)), dim3(256), 0, 0, cx->d_qlog, cx->logcap, cx->d_qlog_n,
+                       cx->log_holds, bm.p, tot.p);
+    hipLaunchKernelGGL(rg::rg_bitmap_count_kernel, dim3(2048), dim3(256), 0, 0, bm.p, words, tot.p + 1);
+    unsigned long long h[2];
+    RG_HIP(hipMemcpy(h, tot.p, 16, hipMemcpyDeviceToHost));
+    *evaluations = h[0];
+    *distinct_rows = h[1];
+    return RG_OK;
+}
+
 rg_status rg_search_wait(rg_index *ix, void *stream) {
     if (!ix) return set_error(RG_ERR_ARG, "null index");
     RG_HIP(hipSetDevice(ix->device));
@@ -1213,7 +1270,12 @@ rg_status rg_search_wait(rg_index *ix, void *stream) {
         return RG_OK;
     }
     rg_status st = rg::finish_batches(ix, cx, (hipStream_t)stream, 0);
-    const std::string msg = st != RG_OK ? rg_last_error() : "";
+    std::string msg = st != RG_OK ? rg_last_error() : "";
+    if (cx->deferred != RG_OK) {   // a "not enough results" of batches collected early (more than 32 pending): the oldest first
+        if (st == RG_OK || st == RG_ERR_NOT_ENOUGH) { st = cx->deferred; msg = cx->deferred_msg; }
+        cx->deferred = RG_OK;
+        cx->deferred_msg.clear();
+    }
     rg::release_ctx(ix, cx);
     if (st != RG_OK) return set_error(st, msg);
     return RG_OK;

@@ -137,6 +137,12 @@ class IndexBipartite:
     def search_wait(self, stream=0):
         check(lib().rg_search_wait(self.handle, C.c_void_p(stream)))
 
+    def reuse_stats(self, stream=0):
+        """(evaluations performed, distinct base rows among them) of the last default-mode batch on `stream`."""
+        ev, dr = C.c_uint64(), C.c_uint64()
+        check(lib().rg_search_reuse_stats(self.handle, C.c_void_p(stream), C.byref(ev), C.byref(dr)))
+        return ev.value, dr.value
+
 
 def search_sharded(replicas, queries, k, L_pq):
     """rg_search_sharded: one IndexBipartite replica per device, the query batch split in contiguous slices that run

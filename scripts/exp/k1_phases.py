@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--nq", type=int, default=10_000)
     ap.add_argument("--metric", default="ip")
     ap.add_argument("--data", default="lowrank")
+    ap.add_argument("--rank", type=int, default=32)
     ap.add_argument("--Ls", default="100,500,1000,2000")
     ap.add_argument("--modes", default="1,0,2")
     ap.add_argument("--save", default="")
@@ -42,7 +43,7 @@ def main():
     dev = torch.device("cuda", 0)
     prof = hasattr(lib(), "rg_prof_buffer")
     ntrain = args.nb // 5
-    base, train, q, desc = synth.make_device_set(dev, 1234, args.nb, ntrain, args.nq, args.dim, data=args.data)
+    base, train, q, desc = synth.make_device_set(dev, 1234, args.nb, ntrain, args.nq, args.dim, data=args.data, rank=args.rank, q_seed=99)
     st = torch.cuda.current_stream().cuda_stream
     if args.load:
         z = np.load(args.load + ".npz")
@@ -103,6 +104,7 @@ def main():
                 row["spec_hit_rate"] = 0.0
                 row["spec_tries_per_hop"] = float(c[2] / max(hp.float().sum().item(), 1))
                 row["deg_per_hop"] = float(c[5] / max(hp.float().sum().item(), 1))
+                row["lookahead_hits_per_hop"] = float(c[6] / max(hp.float().sum().item(), 1))   # VIS = 2: the early-fetched node was the one popped
             rows.append(row)
             print(json.dumps(row), flush=True)
     out = {"lib": os.path.basename(LIB_PATH), "dataset": desc, "nb": args.nb, "avg_degree": nbrs.size / args.nb, "rows": rows}

@@ -175,6 +175,50 @@ def test_bench_multi_rank_control_flow_on_one_gpu():
     assert [p["L_pq"] for p in d["L_pq_sweep"]] == [20, 100, 500] and all(p["recall_at_10"] > 0.5 for p in d["L_pq_sweep"][1:])
 
 
+def test_bench_gpus_flag_launches_its_own_ranks():
+    """`python bench.py --gpus 2 --backend gloo` with NO launcher around it: the script re-executes itself under
+    torch.distributed.run with two ranks (here both on the one visible GPU) and reports the ranks that took part; with the
+    RCCL backend it must refuse to start when fewer GPUs than ranks are visible."""
+    import json
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--backend", "gloo",
+           "--nb", "200000", "--nq", "512", "--gt-nq", "4096", "--cpu-seconds", "0", "--sweep", "50", "--no-worstcase", "--no-fast",
+           "--config1-nb", "0"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "exactly one JSON line, from rank 0"
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["value"] > 0
+    assert "query-sharded x2" in d["config"]["parallelism"]
+    import torch
+    if torch.cuda.device_count() < 2:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1"], capture_output=True, text=True,
+                           timeout=300, env=env)
+        assert r.returncode != 0 and "device(s) visible" in (r.stdout + r.stderr)
+
+
+def test_bench_one_gpu_small_run_reports_every_block():
+    """The default one-GPU flow on a small set: distinct query batches per step, the replay figure, first-touch share of the
+    row reads, both CPU loop forms, the native ground-truth leg (rg_groundtruth_rank, four streamed batches)."""
+    import json
+    import sys
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--nb", "300000", "--nq", "1000", "--gt-nq", "65536",
+           "--cpu-seconds", "1", "--sweep", "20,100", "--no-worstcase", "--no-fast", "--config1-nb", "0"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert d["n_gpus"] == 1 and d["config"]["distinct_query_batches"] == 6
+    rf = d["roofline"]
+    assert 0.0 < rf["frac"] and rf["distinct_rows_frac"] is not None and 0.0 < rf["distinct_rows_frac"] <= 1.0
+    assert rf["replay_same_batch"]["kernel_ms_avg"] > 0
+    cb = d["cpu_baseline"]
+    assert cb["value"] > 0 and (cb["kind"] != "reference" or cb["value_without_prefetch"] > 0)
+    g = d["gt_build"]
+    assert g["value"] > 0 and "4 query batches" in g["form"] and g["k2_device_resident"]["value"] > 0
+
+
 def test_bench_on_the_reference_file_layout(tmp_path):
     """bench.py --data-root: the reference's own file names (README.md:93-117).  First run: base + queries + training queries
     -> the index is built in the run; second run: an index file beside them is searched as it is.  Same base and queries, so
