@@ -30,6 +30,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -111,6 +112,10 @@ struct LocalGroup {
         return !failed;
     }
     void fail() { std::lock_guard<std::mutex> lk(mu); failed = true; cv.notify_all(); }
+    // buffers of a rank that gave up: peers may still have copies out of them queued on their own streams, so they are
+    // released with the group (after every rank has left and drained), not by the failing rank
+    std::vector<std::shared_ptr<void>> parked;
+    void park(std::shared_ptr<void> p) { std::lock_guard<std::mutex> lk(mu); parked.push_back(std::move(p)); }
 };
 
 }  // namespace rg
@@ -165,8 +170,8 @@ struct RankBufs {   // everything a rank allocates, released on every exit path
 };
 
 // one rank's whole job.  d_base: its shard (nb_shard rows at bstride floats, already normalised for cosine).
-static rg_status gt_rank_run(rg_comm *cm, const float *d_base, uint32_t nb_shard, uint32_t bstride, uint32_t id_base, uint32_t nq,
-                             uint32_t dim, int metric, uint32_t K, uint32_t batch, const GtIo &io) {
+static rg_status gt_rank_body(rg_comm *cm, const float *d_base, uint32_t nb_shard, uint32_t bstride, uint32_t id_base, uint32_t nq,
+                              uint32_t dim, int metric, uint32_t K, uint32_t batch, const GtIo &io, RankBufs &B) {
     const int world = cm->world, rank = cm->rank;
     if (K == 0 || K > nb_shard) return set_error(RG_ERR_ARG, "K must be in [1, rows in the shard]");
     if ((uint64_t)world * K > 1024) return set_error(RG_ERR_ARG, "world * K larger than 1024 is not supported by the merge");
@@ -176,7 +181,6 @@ static rg_status gt_rank_run(rg_comm *cm, const float *d_base, uint32_t nb_shard
     const uint32_t per = (Qb + (uint32_t)world - 1) / (uint32_t)world;   // longest owned range of a batch
     const int m = metric == RG_METRIC_COSINE ? RG_METRIC_IP : metric;
     RG_HIP(hipSetDevice(cm->device));
-    RankBufs B;
     B.device = cm->device;
     RG_HIP(hipStreamCreateWithFlags(&B.s_comp, hipStreamNonBlocking));
     RG_HIP(hipStreamCreateWithFlags(&B.s_comm, hipStreamNonBlocking));
@@ -284,6 +288,25 @@ static rg_status gt_rank_run(rg_comm *cm, const float *d_base, uint32_t nb_shard
     // when this rank is done -- nobody releases anything before every rank has drained its own streams
     if (lg && !lg->barrier()) return set_error(RG_ERR_DEVICE, "a peer rank failed");
     return RG_OK;
+}
+
+// Every exit of a rank that is not RG_OK -- a precondition that fails on this rank only (K > rows of ITS shard), an
+// allocation, a fill / emit callback, a kernel -- must release the peers of the in-process transport, which would
+// otherwise wait in LocalGroup::barrier() for ever; and the buffers they may still be copying from must outlive them.
+static rg_status gt_rank_run(rg_comm *cm, const float *d_base, uint32_t nb_shard, uint32_t bstride, uint32_t id_base, uint32_t nq,
+                             uint32_t dim, int metric, uint32_t K, uint32_t batch, const GtIo &io) {
+    std::shared_ptr<RankBufs> B = std::make_shared<RankBufs>();
+    const rg_status st = gt_rank_body(cm, d_base, nb_shard, bstride, id_base, nq, dim, metric, K, batch, io, *B);
+    if (st != RG_OK && cm->local) {
+        const std::string msg = rg_last_error();
+        cm->local->fail();
+        (void)hipSetDevice(cm->device);
+        if (B->s_comp) (void)hipStreamSynchronize(B->s_comp);     // nothing of this rank's is queued any more
+        if (B->s_comm) (void)hipStreamSynchronize(B->s_comm);
+        cm->local->park(B);
+        return set_error(st, msg);
+    }
+    return st;
 }
 
 // rows [row0, row0+n) of a host matrix (or file) -> device at the aligned stride, zero padded, cosine rows normalised;

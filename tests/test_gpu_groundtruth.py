@@ -182,3 +182,35 @@ def test_rank_form_owned_rows_and_rccl_loopback(oracle, monkeypatch):
     groundtruth.groundtruth_rank(c, torch.from_numpy(base).to(dev), 0, q, "ip", K, out_i, out_d, batch=batch)
     c.destroy()
     assert (out_i == want_i).all() and (out_d.view(np.uint32) == want_d.view(np.uint32)).all()
+
+
+def test_rank_form_a_failing_rank_releases_its_peers():
+    """Three in-process ranks (threads) through rg_comm_init_local + rg_groundtruth_rank, the public path.  Rank 2's shard has
+    fewer rows than K, a precondition that fails on that rank only: the other two must come back with an error instead of
+    waiting for it in the exchange barrier for ever, and tearing the group down afterwards must be safe."""
+    import threading
+    import torch
+    from roargraph_amd import groundtruth
+    base, q = synth.make_synth(63, 3000, 150, 200)
+    K, batch = 40, 64
+    dev = torch.device("cuda", 0)
+    comms = groundtruth.Comm.local([0, 0, 0])
+    out_i = np.zeros((150, K), np.uint32); out_d = np.zeros((150, K), np.float32)
+    shards = [(0, 1500), (1500, 2980), (2980, 3000)]          # 20 rows < K on rank 2
+    errs = [None] * 3
+
+    def work(r):
+        try:
+            lo, hi = shards[r]
+            bt = torch.from_numpy(base[lo:hi]).to(dev)
+            groundtruth.groundtruth_rank(comms[r], bt, lo, q, "ip", K, out_i, out_d, batch=batch)
+        except Exception as e:  # noqa: BLE001
+            errs[r] = str(e)
+
+    th = [threading.Thread(target=work, args=(r,), daemon=True) for r in range(3)]
+    [t.start() for t in th]
+    [t.join(timeout=120) for t in th]
+    assert not any(t.is_alive() for t in th), "a rank is still waiting for the one that failed"
+    assert errs[2] is not None and "K must be in" in errs[2]
+    assert errs[0] is not None and errs[1] is not None and all("peer rank failed" in e for e in errs[:2]), errs
+    [c.destroy() for c in comms]
