@@ -270,6 +270,32 @@ __device__ __forceinline__ float bounce_score_q(float *stage1k, const v4f_t (&rv
     return L2 ? acc : -acc;
 }
 
+// The same value once more for a row fetched in the COMPUTE layout (round 3, gather form 1): lane a of the row's group
+// loaded elements a, a + 16, a + 32, ... itself (one dword each: every load instruction of the wave reads four 64-byte
+// segments, two consecutive instructions cover a row's 128-byte line), so rv[t] IS the operand of step t and the score
+// is twelve (d = 200) / thirty-two (d = 512) FMAs on registers -- no LDS bounce, no transposition.  Same FMA order.
+template <bool L2, int DIMC>
+__device__ __forceinline__ float regs_score_q(const float (&rv)[DIMC / 16], float t8, const float (&qr)[(DIMC + 15) / 16]) {
+    static_assert(DIMC % 8 == 0 && DIMC > 0, "dimension");
+    constexpr int NT = DIMC / 16, rem = DIMC & 15;
+    float acc = 0.0f;
+#define RG_STEPR(v_, q_)                                   \
+    {                                                      \
+        const float v = (v_), q = (q_);                    \
+        if (L2) { const float t = v - q; acc = __builtin_fmaf(t, t, acc); } \
+        else acc = __builtin_fmaf(v, q, acc);              \
+    }
+#pragma unroll
+    for (int t = 0; t < NT; ++t) RG_STEPR(rv[t], qr[t]);
+    acc = acc + dpp_f<0x128>(acc);                       // 16 -> 8
+    if constexpr (rem == 8) RG_STEPR(t8, qr[(DIMC + 15) / 16 - 1]);   // 8-wide tail on the folded sum
+#undef RG_STEPR
+    acc = acc + dpp_f<0x124>(acc);
+    acc = acc + dpp_f<0xB1>(acc);
+    acc = acc + dpp_f<0x4E>(acc);
+    return L2 ? acc : -acc;
+}
+
 // ---- opt-in fast mode (NOT parity): traversal over a bf16 copy of the base ---------------------------
 // Rows of the copy are padded with zeros to a multiple of 128 elements (256 B: whole LDS-DMA instructions, whole
 // 128-B lines: 512 B per d = 200 row instead of the 7 lines = 896 B of the fp32 row).  One 16-lane group per row as in

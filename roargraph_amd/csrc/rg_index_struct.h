@@ -99,6 +99,7 @@ struct rg_index {
     uint32_t main_dim = 0, tail_dim = 0;
     bool split_rows = true;      // knob: use them (when they exist)
     bool exact_filter = true;    // mode 0: the LDS filter screens the exact HBM words (hits skip the atomics)
+    int gather_form = 0;         // register-staged K1: 0 = 16-byte loads + LDS bounce, 1 = compute-layout loads (knob "gather_form")
     bool lookahead = true;       // mode 0: the look-ahead form of K1 where it applies (knob "lookahead"; same results either way)
     bool adj_dups = false;       // some adjacency list names a node twice (found at open): the look-ahead form is not used
     bool query_in_lds = false;   // K1: force the generic (query staged in LDS) instantiation for d = 200 / 512

@@ -648,6 +648,8 @@ static rg_status launch_k1(rg_index *ix, SearchCtx *cx, int mode, const float *d
     if (mode == 0 && ix->lookahead && !ix->adj_dups && !ix->multi_expand && !bf && !bp && ix->diag == 0 &&
         ((c.dimc == 200 && R >= 2) || (c.dimc == 512 && (R == 2 || R == 4))))
         c.vis = 2;
+    // gather form (rg_search_kernel.h, GF): compute-layout loads where an instantiation exists
+    if (ix->gather_form == 1 && !bf && ((c.dimc == 200 && (R == 4 || R == 8)) || (c.dimc == 512 && R == 2))) c.gf = 1;
     const bool l2 = ix->metric == RG_METRIC_L2, ell = ix->d_ell != nullptr;
     auto dispatch = [&](const SearchParams &sp) -> rg_status {
         if (l2 && ell) return launch_search_l2_ell(sp, c, s);
@@ -1165,6 +1167,7 @@ rg_status rg_index_set(rg_index *ix, const char *name, int value) {
     else if (!strcmp(name, "query_in_lds")) ix->query_in_lds = value != 0;
     else if (!strcmp(name, "exact_filter")) ix->exact_filter = value != 0;
     else if (!strcmp(name, "lookahead")) ix->lookahead = value != 0;
+    else if (!strcmp(name, "gather_form")) ix->gather_form = value;
     else if (!strcmp(name, "multi_expand")) ix->multi_expand = value;
     else if (!strcmp(name, "split_rows")) ix->split_rows = value != 0;
     else if (!strcmp(name, "fast_bf16")) {

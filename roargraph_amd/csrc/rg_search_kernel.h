@@ -385,9 +385,18 @@ __device__ __forceinline__ void beam_insert(Beam &bm, float cd, uint32_t cid, bo
 //      Exactness: the words read early can miss only the marks of the hop during which they were read (everything older
 //      has been acknowledged: the row loads issued after those marks were waited for), and exactly those ids are at hand
 //      -- the previous hop's fresh list -- so every early-tested neighbour is checked against them.
-template <bool L2, bool ELL, int R, int VIS, int DIMC, bool BF>
+//
+// GF: gather form of the register-staged instantiations
+//   0  rows fetched 16 bytes per lane (global_load_dwordx4), then bounced block by block through a 1-KiB LDS buffer into
+//      the layout the scoring routine reads (round 2)
+//   1  rows fetched in the COMPUTE layout, one dword per lane and step (round 3): the same bytes per wave instruction
+//      reach the texture unit, a row's 128-byte line is covered by two consecutive instructions, and the score is a
+//      dozen FMAs on the registers the loads filled -- the LDS round trips of the bounce (a fifth of a wide-beam hop's
+//      wave cycles, profiles/r03/k1_phases_10m_*.json) are gone.  Same accumulation order, same bits.
+template <bool L2, bool ELL, int R, int VIS, int DIMC, bool BF, int GF = 0>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC == 512 ? (R <= 1 ? 4 : R <= 2 ? 3 : 2) : (R <= 4 ? 4 : 2)))) rg_search_kernel(SearchParams P) {
     static_assert(!BF || (DIMC != 0 && ELL), "fast mode: compile-time dimension, ELL adjacency");
+    static_assert(GF == 0 || (DIMC != 0 && !BF), "compute-layout gather: register-staged instantiations");
     static_assert(VIS != 2 || (DIMC != 0 && ELL && !BF), "look-ahead form: register-staged gather over ELL rows");
     constexpr bool EXACT = VIS != 1;   // visited words in HBM
     constexpr bool LOOK = VIS == 2;
@@ -551,7 +560,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
                 const bool split = REM != 0 && P.tail_off != nullptr;
                 const uint32_t tix0 = split ? cand_x[0] : rid0;
                 auto batch = [&](uint32_t p0, auto first_batch) __attribute__((always_inline)) {
-                    v4f rv[R][NFULL];
+                    constexpr int NV = GF == 1 ? DIMC / 16 : 1;
+                    v4f rv[GF == 1 ? 1 : R][NFULL];
+                    float rw[GF == 1 ? R : 1][NV];
                     float t8[R];
                     uint32_t rid[R], tix[R];
 #pragma unroll
@@ -565,9 +576,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
                     }
 #pragma unroll
                     for (int j = 0; j < R; ++j) {
-                        const float *src = P.base + (size_t)rid[j] * P.stride + 4 * jsrc;
+                        if constexpr (GF == 1) {
+                            const float *src = P.base + (size_t)rid[j] * P.stride + (lane & 15);
 #pragma unroll
-                        for (int b = 0; b < NFULL; ++b) rv[j][b] = *reinterpret_cast<const v4f *>(src + 64 * b);
+                            for (int t = 0; t < NV; ++t) rw[j][t] = src[16 * t];
+                        } else {
+                            const float *src = P.base + (size_t)rid[j] * P.stride + 4 * jsrc;
+#pragma unroll
+                            for (int b = 0; b < NFULL; ++b) rv[j][b] = *reinterpret_cast<const v4f *>(src + 64 * b);
+                        }
                         // the 8-wide tail: lane a's own element 192 + (a & 7), straight into the register that scores it
                         if constexpr (REM != 0) t8[j] = P.tail_base[(size_t)tix[j] * P.tail_stride + (lane & 7)];
                         else t8[j] = 0.0f;
@@ -577,7 +594,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
                     for (int j = 0; j < R; ++j) {
                         if (p0 + j < npass) {
                             RG_PROF(6);
-                            const float d = bounce_score_q<L2, DIMC>(stage, rv[j], t8[j], qr, lane);
+                            float d;
+                            if constexpr (GF == 1) d = regs_score_q<L2, DIMC>(rw[j], t8[j], qr);
+                            else d = bounce_score_q<L2, DIMC>(stage, rv[j], t8[j], qr, lane);
                             const uint32_t c = 4 * (p0 + j) + g;
                             if (c < n && (lane & 15) == 0) cand_x[c] = __float_as_uint(d);
                             lds_fence();
@@ -916,14 +935,15 @@ struct K1Launch {
     int vis = 1;      // 0 = exact HBM visited words, 1 = LDS filter, 2 = exact words, look-ahead form
     int dimc = 0;     // compile-time dimension instantiation (0 = generic)
     bool bf = false;  // opt-in bf16 traversal
+    int gf = 0;       // gather form of the register-staged instantiations: 0 = 16-byte loads + LDS bounce, 1 = compute layout
     uint32_t grid = 0;
     size_t lds = 0;
     int *occupancy = nullptr;   // non-null: do not launch, report the resident single-wave workgroups per CU of the kernel
 };
 
-template <bool L2, bool ELL, int R, int VIS, int DIMC, bool BF = false>
+template <bool L2, bool ELL, int R, int VIS, int DIMC, bool BF = false, int GF = 0>
 static rg_status launch_search_d(const SearchParams &P, const K1Launch &c, hipStream_t s) {
-    auto kern = rg_search_kernel<L2, ELL, R, VIS, DIMC, BF>;
+    auto kern = rg_search_kernel<L2, ELL, R, VIS, DIMC, BF, GF>;
     RG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)c.lds));
     if (c.occupancy) {   // registers as well as LDS bound the resident queries (the register-staged forms are VGPR-heavy)
         RG_HIP(hipOccupancyMaxActiveBlocksPerMultiprocessor(c.occupancy, reinterpret_cast<const void *>(kern), 64, c.lds));
@@ -964,8 +984,23 @@ static rg_status launch_search_t(const SearchParams &P, const K1Launch &c, hipSt
 }
 
 // every instantiation of one (metric, adjacency layout) family; one translation unit each (rg_search_inst_*.hip)
+// compute-layout gather (GF = 1): d = 200 with four or eight register sets, d = 512 with two (k1_gf_ok, rg_search.hip)
+template <bool L2, bool ELL, int R, int DIMC>
+static rg_status launch_search_gf1(const SearchParams &P, const K1Launch &c, hipStream_t s) {
+    if (c.vis == 2) return launch_search_d<L2, ELL, R, 2, DIMC, false, 1>(P, c, s);
+    return c.vis == 1 ? launch_search_d<L2, ELL, R, 1, DIMC, false, 1>(P, c, s) : launch_search_d<L2, ELL, R, 0, DIMC, false, 1>(P, c, s);
+}
+
 template <bool L2, bool ELL>
 static rg_status launch_search_family(const SearchParams &P, const K1Launch &c, hipStream_t s) {
+    if constexpr (ELL) {
+        if (c.gf == 1 && !c.bf) {
+            if (c.dimc == 200 && c.R == 8) return launch_search_gf1<L2, ELL, 8, 200>(P, c, s);
+            if (c.dimc == 200 && c.R == 4) return launch_search_gf1<L2, ELL, 4, 200>(P, c, s);
+            if (c.dimc == 512 && c.R == 2) return launch_search_gf1<L2, ELL, 2, 512>(P, c, s);
+            return set_error(RG_ERR_ARG, "internal: compute-layout gather requested for a launch that has no such instantiation");
+        }
+    }
     if constexpr (ELL) {   // eight register sets (32 rows in flight): d = 200 only, for launches with few resident queries
         if (c.R == 8 && c.dimc == 200 && !c.bf) {
             if (c.vis == 2) return launch_search_d<L2, ELL, 8, 2, 200>(P, c, s);

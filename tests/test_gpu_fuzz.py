@@ -60,6 +60,7 @@ def make_case(seed):
              "log_cap": int(rng.choice([0, 0, 64, 1024]))}
     knobs["_csr"] = int(rng.random() < 0.2)     # adjacency layout (read from the environment at open)
     knobs["lookahead"] = int(rng.random() < 0.7)
+    knobs["gather_form"] = int(rng.random() < 0.5)
     # lists without repeated ids (what every real index has): the look-ahead form of the exact words applies to them.
     # Cases 60+ aim at it: register-staged dimensions, exact words, ELL rows, beams wide enough to run for a while
     if seed >= 60 or rng.random() < 0.5:

@@ -70,6 +70,28 @@ def test_search_lds_filter_mode(rg, oracle, metric, d, nb, L, k, flt):
 
 
 @pytest.mark.parametrize("metric,d,nb", [("ip", 200, 4000), ("l2", 512, 2000), ("l2", 200, 3000), ("ip", 512, 1500)])
+@pytest.mark.parametrize("visited", [2, 1, 0])
+def test_compute_layout_gather_form(rg, oracle, metric, d, nb, visited):
+    """gather_form = 1: rows fetched in the layout the FMAs consume (one dword per lane and step, no LDS bounce) instead of
+    16 bytes per lane + transposition.  The accumulation order is the same, so every output bit is: all visited modes, with
+    and without the split-row copy, every register-set depth that has the form."""
+    base, q, off, nbrs, ep = small_set(metric, nb, d)
+    ix = rg.IndexBipartite.from_arrays(base, off, nbrs, ep, metric=metric)
+    ix.set("gather_form", 1)
+    ix.set("visited", visited)
+    for L, k in ((10, 10), (100, 100), (700, 10)):
+        want = oracle.search(base, metric, off, nbrs, ep, q, k, L, nthreads=4)
+        for rpp in ((16, 32) if d == 200 else (8,)):
+            for split in ((1, 0) if d == 200 else (1,)):
+                ix.set("rows_per_pass", rpp)
+                ix.set("split_rows", split)
+                got = ix.SearchRoarGraph(q, k, L)
+                assert (got[3] == want[3]).all() and (got[0] == want[0]).all() and (bits(got[1]) == bits(want[1])).all(), (L, rpp, split)
+                assert (got[2] == want[2]).all() if visited != 1 else (got[2] >= want[2]).all(), ("cmps", L, rpp, split)
+    ix.close()
+
+
+@pytest.mark.parametrize("metric,d,nb", [("ip", 200, 4000), ("l2", 512, 2000), ("l2", 200, 3000), ("ip", 512, 1500)])
 @pytest.mark.parametrize("lookahead,exact_filter", [(1, 1), (1, 0), (0, 1), (0, 0)])
 def test_exact_words_forms(rg, oracle, metric, d, nb, lookahead, exact_filter):
     """visited=0, the reference's tag array (visited_list_pool.h:8-29) as epoch-tagged words in HBM, in both kernel forms:
