@@ -95,7 +95,7 @@ void rg_index_close(rg_index *idx);
 rg_status rg_index_info(const rg_index *idx, uint32_t *nd, uint32_t *dim, uint32_t *stride, uint32_t *ep,
                         float *avg_degree, uint32_t *max_degree, int *device);
 /* tuning knobs: "waves_per_cu", "rows_per_pass", "filter_log2", "log_cap", "log_budget_kb", "count_table_log2",
- * "count_full_ids", "query_in_lds", "exact_filter", "split_rows" never change results (0 = automatic where a knob has an
+ * "count_full_ids", "query_in_lds", "exact_filter", "split_rows", "lookahead", "gather_form", "visited_budget_kb" never change results (0 = automatic where a knob has an
  * automatic choice: "rows_per_pass", "filter_log2", "waves_per_cu").
  * "split_rows" (default 1; d = 200 with the default adjacency layout): searches read a split copy of the base made at
  * open -- the first 192 elements of every row at a 768-byte stride (six whole 128-byte lines instead of the seven an
@@ -153,6 +153,11 @@ rg_status rg_search_dev(rg_index *idx, const float *d_queries, uint32_t nq, uint
                         uint32_t L_pq, uint32_t *d_ids, float *d_dists, uint32_t *d_cmps, uint32_t *d_hops,
                         void *stream);
 rg_status rg_search_wait(rg_index *idx, void *stream);
+/* Optional: allocate now what batches of up to nq queries at beam widths up to L_pq will need on `stream` (the id logs of
+ * the default visited mode, the visited words of the exact form), so that the first search does not pay for it.  Plays
+ * the part of InitVisitedListPool(num_threads) (index_bipartite.h:133; tests/test_search_roargraph.cpp:173), which the
+ * reference calls before its timed loop.  Never required: searches allocate on first use. */
+rg_status rg_search_prepare(rg_index *idx, void *stream, uint32_t nq, uint32_t L_pq);
 /* Measurement aid (bench.py's roofline block; no counterpart in the reference): over the id logs the last batch on
  * `stream` left behind -- it must have run in the default visited mode in one piece and have been waited for --
  * the number of distance evaluations the launch performed (re-scored rows included: each is a row read) and the number

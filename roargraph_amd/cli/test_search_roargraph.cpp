@@ -116,12 +116,20 @@ int main(int argc, char **argv) {
     std::ofstream evaluation_out;
     if (!a.str("evaluation_save_path").empty()) evaluation_out.open(a.str("evaluation_save_path"), std::ios::out);
     std::cout << "Using thread: " << a.u("num_threads") << " (GPU path: one wave per in-flight query)" << std::endl;
-    std::cout << "L_pq" << "\t\tQPS" << "\t\t\tavg_visited" << "\tmean_latency" << "\trecall@" << k << "\tavg_hops" << std::endl;
+    // InitVisitedListPool (test_search_roargraph.cpp:173): what the searches below will need is allocated before the loop,
+    // as the reference allocates its visited lists before its own
+    uint32_t L_max = k;
+    for (const std::string &ls : a.list("L_pq")) L_max = std::max<uint32_t>(L_max, (uint32_t)std::strtoul(ls.c_str(), nullptr, 10));
+    if (replicas.size() == 1) CK(rg_search_prepare(index, nullptr, q_pts, L_max));
+    // Columns: the reference's six (QPS = its protocol: 100 warm-up queries, then ONE timed pass over the query file,
+    // :198-213), plus QPS_steady = a later pass over the same queries, after the device path has settled on one of its two
+    // exact visited forms for this beam width (same results either way; RG_TRACE_ADAPTIVE=1 shows the decisions)
+    std::cout << "L_pq" << "\t\tQPS" << "\t\t\tavg_visited" << "\tmean_latency" << "\trecall@" << k << "\tavg_hops" << "\tQPS_steady" << std::endl;
     for (const std::string &ls : a.list("L_pq")) {
         const uint32_t L_pq = (uint32_t)std::strtoul(ls.c_str(), nullptr, 10);
         if (k > L_pq) { std::cout << "L_pq must greater or equal than k" << std::endl; return 1; }
         const uint32_t warm = q_pts < 100 ? q_pts : 100;
-        double ms = 0.0;
+        double ms = 0.0, ms_steady = 0.0;
         if (replicas.size() > 1) {
             std::vector<float> dist_h((size_t)q_pts * k);
             CK(rg_search_sharded(replicas.data(), (int)replicas.size(), query, warm, q_stride, k, L_pq, res.data(), dist_h.data(),
@@ -131,18 +139,17 @@ int main(int argc, char **argv) {
                                  cmps.data(), hops.data()));
             auto t1 = std::chrono::high_resolution_clock::now();
             ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+            CK(rg_search_sharded(replicas.data(), (int)replicas.size(), query, q_pts, q_stride, k, L_pq, res.data(), dist_h.data(),
+                                 cmps.data(), hops.data()));
+            auto t2 = std::chrono::high_resolution_clock::now();
+            CK(rg_search_sharded(replicas.data(), (int)replicas.size(), query, q_pts, q_stride, k, L_pq, res.data(), dist_h.data(),
+                                 cmps.data(), hops.data()));
+            auto t3 = std::chrono::high_resolution_clock::now();
+            ms_steady = std::chrono::duration<double, std::milli>(t3 - t2).count();
         } else {
-            CK(rg_search_dev(index, d_q, warm, q_stride, k, L_pq, d_ids, d_dist, d_cmps, d_hops, nullptr));
+            CK(rg_search_dev(index, d_q, warm, q_stride, k, L_pq, d_ids, d_dist, d_cmps, d_hops, nullptr));   // :198-201
             CK(rg_search_wait(index, nullptr));
-            // The reference warms its caches with 100 queries (:198-201).  The device path also has first-use work per beam
-            // width that a timed pass must not carry: the id logs / visited words are allocated by the first full batch,
-            // and the adaptive visited default decides between its two exact forms over the first two full batches of a
-            // width (same results either way).  Two untimed full passes, then the timed one.
-            for (int settle = 0; settle < 2; ++settle) {
-                CK(rg_search_dev(index, d_q, q_pts, q_stride, k, L_pq, d_ids, d_dist, d_cmps, d_hops, nullptr));
-                CK(rg_search_wait(index, nullptr));
-            }
-            auto t0 = std::chrono::high_resolution_clock::now();
+            auto t0 = std::chrono::high_resolution_clock::now();                                               // :203-210
             CK(rg_search_dev(index, d_q, q_pts, q_stride, k, L_pq, d_ids, d_dist, d_cmps, d_hops, nullptr));
             CK(rg_search_wait(index, nullptr));
             auto t1 = std::chrono::high_resolution_clock::now();
@@ -150,6 +157,14 @@ int main(int argc, char **argv) {
             HK(hipMemcpy(res.data(), d_ids, res.size() * 4, hipMemcpyDeviceToHost));
             HK(hipMemcpy(cmps.data(), d_cmps, cmps.size() * 4, hipMemcpyDeviceToHost));
             HK(hipMemcpy(hops.data(), d_hops, hops.size() * 4, hipMemcpyDeviceToHost));
+            // steady state: one more untimed pass (where the adaptive default may try its other exact form), then a timed one
+            CK(rg_search_dev(index, d_q, q_pts, q_stride, k, L_pq, d_ids, d_dist, d_cmps, d_hops, nullptr));
+            CK(rg_search_wait(index, nullptr));
+            auto t2 = std::chrono::high_resolution_clock::now();
+            CK(rg_search_dev(index, d_q, q_pts, q_stride, k, L_pq, d_ids, d_dist, d_cmps, d_hops, nullptr));
+            CK(rg_search_wait(index, nullptr));
+            auto t3 = std::chrono::high_resolution_clock::now();
+            ms_steady = std::chrono::duration<double, std::milli>(t3 - t2).count();
         }
         const float qps = (float)q_pts / ((float)ms / 1000.0f);
         const float recall = rg_recall(q_pts, k, gt_dim, res.data(), gt_ids);
@@ -158,7 +173,7 @@ int main(int argc, char **argv) {
         avg_cmps /= q_pts;
         avg_hops /= (float)q_pts;
         std::cout << L_pq << "\t\t" << qps << "\t\t" << avg_cmps << "\t\t" << ((float)ms / q_pts) << "\t\t" << recall
-                  << "\t\t" << avg_hops << std::endl;
+                  << "\t\t" << avg_hops << "\t\t" << ((float)q_pts / ((float)ms_steady / 1000.0f)) << std::endl;
         if (evaluation_out.is_open())
             evaluation_out << L_pq << "," << qps << "," << avg_cmps << "," << ((float)ms / q_pts) << "," << recall << ","
                            << avg_hops << std::endl;

@@ -85,6 +85,7 @@ struct rg_index {
     // 2 = LDS filter + id log + exact distinct count (K4): everything bit-exact incl. cmps (default)
     int visited_mode = 2;
     int log_budget_kb = 16 << 20;  // HBM budget of the id logs per context (KiB, default 16 GiB = 32768 queries): larger batches are searched in sub-batches
+    int visited_budget_kb = 16 << 20;  // HBM budget of the exact visited words per context (KiB, default 16 GiB): caps the slots = the grid of a mode-0 launch
     int log_cap_knob = 0;       // 0 = auto; tests force small logs to exercise the exact fallback
     int count_table_log2 = 15;  // K4 LDS table: at most 2^15 words = 128 KiB
     bool count_table_auto = true;   // sized per launch from L_pq (knob "count_table_log2" <= 0) or fixed by the knob
@@ -100,7 +101,8 @@ struct rg_index {
     bool split_rows = true;      // knob: use them (when they exist)
     bool exact_filter = true;    // mode 0: the LDS filter screens the exact HBM words (hits skip the atomics)
     int gather_form = 0;         // register-staged K1: 0 = 16-byte loads + LDS bounce, 1 = compute-layout loads (knob "gather_form")
-    bool lookahead = true;       // mode 0: the look-ahead form of K1 where it applies (knob "lookahead"; same results either way)
+    int lookahead = 1;           // mode 0, knob "lookahead": 0 = returning atomics; 2 = plain-load test + fire-and-forget marks; 1 = that, with
+                                 // the predicted next pop's adjacency row and words fetched early (same results in every form)
     bool adj_dups = false;       // some adjacency list names a node twice (found at open): the look-ahead form is not used
     bool query_in_lds = false;   // K1: force the generic (query staged in LDS) instantiation for d = 200 / 512
     bool count_full_ids = false; // K4: force the full-id bucket form (the half-word form is used when the remainder fits)

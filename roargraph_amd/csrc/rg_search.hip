@@ -572,18 +572,30 @@ static size_t search_lds_bytes(const rg_index *ix, uint32_t L, int R, int mode, 
     return (b + 15) / 16 * 16;
 }
 
+// visited words of mode 0: slots x ceil(nd / 16) words per context (2.5 MB per slot at 10M nodes).  Grow-only; the slot
+// count (and with it the launch grid) is capped by "visited_budget_kb" (default 16 GiB per context), and an allocation
+// that fails returns RG_ERR_OOM without touching what the context already had -- the caller then runs the batch in the
+// filter + log form, which returns the same bits
+static uint32_t visited_slot_cap(const rg_index *ix) {
+    const size_t per = (size_t)((ix->nd + 15) / 16) * 4;
+    return (uint32_t)std::max<size_t>(1, std::min<size_t>(0x7fffffffu, ((size_t)std::max(1, ix->visited_budget_kb) << 10) / std::max<size_t>(per, 1)));
+}
 static rg_status ensure_visited(rg_index *ix, SearchCtx *cx, uint32_t slots) {
     const uint32_t vwords = (ix->nd + 15) / 16;
     if (cx->slots >= slots && cx->vwords == vwords) return RG_OK;
+    uint32_t *nv = nullptr, *ne = nullptr;
+    if (hipMalloc(&nv, (size_t)slots * vwords * 4) != hipSuccess || hipMalloc(&ne, (size_t)slots * 4) != hipSuccess) {
+        (void)hipGetLastError();
+        if (nv) (void)hipFree(nv);
+        return set_error(RG_ERR_OOM, "no room for the visited words of the exact form");
+    }
     if (cx->d_visited) (void)hipFree(cx->d_visited);
     if (cx->d_epoch) (void)hipFree(cx->d_epoch);
-    cx->d_visited = nullptr;
-    cx->d_epoch = nullptr;
+    cx->d_visited = nv;
+    cx->d_epoch = ne;
     cx->slots = 0;
     ++cx->allocs;
-    RG_HIP(hipMalloc(&cx->d_visited, (size_t)slots * vwords * 4));
     RG_HIP(hipMemset(cx->d_visited, 0, (size_t)slots * vwords * 4));
-    RG_HIP(hipMalloc(&cx->d_epoch, (size_t)slots * 4));
     RG_HIP(hipMemset(cx->d_epoch, 0, (size_t)slots * 4));
     cx->slots = slots;
     cx->vwords = vwords;
@@ -667,6 +679,7 @@ static rg_status launch_k1(rg_index *ix, SearchCtx *cx, int mode, const float *d
         if (occ > 0) wpc = std::min(wpc, occ);
     }
     c.grid = (uint32_t)std::min<uint64_t>(nq, (uint64_t)ix->num_cu * wpc);
+    if (mode == 0) c.grid = std::min(c.grid, visited_slot_cap(ix));
     if (mode == 0) {
         rg_status st = ensure_visited(ix, cx, c.grid);
         if (st != RG_OK) return st;
@@ -699,6 +712,7 @@ static rg_status launch_k1(rg_index *ix, SearchCtx *cx, int mode, const float *d
     // opt-in, NOT parity: two expansions per iteration (never in the build-mode searches, whose expansion lists must be the
     // reference's)
     P.spec = (ix->multi_expand && !bp) ? 2u : 0u;
+    P.look = ix->lookahead == 1 ? 1u : 0u;
 #ifdef RG_K1_PROF
     P.prof = (qlist || bp) ? nullptr : g_prof_buf;
 #endif
@@ -792,9 +806,12 @@ static rg_status search_dev(rg_index *ix, SearchCtx *cx, const float *d_q, uint3
         (void)hipEventRecord(b->ev0, s);
         if (b->mode == 0) {
             st = launch_k1(ix, cx, 0, d_q, nq, qstride, k, L, d_ids, d_dists, d_cmps, d_hops, nullptr, false, b->d_stat, s);
-            if (st != RG_OK) return fail(st);
-            (void)hipEventRecord(b->ev1, s);
-            return done();
+            if (st == RG_OK) {
+                (void)hipEventRecord(b->ev1, s);
+                return done();
+            }
+            if (st != RG_ERR_OOM) return fail(st);
+            b->mode = 2; b->timed = false; b->is_trial = false;   // no room for the words: the other exact form, same bits
         }
     }
     if (!exact_count) {
@@ -1164,9 +1181,10 @@ rg_status rg_index_set(rg_index *ix, const char *name, int value) {
     else if (!strcmp(name, "filter_log2")) ix->filter_log2 = value;
     else if (!strcmp(name, "log_cap")) ix->log_cap_knob = value;
     else if (!strcmp(name, "log_budget_kb")) ix->log_budget_kb = value;
+    else if (!strcmp(name, "visited_budget_kb")) ix->visited_budget_kb = value;
     else if (!strcmp(name, "query_in_lds")) ix->query_in_lds = value != 0;
     else if (!strcmp(name, "exact_filter")) ix->exact_filter = value != 0;
-    else if (!strcmp(name, "lookahead")) ix->lookahead = value != 0;
+    else if (!strcmp(name, "lookahead")) ix->lookahead = value;
     else if (!strcmp(name, "gather_form")) ix->gather_form = value;
     else if (!strcmp(name, "multi_expand")) ix->multi_expand = value;
     else if (!strcmp(name, "split_rows")) ix->split_rows = value != 0;
@@ -1228,6 +1246,26 @@ rg_status rg_search_dev(rg_index *ix, const float *d_queries, uint32_t nq, uint3
     st = rg::search_dev(ix, cx, d_queries, nq, qstride, k, L_pq, d_ids, d_dists, d_cmps, d_hops, (hipStream_t)stream);
     if (st != RG_OK) rg::release_ctx(ix, cx);
     return st;
+}
+
+rg_status rg_search_prepare(rg_index *ix, void *stream, uint32_t nq, uint32_t L_pq) {
+    if (!ix) return set_error(RG_ERR_ARG, "null index");
+    if (nq == 0) return RG_OK;
+    RG_HIP(hipSetDevice(ix->device));
+    rg::SearchCtx *cx = nullptr;
+    rg_status st = rg::acquire_ctx(ix, (hipStream_t)stream, false, &cx);
+    if (st != RG_OK) return st;
+    if (ix->visited_mode == 2) st = rg::ensure_qlog(ix, cx, nq);
+    if (st == RG_OK && ix->visited_mode != 1) {
+        // the slots a wide-beam launch of the exact-words form uses (its grid): at most eight to ten resident queries per CU
+        const uint32_t slots = std::min(std::min<uint32_t>(nq, (uint32_t)ix->num_cu * (L_pq >= 700 ? 8u : 12u)), rg::visited_slot_cap(ix));
+        st = rg::ensure_visited(ix, cx, slots);
+        if (st == RG_ERR_OOM && ix->visited_mode == 2) st = RG_OK;   // the default falls back to its filter + log form
+    }
+    const std::string msg = st != RG_OK ? rg_last_error() : "";
+    rg::release_ctx(ix, cx);
+    if (st != RG_OK) return set_error(st, msg);
+    return RG_OK;
 }
 
 rg_status rg_search_reuse_stats(rg_index *ix, void *stream, uint64_t *evaluations, uint64_t *distinct_rows) {

@@ -78,6 +78,7 @@ struct SearchParams {
     const uint32_t *tail_off; // [nd] first edge of the node (null = rows are not split)
     uint32_t ep_tail;         // tail slot of the entry point (it is scored without an edge leading to it)
     uint32_t spec;            // 2 = "multi_expand": two expansions per iteration (opt-in, NOT parity); 0 = the reference's order
+    uint32_t look;            // VIS = 2: 1 = fetch the predicted next pop's adjacency row and visited words early, 0 = no speculation
 #ifdef RG_K1_PROF
     unsigned long long *prof; // instrumented build only: [nq][16] per-phase cycle sums and event counts
 #endif
@@ -783,15 +784,19 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
                 cmps += n;                                                 // :2397
                 // the prediction: what the next pop returns unless one of this hop's candidates is closer
                 uint32_t pn = node;
-                const bool pv = beam_peek(bm, lane, pn);
+                const bool pv = P.look == 1u && beam_peek(bm, lane, pn);
                 la_node = pv ? pn : 0xffffffffu;
-                la_first = (uint32_t)lane < P.ell_stride ? P.ell[(size_t)pn * P.ell_stride + lane] : 0u;
-                la_toff = P.tail_off ? P.tail_off[pn] : 0u;
+                if (pv) {
+                    la_first = (uint32_t)lane < P.ell_stride ? P.ell[(size_t)pn * P.ell_stride + lane] : 0u;
+                    la_toff = P.tail_off ? P.tail_off[pn] : 0u;
+                }
                 auto early_words = [&]() __attribute__((always_inline)) {
-                    const uint32_t ldeg = readlane_u(la_first, 0);
-                    const uint32_t lid = (uint32_t)__shfl_down((int)la_first, 1, 64);
-                    const bool lhave = (uint32_t)lane < min(ldeg, 63u);
-                    la_word = __hip_atomic_load(&vmap[(lhave ? lid : 0u) >> 4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (pv) {
+                        const uint32_t ldeg = readlane_u(la_first, 0);
+                        const uint32_t lid = (uint32_t)__shfl_down((int)la_first, 1, 64);
+                        const bool lhave = (uint32_t)lane < min(ldeg, 63u);
+                        la_word = __hip_atomic_load(&vmap[(lhave ? lid : 0u) >> 4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
                 };
                 RG_PROF(2);
                 if (n) gather_list(n, early_words);

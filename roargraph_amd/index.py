@@ -137,6 +137,10 @@ class IndexBipartite:
     def search_wait(self, stream=0):
         check(lib().rg_search_wait(self.handle, C.c_void_p(stream)))
 
+    def search_prepare(self, nq, L_pq, stream=0):
+        """Allocate ahead of time what batches of up to nq queries at beam widths up to L_pq need on `stream`."""
+        check(lib().rg_search_prepare(self.handle, C.c_void_p(stream), C.c_uint32(nq), C.c_uint32(L_pq)))
+
     def reuse_stats(self, stream=0):
         """(evaluations performed, distinct base rows among them) of the last default-mode batch on `stream`."""
         ev, dr = C.c_uint64(), C.c_uint64()

@@ -41,7 +41,9 @@ def test_compute_groundtruth_then_search_cli(bins, oracle, tmp_path):
                         "--projection_index_save_path", gf, "--L_pq", "20", "100", "--k", "10", "-T", "16",
                         "--evaluation_save_path", csv], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "L_pq\t\tQPS\t\t\tavg_visited\tmean_latency\trecall@10\tavg_hops" in r.stdout
+    assert "L_pq\t\tQPS\t\t\tavg_visited\tmean_latency\trecall@10\tavg_hops\tQPS_steady" in r.stdout
+    table = [l.split() for l in r.stdout.splitlines() if l.split() and l.split()[0] in ("20", "100")]
+    assert len(table) == 2 and all(len(t) == 7 and float(t[1]) > 0 and float(t[6]) > 0 for t in table), "first-pass and steady QPS"
     rows = [l.split(",") for l in open(csv).read().strip().splitlines()]
     assert [int(x[0]) for x in rows] == [20, 100] and all(len(x) == 6 for x in rows)
     for row in rows:
