@@ -168,18 +168,19 @@ __device__ __forceinline__ uint2 beam_pop(Beam &bm, int lane) {
 
 // the entry the next beam_pop would return if nothing were inserted before it (no state changes): the prediction of the
 // look-ahead form (VIS = 2)
-__device__ __forceinline__ bool beam_peek(const Beam &bm, int lane, uint32_t &id) {
+__device__ __forceinline__ bool beam_peek(const Beam &bm, int lane, float &d, uint32_t &id) {
     const unsigned long long pm = __ballot((uint32_t)lane < bm.psize && !(bm.pi & kFlagBit));
     const bool in_main = bm.cur < bm.size;
     if (!in_main && !pm) return false;
     uint2 e = make_uint2(0u, 0u);
     if (in_main) e = bm.ent[bm.cur];
+    d = __uint_as_float(e.x);
     id = e.y;
     if (pm) {
         const int j = __ffsll((long long)pm) - 1;
-        const float d = readlane_f(bm.pd, j);
-        const uint32_t i = readlane_u(bm.pi, j);
-        if (!in_main || nb_less(d, i, __uint_as_float(e.x), e.y)) id = i;
+        const float dj = readlane_f(bm.pd, j);
+        const uint32_t ij = readlane_u(bm.pi, j);
+        if (!in_main || nb_less(dj, ij, d, id)) { d = dj; id = ij; }
     }
     return true;
 }
@@ -378,14 +379,17 @@ __device__ __forceinline__ void beam_insert(Beam &bm, float cd, uint32_t cid, bo
 //   1  lossy exact-match filter in LDS (+ id log -> K4 for the exact cmps)
 //   2  LOOK-AHEAD over the same exact words (round 3; d = 200 / 512, ELL rows without repeated ids): the test is a plain
 //      load of the word, the mark a fire-and-forget atomic issued only for fresh neighbours -- so testing has no side
-//      effect and can be done EARLY: while the rows of the node being expanded are in flight, the adjacency row of the
-//      entry that would be popped next (beam_peek: right in ~90 % of the hops) and the visited words of its neighbours
-//      are fetched too.  When the next pop is that node, its fresh list is ready after a few register operations and the
-//      hop's dependent chain is ONE memory latency (the row gather) instead of three (adjacency -> visited -> rows).
-//      A wrong prediction costs one small wasted read and takes the two-latency path (adjacency -> words).
-//      Exactness: the words read early can miss only the marks of the hop during which they were read (everything older
-//      has been acknowledged: the row loads issued after those marks were waited for), and exactly those ids are at hand
-//      -- the previous hop's fresh list -- so every early-tested neighbour is checked against them.
+//      effect and can be done EARLY.  Once a hop's candidates are scored, the node the next pop will return is known
+//      (the closest of the beam's best unexpanded entry and the new candidates) -- before the inserts and the pop, a
+//      quarter of a wide-beam hop.  Its adjacency row is requested there and then, its visited words as soon as the
+//      row is in; where a cheap guess made before the gather (the beam's best unexpanded entry: right in about half of
+//      the hops) turns out right, the row is already there and the words leave at once.  The next hop then starts
+//      with its fresh list a few register operations away: the dependent chain of a hop is the row gather plus whatever
+//      of the two small reads the inserts and the pop did not cover, instead of adjacency -> visited -> rows.
+//      Exactness: the words of the next node are read after an explicit vmcnt(0) behind the scoring, i.e. after every
+//      mark of the current hop has been acknowledged by the L2 (the loads bypass the L1: agent-scope atomic loads).
+//      A first version fetched the guessed node's visited words under the gather: with half the guesses wrong the
+//      wasted sector reads cost more than the hits gained (profiles/r03/k1_ab_lookahead_10m.jsonl).
 //
 // GF: gather form of the register-staged instantiations
 //   0  rows fetched 16 bytes per lane (global_load_dwordx4), then bounced block by block through a 1-KiB LDS buffer into
@@ -722,90 +726,115 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
         };
         RG_PROF(5);
         if constexpr (LOOK) {
-            // ---- look-ahead form over the exact visited words (see the template's comment)
-            uint32_t la_node = 0xffffffffu;      // the node whose adjacency row / visited words were fetched early
-            uint32_t la_first = 0, la_word = 0, la_toff = 0;
-            uint32_t prev_id = 0xffffffffu;      // fresh ids of the previous hop, the j-th in lane j: the only marks an early
-            uint32_t prev_n = 0;                 // read of the words can have missed
+            // ---- look-ahead form over the exact visited words (see the template's comment).  Carried from hop to hop:
+            // the adjacency row (two reads: up to 126 neighbours) and the visited words of the node the NEXT pop will return.
+            constexpr uint32_t NONE = 0xffffffffu;
+            uint32_t la_node = NONE, la_a = 0, la_b = 0, la_toff = 0, la_wa = 0, la_wb = 0;
+            const bool two = P.ell_stride > 64u;                           // rows may need a second read
+            auto row_a = [&](uint32_t nd_) __attribute__((always_inline)) { return (uint32_t)lane < P.ell_stride ? P.ell[(size_t)nd_ * P.ell_stride + lane] : 0u; };
+            auto row_b = [&](uint32_t nd_) __attribute__((always_inline)) { return two && 64u + (uint32_t)lane < P.ell_stride ? P.ell[(size_t)nd_ * P.ell_stride + 64u + lane] : 0u; };
+            // visited words of a row's neighbours: ids 0..62 sit in words 1..63 of the first read, ids 63.. in the second
+            auto words_of = [&](uint32_t fa, uint32_t fb, uint32_t &wa, uint32_t &wb) __attribute__((always_inline)) {
+                const uint32_t dg = readlane_u(fa, 0);
+                const uint32_t ia = (uint32_t)__shfl_down((int)fa, 1, 64);
+                wa = __hip_atomic_load(&vmap[((uint32_t)lane < min(dg, 63u) ? ia : 0u) >> 4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                wb = 0u;
+                if (dg > 63u) wb = __hip_atomic_load(&vmap[(63u + (uint32_t)lane < dg ? fb : 0u) >> 4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            };
             while (beam_has_unexpanded(bm, lane)) {                        // has_unexpanded_node, :2356
                 const uint2 popped = beam_pop(bm, lane);                   // :2358
                 const uint32_t node = popped.y;
                 ++hops;                                                    // :2366
                 const bool hit = node == la_node;
-                uint32_t first, toff = 0, word = 0;
-                if (hit) { first = la_first; toff = la_toff; word = la_word; }
+                uint32_t fa, fb, toff, wa, wb;
+                if (hit) { fa = la_a; fb = la_b; toff = la_toff; wa = la_wa; wb = la_wb; }
                 else {
-                    first = (uint32_t)lane < P.ell_stride ? P.ell[(size_t)node * P.ell_stride + lane] : 0u;
-                    if (P.tail_off) toff = P.tail_off[node];
+                    fa = row_a(node); fb = row_b(node);
+                    toff = P.tail_off ? P.tail_off[node] : 0u;
                 }
                 RG_PROF(0);
-                const uint32_t deg = readlane_u(first, 0);
-                if (deg > 63u) {                 // a row longer than one read: the general path (returning atomics)
-                    expand(node, first, toff);
-                    la_node = 0xffffffffu;
-                    prev_n = 0;
+                const uint32_t deg = readlane_u(fa, 0);
+                if (deg > 126u) {                // longer than two reads: the general path (returning atomics)
+                    expand(node, fa, toff);
+                    la_node = NONE;
                     continue;
                 }
-                const uint32_t id = (uint32_t)__shfl_down((int)first, 1, 64);
-                const bool have = (uint32_t)lane < deg;
-                if (!hit) word = __hip_atomic_load(&vmap[(have ? id : 0u) >> 4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!hit) words_of(fa, fb, wa, wb);
 #ifdef RG_K1_PROF
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
                 RG_PROF(1);
                 RG_PROF_CNT(5, deg); RG_PROF_CNT(6, hit ? 1 : 0);
-                bool known = false;              // the LDS filter in front of the words: a hit proves "visited"
-                if (P.vf_front && have) {
+                const uint32_t idA = (uint32_t)__shfl_down((int)fa, 1, 64), idB = fb;
+                const bool haveA = (uint32_t)lane < min(deg, 63u), haveB = 63u + (uint32_t)lane < deg;
+                bool knownA = false, knownB = false;   // the LDS filter in front of the words: a hit proves "visited"
+                if (P.vf_front) {
                     uint32_t slot; uint16_t rem;
-                    vf_hash(id, slot, rem);
-                    known = vtab[slot] == rem;
-                    if (!known) vtab[slot] = rem;
+                    if (haveA) { vf_hash(idA, slot, rem); knownA = vtab[slot] == rem; if (!knownA) vtab[slot] = rem; }
+                    lds_fence();
+                    if (haveB) { vf_hash(idB, slot, rem); knownB = vtab[slot] == rem; if (!knownB) vtab[slot] = rem; }
                 }
-                const uint32_t bit = 1u << (id & 15u);
-                bool fresh = have && !known && !((word >> 16) == epoch && (word & bit));   // :2378
-                if (hit)                         // words read during the previous hop: its marks may not have landed yet
-                    for (uint32_t j = 0; j < prev_n; ++j) fresh = fresh && readlane_u(prev_id, (int)j) != id;
-                if (fresh) {                     // :2385, fire and forget
-                    uint32_t *w = &vmap[id >> 4];
+                const uint32_t bitA = 1u << (idA & 15u), bitB = 1u << (idB & 15u);
+                const bool freshA = haveA && !knownA && !((wa >> 16) == epoch && (wa & bitA));   // :2378
+                const bool freshB = haveB && !knownB && !((wb >> 16) == epoch && (wb & bitB));
+                if (freshA) {                    // :2385, fire and forget
+                    uint32_t *w = &vmap[idA >> 4];
                     (void)__hip_atomic_fetch_max(w, etag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // stale epoch -> (epoch, no bits)
-                    (void)__hip_atomic_fetch_or(w, bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // same address: behind the max
+                    (void)__hip_atomic_fetch_or(w, bitA, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // same address: behind the max
                 }
-                const unsigned long long fm = __ballot(fresh);
-                const uint32_t n = __popcll(fm);
+                if (freshB) {
+                    uint32_t *w = &vmap[idB >> 4];
+                    (void)__hip_atomic_fetch_max(w, etag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    (void)__hip_atomic_fetch_or(w, bitB, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                const unsigned long long fmA = __ballot(freshA), fmB = __ballot(freshB);
+                const uint32_t nA = __popcll(fmA), n = nA + (uint32_t)__popcll(fmB);
                 RG_PROF_CNT(0, 1); RG_PROF_CNT(1, n);
-                if (fresh) {
-                    const uint32_t pos = __popcll(fm & ((1ull << lane) - 1ull));
-                    cand_id[pos] = id;
-                    if (P.tail_off) cand_x[pos] = toff + lane;
-                }
+                const unsigned long long below = (1ull << lane) - 1ull;
+                if (freshA) { const uint32_t pos = __popcll(fmA & below); cand_id[pos] = idA; if (P.tail_off) cand_x[pos] = toff + lane; }
+                if (freshB) { const uint32_t pos = nA + __popcll(fmB & below); cand_id[pos] = idB; if (P.tail_off) cand_x[pos] = toff + 63u + lane; }
                 lds_fence();
-                prev_id = (uint32_t)lane < n ? cand_id[lane] : 0xffffffffu;
-                prev_n = n;
                 cmps += n;                                                 // :2397
-                // the prediction: what the next pop returns unless one of this hop's candidates is closer
-                uint32_t pn = node;
-                const bool pv = P.look == 1u && beam_peek(bm, lane, pn);
-                la_node = pv ? pn : 0xffffffffu;
-                if (pv) {
-                    la_first = (uint32_t)lane < P.ell_stride ? P.ell[(size_t)pn * P.ell_stride + lane] : 0u;
-                    la_toff = P.tail_off ? P.tail_off[pn] : 0u;
-                }
-                auto early_words = [&]() __attribute__((always_inline)) {
-                    if (pv) {
-                        const uint32_t ldeg = readlane_u(la_first, 0);
-                        const uint32_t lid = (uint32_t)__shfl_down((int)la_first, 1, 64);
-                        const bool lhave = (uint32_t)lane < min(ldeg, 63u);
-                        la_word = __hip_atomic_load(&vmap[(lhave ? lid : 0u) >> 4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                };
+                // a cheap early guess: the entry the next pop returns unless one of this hop's candidates is closer (right
+                // in about half of the hops); only its adjacency row is fetched on the guess -- one small read under the gather
+                float ed = 0.0f;
+                uint32_t en = node, ea = 0, eb = 0, etoff = 0;
+                const bool ev = beam_peek(bm, lane, ed, en);
+                const bool guess = ev && P.look == 1u;
+                if (guess) { ea = row_a(en); eb = row_b(en); etoff = P.tail_off ? P.tail_off[en] : 0u; }
                 RG_PROF(2);
-                if (n) gather_list(n, early_words);
-                else early_words();
-                const float cd = (uint32_t)lane < n ? __uint_as_float(cand_x[lane]) : 0.0f;
-                const uint32_t cid = (uint32_t)lane < n ? cand_id[lane] : 0u;
+                if (n) gather_list(n, no_hook);
+                // the candidates, one per lane and chunk of 64
+                const bool cvA = (uint32_t)lane < n, cvB = 64u + (uint32_t)lane < n;
+                const float cdA = cvA ? __uint_as_float(cand_x[lane]) : 0.0f, cdB = cvB ? __uint_as_float(cand_x[64 + lane]) : 0.0f;
+                const uint32_t ciA = cvA ? cand_id[lane] : 0u, ciB = cvB ? cand_id[64 + lane] : 0u;
                 lds_fence();
                 RG_PROF(3);
-                if (n) beam_insert<false>(bm, cd, cid, (uint32_t)lane < n, P.ep, lane, mscr RG_PROF_MERGE);
+                // the node the next pop WILL return: the closest of the guess and this hop's candidates (all of them are
+                // unexpanded; the entry point, whose second insert is dropped, is left out).  Known here, before the inserts
+                // and the pop, its adjacency row and then its visited words travel under them.
+                uint32_t bo = 0xffffffffu, bi = 0xffffffffu;             // best candidate: (ordered distance bits, id)
+                {
+                    const uint32_t ua = __float_as_uint(cdA), ub = __float_as_uint(cdB);
+                    const uint32_t oa = cvA && ciA != P.ep ? ((ua & 0x80000000u) ? ~ua : (ua | 0x80000000u)) : 0xffffffffu;
+                    const uint32_t ob = cvB && ciB != P.ep ? ((ub & 0x80000000u) ? ~ub : (ub | 0x80000000u)) : 0xffffffffu;
+                    bo = wave_min_u32(min(oa, ob));
+                    if (bo != 0xffffffffu) bi = wave_min_u32(min(oa == bo ? ciA : 0xffffffffu, ob == bo ? ciB : 0xffffffffu));
+                }
+                uint32_t xn = ev ? en : NONE;
+                if (bi != 0xffffffffu) {
+                    const uint32_t ue = __float_as_uint(ed), oe = (ue & 0x80000000u) ? ~ue : (ue | 0x80000000u);
+                    if (!ev || bo < oe || (bo == oe && bi < en)) xn = bi;
+                }
+                // every mark of this hop has been acknowledged before the words of the next node are read
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                bool words_out = false;
+                if (xn == NONE) la_node = NONE;
+                else if (guess && xn == en) { la_node = en; la_a = ea; la_b = eb; la_toff = etoff; words_of(la_a, la_b, la_wa, la_wb); words_out = true; }
+                else { la_node = xn; la_a = row_a(xn); la_b = row_b(xn); la_toff = P.tail_off ? P.tail_off[xn] : 0u; }
+                if (n) beam_insert<false>(bm, cdA, ciA, cvA, P.ep, lane, mscr RG_PROF_MERGE);
+                if (n > 64u) beam_insert<false>(bm, cdB, ciB, cvB, P.ep, lane, mscr RG_PROF_MERGE);
+                if (la_node != NONE && !words_out) words_of(la_a, la_b, la_wa, la_wb);   // its row left before the inserts
                 RG_PROF(4);
             }
         } else
