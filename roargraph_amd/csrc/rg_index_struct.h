@@ -59,6 +59,8 @@ struct SearchCtx {
     float *d_q = nullptr, *d_dist = nullptr;
     uint32_t *d_ids = nullptr, *d_ch = nullptr;
     size_t q_cap = 0, res_cap = 0, ch_cap = 0;
+    void *h_pin = nullptr;       // pinned staging of the host form: queries up, then ids | dists | cmps | hops down
+    size_t h_cap = 0;
 };
 
 }  // namespace rg
@@ -100,6 +102,8 @@ struct rg_index {
     uint32_t main_dim = 0, tail_dim = 0;
     bool split_rows = true;      // knob: use them (when they exist)
     bool exact_filter = true;    // mode 0: the LDS filter screens the exact HBM words (hits skip the atomics)
+    bool ell_tagged = false;     // ELL neighbour words carry min(255, in-degree) in their top byte (nd <= 2^24)
+    int filter_min_indeg = 0;    // knob: the LDS visited filter keeps entries only for nodes of at least this in-degree (0 = all)
     int gather_form = 0;         // register-staged K1: 0 = 16-byte loads + LDS bounce, 1 = compute-layout loads (knob "gather_form")
     int lookahead = 1;           // mode 0, knob "lookahead": 0 = returning atomics; 2 = plain-load test + fire-and-forget marks; 1 = that, with
                                  // the predicted next pop's adjacency row and words fetched early (same results in every form)

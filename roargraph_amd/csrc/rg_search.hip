@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "rg.h"
@@ -260,6 +261,22 @@ __global__ void rg_csr_to_ell_kernel(const uint64_t *offsets, const uint32_t *nb
     }
 }
 
+// in-degree of every node / min(255, in-degree of the neighbour) into the top byte of every ELL neighbour word (indexes of
+// at most 2^24 nodes; SearchParams::id_mask)
+__global__ void rg_indeg_kernel(const uint32_t *__restrict__ nbrs, uint64_t ne, uint32_t *__restrict__ indeg) {
+    for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < ne; e += (size_t)gridDim.x * blockDim.x) atomicAdd(&indeg[nbrs[e]], 1u);
+}
+__global__ void rg_ell_tag_kernel(uint32_t *__restrict__ ell, uint32_t nd, uint32_t ell_stride, const uint32_t *__restrict__ indeg) {
+    const size_t total = (size_t)nd * ell_stride;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+        const size_t row = i / ell_stride;
+        const uint32_t j = (uint32_t)(i - row * ell_stride);
+        if (j == 0 || j > ell[row * ell_stride]) continue;      // word 0 = degree; words beyond it are padding
+        const uint32_t id = ell[i];
+        ell[i] = id | (min(255u, indeg[id]) << 24);
+    }
+}
+
 // max degree, max neighbour id, edge count check
 __global__ void rg_graph_stats_kernel(const uint64_t *offsets, const uint32_t *nbrs, uint32_t nd, uint32_t *max_deg,
                                       uint32_t *max_id) {
@@ -417,6 +434,15 @@ static rg_status finish_graph(rg_index *ix, const uint64_t *d_off, const uint32_
         uint32_t dups = 0;
         RG_HIP(hipMemcpy(&dups, d_stat, 4, hipMemcpyDeviceToHost));
         ix->adj_dups = dups != 0;
+        if (ix->nd <= (1u << 24) && ne > 0) {   // in-degree tags for the admission rule of the LDS visited filter
+            DevBuf<uint32_t> indeg;
+            if (indeg.alloc(ix->nd) == hipSuccess && hipMemset(indeg.p, 0, (size_t)ix->nd * 4) == hipSuccess) {
+                hipLaunchKernelGGL(rg_indeg_kernel, dim3(4096), dim3(256), 0, 0, d_nb, (uint64_t)ne, indeg.p);
+                hipLaunchKernelGGL(rg_ell_tag_kernel, dim3(8192), dim3(256), 0, 0, ix->d_ell, ix->nd, es, indeg.p);
+                if (hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess) ix->ell_tagged = true;
+                else return set_error(RG_ERR_DEVICE, "tagging the adjacency rows failed");
+            } else (void)hipGetLastError();
+        }
         // split rows: an 800-B row (d = 200) spans seven 128-B lines wherever it starts; its first 192 elements at a 768-B
         // stride span six, and the 8-element tails, stored per edge in adjacency order, are read from ceil(deg/4) lines
         // per hop instead of one more line per fresh neighbour.  7.7 GB + 32 B per edge at 10M rows.
@@ -471,6 +497,7 @@ static void free_ctx(SearchCtx *cx) {
     for (Batch *b : cx->pending) free_batch(b);
     for (Batch *b : cx->spare) free_batch(b);
     if (cx->own) (void)hipStreamDestroy(cx->own);
+    if (cx->h_pin) (void)hipHostFree(cx->h_pin);
     void *bufs[] = {cx->d_counter, cx->d_scratch_stat, cx->d_visited, cx->d_epoch, cx->d_qlog, cx->d_qlog_n,
                     cx->d_q, cx->d_dist, cx->d_ids, cx->d_ch};
     for (void *p : bufs)
@@ -713,6 +740,8 @@ static rg_status launch_k1(rg_index *ix, SearchCtx *cx, int mode, const float *d
     // reference's)
     P.spec = (ix->multi_expand && !bp) ? 2u : 0u;
     P.look = ix->lookahead == 1 ? 1u : 0u;
+    P.id_mask = (ix->ell_tagged && !bp) ? 0x00ffffffu : 0xffffffffu;
+    P.vf_min_indeg = (uint32_t)std::max(0, std::min(255, ix->filter_min_indeg));
 #ifdef RG_K1_PROF
     P.prof = (qlist || bp) ? nullptr : g_prof_buf;
 #endif
@@ -1028,7 +1057,30 @@ static rg_status host_search_begin(rg_index *ix, const float *hq, uint32_t n, ui
     }
     if (cx->ch_cap < cn) { if (cx->d_ch) (void)hipFree(cx->d_ch); cx->d_ch = nullptr; cx->ch_cap = 0; RG_HIP(hipMalloc(&cx->d_ch, cn * 4)); cx->ch_cap = cn; }
     hipStream_t s = cx->own;
-    RG_HIP(hipMemcpyAsync(cx->d_q, hq, qn * 4, hipMemcpyHostToDevice, s));
+    // Pinned staging (round 3): the caller's buffers are pageable, and a pageable hipMemcpy stages through the runtime's own
+    // bounce buffers one chunk at a time on the calling thread.  The queries are copied into this context's pinned buffer
+    // by a few threads and leave with ONE asynchronous DMA; the results come back into pinned memory the same way, the
+    // whole call synchronises once.
+    const size_t hb = std::max(qn * 4, (rn * 2 + cn) * 4);
+    if (cx->h_cap < hb) {
+        if (cx->h_pin) (void)hipHostFree(cx->h_pin);
+        cx->h_pin = nullptr; cx->h_cap = 0;
+        RG_HIP(hipHostMalloc(&cx->h_pin, hb));
+        cx->h_cap = hb;
+    }
+    {
+        const size_t bytes = qn * 4;
+        const int nth = bytes >= (2u << 20) ? 4 : 1;
+        auto part = [&](int t) {
+            const size_t lo = bytes * (size_t)t / (size_t)nth, hi = bytes * (size_t)(t + 1) / (size_t)nth;
+            std::memcpy(static_cast<char *>(cx->h_pin) + lo, reinterpret_cast<const char *>(hq) + lo, hi - lo);
+        };
+        std::vector<std::thread> th;
+        for (int t = 1; t < nth; ++t) th.emplace_back(part, t);
+        part(0);
+        for (auto &t : th) t.join();
+    }
+    RG_HIP(hipMemcpyAsync(cx->d_q, cx->h_pin, qn * 4, hipMemcpyHostToDevice, s));
     RG_HIP(hipMemsetAsync(cx->d_ids, 0, rn * 4, s));
     RG_HIP(hipMemsetAsync(cx->d_dist, 0, rn * 4, s));
     return search_dev(ix, cx, cx->d_q, n, d, k, L, cx->d_ids, cx->d_dist, cx->d_ch, cx->d_ch + n, s);
@@ -1043,10 +1095,16 @@ static rg_status host_search_end(HostSearch *hs, uint32_t k, uint32_t *out_ids, 
     if (st == RG_OK || st == RG_ERR_NOT_ENOUGH) {
         const std::string msg = st != RG_OK ? rg_last_error() : "";
         const uint32_t n = hs->n;
-        (void)hipMemcpy(out_ids, cx->d_ids, (size_t)n * k * 4, hipMemcpyDeviceToHost);
-        (void)hipMemcpy(out_dists, cx->d_dist, (size_t)n * k * 4, hipMemcpyDeviceToHost);
-        if (out_cmps) (void)hipMemcpy(out_cmps, cx->d_ch, (size_t)n * 4, hipMemcpyDeviceToHost);
-        if (out_hops) (void)hipMemcpy(out_hops, cx->d_ch + n, (size_t)n * 4, hipMemcpyDeviceToHost);
+        char *hp = static_cast<char *>(cx->h_pin);   // queries are on the device by now: the pinned buffer takes the results
+        const size_t rb = (size_t)n * k * 4, cb = (size_t)n * 4;
+        (void)hipMemcpyAsync(hp, cx->d_ids, rb, hipMemcpyDeviceToHost, cx->own);
+        (void)hipMemcpyAsync(hp + rb, cx->d_dist, rb, hipMemcpyDeviceToHost, cx->own);
+        (void)hipMemcpyAsync(hp + 2 * rb, cx->d_ch, 2 * cb, hipMemcpyDeviceToHost, cx->own);
+        (void)hipStreamSynchronize(cx->own);
+        std::memcpy(out_ids, hp, rb);
+        std::memcpy(out_dists, hp + rb, rb);
+        if (out_cmps) std::memcpy(out_cmps, hp + 2 * rb, cb);
+        if (out_hops) std::memcpy(out_hops, hp + 2 * rb + cb, cb);
         if (st != RG_OK) set_error(st, msg);
     }
     release_ctx(ix, cx);
@@ -1186,6 +1244,7 @@ rg_status rg_index_set(rg_index *ix, const char *name, int value) {
     else if (!strcmp(name, "exact_filter")) ix->exact_filter = value != 0;
     else if (!strcmp(name, "lookahead")) ix->lookahead = value;
     else if (!strcmp(name, "gather_form")) ix->gather_form = value;
+    else if (!strcmp(name, "filter_min_indeg")) ix->filter_min_indeg = value;
     else if (!strcmp(name, "multi_expand")) ix->multi_expand = value;
     else if (!strcmp(name, "split_rows")) ix->split_rows = value != 0;
     else if (!strcmp(name, "fast_bf16")) {

@@ -78,6 +78,11 @@ struct SearchParams {
     const uint32_t *tail_off; // [nd] first edge of the node (null = rows are not split)
     uint32_t ep_tail;         // tail slot of the entry point (it is scored without an edge leading to it)
     uint32_t spec;            // 2 = "multi_expand": two expansions per iteration (opt-in, NOT parity); 0 = the reference's order
+    // ELL neighbour words of indexes with at most 2^24 nodes carry min(255, in-degree of the neighbour) in their top byte
+    // (id_mask = 0x00ffffff; 0xffffffff = untagged).  A node is tested at most in-degree times per query, so the LDS
+    // filter only spends entries on nodes whose in-degree reaches vf_min_indeg: the others are never remembered (and at
+    // worst scored again the few times they are met again) -- same results, more of the filter for the nodes that return.
+    uint32_t id_mask, vf_min_indeg;
     uint32_t look;            // VIS = 2: 1 = fetch the predicted next pop's adjacency row and visited words early, 0 = no speculation
 #ifdef RG_K1_PROF
     unsigned long long *prof; // instrumented build only: [nq][16] per-phase cycle sums and event counts
@@ -486,16 +491,24 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
         };
         // visited test-and-set of this lane's neighbour (:2378, :2385); same-hop duplicates are resolved by the atomic's
         // order (VIS = 0) or by the merge's de-duplication (VIS = 1)
-        auto visit_set = [&](uint32_t id, bool have) __attribute__((always_inline)) -> bool {
+        // neighbour word of an adjacency row -> id, and whether the LDS filter keeps an entry for it (see id_mask)
+        const uint32_t idm = P.id_mask;
+        auto keeps = [&](uint32_t idw) __attribute__((always_inline)) -> bool {
+            return idm == 0xffffffffu || (idw >> 24) >= P.vf_min_indeg;
+        };
+        auto visit_set = [&](uint32_t id, bool have, bool keep) __attribute__((always_inline)) -> bool {
             bool fresh = false;
             if (VIS == 1) {
                 // exact-match lookup: a hit proves "visited"; a miss is treated as fresh (may re-score a node whose
                 // entry was overwritten -- harmless for the beam, see beam_insert<true>)
                 if (have) {
-                    uint32_t slot; uint16_t rem;
-                    vf_hash(id, slot, rem);
-                    fresh = vtab[slot] != rem;
-                    if (fresh) vtab[slot] = rem;
+                    fresh = true;
+                    if (keep) {
+                        uint32_t slot; uint16_t rem;
+                        vf_hash(id, slot, rem);
+                        fresh = vtab[slot] != rem;
+                        if (fresh) vtab[slot] = rem;
+                    }
                 }
             } else if (have && (P.diag & 1u)) fresh = true;
             else if (have && (P.diag & 2u)) {  // traffic without the dependency: fire-and-forget atomics
@@ -507,7 +520,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
                 // the LDS filter in front of the exact words: a hit proves "visited" and saves the two atomics (most
                 // repeat encounters on indexes with locality); a miss goes to the words, which decide
                 bool known = false;
-                if (P.vf_front) {
+                if (P.vf_front && keep) {
                     uint32_t slot; uint16_t rem;
                     vf_hash(id, slot, rem);
                     known = vtab[slot] == rem;
@@ -698,8 +711,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
                     have = c0 + lane < deg;
                     if (have) id = list[c0 + lane];
                 }
+                const bool keep = keeps(id);
+                if (ELL) id &= idm;
                 if (build && id == tgt) have = false;
-                const bool fresh = visit_set(id, have);
+                const bool fresh = visit_set(id, have, keep);
                 const unsigned long long fm = __ballot(fresh);
                 const uint32_t n = __popcll(fm);
                 RG_PROF_CNT(0, 1); RG_PROF_CNT(1, n);
@@ -736,10 +751,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
             // visited words of a row's neighbours: ids 0..62 sit in words 1..63 of the first read, ids 63.. in the second
             auto words_of = [&](uint32_t fa, uint32_t fb, uint32_t &wa, uint32_t &wb) __attribute__((always_inline)) {
                 const uint32_t dg = readlane_u(fa, 0);
-                const uint32_t ia = (uint32_t)__shfl_down((int)fa, 1, 64);
+                const uint32_t ia = (uint32_t)__shfl_down((int)fa, 1, 64) & idm;
                 wa = __hip_atomic_load(&vmap[((uint32_t)lane < min(dg, 63u) ? ia : 0u) >> 4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 wb = 0u;
-                if (dg > 63u) wb = __hip_atomic_load(&vmap[(63u + (uint32_t)lane < dg ? fb : 0u) >> 4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (dg > 63u) wb = __hip_atomic_load(&vmap[(63u + (uint32_t)lane < dg ? (fb & idm) : 0u) >> 4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             };
             while (beam_has_unexpanded(bm, lane)) {                        // has_unexpanded_node, :2356
                 const uint2 popped = beam_pop(bm, lane);                   // :2358
@@ -765,14 +780,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
 #endif
                 RG_PROF(1);
                 RG_PROF_CNT(5, deg); RG_PROF_CNT(6, hit ? 1 : 0);
-                const uint32_t idA = (uint32_t)__shfl_down((int)fa, 1, 64), idB = fb;
+                const uint32_t wA = (uint32_t)__shfl_down((int)fa, 1, 64), idA = wA & idm, idB = fb & idm;
                 const bool haveA = (uint32_t)lane < min(deg, 63u), haveB = 63u + (uint32_t)lane < deg;
                 bool knownA = false, knownB = false;   // the LDS filter in front of the words: a hit proves "visited"
                 if (P.vf_front) {
                     uint32_t slot; uint16_t rem;
-                    if (haveA) { vf_hash(idA, slot, rem); knownA = vtab[slot] == rem; if (!knownA) vtab[slot] = rem; }
+                    if (haveA && keeps(wA)) { vf_hash(idA, slot, rem); knownA = vtab[slot] == rem; if (!knownA) vtab[slot] = rem; }
                     lds_fence();
-                    if (haveB) { vf_hash(idB, slot, rem); knownB = vtab[slot] == rem; if (!knownB) vtab[slot] = rem; }
+                    if (haveB && keeps(fb)) { vf_hash(idB, slot, rem); knownB = vtab[slot] == rem; if (!knownB) vtab[slot] = rem; }
                 }
                 const uint32_t bitA = 1u << (idA & 15u), bitB = 1u << (idB & 15u);
                 const bool freshA = haveA && !knownA && !((wa >> 16) == epoch && (wa & bitA));   // :2378
@@ -857,13 +872,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
                 RG_PROF(0);
                 const uint32_t deg = readlane_u(first, 0), deg2 = readlane_u(first2, 0);
                 if (deg <= 63u && deg2 <= 63u) {
-                    const uint32_t idA = (uint32_t)__shfl_down((int)first, 1, 64), idB = (uint32_t)__shfl_down((int)first2, 1, 64);
+                    const uint32_t wA = (uint32_t)__shfl_down((int)first, 1, 64), wB = (uint32_t)__shfl_down((int)first2, 1, 64);
+                    const uint32_t idA = wA & idm, idB = wB & idm;
 #ifdef RG_K1_PROF
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
                     RG_PROF(1);
-                    const bool freshA = visit_set(idA, (uint32_t)lane < deg);
-                    const bool freshB = visit_set(idB, (uint32_t)lane < deg2);     // after A's marks: a common neighbour counts once
+                    const bool freshA = visit_set(idA, (uint32_t)lane < deg, keeps(wA));
+                    const bool freshB = visit_set(idB, (uint32_t)lane < deg2, keeps(wB));     // after A's marks: a common neighbour counts once
                     const unsigned long long fmA = __ballot(freshA), fmB = __ballot(freshB);
                     const uint32_t nA = __popcll(fmA), nB = __popcll(fmB);
                     const unsigned long long below = (1ull << lane) - 1ull;

@@ -61,6 +61,7 @@ def make_case(seed):
     knobs["_csr"] = int(rng.random() < 0.2)     # adjacency layout (read from the environment at open)
     knobs["lookahead"] = int(rng.random() < 0.7)
     knobs["gather_form"] = int(rng.random() < 0.5)
+    knobs["filter_min_indeg"] = int(rng.choice([0, 0, 2, 4, 12, 255]))
     # lists without repeated ids (what every real index has): the look-ahead form of the exact words applies to them.
     # Cases 60+ aim at it: register-staged dimensions, exact words, ELL rows, beams wide enough to run for a while
     if seed >= 60 or rng.random() < 0.5:

@@ -69,6 +69,26 @@ def test_search_lds_filter_mode(rg, oracle, metric, d, nb, L, k, flt):
     ix.close()
 
 
+@pytest.mark.parametrize("metric,d,nb", [("ip", 200, 4000), ("l2", 24, 3000), ("l2", 512, 2000)])
+@pytest.mark.parametrize("min_indeg", [2, 6, 40, 255])
+def test_filter_admission_by_in_degree(rg, oracle, metric, d, nb, min_indeg):
+    """filter_min_indeg: the LDS visited filter keeps entries only for neighbours whose in-degree (carried in the top byte of
+    the adjacency words) reaches the threshold -- a node can be met again at most in-degree - 1 times.  Nodes below it are
+    never remembered, i.e. possibly scored again, which cannot change the beam: ids / distances / hops and (through the
+    id log + K4, or the exact words behind the filter) cmps stay bit-exact at any threshold."""
+    base, q, off, nbrs, ep = small_set(metric, nb, d)
+    ix = rg.IndexBipartite.from_arrays(base, off, nbrs, ep, metric=metric)
+    ix.set("filter_min_indeg", min_indeg)
+    for L, k in ((10, 10), (100, 100), (600, 10)):
+        want = oracle.search(base, metric, off, nbrs, ep, q, k, L, nthreads=4)
+        for visited in (2, 1, 0):
+            ix.set("visited", visited)
+            got = ix.SearchRoarGraph(q, k, L)
+            assert (got[3] == want[3]).all() and (got[0] == want[0]).all() and (bits(got[1]) == bits(want[1])).all(), (L, visited)
+            assert (got[2] == want[2]).all() if visited != 1 else (got[2] >= want[2]).all(), ("cmps", L, visited)
+    ix.close()
+
+
 @pytest.mark.parametrize("metric,d,nb", [("ip", 200, 4000), ("l2", 512, 2000), ("l2", 200, 3000), ("ip", 512, 1500)])
 @pytest.mark.parametrize("visited", [2, 1, 0])
 def test_compute_layout_gather_form(rg, oracle, metric, d, nb, visited):
