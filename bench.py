@@ -493,7 +493,7 @@ def main():
             assert torch.equal(o["dists"].view(torch.int32), keep[1].view(torch.int32)), "visited modes disagree on distances"
             if args.visited == 2:
                 assert torch.equal(o["cmps"], keep[2]), "cmps differ from the exact visited mode"
-        index.set("lookahead", 1)
+        index.set("lookahead", -1)
         index.set("visited", args.visited)
     kavg = float(np.mean(kernel_ms)) / 1e3
     alg_bytes = head["mean_evals"] * args.nq * 4.0 * args.dim

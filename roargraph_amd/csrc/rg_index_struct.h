@@ -103,10 +103,11 @@ struct rg_index {
     bool split_rows = true;      // knob: use them (when they exist)
     bool exact_filter = true;    // mode 0: the LDS filter screens the exact HBM words (hits skip the atomics)
     bool ell_tagged = false;     // ELL neighbour words carry min(255, in-degree) in their top byte (nd <= 2^24)
-    int filter_min_indeg = 0;    // knob: the LDS visited filter keeps entries only for nodes of at least this in-degree (0 = all)
-    int gather_form = 0;         // register-staged K1: 0 = 16-byte loads + LDS bounce, 1 = compute-layout loads (knob "gather_form")
-    int lookahead = 1;           // mode 0, knob "lookahead": 0 = returning atomics; 2 = plain-load test + fire-and-forget marks; 1 = that, with
-                                 // the predicted next pop's adjacency row and words fetched early (same results in every form)
+    int filter_min_indeg = 2;    // knob: the LDS visited filter keeps entries only for nodes of at least this in-degree (a node of in-degree 1 is
+                                 // met once per query at most: remembering it is wasted; larger thresholds gain about 1 % on the bench index)
+    int gather_form = -1;        // register-staged K1: 0 = 16-byte loads + LDS bounce, otherwise compute-layout loads where instantiated
+    int lookahead = -1;          // mode 0, knob "lookahead": -1 = automatic (by beam width), 0 = returning atomics, 1 = look-ahead form, 2 = look-ahead
+                                 // form without the early guess (same results in every form; rg_search.hip: launch_k1)
     bool adj_dups = false;       // some adjacency list names a node twice (found at open): the look-ahead form is not used
     bool query_in_lds = false;   // K1: force the generic (query staged in LDS) instantiation for d = 200 / 512
     bool count_full_ids = false; // K4: force the full-id bucket form (the half-word form is used when the remainder fits)

@@ -588,9 +588,17 @@ static int dimc_of(const rg_index *ix) {
 static size_t stage_pass_floats(const rg_index *ix, bool bf) {
     return bf ? (size_t)((ix->dim + 127) / 128) * 256 : (size_t)((ix->dim + 63) / 64) * 256;
 }
+// gather form of a launch (rg_search_kernel.h, GF): compute-layout loads wherever an instantiation exists -- d = 200 with
+// four or eight register sets, d = 512 with two -- unless the knob "gather_form" says 0
+static int gather_form_of(const rg_index *ix, int R, bool bf) {
+    const int dc = (ix->d_ell != nullptr && (ix->dim == 200 || ix->dim == 512) && !ix->query_in_lds) ? (int)ix->dim : 0;
+    if (ix->gather_form == 0 || bf) return 0;
+    return ((dc == 200 && (R == 4 || R == 8)) || (dc == 512 && R == 2)) ? 1 : 0;
+}
 static size_t stage_total_floats(const rg_index *ix, int R, bool bf) {   // the fast mode's exact re-rank needs one fp32 pass
-    // register-staged instantiations (compile-time dimension, fp32): rows in flight live in VGPRs, one LDS bounce buffer
-    if (dimc_of(ix) && !bf) return 256;   // one 1-KiB block at a time (bounce_score_q)
+    // register-staged instantiations (compile-time dimension, fp32): rows in flight live in VGPRs; the bounce form needs one
+    // 1-KiB LDS block at a time (bounce_score_q), the compute-layout form none
+    if (dimc_of(ix) && !bf) return gather_form_of(ix, R, bf) ? 0 : 256;
     return std::max((size_t)R * stage_pass_floats(ix, bf), (size_t)((ix->dim + 63) / 64) * 256);
 }
 static size_t search_lds_bytes(const rg_index *ix, uint32_t L, int R, int mode, bool bf, int filter_auto) {
@@ -677,18 +685,23 @@ static rg_status launch_k1(rg_index *ix, SearchCtx *cx, int mode, const float *d
     if (lds > ix->lds_per_cu) return set_error(RG_ERR_ARG, "L_pq too large for the 160 KiB LDS of one CU");
     int wpc = (int)std::min<size_t>(ix->lds_per_cu / lds, 32);
     // few resident queries (wide beams): each keeps 32 rows in flight (8 register sets, about 190 VGPRs: 8 waves per CU)
-    if (ix->rows_per_pass <= 0 && dimc_of(ix) == 200 && !bf && wpc <= 8) R = 8;
+    if (ix->rows_per_pass <= 0 && dimc_of(ix) == 200 && !bf && wpc <= 8) { R = 8; lds = search_lds_bytes(ix, L, R, mode, bf, filter_auto); }
     if (ix->waves_per_cu > 0) wpc = std::min(wpc, ix->waves_per_cu);
     else wpc = std::min(wpc, 24);
     K1Launch c;
     c.R = R; c.vis = mode == 0 ? 0 : 1; c.dimc = dimc_of(ix); c.bf = bf; c.lds = lds;
     // exact words, look-ahead form (rg_search_kernel.h, VIS = 2): the register-staged instantiations over ELL rows that
-    // name no node twice; never with the opt-in second expansion, whose two lists share one test phase
-    if (mode == 0 && ix->lookahead && !ix->adj_dups && !ix->multi_expand && !bf && !bp && ix->diag == 0 &&
+    // name no node twice; never with the opt-in second expansion, whose two lists share one test phase.  Knob "lookahead":
+    // -1 (default) = from L_pq 1200 up, where it is the faster of the two forms of the exact words on the 10M bench index
+    // (profiles/r03/k1_forms_10m.txt: 50 - 54 vs 47 - 51 % of 8 TB/s at 2000, level at 1000, 4 - 8 % behind at 300 - 700: its
+    // plain-load tests spare the write-back of every word a returning atomic touches without changing, its two small
+    // reads per hop travel under the inserts and the pop -- but it issues more memory instructions per hop); 0 = never;
+    // 1 = always; 2 = always, without the early guess of the next adjacency row
+    const bool look_wanted = ix->lookahead > 0 || (ix->lookahead < 0 && L >= 1200);
+    if (mode == 0 && look_wanted && !ix->adj_dups && !ix->multi_expand && !bf && !bp && ix->diag == 0 &&
         ((c.dimc == 200 && R >= 2) || (c.dimc == 512 && (R == 2 || R == 4))))
         c.vis = 2;
-    // gather form (rg_search_kernel.h, GF): compute-layout loads where an instantiation exists
-    if (ix->gather_form == 1 && !bf && ((c.dimc == 200 && (R == 4 || R == 8)) || (c.dimc == 512 && R == 2))) c.gf = 1;
+    c.gf = gather_form_of(ix, R, bf);
     const bool l2 = ix->metric == RG_METRIC_L2, ell = ix->d_ell != nullptr;
     auto dispatch = [&](const SearchParams &sp) -> rg_status {
         if (l2 && ell) return launch_search_l2_ell(sp, c, s);
@@ -739,7 +752,7 @@ static rg_status launch_k1(rg_index *ix, SearchCtx *cx, int mode, const float *d
     // opt-in, NOT parity: two expansions per iteration (never in the build-mode searches, whose expansion lists must be the
     // reference's)
     P.spec = (ix->multi_expand && !bp) ? 2u : 0u;
-    P.look = ix->lookahead == 1 ? 1u : 0u;
+    P.look = ix->lookahead == 2 ? 0u : 1u;
     P.id_mask = (ix->ell_tagged && !bp) ? 0x00ffffffu : 0xffffffffu;
     P.vf_min_indeg = (uint32_t)std::max(0, std::min(255, ix->filter_min_indeg));
 #ifdef RG_K1_PROF
