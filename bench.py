@@ -476,8 +476,15 @@ def main():
     reuse = None
     if args.visited == 2:
         try:
-            ev_n, dr_n = index.reuse_stats(stream)
-            reuse = {"evaluations_performed": ev_n, "distinct_rows": dr_n, "distinct_rows_frac": dr_n / max(ev_n, 1)}
+            counts = torch.zeros(args.nb, dtype=torch.int32, device=dev)
+            ev_n, dr_n = index.reuse_stats(stream, counts)
+            srt = torch.sort(counts, descending=True).values.double()
+            cum = torch.cumsum(srt, 0) / max(float(ev_n), 1.0)
+            reuse = {"evaluations_performed": ev_n, "distinct_rows": dr_n, "distinct_rows_frac": dr_n / max(ev_n, 1),
+                     # popularity: share of the launch's row reads that go to its H most read rows (H rows = H x 768 B)
+                     "share_of_reads_to_top_rows": {str(h): float(cum[min(h, args.nb) - 1].item()) for h in (64, 1024, 16384, 131072, 349525, 1048576)},
+                     "rows_read_by_every_query": int((counts >= args.nq).sum().item())}
+            del counts, srt, cum
         except Exception as e:  # noqa: BLE001  (the launch ran on the exact words: no logs)
             reuse = {"unavailable": str(e)}
     ids_head = S.out[0]["ids"].cpu().numpy().view(np.uint32).copy()

@@ -162,8 +162,10 @@ rg_status rg_search_prepare(rg_index *idx, void *stream, uint32_t nq, uint32_t L
  * `stream` left behind -- it must have run in the default visited mode in one piece and have been waited for --
  * the number of distance evaluations the launch performed (re-scored rows included: each is a row read) and the number
  * of DISTINCT base rows among them.  distinct / evaluations is the share of a launch's row reads that are first touches,
- * i.e. that no cache can have served from an earlier read of the same launch. */
-rg_status rg_search_reuse_stats(rg_index *idx, void *stream, uint64_t *evaluations, uint64_t *distinct_rows);
+ * i.e. that no cache can have served from an earlier read of the same launch.  d_row_counts (optional, device, one
+ * zero-initialised counter per base row) receives how often each row was read: the popularity distribution. */
+rg_status rg_search_reuse_stats(rg_index *idx, void *stream, uint64_t *evaluations, uint64_t *distinct_rows,
+                                uint32_t *d_row_counts);
 
 /* ------------------------------------------------------------- ground truth
  * Replaces: the external `compute_groundtruth --data_type float --dist_fn {l2,mips,cosine} --base_file F

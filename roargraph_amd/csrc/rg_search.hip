@@ -203,7 +203,7 @@ __global__ void __launch_bounds__(64) rg_score_kernel(const float *__restrict__ 
 
 // rg_search_reuse_stats: mark every row id of the id logs in a bitmap / count the marks
 __global__ void rg_log_mark_kernel(const uint32_t *__restrict__ qlog, uint32_t logcap, const uint32_t *__restrict__ qlog_n, uint32_t nq,
-                                   uint32_t *__restrict__ bitmap, unsigned long long *__restrict__ total) {
+                                   uint32_t *__restrict__ bitmap, unsigned long long *__restrict__ total, uint32_t *__restrict__ row_counts) {
     unsigned long long mine = 0;
     for (uint32_t q = blockIdx.x; q < nq; q += gridDim.x) {
         const uint32_t n = min(qlog_n[q], logcap);
@@ -211,6 +211,7 @@ __global__ void rg_log_mark_kernel(const uint32_t *__restrict__ qlog, uint32_t l
         for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
             const uint32_t id = log[i];
             atomicOr(&bitmap[id >> 5], 1u << (id & 31u));
+            if (row_counts) atomicAdd(&row_counts[id], 1u);
         }
         if (threadIdx.x == 0) mine += n;
     }
@@ -1340,7 +1341,7 @@ rg_status rg_search_prepare(rg_index *ix, void *stream, uint32_t nq, uint32_t L_
     return RG_OK;
 }
 
-rg_status rg_search_reuse_stats(rg_index *ix, void *stream, uint64_t *evaluations, uint64_t *distinct_rows) {
+rg_status rg_search_reuse_stats(rg_index *ix, void *stream, uint64_t *evaluations, uint64_t *distinct_rows, uint32_t *d_row_counts) {
     if (!ix || !evaluations || !distinct_rows) return set_error(RG_ERR_ARG, "null argument");
     RG_HIP(hipSetDevice(ix->device));
     rg::SearchCtx *cx = nullptr;
@@ -1360,7 +1361,7 @@ rg_status rg_search_reuse_stats(rg_index *ix, void *stream, uint64_t *evaluation
     RG_HIP(hipMemset(bm.p, 0, words * 4));
     RG_HIP(hipMemset(tot.p, 0, 16));
     hipLaunchKernelGGL(rg::rg_log_mark_kernel, dim3(std::min<uint32_t>(cx->log_holds, 4096u)), dim3(256), 0, 0, cx->d_qlog, cx->logcap, cx->d_qlog_n,
-                       cx->log_holds, bm.p, tot.p);
+                       cx->log_holds, bm.p, tot.p, d_row_counts);
     hipLaunchKernelGGL(rg::rg_bitmap_count_kernel, dim3(2048), dim3(256), 0, 0, bm.p, words, tot.p + 1);
     unsigned long long h[2];
     RG_HIP(hipMemcpy(h, tot.p, 16, hipMemcpyDeviceToHost));

@@ -141,10 +141,12 @@ class IndexBipartite:
         """Allocate ahead of time what batches of up to nq queries at beam widths up to L_pq need on `stream`."""
         check(lib().rg_search_prepare(self.handle, C.c_void_p(stream), C.c_uint32(nq), C.c_uint32(L_pq)))
 
-    def reuse_stats(self, stream=0):
-        """(evaluations performed, distinct base rows among them) of the last default-mode batch on `stream`."""
+    def reuse_stats(self, stream=0, row_counts_t=None):
+        """(evaluations performed, distinct base rows among them) of the last default-mode batch on `stream`;
+        row_counts_t: optional zeroed int32 CUDA tensor [nd] that receives the reads per row."""
         ev, dr = C.c_uint64(), C.c_uint64()
-        check(lib().rg_search_reuse_stats(self.handle, C.c_void_p(stream), C.byref(ev), C.byref(dr)))
+        check(lib().rg_search_reuse_stats(self.handle, C.c_void_p(stream), C.byref(ev), C.byref(dr),
+                                          C.c_void_p(row_counts_t.data_ptr() if row_counts_t is not None else 0)))
         return ev.value, dr.value
 
 
