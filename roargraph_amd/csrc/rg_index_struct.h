@@ -88,6 +88,7 @@ struct rg_index {
     int visited_mode = 2;
     int log_budget_kb = 16 << 20;  // HBM budget of the id logs per context (KiB, default 16 GiB = 32768 queries): larger batches are searched in sub-batches
     int visited_budget_kb = 16 << 20;  // HBM budget of the exact visited words per context (KiB, default 16 GiB): caps the slots = the grid of a mode-0 launch
+    int visited_uncached = 0;        // knob: exact visited words in 1 = uncached (MTYPE_UC), 2 = fine-grained device memory
     int log_cap_knob = 0;       // 0 = auto; tests force small logs to exercise the exact fallback
     int count_table_log2 = 15;  // K4 LDS table: at most 2^15 words = 128 KiB
     bool count_table_auto = true;   // sized per launch from L_pq (knob "count_table_log2" <= 0) or fixed by the knob

@@ -620,7 +620,12 @@ static rg_status ensure_visited(rg_index *ix, SearchCtx *cx, uint32_t slots) {
     const uint32_t vwords = (ix->nd + 15) / 16;
     if (cx->slots >= slots && cx->vwords == vwords) return RG_OK;
     uint32_t *nv = nullptr, *ne = nullptr;
-    if (hipMalloc(&nv, (size_t)slots * vwords * 4) != hipSuccess || hipMalloc(&ne, (size_t)slots * 4) != hipSuccess) {
+    // knob "visited_uncached": the words in memory the L2 does not cache (MTYPE_UC) -- a test then moves a 32-byte sector
+    // over the fabric instead of the 128-byte line the L2 fetches for a 4-byte word it will not see again
+    const hipError_t ev = ix->visited_uncached ? hipExtMallocWithFlags(reinterpret_cast<void **>(&nv), (size_t)slots * vwords * 4,
+                                                                       ix->visited_uncached == 2 ? hipDeviceMallocFinegrained : hipDeviceMallocUncached)
+                                               : hipMalloc(&nv, (size_t)slots * vwords * 4);
+    if (ev != hipSuccess || hipMalloc(&ne, (size_t)slots * 4) != hipSuccess) {
         (void)hipGetLastError();
         if (nv) (void)hipFree(nv);
         return set_error(RG_ERR_OOM, "no room for the visited words of the exact form");
@@ -1254,6 +1259,18 @@ rg_status rg_index_set(rg_index *ix, const char *name, int value) {
     else if (!strcmp(name, "log_cap")) ix->log_cap_knob = value;
     else if (!strcmp(name, "log_budget_kb")) ix->log_budget_kb = value;
     else if (!strcmp(name, "visited_budget_kb")) ix->visited_budget_kb = value;
+    else if (!strcmp(name, "visited_uncached")) {
+        if (value != ix->visited_uncached) {      // contexts re-allocate their words on the next exact-words launch
+            std::lock_guard<std::mutex> lk(ix->mu);
+            for (rg::SearchCtx *c : ix->ctxs) {
+                if (c->d_visited) (void)hipFree(c->d_visited);
+                if (c->d_epoch) (void)hipFree(c->d_epoch);
+                c->d_visited = c->d_epoch = nullptr;
+                c->slots = 0;
+            }
+        }
+        ix->visited_uncached = value;
+    }
     else if (!strcmp(name, "query_in_lds")) ix->query_in_lds = value != 0;
     else if (!strcmp(name, "exact_filter")) ix->exact_filter = value != 0;
     else if (!strcmp(name, "lookahead")) ix->lookahead = value;
