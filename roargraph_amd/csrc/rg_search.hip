@@ -72,6 +72,7 @@ __global__ void __launch_bounds__(1024) rg_distinct_kernel(const uint32_t *qlog,
         if (tid == 0) s_cnt = 0;
         __syncthreads();
         const uint32_t n = qlog_n[q];
+        if (n & 0x80000000u) continue;       // counted by the wave that ran the query (K1, narrow beams): out_cmps[q] is final
         if (tid == 0) s_fail = n > logcap ? 1u : 0u;
         uint32_t mine = 0;
         if (n <= logcap && n > 0) {
@@ -206,7 +207,7 @@ __global__ void rg_log_mark_kernel(const uint32_t *__restrict__ qlog, uint32_t l
                                    uint32_t *__restrict__ bitmap, unsigned long long *__restrict__ total, uint32_t *__restrict__ row_counts) {
     unsigned long long mine = 0;
     for (uint32_t q = blockIdx.x; q < nq; q += gridDim.x) {
-        const uint32_t n = min(qlog_n[q], logcap);
+        const uint32_t n = min(qlog_n[q] & 0x7fffffffu, logcap);      // (top bit: counted inside K1)
         const uint32_t *log = qlog + (size_t)q * logcap;
         for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) {
             const uint32_t id = log[i];
@@ -652,7 +653,7 @@ static unsigned long long *g_prof_buf = nullptr;   // [nq][16], set through rg_p
 static rg_status launch_k1(rg_index *ix, SearchCtx *cx, int mode, const float *d_q, uint32_t nq, uint32_t qstride, uint32_t k,
                            uint32_t L, uint32_t *d_ids, float *d_dists, uint32_t *d_cmps, uint32_t *d_hops,
                            const uint32_t *qlist, bool with_log, unsigned long long *d_status, hipStream_t s,
-                           const BuildOut *bp = nullptr, uint32_t qbase = 0) {
+                           const BuildOut *bp = nullptr, uint32_t qbase = 0, unsigned long long *d_totals = nullptr) {
     // rows in flight per query: two passes of four pay on graphs with many fresh neighbours per hop (measured: +4 % at
     // out-degree 40, -4 % at 16, where the extra staging only costs resident queries)
     // A batch that leaves most wave slots empty is latency bound per query: LDS is plentiful then, so each query keeps
@@ -703,7 +704,7 @@ static rg_status launch_k1(rg_index *ix, SearchCtx *cx, int mode, const float *d
     // plain-load tests spare the write-back of every word a returning atomic touches without changing, its two small
     // reads per hop travel under the inserts and the pop -- but it issues more memory instructions per hop); 0 = never;
     // 1 = always; 2 = always, without the early guess of the next adjacency row
-    const bool look_wanted = ix->lookahead > 0 || (ix->lookahead < 0 && L >= 1200);
+    const bool look_wanted = ix->lookahead > 0 || (ix->lookahead < 0 && L >= 1200 && dimc_of(ix) == 200);   // (measured at d = 200 only)
     if (mode == 0 && look_wanted && !ix->adj_dups && !ix->multi_expand && !bf && !bp && ix->diag == 0 &&
         ((c.dimc == 200 && R >= 2) || (c.dimc == 512 && (R == 2 || R == 4))))
         c.vis = 2;
@@ -759,6 +760,22 @@ static rg_status launch_k1(rg_index *ix, SearchCtx *cx, int mode, const float *d
     // reference's)
     P.spec = (ix->multi_expand && !bp) ? 2u : 0u;
     P.look = ix->lookahead == 2 ? 0u : 1u;
+    // In-kernel exact distinct count (rg_search_kernel.h: wave_distinct_half): beams up to "count_in_k1" wide (default 150)
+    // log a few thousand ids per query, which the wave counts itself at the end of the query -- at L_pq = 50 K4 was 0.13 of
+    // a 3.25 ms step and started only when the last query of K1 had finished.  The table takes the LDS from the merge
+    // scratch on (beam, log line, filter): the largest power of two of words whose buckets + side table fit; remainders
+    // must fit 15 bits (indexes of up to 2^(tbits + 13) nodes).
+    P.count_tbits = 0;
+    P.totals = d_totals;
+    if (with_log && d_totals && !qlist && !bp && ix->count_in_k1 != 0 && L <= (uint32_t)(ix->count_in_k1 < 0 ? 150 : ix->count_in_k1) &&
+        ix->count_table_auto && !ix->count_full_ids && ix->log_cap_knob <= 0) {
+        const size_t fixed = (size_t)P.stage_total * 4 + (dimc_of(ix) ? 0 : (size_t)ix->dim * 4) + 2 * kCand * 4;   // in front of the merge scratch
+        const size_t region = lds > fixed ? lds - fixed : 0;
+        uint32_t tb = 0;
+        for (uint32_t t = 8; t <= 13; ++t)
+            if (((size_t)4 << t) + ((size_t)4 << (t - 3)) <= region) tb = t;
+        if (tb >= 8 && id_bits_of(ix->nd) <= tb - 2 + 15) P.count_tbits = tb;
+    }
     P.id_mask = (ix->ell_tagged && !bp) ? 0x00ffffffu : 0xffffffffu;
     P.vf_min_indeg = (uint32_t)std::max(0, std::min(255, ix->filter_min_indeg));
 #ifdef RG_K1_PROF
@@ -888,7 +905,7 @@ static rg_status search_dev(rg_index *ix, SearchCtx *cx, const float *d_q, uint3
         if (q0) (void)hipMemsetAsync(b->d_ovf + 1, 0, 4, s);   // K4 work counter; the overflow count keeps running
         st = launch_k1(ix, cx, 1, d_q + (size_t)q0 * qstride, nqc, qstride, k, L, d_ids ? d_ids + (size_t)q0 * k : nullptr,
                        d_dists ? d_dists + (size_t)q0 * k : nullptr, d_cmps + q0, d_hops ? d_hops + q0 : nullptr, nullptr, true,
-                       b->d_stat, s, nullptr, q0);
+                       b->d_stat, s, nullptr, q0, b->d_stat + 1);
         if (st != RG_OK) return fail(st);
         // workgroup width by table size: a few thousand ids per query want many small workgroups per CU (a 1024-thread
         // group spends its time in barriers), the full table wants the 16 waves that cover its LDS latency
@@ -1275,6 +1292,7 @@ rg_status rg_index_set(rg_index *ix, const char *name, int value) {
     else if (!strcmp(name, "exact_filter")) ix->exact_filter = value != 0;
     else if (!strcmp(name, "lookahead")) ix->lookahead = value;
     else if (!strcmp(name, "gather_form")) ix->gather_form = value;
+    else if (!strcmp(name, "count_in_k1")) ix->count_in_k1 = value;
     else if (!strcmp(name, "filter_min_indeg")) ix->filter_min_indeg = value;
     else if (!strcmp(name, "multi_expand")) ix->multi_expand = value;
     else if (!strcmp(name, "split_rows")) ix->split_rows = value != 0;

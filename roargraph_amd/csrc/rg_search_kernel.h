@@ -83,6 +83,11 @@ struct SearchParams {
     // filter only spends entries on nodes whose in-degree reaches vf_min_indeg: the others are never remembered (and at
     // worst scored again the few times they are met again) -- same results, more of the filter for the nodes that return.
     uint32_t id_mask, vf_min_indeg;
+    // in-kernel exact distinct count (round 3): narrow beams log a few thousand ids per query, which the wave that ran the
+    // query can count itself when the query is over, in the LDS its beam and filter no longer need (K4's bucketed set,
+    // count_tbits = log2 of its table words; 0 = off: K4 counts).  qlog_n[q] then carries kCountedBit and K4 skips the query.
+    uint32_t count_tbits;
+    unsigned long long *totals;   // [2] evaluations performed / distinct nodes of the queries counted here (as K4 reports them)
     uint32_t look;            // VIS = 2: 1 = fetch the predicted next pop's adjacency row and visited words early, 0 = no speculation
 #ifdef RG_K1_PROF
     unsigned long long *prof; // instrumented build only: [nq][16] per-phase cycle sums and event counts
@@ -366,6 +371,74 @@ __device__ __forceinline__ void beam_insert(Beam &bm, float cd, uint32_t cid, bo
     RG_PROF_M(1);
 }
 
+constexpr uint32_t kCountedBit = 0x80000000u;   // qlog_n[q]: the distinct count of the query's log is already in out_cmps[q]
+
+// Exact number of DISTINCT ids among log[0, n) -- one wave, K4's half-word bucket set (rg_distinct_kernel<true>,
+// rg_search.hip) over `tab`: T = 2^tbits words of 8-slot buckets (16-bit remainders of the bijective hash id * odd mod
+// 2^id_bits, bucket = its top bits) + T/8 words of exact side table for ids whose bucket is full; logs above 5T/4 ids are
+// counted in hash partitions.  fail = the side table filled up (the query is then left to K4).
+__device__ __forceinline__ uint32_t wave_distinct_half(const uint32_t *__restrict__ log, uint32_t n, uint32_t *tab, uint32_t tbits,
+                                                       uint32_t id_bits, int lane, bool &fail) {
+    const uint32_t T = 1u << tbits, bbits = tbits - 2u, OV = T / 8u;
+    uint32_t *side = tab + T;
+    const uint32_t cap = (T / 4u) * 5u;
+    const uint32_t rbits = id_bits - bbits, hmask = id_bits >= 32u ? 0xffffffffu : (1u << id_bits) - 1u;
+    const uint32_t parts = (n + cap - 1u) / cap;
+    uint32_t mine = 0;
+    bool bad = false;
+    for (uint32_t p = 0; p < parts; ++p) {
+        for (uint32_t i = (uint32_t)lane * 4u; i < T + OV; i += kWave * 4u) *reinterpret_cast<uint4 *>(tab + i) = make_uint4(~0u, ~0u, ~0u, ~0u);
+        lds_fence();
+        for (uint32_t i0 = (uint32_t)lane; i0 < n; i0 += kWave * 4u) {
+            uint32_t v[4];   // four independent loads in flight, then the inserts
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t i = i0 + (uint32_t)u * kWave;
+                v[u] = i < n ? __hip_atomic_load(log + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;   // from the L2: the wave's own stores
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t id = v[u];
+                if (id == 0xffffffffu) continue;
+                if (parts > 1u && ((id * 0x85EBCA6Bu) >> 16) % parts != p) continue;
+                const uint32_t h = (id * 0x9E3779B1u) & hmask;
+                const uint32_t b = h >> rbits, rem = h & ((1u << rbits) - 1u);
+                for (;;) {
+                    const uint4 t = *reinterpret_cast<const uint4 *>(tab + 4u * b);
+                    const uint32_t w4[4] = {t.x, t.y, t.z, t.w};
+                    int e = 8;
+                    bool found = false;
+#pragma unroll
+                    for (int k2 = 7; k2 >= 0; --k2) {
+                        const uint32_t hv = (k2 & 1) ? w4[k2 >> 1] >> 16 : w4[k2 >> 1] & 0xffffu;
+                        found |= hv == rem;
+                        if (hv == 0xffffu) e = k2;
+                    }
+                    if (found) break;
+                    if (e == 8) {   // home bucket full: exact side table of full ids
+                        uint32_t slot = (id * 0x85EBCA6Bu) >> (32u - (tbits - 3u)), probes = 0;
+                        for (;;) {
+                            const uint32_t old = atomicCAS(&side[slot], 0xffffffffu, id);
+                            if (old == 0xffffffffu) { ++mine; break; }
+                            if (old == id) break;
+                            slot = (slot + 1u) & (OV - 1u);
+                            if (++probes >= OV) { bad = true; break; }
+                        }
+                        break;
+                    }
+                    const uint32_t w = e < 2 ? t.x : e < 4 ? t.y : e < 6 ? t.z : t.w;
+                    const uint32_t nw = (e & 1) ? (w & 0x0000ffffu) | (rem << 16) : (w & 0xffff0000u) | rem;
+                    if (atomicCAS(&tab[4u * b + (uint32_t)(e >> 1)], w, nw) == w) { ++mine; break; }
+                }
+            }
+        }
+        lds_fence();
+    }
+    fail = __any(bad);
+    for (int o = 32; o; o >>= 1) mine += (uint32_t)__shfl_xor((int)mine, o, 64);
+    return mine;
+}
+
 // DIMC: 0 = any dimension (query staged in LDS), else the compile-time dimension (query in registers)
 // BF:   opt-in fast mode, NOT parity: the traversal scores a bf16 copy of the base (4 instead of 7 HBM
 //       lines per d = 200 evaluation); at the end the whole beam is re-scored with the exact fp32 routine and the k best
@@ -437,6 +510,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
 
     uint32_t *vmap = P.visited + (size_t)blockIdx.x * P.vwords;
     uint32_t epoch = EXACT ? P.slot_epoch[blockIdx.x] : 0u;
+    unsigned long long tot_n = 0, tot_d = 0;   // in-kernel distinct count: this slot's share of the batch totals
 
     for (;;) {
         uint32_t qi = 0;
@@ -968,12 +1042,32 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
             for (int i = 0; i < 4; ++i) P.prof[(size_t)qi * 24 + 16 + i] = pf_m[i];
         }
 #endif
+        uint32_t logn_out = logn;
+        if (VIS == 1 && qlog && P.count_tbits && logn <= P.logcap && logn > 0 && !cmps_only && !build) {
+            // the query is over: its log is complete (the tail stores above included) and the LDS from the merge scratch on
+            // -- beam, log line, filter -- is free until the next query initialises it
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            lds_fence();
+            bool bad = false;
+            const uint32_t distinct = wave_distinct_half(qlog, logn, mscr, P.count_tbits, max(P.id_bits, P.count_tbits - 1u), lane, bad);
+            if (!bad) {
+                cmps = distinct;                 // the reference's cmps (:2397 counts every node once)
+                logn_out = logn | kCountedBit;
+                tot_n += logn;
+                tot_d += distinct;
+            }
+            lds_fence();
+        }
         if (lane == 0) {
             if (P.out_cmps) P.out_cmps[qi] = cmps;
             if (P.out_hops && !cmps_only) P.out_hops[qi] = hops;
-            if (VIS == 1 && P.qlog_n) P.qlog_n[qi] = logn;
+            if (VIS == 1 && P.qlog_n) P.qlog_n[qi] = logn_out;
         }
         wave_sync();
+    }
+    if (VIS == 1 && tot_n && lane == 0) {
+        atomicAdd(&P.totals[0], tot_n);
+        atomicAdd(&P.totals[1], tot_d);
     }
     if (EXACT && lane == 0) P.slot_epoch[blockIdx.x] = epoch;
 }
