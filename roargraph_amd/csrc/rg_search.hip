@@ -760,14 +760,16 @@ static rg_status launch_k1(rg_index *ix, SearchCtx *cx, int mode, const float *d
     // reference's)
     P.spec = (ix->multi_expand && !bp) ? 2u : 0u;
     P.look = ix->lookahead == 2 ? 0u : 1u;
-    // In-kernel exact distinct count (rg_search_kernel.h: wave_distinct_half): beams up to "count_in_k1" wide (default 150)
-    // log a few thousand ids per query, which the wave counts itself at the end of the query -- at L_pq = 50 K4 was 0.13 of
-    // a 3.25 ms step and started only when the last query of K1 had finished.  The table takes the LDS from the merge
-    // scratch on (beam, log line, filter): the largest power of two of words whose buckets + side table fit; remainders
-    // must fit 15 bits (indexes of up to 2^(tbits + 13) nodes).
+    // In-kernel exact distinct count (rg_search_kernel.h: wave_distinct_half): beams up to "count_in_k1" wide (default 40)
+    // log a thousand or two ids per query, which the wave counts itself at the end of the query; K4 then finds nothing to
+    // do.  Measured on the 10M bench index (profiles/r03/k1_ab_box11.jsonl, % of 8 TB/s, K4 -> in-kernel): 81.6 -> 83.4 at
+    // L_pq = 20 (the sweep's 10 - 40 points gain 3 - 4 %: a separate launch and its tail weigh most where a step takes a
+    // millisecond or two), level at 50 - 60, 1 - 2 % behind from 80 up (one wave's CAS chains against K4's full workgroups).
+    // The table takes the LDS from the merge scratch on (beam, log line, filter): the largest power of two of words whose
+    // buckets + side table fit; remainders must fit 15 bits (indexes of up to 2^(tbits + 13) nodes).
     P.count_tbits = 0;
     P.totals = d_totals;
-    if (with_log && d_totals && !qlist && !bp && ix->count_in_k1 != 0 && L <= (uint32_t)(ix->count_in_k1 < 0 ? 150 : ix->count_in_k1) &&
+    if (with_log && d_totals && !qlist && !bp && ix->count_in_k1 != 0 && L <= (uint32_t)(ix->count_in_k1 < 0 ? 40 : ix->count_in_k1) &&
         ix->count_table_auto && !ix->count_full_ids && ix->log_cap_knob <= 0) {
         const size_t fixed = (size_t)P.stage_total * 4 + (dimc_of(ix) ? 0 : (size_t)ix->dim * 4) + 2 * kCand * 4;   // in front of the merge scratch
         const size_t region = lds > fixed ? lds - fixed : 0;

@@ -164,7 +164,7 @@ def test_exact_words_on_rows_with_repeats_and_long_rows(rg, oracle, lookahead):
 @pytest.mark.parametrize("metric,d,nb", [("ip", 200, 4000), ("l2", 24, 3000), ("l2", 512, 2000)])
 @pytest.mark.parametrize("count_in_k1", [-1, 0, 1000])
 def test_distinct_count_inside_k1(rg, oracle, metric, d, nb, count_in_k1):
-    """Default visited mode: beams up to "count_in_k1" wide (default 150) count the distinct ids of their log inside K1, at the
+    """Default visited mode: beams up to "count_in_k1" wide (default 40) count the distinct ids of their log inside K1, at the
     end of each query (K4's bucket set in the LDS the beam and the filter no longer need, hash partitions when the log is
     longer than the table); wider beams -- or the knob at 0 -- leave the count to K4.  cmps is the reference's either way,
     with a forgetful filter that makes re-scored nodes plentiful."""
@@ -173,7 +173,7 @@ def test_distinct_count_inside_k1(rg, oracle, metric, d, nb, count_in_k1):
     ix.set("count_in_k1", count_in_k1)
     for flt in (0, 5):
         ix.set("filter_log2", flt)
-        for L, k in ((10, 10), (60, 10), (150, 100), (151, 10), (700, 10)):
+        for L, k in ((10, 10), (40, 10), (41, 10), (150, 100), (700, 10)):
             got = ix.SearchRoarGraph(q, k, L)
             want = oracle.search(base, metric, off, nbrs, ep, q, k, L, nthreads=4)
             assert (got[2] == want[2]).all(), ("cmps", L, flt)
