@@ -240,6 +240,28 @@ class Searcher:
                 "distinct_batches": len(used), "GBps": gbps, "pct_of_8000": 100.0 * gbps / 8000.0, "pct_of_6290": 100.0 * gbps / 6290.0}
 
 
+MALL_ROWS = 349525      # rows of 768 B the 256-MiB Infinity Cache can hold
+
+
+def reuse_of_last_launch(torch, index, stream, nb, nq, dev, full=False):
+    """First touches and popularity of the rows the last default-mode launch on `stream` read (rg_search_reuse_stats over its
+    id logs); None when that launch ran on the exact words (no logs)."""
+    try:
+        counts = torch.zeros(nb, dtype=torch.int32, device=dev)
+        ev_n, dr_n = index.reuse_stats(stream, counts)
+    except Exception:  # noqa: BLE001
+        return None
+    srt = torch.sort(counts, descending=True).values.double()
+    cum = torch.cumsum(srt, 0) / max(float(ev_n), 1.0)
+    out = {"distinct_rows_frac": dr_n / max(ev_n, 1), "share_of_reads_to_top_%d_rows" % MALL_ROWS: float(cum[min(MALL_ROWS, nb) - 1].item())}
+    if full:
+        out.update({"evaluations_performed": ev_n, "distinct_rows": dr_n,
+                    # popularity: share of the launch's row reads that go to its H most read rows (H rows = H x 768 B)
+                    "share_of_reads_to_top_rows": {str(h): float(cum[min(h, nb) - 1].item()) for h in (64, 1024, 16384, 131072, MALL_ROWS, 1048576)},
+                    "rows_read_by_every_query": int((counts >= nq).sum().item())})
+    return out
+
+
 def self_launch(args):
     """`python bench.py --gpus N` with no launcher around it: N ranks of this script under torch.distributed.run, one per
     GPU, rendezvous on 127.0.0.1 (the container's hostname may not resolve)."""
@@ -427,7 +449,14 @@ def main():
     sweep = []
     for L in sweep_Ls:
         ms, used = S.timed(L, reps=3 if L <= 500 else 2)
-        sweep.append(S.point(L, ms, used))
+        pt = S.point(L, ms, used)
+        if args.visited == 2 and rank == 0:
+            # what explains a point above the 6.29 TB/s streaming-copy ceiling: how few of the launch's row reads are first
+            # touches, and how many go to rows a 256-MiB cache could hold (null: the launch ran on the exact words)
+            ru = reuse_of_last_launch(torch, index, stream, args.nb, args.nq, dev)
+            pt["distinct_rows_frac"] = ru["distinct_rows_frac"] if ru else None
+            pt["share_of_reads_to_rows_a_256MiB_cache_can_hold"] = ru["share_of_reads_to_top_%d_rows" % MALL_ROWS] if ru else None
+        sweep.append(pt)
     if args.L > 0:
         L_star = args.L
     else:
@@ -475,18 +504,7 @@ def main():
     # first touches: distinct base rows among the evaluations of one launch (the id logs of the default visited mode)
     reuse = None
     if args.visited == 2:
-        try:
-            counts = torch.zeros(args.nb, dtype=torch.int32, device=dev)
-            ev_n, dr_n = index.reuse_stats(stream, counts)
-            srt = torch.sort(counts, descending=True).values.double()
-            cum = torch.cumsum(srt, 0) / max(float(ev_n), 1.0)
-            reuse = {"evaluations_performed": ev_n, "distinct_rows": dr_n, "distinct_rows_frac": dr_n / max(ev_n, 1),
-                     # popularity: share of the launch's row reads that go to its H most read rows (H rows = H x 768 B)
-                     "share_of_reads_to_top_rows": {str(h): float(cum[min(h, args.nb) - 1].item()) for h in (64, 1024, 16384, 131072, 349525, 1048576)},
-                     "rows_read_by_every_query": int((counts >= args.nq).sum().item())}
-            del counts, srt, cum
-        except Exception as e:  # noqa: BLE001  (the launch ran on the exact words: no logs)
-            reuse = {"unavailable": str(e)}
+        reuse = reuse_of_last_launch(torch, index, stream, args.nb, args.nq, dev, full=True) or {"unavailable": "the launch ran on the exact words: no id logs"}
     ids_head = S.out[0]["ids"].cpu().numpy().view(np.uint32).copy()
     # the exact HBM-visited form returns the same bits (parity between the two exact forms, checked every run)
     if args.visited != 0:
@@ -635,11 +653,25 @@ def main():
         shard = base[lo:hi]
         native = world == 1 or args.backend == "nccl"
         gt_batch = 65536
+        if native and world > 1:     # every rank must be able to join the RCCL communicator, or none takes the native path
+            ok = torch.tensor([1], dtype=torch.int32, device=cdev)
+            try:
+                comm = groundtruth.Comm.from_torch_dist(local)
+            except Exception as e:  # noqa: BLE001
+                print("[bench] rank %d: native ground-truth path unavailable (%r): torch.distributed form instead" % (rank, e), file=sys.stderr)
+                comm = None
+                ok[0] = 0
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                if comm is not None:
+                    comm.destroy()
+                native = False
+        elif native:
+            comm = groundtruth.Comm.local([local])[0]
         if native:
             nq_gt = max(args.gt_nq, 4 * gt_batch) if args.gt_nq >= gt_batch else args.gt_nq
             gq_h = (torch.empty((nq_gt, args.dim), dtype=torch.float32, device=dev).normal_(generator=g) * 0.5 + 0.3).cpu().numpy()
             out_i = np.zeros((nq_gt, args.gt_K), np.uint32); out_d = np.zeros((nq_gt, args.gt_K), np.float32)
-            comm = groundtruth.Comm.from_torch_dist(local) if world > 1 else groundtruth.Comm.local([local])[0]
             # warm-up: a small call (allocations, module load, communicator), then one batch of the timed size -- the leg
             # follows half a minute of CPU-only baselines, and the first seconds of MFMA work after that idle run slower
             groundtruth.groundtruth_rank(comm, shard, lo, gq_h[:4096], args.metric, args.gt_K, out_i[:4096], out_d[:4096], batch=2048)
@@ -727,14 +759,18 @@ def main():
                          "kernel": "rg_search_kernel (+ rg_distinct_kernel in visited mode 2)", "kernel_ms_avg": kavg * 1e3,
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "frac_of_measured_stream_ceiling_6290": achieved / 6290.0,
-                         # how much of `achieved` HBM itself had to serve: the share of a launch's row reads that are FIRST
-                         # touches of a row within the launch (rg_search_reuse_stats over the id logs); the rest re-reads rows
-                         # other queries of the same launch read moments earlier (the neighbourhood of the entry point)
-                         # and can come from the L2s / Infinity Cache.  hbm_frac_floor = frac x that share; the cache
-                         # counters of the same command are in profiles/r03/ (TCC hit rate, FETCH_SIZE calibration).
+                         # how much of `achieved` HBM itself had to serve.  distinct_rows_frac: the share of a launch's row reads
+                         # that are FIRST touches of a row within the launch (rg_search_reuse_stats over the id logs); the rest
+                         # re-reads rows other queries of the same launch read moments earlier (the neighbourhood of the entry
+                         # point), which the Infinity Cache can serve -- FETCH_SIZE counts those reads, no counter separates them.
                          "distinct_rows_frac": reuse.get("distinct_rows_frac") if reuse else None,
-                         "cache_served_frac_ceiling": (1.0 - reuse["distinct_rows_frac"]) if reuse and "distinct_rows_frac" in reuse else None,
-                         "hbm_frac_floor": (achieved / 8000.0 * reuse["distinct_rows_frac"]) if reuse and "distinct_rows_frac" in reuse else None,
+                         # cache_served_frac_ceiling: the share of the launch's reads that go to its 349,525 most read rows --
+                         # what a 256-MiB cache can hold; no cache of that size could have served more.  hbm_frac_floor =
+                         # frac x (1 - that): the part of the algorithmic rate HBM itself certainly delivered.  The counters
+                         # of the same command (L2 hit rate 6.6 %, FETCH_SIZE calibrated x2.000) are in profiles/r03/.
+                         "cache_served_frac_ceiling": reuse.get("share_of_reads_to_top_%d_rows" % MALL_ROWS) if reuse else None,
+                         "hbm_frac_floor": (achieved / 8000.0 * (1.0 - reuse["share_of_reads_to_top_%d_rows" % MALL_ROWS]))
+                         if reuse and ("share_of_reads_to_top_%d_rows" % MALL_ROWS) in reuse else None,
                          "reuse": reuse,
                          "replay_same_batch": {"what": "the same launch replaying ONE batch back to back (round 2's protocol): the rows of "
                                                        "the previous launch are still in the Infinity Cache; not `value`",

@@ -214,6 +214,8 @@ def test_bench_one_gpu_small_run_reports_every_block():
     assert d["n_gpus"] == 1 and d["config"]["distinct_query_batches"] == 6
     rf = d["roofline"]
     assert 0.0 < rf["frac"] and rf["distinct_rows_frac"] is not None and 0.0 < rf["distinct_rows_frac"] <= 1.0
+    assert 0.0 < rf["cache_served_frac_ceiling"] <= 1.0 and rf["hbm_frac_floor"] is not None
+    assert all("distinct_rows_frac" in p for p in d["L_pq_sweep"])
     assert rf["replay_same_batch"]["kernel_ms_avg"] > 0
     cb = d["cpu_baseline"]
     assert cb["value"] > 0 and (cb["kind"] != "reference" or cb["value_without_prefetch"] > 0)
