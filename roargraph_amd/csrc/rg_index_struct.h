@@ -106,6 +106,7 @@ struct rg_index {
     bool ell_tagged = false;     // ELL neighbour words carry min(255, in-degree) in their top byte (nd <= 2^24)
     int filter_min_indeg = 2;    // knob: the LDS visited filter keeps entries only for nodes of at least this in-degree (a node of in-degree 1 is
                                  // met once per query at most: remembering it is wasted; larger thresholds gain about 1 % on the bench index)
+    bool log_early = true;       // knob: the id-log store of a hop leaves right behind the row loads (rg_search_kernel.h: expand)
     int count_in_k1 = -1;        // knob: beams up to this wide count their distinct ids inside K1 (-1 = 40, 0 = never: K4 counts)
     int gather_form = -1;        // register-staged K1: 0 = 16-byte loads + LDS bounce, otherwise compute-layout loads where instantiated
     int lookahead = -1;          // mode 0, knob "lookahead": -1 = automatic (by beam width), 0 = returning atomics, 1 = look-ahead form, 2 = look-ahead

@@ -760,6 +760,7 @@ static rg_status launch_k1(rg_index *ix, SearchCtx *cx, int mode, const float *d
     // reference's)
     P.spec = (ix->multi_expand && !bp) ? 2u : 0u;
     P.look = ix->lookahead == 2 ? 0u : 1u;
+    P.log_early = ix->log_early ? 1u : 0u;
     // In-kernel exact distinct count (rg_search_kernel.h: wave_distinct_half): beams up to "count_in_k1" wide (default 40)
     // log a thousand or two ids per query, which the wave counts itself at the end of the query; K4 then finds nothing to
     // do.  Measured on the 10M bench index (profiles/r03/k1_ab_box11.jsonl, % of 8 TB/s, K4 -> in-kernel): 81.6 -> 83.4 at
@@ -1295,6 +1296,7 @@ rg_status rg_index_set(rg_index *ix, const char *name, int value) {
     else if (!strcmp(name, "lookahead")) ix->lookahead = value;
     else if (!strcmp(name, "gather_form")) ix->gather_form = value;
     else if (!strcmp(name, "count_in_k1")) ix->count_in_k1 = value;
+    else if (!strcmp(name, "log_early")) ix->log_early = value != 0;
     else if (!strcmp(name, "filter_min_indeg")) ix->filter_min_indeg = value;
     else if (!strcmp(name, "multi_expand")) ix->multi_expand = value;
     else if (!strcmp(name, "split_rows")) ix->split_rows = value != 0;

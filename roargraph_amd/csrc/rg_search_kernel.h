@@ -88,6 +88,7 @@ struct SearchParams {
     // count_tbits = log2 of its table words; 0 = off: K4 counts).  qlog_n[q] then carries kCountedBit and K4 skips the query.
     uint32_t count_tbits;
     unsigned long long *totals;   // [2] evaluations performed / distinct nodes of the queries counted here (as K4 reports them)
+    uint32_t log_early;       // VIS = 1: the id-log store of a hop is issued right behind the row loads (else after the scoring)
     uint32_t look;            // VIS = 2: 1 = fetch the predicted next pop's adjacency row and visited words early, 0 = no speculation
 #ifdef RG_K1_PROF
     unsigned long long *prof; // instrumented build only: [nq][16] per-phase cycle sums and event counts
@@ -642,7 +643,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
         //    once only the loads of the passes issued after it are still outstanding.
         // `hook` runs once, right behind the load instructions of the first batch (the look-ahead form issues its early
         // visited-word loads there: behind the rows in the memory queue, ahead of the first wait)
-        auto gather_list = [&](uint32_t n, auto hook) __attribute__((always_inline)) {
+        auto gather_list = [&](uint32_t n, auto hook, auto hooked) __attribute__((always_inline)) {
             const uint32_t npass = (n + 3u) >> 2;
             if constexpr (DIMC != 0 && !BF) {
                 typedef v4f_t v4f;
@@ -696,7 +697,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
                         }
                     }
                 };
-                if constexpr (LOOK) {
+                if constexpr (decltype(hooked)::value) {
                     batch(0u, std::true_type{});
                     for (uint32_t p0 = R; p0 < npass; p0 += R) batch(p0, std::false_type{});
                 } else {
@@ -709,6 +710,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
                     const uint32_t rid = c < n ? cand_id[c] : 0u;
                     issue(rid, c < n, stage + (size_t)p * P.stage_floats);
                 }
+                if constexpr (decltype(hooked)::value) hook();
                 for (uint32_t p = 0; p < npass; ++p) {
                     const uint32_t last = min(npass, p + (uint32_t)R) - 1u;
                     if constexpr (DIMC != 0) {
@@ -739,7 +741,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
         if constexpr (DIMC != 0 && !BF) {
             if (lane == 0) { cand_id[0] = P.ep; cand_x[0] = P.ep_tail; }
             lds_fence();
-            gather_list(1, no_hook);
+            gather_list(1, no_hook, std::false_type{});
             epd = __uint_as_float(cand_x[0]);
             lds_fence();
         } else {
@@ -802,8 +804,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
                 log_append(0, n);
                 cmps += n;                                                 // :2397
                 RG_PROF(2);
-                gather_list(n, no_hook);
-                log_flush();
+                // the id-log line of this hop leaves BEHIND the row loads (knob "log_early", default): a store issued after the
+                // gather has been consumed sits in front of the next hop's adjacency load in the in-order memory counter and
+                // puts its write acknowledgement on that load's wait; behind the row loads it is covered by the gather's own wait
+                if (VIS == 1 && P.log_early) gather_list(n, [&]() __attribute__((always_inline)) { log_flush(); }, std::true_type{});
+                else {
+                    gather_list(n, no_hook, std::false_type{});
+                    log_flush();
+                }
                 // queue inserts (:2398)
                 const float cd = (uint32_t)lane < n ? __uint_as_float(cand_x[lane]) : 0.0f;
                 const uint32_t cid = (uint32_t)lane < n ? cand_id[lane] : 0u;
@@ -892,7 +900,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
                 const bool guess = ev && P.look == 1u;
                 if (guess) { ea = row_a(en); eb = row_b(en); etoff = P.tail_off ? P.tail_off[en] : 0u; }
                 RG_PROF(2);
-                if (n) gather_list(n, no_hook);
+                if (n) gather_list(n, no_hook, std::false_type{});
                 // the candidates, one per lane and chunk of 64
                 const bool cvA = (uint32_t)lane < n, cvB = 64u + (uint32_t)lane < n;
                 const float cdA = cvA ? __uint_as_float(cand_x[lane]) : 0.0f, cdB = cvB ? __uint_as_float(cand_x[64 + lane]) : 0.0f;
@@ -966,7 +974,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
                     cmps += nA + nB;
                     RG_PROF_CNT(0, 2); RG_PROF_CNT(1, nA + nB);
                     RG_PROF(2);
-                    if (nA + nB) gather_list(nA + nB, no_hook);
+                    if (nA + nB) gather_list(nA + nB, no_hook, std::false_type{});
                     log_flush();
                     const float cdA = (uint32_t)lane < nA ? __uint_as_float(cand_x[lane]) : 0.0f, cdB = (uint32_t)lane < nB ? __uint_as_float(cand_x[nA + lane]) : 0.0f;
                     const uint32_t ciA = (uint32_t)lane < nA ? cand_id[lane] : 0u, ciB = (uint32_t)lane < nB ? cand_id[nA + lane] : 0u;
