@@ -100,6 +100,27 @@ def projection_ep(base, dim=None):
                                        C.c_uint(dim if dim is not None else base.shape[1])))
 
 
+def build_roargraph(base, knn_ids, metric, M_sq=100, M_pjbp=35, L_pjpq=500, dim=None):
+    """rgo_build_roargraph: the reference's one-thread BuildRoarGraph restated (oracle/rg_oracle_build.c).
+    Returns (offsets u64[nb+1], nbrs u32[], ep)."""
+    base = np.ascontiguousarray(base, np.float32)
+    knn_ids = np.ascontiguousarray(knn_ids, np.uint32)
+    nb, stride = base.shape
+    ep = C.c_uint32()
+    po, pn = C.c_void_p(), C.c_void_p()
+    rc = lib().rgo_build_roargraph(_p(base), C.c_size_t(stride), C.c_uint32(nb), C.c_uint(dim or stride), METRIC[metric], _p(knn_ids),
+                                   C.c_uint32(knn_ids.shape[0]), C.c_uint32(knn_ids.shape[1]), C.c_uint32(M_sq), C.c_uint32(M_pjbp),
+                                   C.c_uint32(L_pjpq), C.byref(ep), C.byref(po), C.byref(pn))
+    if rc != 0:
+        raise RuntimeError(lib().rgo_last_error().decode())
+    off = np.ctypeslib.as_array(C.cast(po, C.POINTER(C.c_uint64)), shape=(nb + 1,)).copy()
+    ne = int(off[-1])
+    nbrs = np.ctypeslib.as_array(C.cast(pn, C.POINTER(C.c_uint32)), shape=(max(ne, 1),)).copy()[:ne]
+    lib().rgo_free(po)
+    lib().rgo_free(pn)
+    return off, nbrs, ep.value
+
+
 def ref_projection_ep(base):
     """The same loops compiled with the reference's Release flags (oracle/_ref/rg_ref ep)."""
     base = np.ascontiguousarray(base, np.float32)

@@ -96,6 +96,14 @@ void rgo_normalize_rows(float *data, size_t n, size_t stride, unsigned d);   /* 
 /* f-2: CalculateProjectionep (src/index_bipartite.cpp:2004-2041): argmin squared L2 to the float centroid */
 uint32_t rgo_projection_ep(const float *base, size_t stride, uint32_t nd, unsigned d);
 
+/* f-1: BuildRoarGraph at ONE thread (src/index_bipartite.cpp:143-218, 1043-1277 and the pruning rules :1352-1940), restated
+ * sweep by sweep in rg_oracle_build.c -- a second restatement beside the product's builder, NOT a pin (the reference's
+ * translation unit cannot be compiled in this image).  knn: nq rows of knn_k base ids, best first (LoadLearnBaseKNN).
+ * Returns 0; *out_off (nb + 1 entries) and *out_nbrs are malloc'ed (rgo_free). */
+int rgo_build_roargraph(const float *base, size_t stride, uint32_t nb, unsigned d, int metric, const uint32_t *knn, uint32_t nq,
+                        uint32_t knn_k, uint32_t M_sq, uint32_t M_pjbp, uint32_t L_pjpq, uint32_t *out_ep, uint64_t **out_off,
+                        uint32_t **out_nbrs);
+
 /* a10: exact top-K ground truth (DiskANN compute_groundtruth; source absent, README.md:62-75).
  * fp64 accumulation; order: mips = score desc then id asc, l2 = dist asc then id asc.
  * dists written as +inner product for mips (test_search_bipartite.cpp:46-48), squared L2 for l2. */

@@ -1,7 +1,10 @@
 """CPU: graph construction (rg_build_roargraph, the restated BuildRoarGraph) -- a 'next' row.
 
-Parity status: UNPINNED.  The reference's build translation unit cannot be compiled under this round's rules (Boost /
-tsl headers absent, stand-ins not allowed), so these tests check properties, determinism, and one regression value.
+Parity status: UNPINNED.  The reference's build translation unit cannot be compiled under the rules (Boost / tsl headers
+absent, stand-ins not allowed).  What stands in for a pin: TWO restatements written independently from
+src/index_bipartite.cpp -- the product's builder (csrc/rg_build.cpp, with its shortcuts) and the oracle's
+(oracle/rg_oracle_build.c, sweep by sweep) -- must produce the same index byte for byte, and both reproduce the md5 of the
+index the survey's probe build of the reference wrote.  Plus properties and determinism.
 """
 import hashlib
 import os
@@ -58,6 +61,28 @@ def test_small_build_properties_and_recall(rgb, oracle):
     assert ep8 == ep and np.diff(off8.astype(np.int64)).max() <= 2 * M and oracle.recall(ids8, gt, 10) > 0.95
 
 
+@pytest.mark.parametrize("metric,nb,nt,d,knn_k,M_sq,M,L", [("ip", 4000, 1500, 64, 100, 100, 20, 200), ("l2", 3000, 1000, 32, 50, 50, 16, 100),
+                                                          ("cosine", 2500, 900, 40, 60, 40, 12, 80), ("ip", 1500, 700, 24, 30, 100, 35, 60)])
+def test_product_build_equals_oracle_build(rgb, oracle, metric, nb, nt, d, knn_k, M_sq, M, L):
+    """rg_build_roargraph at one thread against rgo_build_roargraph (the oracle's restatement of BuildRoarGraph /
+    LinkProjection / the four pruning rules, :143-218, :1043-1277, :1352-1940): entry point, offsets and neighbour lists
+    equal byte for byte -- inner product, L2, cosine (base normalised first, :176-182), fewer knn columns than M_sq, an M
+    above what the lists reach."""
+    base, train, _ = gen(nb + d, nb, nt, 10, d)
+    if metric == "l2":
+        s = ((train.astype(np.float64)[:, None, :] - base.astype(np.float64)[None, :, :]) ** 2).sum(-1)
+        knn = np.argsort(s, axis=1, kind="stable")[:, :knn_k].astype(np.uint32)
+    else:
+        knn = np_gt(train, base, knn_k)
+    base[7] = base[3]; base[11] = base[3]                                   # exact ties in distance
+    oracle.use_avx512(True)
+    want = oracle.build_roargraph(base, knn, metric, M_sq, M, L)
+    oracle.use_avx512(False)
+    got = rgb.build_roargraph(base, knn, metric, M_sq, M, L, num_threads=1)
+    assert got[2] == want[2], "entry point"
+    assert (got[0] == want[0]).all() and (got[1] == want[1]).all(), "index differs from the oracle's"
+
+
 def test_l2_build(rgb, oracle):
     base, train, query = gen(9, 3000, 1000, 80, 32)
     s = ((train.astype(np.float64)[:, None, :] - base.astype(np.float64)[None, :, :]) ** 2).sum(-1)
@@ -81,6 +106,10 @@ def test_survey_probe_regression(rgb, oracle):
     deg = np.diff(off.astype(np.int64))
     assert abs(deg.mean() - 41.9) < 0.05 and deg.max() == 70
     import tempfile
+    oracle.use_avx512(True)
+    o_off, o_nbrs, o_ep = oracle.build_roargraph(base, knn, "ip", 100, 35, 500)     # the second restatement: same bytes, same md5
+    oracle.use_avx512(False)
+    assert o_ep == ep and (o_off == off).all() and (o_nbrs == nbrs).all()
     with tempfile.TemporaryDirectory() as td:
         p = os.path.join(td, "t1.index")
         io.write_index(p, off, nbrs, ep)

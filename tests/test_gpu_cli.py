@@ -126,6 +126,29 @@ def test_gpu_assisted_build(oracle, monkeypatch):
         assert rg_ > rc - 0.03, (metric, rc, rg_)
 
 
+@pytest.mark.parametrize("metric,d,nb,M,L", [("ip", 200, 1500, 16, 120), ("l2", 64, 1200, 12, 80)])
+def test_gpu_assisted_build_one_node_at_a_time_equals_the_oracle_build(oracle, metric, d, nb, M, L):
+    """rg_build_roargraph_gpu with batch = 1 and one host thread searches, prunes and links node after node, i.e. in the
+    reference's one-thread order -- so the entry-point kernels, K1 in build mode and the occlusion-pruning kernel together
+    must produce the index of the ORACLE's build (oracle/rg_oracle_build.c, written from the reference alone), byte for
+    byte.  This is the oracle comparison of the f-1 / f-2 device pieces (the tests below compare them with the product's own
+    host code)."""
+    from roargraph_amd import build
+    rng = np.random.default_rng(nb + d)
+    r = 6
+    A = (rng.standard_normal((r, d)) / np.sqrt(r)).astype(np.float32)
+    base = (rng.standard_normal((nb, r)).astype(np.float32) @ A + 0.05 * rng.standard_normal((nb, d)).astype(np.float32))
+    base[rng.integers(0, nb, 60)] = base[rng.integers(0, nb, 60)]            # exact duplicates: ties in distance
+    train = ((0.3 + 0.5 * rng.standard_normal((600, r))).astype(np.float32) @ A).astype(np.float32)
+    knn, _, _ = oracle.groundtruth_f64(base, train, metric, 60, nthreads=16)
+    oracle.use_avx512(True)
+    want = oracle.build_roargraph(base, knn, metric, 60, M, L)
+    oracle.use_avx512(False)
+    got = build.build_roargraph(base, knn, metric, 60, M, L, num_threads=1, device=0, batch=1)
+    assert got[2] == want[2], "entry point"
+    assert (got[0] == want[0]).all() and (got[1] == want[1]).all(), "GPU-assisted build differs from the oracle's"
+
+
 @pytest.mark.parametrize("metric,d,M,L", [("ip", 200, 35, 500), ("l2", 512, 24, 150), ("ip", 104, 12, 100), ("l2", 200, 35, 300),
                                           ("ip", 200, 24, 600)])   # the last: lists longer than the kernel sorts -> host pruning
 def test_gpu_pruning_equals_host_pruning(oracle, monkeypatch, metric, d, M, L):
