@@ -71,7 +71,7 @@ def test_config5_d512_ip_end_to_end(oracle, gpu_build):
 
 def test_config2_10m_x_200_parity_sample(oracle):
     """10M x 200 IP, top-10, L_pq = 500: 256 queries of a 4,096-query batch, every output against the oracle run on the
-    same full-size inputs.  The adjacency mixes uniformly random edges with edges to nearby ids, so that nodes are met
+    same full-size inputs (and, round 3, L_pq = 2000: 48 queries of a 1,024-query batch in every form of the visited set).  The adjacency mixes uniformly random edges with edges to nearby ids, so that nodes are met
     again and again (the LDS filter forgets, the id log + exact distinct count has work to do) -- a random graph alone
     never revisits anything at this size."""
     import torch
@@ -96,6 +96,17 @@ def test_config2_10m_x_200_parity_sample(oracle):
         cm = torch.zeros(nq, dtype=torch.int32, device=dev); hp = torch.zeros(nq, dtype=torch.int32, device=dev)
         ix.search_dev(q, k, L, ids, ds, cm, hp); ix.search_wait()
         outs[vis] = tuple(x.cpu().numpy() for x in (ids, ds, cm, hp))
+    # round 3: a wide beam at full size -- the look-ahead form of the exact words (automatic from L_pq = 1200), the returning
+    # atomics, and the filter + log form, 1,024 queries each at L_pq = 2000
+    L2, nq2, ns2 = 2000, 1024, 48
+    wide = {}
+    for name, knobs in (("look", {"visited": 0, "lookahead": 1}), ("atomics", {"visited": 0, "lookahead": 0}), ("log", {"visited": 2, "lookahead": -1})):
+        for kn, v in knobs.items():
+            ix.set(kn, v)
+        ids = torch.zeros((nq2, k), dtype=torch.int32, device=dev); ds = torch.zeros((nq2, k), device=dev)
+        cm = torch.zeros(nq2, dtype=torch.int32, device=dev); hp = torch.zeros(nq2, dtype=torch.int32, device=dev)
+        ix.search_dev(q[:nq2], k, L2, ids, ds, cm, hp); ix.search_wait()
+        wide[name] = tuple(x.cpu().numpy() for x in (ids, ds, cm, hp))
     ix.close()
     hb, hq = base.cpu().numpy(), q[:ns].cpu().numpy()
     hoff, hn = off.cpu().numpy().view(np.uint64), nbrs.cpu().numpy().view(np.uint32)
@@ -108,6 +119,12 @@ def test_config2_10m_x_200_parity_sample(oracle):
     # the whole batch: both exact visited forms agree bit for bit
     for a, b in zip(outs[2], outs[0]):
         assert (a.view(np.uint32) == b.view(np.uint32)).all()
+    want2 = oracle.search(hb, "ip", hoff, hn, 12345, hq[:ns2], k, L2, nthreads=min(32, os.cpu_count() or 1))
+    for name in ("look", "atomics", "log"):
+        got = tuple(x[:ns2] for x in wide[name])
+        _search_equal((got[0].view(np.uint32), got[1], got[2].view(np.uint32), got[3].view(np.uint32)), want2)
+        for a, b in zip(wide[name], wide["look"]):
+            assert (a.view(np.uint32) == b.view(np.uint32)).all(), name
 
 
 def test_config4_gt_unit_norm_clustered_l2_k100(oracle):
