@@ -583,6 +583,28 @@ def main():
                 fast.append({"mode": name, "error": repr(e)})
             index.set(knob, 0)
 
+    # ---- opt-in EXACT mode (results bit-identical, checked here): the first hop scored once for the batch ----
+    shared = None
+    if rank == 0 and not args.no_fast:
+        try:
+            index.set("shared_frontier", 1)
+            rows = []
+            for L in sorted({L_star, 500}):
+                ms, used_s = S.timed(L, reps=3, settle=1)
+                p = S.point(L, ms, used_s)
+                rows.append({"L_pq": L, "qps": p["qps"], "recall_at_10": p["recall_at_10"], "mean_evals": p["mean_evals"], "pct_of_8000": p["pct_of_8000"]})
+            S.run(L_star, 0); S.wait()
+            same = (S.out[0]["ids"].cpu().numpy().view(np.uint32) == ids_head).all()
+            shared = {"mode": "shared_frontier: the entry point and its neighbours scored once per batch with the exact routine "
+                              "(rg_front_score_kernel), the first hop reads the scores -- opt-in, results bit-identical", "points": rows,
+                      "ids_equal_default": bool(same)}
+            assert same, "shared_frontier changed a result"
+        except AssertionError:
+            raise
+        except Exception as e:  # noqa: BLE001
+            shared = {"mode": "shared_frontier", "error": repr(e)}
+        index.set("shared_frontier", 0)
+
     # ---- CPU baselines on the same index and queries (rank 0, N = 1) ---------------------------------------------------
     cpu = cpu1 = cpu_cfg1 = None
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
@@ -785,6 +807,7 @@ def main():
             "host_form_pcie_inclusive": host_form,
             "two_streams_pipelined": two_streams,
             "non_parity_modes": fast,
+            "exact_opt_in_modes": shared,
             "gt_build": gt,
         }
         print(json.dumps(line), flush=True)

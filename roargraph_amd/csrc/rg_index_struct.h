@@ -59,6 +59,9 @@ struct SearchCtx {
     float *d_q = nullptr, *d_dist = nullptr;
     uint32_t *d_ids = nullptr, *d_ch = nullptr;
     size_t q_cap = 0, res_cap = 0, ch_cap = 0;
+    float *d_front = nullptr, *cur_front = nullptr;   // shared-frontier scores of the batch being enqueued ([nq][front_stride])
+    size_t front_cap = 0;
+    uint32_t front_stride = 0;
     void *h_pin = nullptr;       // pinned staging of the host form: queries up, then ids | dists | cmps | hops down
     size_t h_cap = 0;
 };
@@ -106,6 +109,9 @@ struct rg_index {
     bool ell_tagged = false;     // ELL neighbour words carry min(255, in-degree) in their top byte (nd <= 2^24)
     int filter_min_indeg = 2;    // knob: the LDS visited filter keeps entries only for nodes of at least this in-degree (a node of in-degree 1 is
                                  // met once per query at most: remembering it is wasted; larger thresholds gain about 1 % on the bench index)
+    bool shared_frontier = false;   // opt-in (knob): the first hop of a batch is scored once for all its queries (f-4, third mode; exact)
+    uint32_t *d_front_ids = nullptr;   // [front_n]: the entry point, then its neighbours in adjacency order
+    uint32_t front_n = 0;
     bool log_early = true;       // knob: the id-log store of a hop leaves right behind the row loads (rg_search_kernel.h: expand)
     int count_in_k1 = -1;        // knob: beams up to this wide count their distinct ids inside K1 (-1 = 40, 0 = never: K4 counts)
     int gather_form = -1;        // register-staged K1: 0 = 16-byte loads + LDS bounce, otherwise compute-layout loads where instantiated

@@ -225,6 +225,43 @@ __global__ void rg_bitmap_count_kernel(const uint32_t *__restrict__ bitmap, size
     if ((threadIdx.x & 63) == 0 && mine) atomicAdd(total, mine);
 }
 
+// Shared frontier (third mode; knob "shared_frontier"): out[q][c] = compare(base[ids[c]], queries[q]) for the S
+// rows every query of a batch scores first -- the entry point and its neighbours -- with the exact routine K1 and K1b use
+// (same bits).  One wave per query at a time, the query staged in LDS once, the S rows (hot in the L2s: every wave reads
+// the same 57 KB) streamed through a ring of R passes of four.
+template <bool L2, int R>
+__global__ void __launch_bounds__(64) rg_front_score_kernel(const float *__restrict__ base, uint32_t stride, uint32_t dim,
+                                                            const float *__restrict__ queries, uint32_t nq, uint32_t qstride,
+                                                            const uint32_t *__restrict__ ids, uint32_t n, float *__restrict__ out,
+                                                            uint32_t ostride, uint32_t stage_floats) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x, g = lane >> 4;
+    float *stage = reinterpret_cast<float *>(smem);
+    float *qv = stage + (size_t)R * stage_floats;
+    const uint32_t npass = (n + 3u) >> 2, lpp = loads_per_pass(dim);
+    for (uint32_t q = blockIdx.x; q < nq; q += gridDim.x) {
+        for (uint32_t i = lane; i < dim; i += kWave) qv[i] = queries[(size_t)q * qstride + i];
+        wave_sync();
+        auto issue = [&](uint32_t p, float *buf) {
+            const uint32_t c = 4 * p + g;
+            const bool act = c < n;
+            gather_issue(base + (size_t)(act ? ids[c] : 0u) * stride, dim, act, buf, lane);
+        };
+        for (uint32_t p = 0; p < (uint32_t)R && p < npass; ++p) issue(p, stage + (size_t)p * stage_floats);
+        for (uint32_t p = 0; p < npass; ++p) {
+            const uint32_t last = min(npass, p + (uint32_t)R) - 1u;
+            gather_wait((last - p) * lpp);
+            float *buf = stage + (size_t)(p & (R - 1)) * stage_floats;
+            const uint32_t c = 4 * p + g;
+            const float d = gather_score<L2>(buf, qv, dim, lane);
+            if (c < n && (lane & 15) == 0) out[(size_t)q * ostride + c] = d;
+            lds_sync();
+            if (p + R < npass) issue(p + R, buf);
+        }
+        wave_sync();
+    }
+}
+
 // fp32 base -> bf16 copy (round to nearest even), rows zero-padded to stride_bf elements
 __global__ void rg_base_to_bf16_kernel(const float *__restrict__ base, uint32_t nd, uint32_t dim, uint32_t stride,
                                        uint16_t *__restrict__ out, uint32_t stride_bf) {
@@ -477,6 +514,15 @@ static rg_status finish_graph(rg_index *ix, const uint64_t *d_off, const uint32_
         RG_HIP(hipMemcpy(ix->d_offsets, d_off, ((size_t)ix->nd + 1) * 8, hipMemcpyDeviceToDevice));
         RG_HIP(hipMemcpy(ix->d_nbrs, d_nb, ne * 4, hipMemcpyDeviceToDevice));
     }
+    {   // the shared frontier: the entry point and its neighbours, in adjacency order
+        uint64_t o[2] = {0, 0};
+        RG_HIP(hipMemcpy(o, d_off + ix->ep, 16, hipMemcpyDeviceToHost));
+        const uint32_t dg = (uint32_t)(o[1] - o[0]);
+        ix->front_n = 1 + dg;
+        RG_HIP(hipMalloc(&ix->d_front_ids, (size_t)ix->front_n * 4));
+        RG_HIP(hipMemcpy(ix->d_front_ids, &ix->ep, 4, hipMemcpyHostToDevice));
+        if (dg) RG_HIP(hipMemcpy(ix->d_front_ids + 1, d_nb + o[0], (size_t)dg * 4, hipMemcpyDeviceToDevice));
+    }
     hipDeviceProp_t prop;
     RG_HIP(hipGetDeviceProperties(&prop, ix->device));
     ix->num_cu = prop.multiProcessorCount;
@@ -500,6 +546,7 @@ static void free_ctx(SearchCtx *cx) {
     for (Batch *b : cx->spare) free_batch(b);
     if (cx->own) (void)hipStreamDestroy(cx->own);
     if (cx->h_pin) (void)hipHostFree(cx->h_pin);
+    if (cx->d_front) (void)hipFree(cx->d_front);
     void *bufs[] = {cx->d_counter, cx->d_scratch_stat, cx->d_visited, cx->d_epoch, cx->d_qlog, cx->d_qlog_n,
                     cx->d_q, cx->d_dist, cx->d_ids, cx->d_ch};
     for (void *p : bufs)
@@ -761,6 +808,8 @@ static rg_status launch_k1(rg_index *ix, SearchCtx *cx, int mode, const float *d
     P.spec = (ix->multi_expand && !bp) ? 2u : 0u;
     P.look = ix->lookahead == 2 ? 0u : 1u;
     P.log_early = ix->log_early ? 1u : 0u;
+    P.front_scores = nullptr; P.front_stride = 0;
+    if (cx->cur_front && !qlist && !bp && !bf) { P.front_scores = cx->cur_front + (size_t)qbase * cx->front_stride; P.front_stride = cx->front_stride; }
     // In-kernel exact distinct count (rg_search_kernel.h: wave_distinct_half): beams up to "count_in_k1" wide (default 40)
     // log a thousand or two ids per query, which the wave counts itself at the end of the query; K4 then finds nothing to
     // do.  Measured on the 10M bench index (profiles/r03/k1_ab_box11.jsonl, % of 8 TB/s, K4 -> in-kernel): 81.6 -> 83.4 at
@@ -835,6 +884,30 @@ static rg_status search_dev(rg_index *ix, SearchCtx *cx, const float *d_q, uint3
         return fail(set_error(RG_ERR_DEVICE, "hipMemsetAsync failed"));
     const bool fast = ix->fast_bf16 && ix->d_base_bf && dimc_of(ix);
     const bool exact_count = ix->visited_mode == 2 && d_cmps != nullptr && !fast;
+    cx->cur_front = nullptr;
+    if (ix->shared_frontier && ix->d_front_ids && ix->front_n > 1 && !fast) {
+        // the first hop of every query of the batch scores the same rows: once for the batch, with the exact routine
+        const uint32_t fs = (ix->front_n + 3u) & ~3u;
+        if (cx->front_cap < (size_t)nq * fs) {
+            if (cx->d_front) (void)hipFree(cx->d_front);
+            cx->d_front = nullptr; cx->front_cap = 0;
+            if (hipMalloc(&cx->d_front, (size_t)nq * fs * 4) != hipSuccess) return fail(set_error(RG_ERR_OOM, "no room for the shared-frontier scores"));
+            cx->front_cap = (size_t)nq * fs;
+        }
+        constexpr int FR = 4;
+        const uint32_t stage_floats = ((ix->dim + 63) / 64) * 256;
+        const size_t flds = (size_t)FR * stage_floats * 4 + (size_t)ix->dim * 4;
+        const uint32_t fgrid = std::min<uint32_t>(nq, (uint32_t)ix->num_cu * 16u);
+        if (ix->metric == RG_METRIC_L2)
+            hipLaunchKernelGGL((rg_front_score_kernel<true, FR>), dim3(fgrid), dim3(64), flds, s, ix->d_base, ix->stride, ix->dim, d_q, nq, qstride,
+                               ix->d_front_ids, ix->front_n, cx->d_front, fs, stage_floats);
+        else
+            hipLaunchKernelGGL((rg_front_score_kernel<false, FR>), dim3(fgrid), dim3(64), flds, s, ix->d_base, ix->stride, ix->dim, d_q, nq, qstride,
+                               ix->d_front_ids, ix->front_n, cx->d_front, fs, stage_floats);
+        if (hipGetLastError() != hipSuccess) return fail(set_error(RG_ERR_DEVICE, "shared-frontier launch failed"));
+        cx->cur_front = cx->d_front;
+        cx->front_stride = fs;
+    }
     uint32_t exact_from_L, trial_L;
     {
         std::lock_guard<std::mutex> lk(ix->mu);
@@ -1103,6 +1176,7 @@ static rg_status host_search_begin(rg_index *ix, const float *hq, uint32_t n, ui
     const size_t hb = std::max(qn * 4, (rn * 2 + cn) * 4);
     if (cx->h_cap < hb) {
         if (cx->h_pin) (void)hipHostFree(cx->h_pin);
+    if (cx->d_front) (void)hipFree(cx->d_front);
         cx->h_pin = nullptr; cx->h_cap = 0;
         RG_HIP(hipHostMalloc(&cx->h_pin, hb));
         cx->h_cap = hb;
@@ -1176,6 +1250,7 @@ void rg_index_close(rg_index *ix) {
     if (ix->d_offsets) (void)hipFree(ix->d_offsets);
     if (ix->d_nbrs) (void)hipFree(ix->d_nbrs);
     if (ix->d_ell) (void)hipFree(ix->d_ell);
+    if (ix->d_front_ids) (void)hipFree(ix->d_front_ids);
     if (ix->d_base_bf) (void)hipFree(ix->d_base_bf);
     if (ix->d_main) (void)hipFree(ix->d_main);
     if (ix->d_etail) (void)hipFree(ix->d_etail);
@@ -1297,6 +1372,7 @@ rg_status rg_index_set(rg_index *ix, const char *name, int value) {
     else if (!strcmp(name, "gather_form")) ix->gather_form = value;
     else if (!strcmp(name, "count_in_k1")) ix->count_in_k1 = value;
     else if (!strcmp(name, "log_early")) ix->log_early = value != 0;
+    else if (!strcmp(name, "shared_frontier")) ix->shared_frontier = value != 0;
     else if (!strcmp(name, "filter_min_indeg")) ix->filter_min_indeg = value;
     else if (!strcmp(name, "multi_expand")) ix->multi_expand = value;
     else if (!strcmp(name, "split_rows")) ix->split_rows = value != 0;

@@ -88,6 +88,12 @@ struct SearchParams {
     // count_tbits = log2 of its table words; 0 = off: K4 counts).  qlog_n[q] then carries kCountedBit and K4 skips the query.
     uint32_t count_tbits;
     unsigned long long *totals;   // [2] evaluations performed / distinct nodes of the queries counted here (as K4 reports them)
+    // shared frontier (third mode; opt-in knob "shared_frontier"): every query of a batch starts at the entry
+    // point, so the first expansion scores the same deg(ep) rows for all of them.  front_scores[q][0] = compare(ep, q) and
+    // [q][1 + j] = compare(j-th neighbour of ep, q) were computed for the whole batch by rg_front_score_kernel (the exact
+    // routine: same bits); the first hop reads them instead of gathering the rows.  null = off.
+    const float *front_scores;
+    uint32_t front_stride;
     uint32_t log_early;       // VIS = 1: the id-log store of a hop is issued right behind the row loads (else after the scoring)
     uint32_t look;            // VIS = 2: 1 = fetch the predicted next pop's adjacency row and visited words early, 0 = no speculation
 #ifdef RG_K1_PROF
@@ -738,7 +744,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
         auto no_hook = []() __attribute__((always_inline)) {};
         // entry point: scored and queued, not marked visited (index_bipartite.cpp:2338-2352)
         float epd;
-        if constexpr (DIMC != 0 && !BF) {
+        const float *front = (P.front_scores && !BF) ? P.front_scores + (size_t)qi * P.front_stride : nullptr;
+        if (front) epd = front[0];
+        else if constexpr (DIMC != 0 && !BF) {
             if (lane == 0) { cand_id[0] = P.ep; cand_x[0] = P.ep_tail; }
             lds_fence();
             gather_list(1, no_hook, std::false_type{});
@@ -795,15 +803,19 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
                 const uint32_t n = __popcll(fm);
                 RG_PROF_CNT(0, 1); RG_PROF_CNT(1, n);
                 if (n == 0) { RG_PROF(2); continue; }
+                const bool from_front = front != nullptr && hops == 1u && node == P.ep;   // the batch-wide scores of ep's neighbours
                 if (fresh) {
                     const uint32_t pos = __popcll(fm & ((1ull << lane) - 1ull));
                     cand_id[pos] = id;
-                    if (P.tail_off) cand_x[pos] = toff + c0 + lane;        // the neighbour's place in the adjacency order
+                    if (from_front) cand_x[pos] = __float_as_uint(front[1u + c0 + lane]);
+                    else if (P.tail_off) cand_x[pos] = toff + c0 + lane;   // the neighbour's place in the adjacency order
                 }
                 lds_fence();
                 log_append(0, n);
                 cmps += n;                                                 // :2397
                 RG_PROF(2);
+                if (from_front) log_flush();
+                else
                 // the id-log line of this hop leaves BEHIND the row loads (knob "log_early", default): a store issued after the
                 // gather has been consumed sits in front of the next hop's adjacency load in the in-order memory counter;
                 // behind the row loads it is covered by the gather's own wait.  (Measured: within 0.4 % either way,
@@ -852,7 +864,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
                 }
                 RG_PROF(0);
                 const uint32_t deg = readlane_u(fa, 0);
-                if (deg > 126u) {                // longer than two reads: the general path (returning atomics)
+                if (deg > 126u || (front != nullptr && hops == 1u)) {   // longer than two reads (or the shared first hop): the general path
                     expand(node, fa, toff);
                     la_node = NONE;
                     continue;

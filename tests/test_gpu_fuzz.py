@@ -63,6 +63,7 @@ def make_case(seed):
     knobs["gather_form"] = int(rng.random() < 0.5)
     knobs["filter_min_indeg"] = int(rng.choice([0, 0, 2, 4, 12, 255]))
     knobs["count_in_k1"] = int(rng.choice([-1, -1, 0, 2000]))
+    knobs["shared_frontier"] = int(rng.random() < 0.3)
     # lists without repeated ids (what every real index has): the look-ahead form of the exact words applies to them.
     # Cases 60+ aim at it: register-staged dimensions, exact words, ELL rows, beams wide enough to run for a while
     if seed >= 60 or rng.random() < 0.5:

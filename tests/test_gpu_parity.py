@@ -69,6 +69,34 @@ def test_search_lds_filter_mode(rg, oracle, metric, d, nb, L, k, flt):
     ix.close()
 
 
+@pytest.mark.parametrize("metric,d,nb", [("ip", 200, 4000), ("l2", 24, 3000), ("l2", 512, 2000), ("ip", 136, 2500)])
+@pytest.mark.parametrize("long_ep_row", [False, True])
+def test_shared_frontier_mode_is_exact(rg, oracle, metric, d, nb, long_ep_row):
+    """shared_frontier = 1 (third mode; opt-in): the rows every query of a batch scores first -- the entry point
+    and its neighbours -- are scored once for the whole batch by rg_front_score_kernel with the exact routine, and K1's
+    first hop reads those scores instead of gathering the rows.  Same bits, so every output stays the oracle's: all visited
+    modes, an entry point with more than 63 neighbours (two chunks), sub-batches over a small log budget."""
+    from roargraph_amd import io
+    base, q, off, nbrs, ep = small_set(metric, nb, d, nq=90)
+    if long_ep_row:
+        lists = [nbrs[int(off[i]):int(off[i + 1])].copy() for i in range(nb)]
+        lists[ep] = np.unique(np.concatenate([lists[ep], (np.arange(ep + 1, ep + 100) % nb).astype(np.uint32)])).astype(np.uint32)
+        lists[ep] = lists[ep][lists[ep] != ep]
+        off, nbrs = io.lists_to_csr(lists)
+    ix = rg.IndexBipartite.from_arrays(base, off, nbrs, ep, metric=metric)
+    ix.set("shared_frontier", 1)
+    for L, k in ((10, 10), (100, 100), (1300, 10)):
+        want = oracle.search(base, metric, off, nbrs, ep, q, k, L, nthreads=4)
+        for visited, budget in ((2, 0), (1, 0), (0, 0), (2, 600)):
+            ix.set("visited", visited)
+            ix.set("log_budget_kb", budget if budget else (16 << 20))
+            ix.set("log_cap", 4096 if budget else 0)
+            got = ix.SearchRoarGraph(q, k, L)
+            assert (got[3] == want[3]).all() and (got[0] == want[0]).all() and (bits(got[1]) == bits(want[1])).all(), (L, visited, budget)
+            assert (got[2] == want[2]).all() if visited != 1 else (got[2] >= want[2]).all(), ("cmps", L, visited, budget)
+    ix.close()
+
+
 @pytest.mark.parametrize("metric,d,nb", [("ip", 200, 4000), ("l2", 24, 3000), ("l2", 512, 2000)])
 @pytest.mark.parametrize("min_indeg", [2, 6, 40, 255])
 def test_filter_admission_by_in_degree(rg, oracle, metric, d, nb, min_indeg):
