@@ -115,6 +115,14 @@ rg_status rg_index_info(const rg_index *idx, uint32_t *nd, uint32_t *dim, uint32
  * fp32 routine and the k best by exact (distance, id) are returned: out_dists are exact for the returned ids, the ids
  * can differ from the reference's (recall is reported separately by bench.py), cmps = evaluations performed.
  * It combines with "visited": 0 = exact HBM words (no repeated evaluations), 1 / 2 = LDS filter only.
+ * Round-3 knobs, none of which changes a result: "lookahead" (-1 automatic / 0 / 1 / 2: form of the exact visited words, see
+ * rg_search_kernel.h VIS = 2), "gather_form" (0 = 16-byte loads + LDS bounce, otherwise compute-layout loads where
+ * instantiated), "filter_min_indeg" (the LDS filter keeps entries only for neighbours of at least this in-degree; default 2),
+ * "count_in_k1" (beams up to this wide count their distinct ids inside the search kernel; default 40, 0 = never),
+ * "log_early", "visited_budget_kb" (cap of the exact visited words per stream; default 16 GiB), "visited_uncached".
+ * "shared_frontier" = 1 (opt-in, EXACT: every output stays bit-identical; SURVEY 8 f-4, third mode): every query of a batch
+ * starts at the entry point, so the first expansion scores the same rows for all of them -- they are scored once for the
+ * batch (rg_front_score_kernel, the exact routine) and the first hop of every query reads the scores.
  * "multi_expand" = 1 is the second OPT-IN mode that is NOT parity (speculative multi-expansion): every
  * iteration pops the TWO closest unexpanded entries and expands both in one adjacency / visited / gather phase, whether or
  * not the second would have been the reference's next pop; twice the fresh neighbours per latency chain, a slightly
