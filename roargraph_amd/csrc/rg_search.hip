@@ -25,6 +25,14 @@
 
 namespace rg {
 
+// RG_TRACE_STALE=1: name a HIP error that an earlier call left behind (hipGetLastError reads AND clears it)
+static void trace_stale(const char *where) {
+    static const bool on = getenv("RG_TRACE_STALE") != nullptr;
+    if (!on) return;
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) fprintf(stderr, "[rg] stale HIP error at %s: %s\n", where, hipGetErrorString(e));
+}
+
 // device allocation released on every exit path of a host wrapper
 template <typename T>
 struct DevBuf {
@@ -476,10 +484,15 @@ static rg_status finish_graph(rg_index *ix, const uint64_t *d_off, const uint32_
         if (ix->nd <= (1u << 24) && ne > 0) {   // in-degree tags for the admission rule of the LDS visited filter
             DevBuf<uint32_t> indeg;
             if (indeg.alloc(ix->nd) == hipSuccess && hipMemset(indeg.p, 0, (size_t)ix->nd * 4) == hipSuccess) {
+                {   // (not this launch's: the runtime keeps the last error of earlier, unrelated calls; RG_TRACE_STALE=1 names it)
+                    const hipError_t stale = hipGetLastError();
+                    if (stale != hipSuccess && getenv("RG_TRACE_STALE")) fprintf(stderr, "[rg_index_open] stale HIP error before tagging: %s\n", hipGetErrorString(stale));
+                }
                 hipLaunchKernelGGL(rg_indeg_kernel, dim3(4096), dim3(256), 0, 0, d_nb, (uint64_t)ne, indeg.p);
                 hipLaunchKernelGGL(rg_ell_tag_kernel, dim3(8192), dim3(256), 0, 0, ix->d_ell, ix->nd, es, indeg.p);
-                if (hipGetLastError() == hipSuccess && hipDeviceSynchronize() == hipSuccess) ix->ell_tagged = true;
-                else return set_error(RG_ERR_DEVICE, "tagging the adjacency rows failed");
+                const hipError_t e1 = hipGetLastError(), e2 = hipDeviceSynchronize();
+                if (e1 == hipSuccess && e2 == hipSuccess) ix->ell_tagged = true;
+                else return set_error(RG_ERR_DEVICE, std::string("tagging the adjacency rows failed: ") + hipGetErrorString(e1 != hipSuccess ? e1 : e2));
             } else (void)hipGetLastError();
         }
         // split rows: an 800-B row (d = 200) spans seven 128-B lines wherever it starts; its first 192 elements at a 768-B
@@ -1010,6 +1023,7 @@ static rg_status search_dev(rg_index *ix, SearchCtx *cx, const float *d_q, uint3
 // synchronise `s` and finish every batch pending on the context, in order: adaptive-mode bookkeeping, the exact recount
 // of overflowed id logs, and the first deferred "not enough results" (index_bipartite.cpp:2408-2412)
 static rg_status finish_batches(rg_index *ix, SearchCtx *cx, hipStream_t s, uint32_t k) {
+    trace_stale("finish_batches (entry: left by the enqueue)");
     std::vector<Batch *> todo;
     {
         std::lock_guard<std::mutex> lk(ix->mu);
@@ -1176,7 +1190,6 @@ static rg_status host_search_begin(rg_index *ix, const float *hq, uint32_t n, ui
     const size_t hb = std::max(qn * 4, (rn * 2 + cn) * 4);
     if (cx->h_cap < hb) {
         if (cx->h_pin) (void)hipHostFree(cx->h_pin);
-    if (cx->d_front) (void)hipFree(cx->d_front);
         cx->h_pin = nullptr; cx->h_cap = 0;
         RG_HIP(hipHostMalloc(&cx->h_pin, hb));
         cx->h_cap = hb;
@@ -1243,6 +1256,7 @@ int rg_device_count(void) {
 
 void rg_index_close(rg_index *ix) {
     if (!ix) return;
+    rg::trace_stale("rg_index_close (entry: left by the searches)");
     (void)hipSetDevice(ix->device);
     (void)hipDeviceSynchronize();
     for (rg::SearchCtx *cx : ix->ctxs) rg::free_ctx(cx);
@@ -1251,6 +1265,7 @@ void rg_index_close(rg_index *ix) {
     if (ix->d_nbrs) (void)hipFree(ix->d_nbrs);
     if (ix->d_ell) (void)hipFree(ix->d_ell);
     if (ix->d_front_ids) (void)hipFree(ix->d_front_ids);
+    rg::trace_stale("rg_index_close (after the frees)");
     if (ix->d_base_bf) (void)hipFree(ix->d_base_bf);
     if (ix->d_main) (void)hipFree(ix->d_main);
     if (ix->d_etail) (void)hipFree(ix->d_etail);
