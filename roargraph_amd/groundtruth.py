@@ -79,10 +79,12 @@ class Comm:
         ident = [None]
         if rank == 0 and world > 1:
             buf = C.create_string_buffer(128)
-            check(lib().rg_comm_unique_id(buf))
-            ident = [buf.raw]
+            if lib().rg_comm_unique_id(buf) == 0:      # (a failure travels as None: no rank is left waiting in the broadcast)
+                ident = [buf.raw]
         if world > 1:
             dist.broadcast_object_list(ident, src=0, group=group)
+            if ident[0] is None:
+                raise RuntimeError("RCCL is not available on rank 0: no communicator (rg_comm_unique_id failed)")
         h = C.c_void_p()
         check(lib().rg_comm_init_rank(ident[0], rank, world, device, C.byref(h)))
         return cls(h, rank, world, device)
