@@ -590,18 +590,53 @@ struct Builder {
         }
         if (!ep_known) rg_projection_ep(base, nd, dim, (uint32_t)stride, &ep);
         lap("entry point");
-        // ---- phase 1 (:1059-1097): every training query links its nearest base point to its other neighbours
+        // ---- phase 1 (:1059-1097): every training query links its nearest base point to its other neighbours.
+        // GPU-assisted build (round 3): the pruned list of a query depends on the base and on its knn row only, not on the
+        // graph, so all of them are computed up front on the GPU (rg_build_prune.hip: rg_knn_score_kernel + the pruning
+        // kernel in its PruneBiSearchBaseGetBase form; the lists prune_get_base returns, checked under RG_BUILD_VERIFY);
+        // what stays on the host is the part that does depend on the graph: the assignment and the reverse edges.
+        std::vector<uint32_t> p1;          // [nq][M + 1]: length (0xffffffff: this query is pruned on the host) + ids
+        std::atomic<uint32_t> p1_mismatches(0);
+        if (gpu_device >= 0 && d_base_pre && !getenv("RG_BUILD_HOST_PRUNE") && nq > 0) {
+            const uint32_t ncol = std::min(kdim, Nq);
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, gpu_device) == hipSuccess && build_prune_knn_supported(dim, M, ncol, 160 * 1024)) {
+                const uint32_t chunk = 262144;
+                uint32_t *d_knn = nullptr, *d_piv = nullptr, *d_out = nullptr;
+                uint2_pod *d_exp = nullptr;
+                bool ok = hipMalloc(&d_knn, (size_t)chunk * kdim * 4) == hipSuccess && hipMalloc(&d_piv, (size_t)chunk * 4) == hipSuccess &&
+                          hipMalloc(&d_out, (size_t)chunk * (M + 1) * 4) == hipSuccess && hipMalloc(&d_exp, (size_t)chunk * ncol * 8) == hipSuccess;
+                if (ok) p1.assign((size_t)nq * (M + 1), 0xffffffffu);
+                for (uint32_t q0 = 0; ok && q0 < nq; q0 += chunk) {
+                    const uint32_t n = std::min(chunk, nq - q0);
+                    ok = hipMemcpy(d_knn, knn + (size_t)q0 * kdim, (size_t)n * kdim * 4, hipMemcpyHostToDevice) == hipSuccess &&
+                         build_prune_knn_dev(d_base_pre, dim, (uint32_t)stride, l2 ? RG_METRIC_L2 : RG_METRIC_IP, gpu_device, prop.multiProcessorCount,
+                                             160 * 1024, d_knn, n, kdim, ncol, M, d_exp, ncol, d_piv, d_out, nullptr) == RG_OK &&
+                         hipMemcpy(p1.data() + (size_t)q0 * (M + 1), d_out, (size_t)n * (M + 1) * 4, hipMemcpyDeviceToHost) == hipSuccess;
+                }
+                for (void *ptr : {(void *)d_knn, (void *)d_piv, (void *)d_out, (void *)d_exp}) if (ptr) (void)hipFree(ptr);
+                if (!ok) { (void)hipGetLastError(); p1.clear(); }      // the host prunes everything, as before
+            }
+            lap("phase 1 pruning (GPU)");
+        }
         auto phase1_query = [&](uint32_t sq) {
             const uint32_t n = std::min(kdim, Nq);
             if (n == 0) return;
             const uint32_t *nn = knn + (size_t)sq * kdim;
             const uint32_t tgt = nn[0];
-            for (uint32_t i = 0; i < n; ++i) prefetch_row(nn[i]);
-            std::vector<Nb> full;
-            for (uint32_t i = 0; i < n; ++i)
-                if (nn[i] != tgt) full.push_back(Nb{nn[i], cmp(nn[i], tgt)});
             std::vector<uint32_t> pruned;
-            prune_get_base(full, tgt, pruned);
+            const uint32_t *po = p1.empty() ? nullptr : p1.data() + (size_t)sq * (M + 1);
+            if (po && po[0] != 0xffffffffu) pruned.assign(po + 1, po + 1 + po[0]);
+            if (!po || po[0] == 0xffffffffu || gpu_verify) {
+                for (uint32_t i = 0; i < n; ++i) prefetch_row(nn[i]);
+                std::vector<Nb> full;
+                for (uint32_t i = 0; i < n; ++i)
+                    if (nn[i] != tgt) full.push_back(Nb{nn[i], cmp(nn[i], tgt)});
+                std::vector<uint32_t> host_list;
+                prune_get_base(full, tgt, host_list);
+                if (po && po[0] != 0xffffffffu && host_list != pruned) p1_mismatches.fetch_add(1);
+                pruned.swap(host_list);
+            }
             {
                 std::lock_guard<std::mutex> guard(locks[tgt]);
                 proj[tgt] = pruned;
@@ -639,6 +674,8 @@ struct Builder {
                         groups.size() > 9 ? groups[9].second - groups[9].first : 0u, groups.size() > 99 ? groups[99].second - groups[99].first : 0u);
         }
         lap("phase 1");
+        if (p1_mismatches.load()) { gpu_error = "GPU phase 1: " + std::to_string(p1_mismatches.load()) + " pruned lists differ from the host pruning"; return false; }
+        p1.clear(); p1.shrink_to_fit();
         // ---- phase 2 (:1100-1136)
         parallel_for(nd, 100, [&](uint32_t node, int) { add_reverse(proj, node, M, false); });
         lap("phase 2 reverse edges");

@@ -41,6 +41,13 @@ struct PruneParams {
     uint32_t node0, n, M;
     uint32_t *out;           // [n][M + 1]: word 0 = length (0xffffffff: left to the host), then the pruned list
     uint32_t stage_floats;   // floats of one 4-row pass: ceil(dim / 64) * 256
+    // phase 1 (round 3): the same greedy scan is the first sweep of PruneBiSearchBaseGetBase (:1612-1694) -- pivot = the
+    // training query's nearest base point, pool = its other near neighbours scored against the pivot (rg_knn_score_kernel).
+    // pivots[i] replaces node0 + i; `have` is null (nothing to skip); topup = the rule's last loop (:1683-1689): the list
+    // is filled up to M with the not yet chosen pool entries in sorted order, occluded or not.  A pool that names an id
+    // twice is left to the host (the rule keeps the first occurrence of every id).
+    const uint32_t *pivots;
+    uint32_t topup;
 };
 
 constexpr uint32_t kPruneKeys = 1024;
@@ -63,11 +70,11 @@ __global__ void __launch_bounds__(64) rg_prune_search_kernel(PruneParams P) {
     const uint32_t nq4 = P.dim / 4;                                                          // float4 pieces of a row
 
     for (uint32_t i = blockIdx.x; i < P.n; i += gridDim.x) {
-        const uint32_t node = P.node0 + i;
+        const uint32_t node = P.pivots ? P.pivots[i] : P.node0 + i;
         uint32_t *out = P.out + (size_t)i * (P.M + 1);
-        const uint32_t ne = P.nexp[i];
-        const uint32_t nh = P.have[(size_t)i * P.hs];
-        if (ne > P.cap || ne > kPruneKeys || nh + 1 > P.hs || nh > 64) {   // the host prunes this one
+        const uint32_t ne = P.nexp ? P.nexp[i] : P.cap;
+        const uint32_t nh = P.have ? P.have[(size_t)i * P.hs] : 0u;
+        if (ne > P.cap || ne > kPruneKeys || (P.have && (nh + 1 > P.hs || nh > 64))) {   // the host prunes this one
             if (lane == 0) out[0] = 0xffffffffu;
             continue;
         }
@@ -88,7 +95,7 @@ __global__ void __launch_bounds__(64) rg_prune_search_kernel(PruneParams P) {
             }
             n += __popcll(m);
         }
-        if (lane < (int)nh) have_l[lane] = P.have[(size_t)i * P.hs + 1 + lane];
+        if (P.have && lane < (int)nh) have_l[lane] = P.have[(size_t)i * P.hs + 1 + lane];
         uint32_t N = 64;
         while (N < n) N <<= 1;
         for (uint32_t j = n + lane; j < N; j += kWave) keys[j] = ~0ull;
@@ -104,6 +111,15 @@ __global__ void __launch_bounds__(64) rg_prune_search_kernel(PruneParams P) {
                 }
                 lds_sync();
             }
+        if (P.topup) {   // the same id twice (same distance: adjacent after the sort): the host's rule drops repeats first
+            bool twice = false;
+            for (uint32_t j = lane; j + 1 < n; j += kWave) twice = twice || keys[j] == keys[j + 1];
+            if (__ballot(twice)) {
+                if (lane == 0) out[0] = 0xffffffffu;
+                lds_sync();
+                continue;
+            }
+        }
         auto pool_id = [&](uint32_t j) { return (uint32_t)(keys[j] & 0xffffffffull); };
         auto pool_dist = [&](uint32_t j) {
             const uint32_t ord = (uint32_t)(keys[j] >> 32);
@@ -190,9 +206,58 @@ __global__ void __launch_bounds__(64) rg_prune_search_kernel(PruneParams P) {
 #undef RG_FETCH
 #undef RG_ARRIVED
         lds_sync();
+        if (P.topup)     // :1683-1689: the sorted pool from its second entry on, whatever was not chosen, until the list is full
+            for (uint32_t j = 1; j < n && cnt < P.M; ++j) {
+                const uint32_t pid = pool_id(j);
+                const bool in = (uint32_t)lane < cnt && res_id[lane] == pid;
+                if (!__ballot(in) && pid != node) {
+                    if (lane == 0) res_id[cnt] = pid;
+                    ++cnt;
+                    lds_sync();
+                }
+            }
         if (lane == 0) out[0] = cnt;
         if ((uint32_t)lane < cnt) out[1 + lane] = res_id[lane];
         lds_sync();
+    }
+}
+
+// Phase 1's pools: exp[i][c] = (bits of compare(base[knn[i][c]], base[knn[i][0]]), knn[i][c]) for c < ncol -- the near
+// neighbours of training query i scored against its nearest base point (:1074-1082), with the exact routine of K1b.  One
+// wave per query at a time, the pivot's row staged in LDS as the "query", the rows through a ring of R passes of four.
+template <bool L2, int R>
+__global__ void __launch_bounds__(64) rg_knn_score_kernel(const float *__restrict__ base, uint32_t stride, uint32_t dim,
+                                                          const uint32_t *__restrict__ knn, uint32_t n, uint32_t kdim, uint32_t ncol,
+                                                          uint2 *__restrict__ exp, uint32_t cap, uint32_t *__restrict__ pivots,
+                                                          uint32_t stage_floats) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x, g = lane >> 4;
+    float *stage = reinterpret_cast<float *>(smem);
+    float *qv = stage + (size_t)R * stage_floats;
+    const uint32_t npass = (ncol + 3u) >> 2, lpp = loads_per_pass(dim);
+    for (uint32_t q = blockIdx.x; q < n; q += gridDim.x) {
+        const uint32_t *ids = knn + (size_t)q * kdim;
+        const uint32_t tgt = ids[0];
+        if (lane == 0) pivots[q] = tgt;
+        for (uint32_t i = lane; i < dim; i += kWave) qv[i] = base[(size_t)tgt * stride + i];
+        wave_sync();
+        auto issue = [&](uint32_t p, float *buf) {
+            const uint32_t c = 4 * p + g;
+            const bool act = c < ncol;
+            gather_issue(base + (size_t)(act ? ids[c] : 0u) * stride, dim, act, buf, lane);
+        };
+        for (uint32_t p = 0; p < (uint32_t)R && p < npass; ++p) issue(p, stage + (size_t)p * stage_floats);
+        for (uint32_t p = 0; p < npass; ++p) {
+            const uint32_t last = min(npass, p + (uint32_t)R) - 1u;
+            gather_wait((last - p) * lpp);
+            float *buf = stage + (size_t)(p & (R - 1)) * stage_floats;
+            const uint32_t c = 4 * p + g;
+            const float d = gather_score<L2>(buf, qv, dim, lane);
+            if (c < ncol && (lane & 15) == 0) exp[(size_t)q * cap + c] = make_uint2(__float_as_uint(d), ids[c]);
+            lds_sync();
+            if (p + R < npass) issue(p + R, buf);
+        }
+        wave_sync();
     }
 }
 
@@ -220,6 +285,7 @@ rg_status build_prune_dev(rg_index *ix, uint32_t node0, uint32_t n, uint32_t M, 
     P.base = ix->d_base; P.stride = ix->stride; P.dim = ix->dim;
     P.exp = reinterpret_cast<const uint2 *>(d_exp); P.cap = exp_cap; P.nexp = d_nexp;
     P.have = d_have; P.hs = hs; P.node0 = node0; P.n = n; P.M = M; P.out = d_out;
+    P.pivots = nullptr; P.topup = 0;
     P.stage_floats = (uint32_t)((ix->dim + 63) / 64) * 256u;
     const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(16, ix->lds_per_cu / lds));
     const dim3 grid(std::min<uint32_t>(n, (uint32_t)ix->num_cu * per_cu));
@@ -236,6 +302,55 @@ rg_status build_prune_dev(rg_index *ix, uint32_t node0, uint32_t n, uint32_t M, 
     else { if (qc == 1) RG_PRUNE_LAUNCH(false, 1); else if (qc == 2) RG_PRUNE_LAUNCH(false, 2); else RG_PRUNE_LAUNCH(false, 4); }
 #undef RG_PRUNE_LAUNCH
     if (hipGetLastError() != hipSuccess) return set_error(RG_ERR_DEVICE, "pruning kernel launch failed");
+    return RG_OK;
+}
+
+// Phase 1 on the GPU: the pruned list of every training query of a chunk (PruneBiSearchBaseGetBase over its knn row).
+// d_knn [n][kdim] (device), ncol = min(kdim, M_sq) columns are used; d_exp [n][cap] and d_pivots [n] are scratch; d_out
+// [n][M + 1] as build_prune_dev writes it.
+bool build_prune_knn_supported(uint32_t dim, uint32_t M, uint32_t ncol, size_t lds_per_cu) {
+    return ncol >= 1 && ncol <= kPruneKeys && prune_lds_bytes(dim, M, lds_per_cu) != 0;
+}
+
+rg_status build_prune_knn_dev(const float *d_base, uint32_t dim, uint32_t stride, int metric, int device, int num_cu, size_t lds_per_cu,
+                              const uint32_t *d_knn, uint32_t n, uint32_t kdim, uint32_t ncol, uint32_t M, uint2_pod *d_exp, uint32_t cap,
+                              uint32_t *d_pivots, uint32_t *d_out, void *stream) {
+    if (!d_base || !d_knn || !d_exp || !d_pivots || !d_out) return set_error(RG_ERR_ARG, "null argument");
+    if (n == 0) return RG_OK;
+    const size_t lds = prune_lds_bytes(dim, M, lds_per_cu);
+    if (!lds || ncol > cap || cap > kPruneKeys) return set_error(RG_ERR_ARG, "pruning kernel: shape not supported");
+    if (hipSetDevice(device) != hipSuccess) return set_error(RG_ERR_DEVICE, "cannot select the build device");
+    const bool l2 = metric == RG_METRIC_L2;
+    {
+        constexpr int R = 4;
+        const uint32_t stage_floats = ((dim + 63) / 64) * 256;
+        const size_t slds = (size_t)R * stage_floats * 4 + (size_t)dim * 4;
+        const dim3 grid(std::min<uint32_t>(n, (uint32_t)num_cu * 16u));
+        if (l2) hipLaunchKernelGGL((rg_knn_score_kernel<true, R>), grid, dim3(kWave), slds, (hipStream_t)stream, d_base, stride, dim, d_knn, n, kdim, ncol,
+                                   reinterpret_cast<uint2 *>(d_exp), cap, d_pivots, stage_floats);
+        else hipLaunchKernelGGL((rg_knn_score_kernel<false, R>), grid, dim3(kWave), slds, (hipStream_t)stream, d_base, stride, dim, d_knn, n, kdim, ncol,
+                                reinterpret_cast<uint2 *>(d_exp), cap, d_pivots, stage_floats);
+    }
+    PruneParams P;
+    P.base = d_base; P.stride = stride; P.dim = dim;
+    P.exp = reinterpret_cast<const uint2 *>(d_exp); P.cap = cap; P.nexp = nullptr;
+    P.have = nullptr; P.hs = 0; P.node0 = 0; P.n = n; P.M = M; P.out = d_out;
+    P.pivots = d_pivots; P.topup = 1;
+    P.stage_floats = (uint32_t)((dim + 63) / 64) * 256u;
+    const uint32_t per_cu = (uint32_t)std::max<size_t>(1, std::min<size_t>(16, lds_per_cu / lds));
+    const dim3 grid(std::min<uint32_t>(n, (uint32_t)num_cu * per_cu));
+    const int qc = dim <= 256 ? 1 : dim <= 512 ? 2 : 4;
+#define RG_PRUNE_LAUNCH(L2_, QC_)                                                                                              \
+    do {                                                                                                                       \
+        auto kern = rg_prune_search_kernel<L2_, QC_>;                                                                          \
+        if (hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) \
+            return set_error(RG_ERR_DEVICE, "pruning kernel: cannot reserve its LDS");                                         \
+        hipLaunchKernelGGL(kern, grid, dim3(kWave), lds, (hipStream_t)stream, P);                                              \
+    } while (0)
+    if (l2) { if (qc == 1) RG_PRUNE_LAUNCH(true, 1); else if (qc == 2) RG_PRUNE_LAUNCH(true, 2); else RG_PRUNE_LAUNCH(true, 4); }
+    else { if (qc == 1) RG_PRUNE_LAUNCH(false, 1); else if (qc == 2) RG_PRUNE_LAUNCH(false, 2); else RG_PRUNE_LAUNCH(false, 4); }
+#undef RG_PRUNE_LAUNCH
+    if (hipGetLastError() != hipSuccess) return set_error(RG_ERR_DEVICE, "phase-1 pruning launch failed");
     return RG_OK;
 }
 

@@ -148,4 +148,10 @@ rg_status build_index_set_ell(rg_index *ix, const uint32_t *h_ell, void *stream)
 bool build_prune_supported(const rg_index *ix, uint32_t M, uint32_t exp_cap);
 rg_status build_prune_dev(rg_index *ix, uint32_t node0, uint32_t n, uint32_t M, const uint2_pod *d_exp, uint32_t exp_cap,
                           const uint32_t *d_nexp, const uint32_t *d_have, uint32_t hs, uint32_t *d_out, void *stream);
+// PruneBiSearchBaseGetBase (:1612-1694) of n training queries' knn rows on the GPU (rg_build_prune.hip): d_out[i] = length + pruned
+// ids (row stride M + 1; length 0xffffffff = left to the host).  Bit-identical to Builder::prune_get_base.
+bool build_prune_knn_supported(uint32_t dim, uint32_t M, uint32_t ncol, size_t lds_per_cu);
+rg_status build_prune_knn_dev(const float *d_base, uint32_t dim, uint32_t stride, int metric, int device, int num_cu, size_t lds_per_cu,
+                              const uint32_t *d_knn, uint32_t n, uint32_t kdim, uint32_t ncol, uint32_t M, uint2_pod *d_exp, uint32_t cap,
+                              uint32_t *d_pivots, uint32_t *d_out, void *stream);
 }  // namespace rg
