@@ -226,7 +226,10 @@ rg_status rg_groundtruth(const char *base_fbin, const char *query_fbin, const ch
  * after LoadLearnBaseKNN (tests/test_build_roargraph.cpp:117-136; src/index_bipartite.cpp:143-233, 1043-1277).
  * CPU code, as in the reference.  knn_ids = the train-query ground truth ids (nq x knn_k,
  * best first); the result is the projection graph in CSR form (release with rg_free) and its entry point.
- * One thread gives the reference's deterministic T=1 construction; more threads are scheduling dependent, as there. */
+ * One thread gives the reference's T=1 construction.  More threads (round 3) give ONE result for any thread count -- the
+ * reference's own multi-threaded build depends on scheduling: phases 1 and 2 come out exactly as at one thread (every
+ * list replays its own reverse edges in the one-thread order), phase 3 runs in the batches of rg_build_schedule(nb, 0):
+ * the nodes of a batch search the graph as it stood when the batch began and are linked in node order. */
 rg_status rg_build_roargraph(const float *base, uint32_t nb, uint32_t dim, uint32_t stride, const uint32_t *knn_ids,
                              uint32_t nq, uint32_t knn_k, int metric, uint32_t M_sq, uint32_t M_pjbp, uint32_t L_pjpq,
                              uint32_t num_threads, uint32_t *out_ep, uint64_t **out_offsets, uint32_t **out_nbrs);
@@ -237,14 +240,20 @@ rg_status rg_build_roargraph(const float *base, uint32_t nb, uint32_t dim, uint3
 rg_status rg_projection_ep(const float *base, uint32_t nd, uint32_t dim, uint32_t stride, uint32_t *out_ep);
 rg_status rg_projection_ep_dev(const float *d_base, uint32_t nd, uint32_t dim, uint32_t stride, int device, uint32_t *out_ep);
 /* Same construction with phase 3 -- the n beam searches of the connectivity enhancement (index_bipartite.cpp:1192-1220,
- * 1279-1350), 85-93 % of the build time -- on the GPU (K1 in build mode), `batch` nodes at a time (0 = auto); pruning
- * and reverse-edge insertion stay on the host threads.  Nodes of a batch search the graph as it stood when the batch
- * started, i.e. a valid scheduling of the reference's (already scheduling dependent) multi-threaded build, not its
- * one-thread result.  Needs dim % 8 == 0 and stride % 4 == 0. */
+ * 1279-1350), 85-93 % of the build time -- on the GPU (K1 in build mode), `batch` nodes at a time (0 = auto), together with
+ * the occlusion pruning of phases 1 and 3; reverse-edge insertion stays on the host threads.  Nodes of a batch search the
+ * graph as it stood when the batch started and are linked in node order: the result is the same for any num_threads, equals
+ * rg_build_roargraph's at more than one thread when batch = 0, and equals the one-thread construction when batch = 1
+ * (tests/test_gpu_cli.py, tests/test_build.py compare all of them with the oracle's restatement byte for byte).
+ * Needs dim % 8 == 0 and stride % 4 == 0. */
 rg_status rg_build_roargraph_gpu(const float *base, uint32_t nb, uint32_t dim, uint32_t stride, const uint32_t *knn_ids,
                                  uint32_t nq, uint32_t knn_k, int metric, uint32_t M_sq, uint32_t M_pjbp,
                                  uint32_t L_pjpq, uint32_t num_threads, int device, uint32_t batch, uint32_t *out_ep,
                                  uint64_t **out_offsets, uint32_t **out_nbrs);
+/* the batches phase 3 runs in for `nb` nodes and this `batch` argument (0 = the builders' own choice: the first 2,048
+ * nodes one by one, then batches of at most a quarter of what is linked): writes up to `cap` batch sizes, *count = how
+ * many there are.  For checkers that restate the construction (oracle/rg_oracle_build.c takes the same list). */
+rg_status rg_build_schedule(uint32_t nb, uint32_t batch, uint32_t *sizes, uint32_t cap, uint32_t *count);
 
 #ifdef __cplusplus
 }

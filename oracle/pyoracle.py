@@ -100,17 +100,22 @@ def projection_ep(base, dim=None):
                                        C.c_uint(dim if dim is not None else base.shape[1])))
 
 
-def build_roargraph(base, knn_ids, metric, M_sq=100, M_pjbp=35, L_pjpq=500, dim=None):
+def build_roargraph(base, knn_ids, metric, M_sq=100, M_pjbp=35, L_pjpq=500, dim=None, sched=None):
     """rgo_build_roargraph: the reference's one-thread BuildRoarGraph restated (oracle/rg_oracle_build.c).
+    `sched`: phase 3 in batches (sizes summing to nb; searches of a batch see the graph as it stood when the batch began).
     Returns (offsets u64[nb+1], nbrs u32[], ep)."""
     base = np.ascontiguousarray(base, np.float32)
     knn_ids = np.ascontiguousarray(knn_ids, np.uint32)
     nb, stride = base.shape
     ep = C.c_uint32()
     po, pn = C.c_void_p(), C.c_void_p()
-    rc = lib().rgo_build_roargraph(_p(base), C.c_size_t(stride), C.c_uint32(nb), C.c_uint(dim or stride), METRIC[metric], _p(knn_ids),
-                                   C.c_uint32(knn_ids.shape[0]), C.c_uint32(knn_ids.shape[1]), C.c_uint32(M_sq), C.c_uint32(M_pjbp),
-                                   C.c_uint32(L_pjpq), C.byref(ep), C.byref(po), C.byref(pn))
+    sc = None if sched is None else np.ascontiguousarray(sched, np.uint32)
+    if sc is not None and int(sc.sum()) != nb:
+        raise ValueError("schedule does not cover the base")
+    rc = lib().rgo_build_roargraph_sched(_p(base), C.c_size_t(stride), C.c_uint32(nb), C.c_uint(dim or stride), METRIC[metric], _p(knn_ids),
+                                         C.c_uint32(knn_ids.shape[0]), C.c_uint32(knn_ids.shape[1]), C.c_uint32(M_sq), C.c_uint32(M_pjbp),
+                                         C.c_uint32(L_pjpq), None if sc is None else _p(sc), C.c_uint32(0 if sc is None else sc.size),
+                                         C.byref(ep), C.byref(po), C.byref(pn))
     if rc != 0:
         raise RuntimeError(lib().rgo_last_error().decode())
     off = np.ctypeslib.as_array(C.cast(po, C.POINTER(C.c_uint64)), shape=(nb + 1,)).copy()

@@ -103,6 +103,12 @@ uint32_t rgo_projection_ep(const float *base, size_t stride, uint32_t nd, unsign
 int rgo_build_roargraph(const float *base, size_t stride, uint32_t nb, unsigned d, int metric, const uint32_t *knn, uint32_t nq,
                         uint32_t knn_k, uint32_t M_sq, uint32_t M_pjbp, uint32_t L_pjpq, uint32_t *out_ep, uint64_t **out_off,
                         uint32_t **out_nbrs);
+/* the same with phase 3 in batches: sched[i] consecutive nodes search the supply graph as it stood when batch i began, then
+ * link in node order (a batch of 1 = the one-thread sequence; NULL = all ones).  This is the order a batched builder works
+ * in; roargraph_amd's deterministic build must equal it byte for byte for its own schedule (rg_build_schedule). */
+int rgo_build_roargraph_sched(const float *base, size_t stride, uint32_t nb, unsigned d, int metric, const uint32_t *knn, uint32_t nq,
+                              uint32_t knn_k, uint32_t M_sq, uint32_t M_pjbp, uint32_t L_pjpq, const uint32_t *sched, uint32_t nsched,
+                              uint32_t *out_ep, uint64_t **out_off, uint32_t **out_nbrs);
 
 /* a10: exact top-K ground truth (DiskANN compute_groundtruth; source absent, README.md:62-75).
  * fp64 accumulation; order: mips = score desc then id asc, l2 = dist asc then id asc.

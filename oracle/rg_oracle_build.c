@@ -214,9 +214,14 @@ static uint32_t scored_unique(const B *b, const list_t *l, uint32_t node, nb_t *
     return n;
 }
 
-int rgo_build_roargraph(const float *base_in, size_t stride, uint32_t nb, unsigned d, int metric, const uint32_t *knn, uint32_t nq,
-                        uint32_t knn_k, uint32_t M_sq, uint32_t M_pjbp, uint32_t L_pjpq, uint32_t *out_ep, uint64_t **out_off,
-                        uint32_t **out_nbrs) {
+/* `sched` (may be NULL): phase 3 as a sequence of batches, sched[i] = number of consecutive nodes in batch i (their sum must be
+ * nb).  The nodes of a batch all search the supply graph AS IT STOOD WHEN THE BATCH BEGAN and are then linked one after the
+ * other in node order -- the order in which a batched (GPU-assisted) builder sees the graph; the reference's own OpenMP loop
+ * (:1192, schedule(dynamic)) lets every thread search a graph that is some other threads' links behind in the same way, only
+ * without saying which.  A batch of one node is the reference's one-thread sequence; NULL means all batches are of one. */
+int rgo_build_roargraph_sched(const float *base_in, size_t stride, uint32_t nb, unsigned d, int metric, const uint32_t *knn, uint32_t nq,
+                              uint32_t knn_k, uint32_t M_sq, uint32_t M_pjbp, uint32_t L_pjpq, const uint32_t *sched, uint32_t nsched,
+                              uint32_t *out_ep, uint64_t **out_off, uint32_t **out_nbrs) {
     B b;
     memset(&b, 0, sizeof b);
     float *normed = NULL;
@@ -260,11 +265,31 @@ int rgo_build_roargraph(const float *base_in, size_t stride, uint32_t nb, unsign
     uint8_t *visited = (uint8_t *)calloc(nb, 1);
     uint32_t *touched = (uint32_t *)malloc((size_t)nb * 4);
     nb_t *full = (nb_t *)malloc(((size_t)nb + 1) * sizeof(nb_t));
-    for (uint32_t node = 0; node < nb; ++node) {
-        uint32_t nf = search_internal(&b, node, visited, touched, full), w = 0;
-        for (uint32_t j = 0; j < nf; ++j) if (full[j].id != node) full[w++] = full[j];   /* :1203-1208 */
-        prune_search(&b, full, w, node, &b.supply[node]);     /* supply_nbrs_[node] = pruned_list, :1209-1214 */
-        add_reverse(&b, b.supply, node, 2 * b.M, 1);          /* SupplyAddReverse, :1215 */
+    for (uint32_t node = 0, bi = 0; node < nb; ++bi) {
+        const uint32_t n = (sched && bi < nsched && sched[bi]) ? sched[bi] : 1;
+        if (n == 1) {                                             /* the reference's one-thread sequence */
+            uint32_t nf = search_internal(&b, node, visited, touched, full), w = 0;
+            for (uint32_t j = 0; j < nf; ++j) if (full[j].id != node) full[w++] = full[j];   /* :1203-1208 */
+            prune_search(&b, full, w, node, &b.supply[node]);     /* supply_nbrs_[node] = pruned_list, :1209-1214 */
+            add_reverse(&b, b.supply, node, 2 * b.M, 1);          /* SupplyAddReverse, :1215 */
+            ++node;
+            continue;
+        }
+        /* a batch: searches over the frozen graph first (their pruned lists kept aside), then the links in node order */
+        const uint32_t hi = node + n < nb ? node + n : nb;
+        list_t *kept = (list_t *)calloc(hi - node, sizeof(list_t));
+        for (uint32_t x = node; x < hi; ++x) {
+            uint32_t nf = search_internal(&b, x, visited, touched, full), w = 0;
+            for (uint32_t j = 0; j < nf; ++j) if (full[j].id != x) full[w++] = full[j];
+            prune_search(&b, full, w, x, &kept[x - node]);
+        }
+        for (uint32_t x = node; x < hi; ++x) {
+            list_assign(&b.supply[x], &kept[x - node]);
+            add_reverse(&b, b.supply, x, 2 * b.M, 1);
+            free(kept[x - node].v);
+        }
+        free(kept);
+        node = hi;
     }
     /* ---- phase 4, :1224-1249: supply lists above M are pruned with the search rule */
     for (uint32_t node = 0; node < nb; ++node) {
@@ -292,4 +317,10 @@ int rgo_build_roargraph(const float *base_in, size_t stride, uint32_t nb, unsign
     for (uint32_t i = 0; i < nb; ++i) { free(b.proj[i].v); free(b.supply[i].v); }
     free(b.proj); free(b.supply); free(pool); free(visited); free(touched); free(full); free(normed);
     return 0;
+}
+
+int rgo_build_roargraph(const float *base_in, size_t stride, uint32_t nb, unsigned d, int metric, const uint32_t *knn, uint32_t nq,
+                        uint32_t knn_k, uint32_t M_sq, uint32_t M_pjbp, uint32_t L_pjpq, uint32_t *out_ep, uint64_t **out_off,
+                        uint32_t **out_nbrs) {
+    return rgo_build_roargraph_sched(base_in, stride, nb, d, metric, knn, nq, knn_k, M_sq, M_pjbp, L_pjpq, NULL, 0, out_ep, out_off, out_nbrs);
 }

@@ -10,7 +10,8 @@ def build_roargraph(base, knn_ids, metric, M_sq=100, M_pjbp=35, L_pjpq=500, num_
                     batch=0):
     """base [nb, stride] fp32, knn_ids [nq, K] (train-query ground truth, best first).
     Returns (offsets u64[nb+1], nbrs u32[], ep).  Defaults are the paper's parameters (README.md:92-97).
-    device=None: all on the CPU (one thread = the reference's T=1 result); device=N: phase 3 searches on GPU N."""
+    device=None: all on the CPU (one thread = the reference's T=1 result; more threads = one result for any thread count,
+    phase 3 in the batches of build_schedule(nb)); device=N: the searches and prunings on GPU N (same result for batch=0)."""
     base = np.ascontiguousarray(base, np.float32)
     knn_ids = np.ascontiguousarray(knn_ids, np.uint32)
     nb, stride = base.shape
@@ -29,3 +30,12 @@ def build_roargraph(base, knn_ids, metric, M_sq=100, M_pjbp=35, L_pjpq=500, num_
     lib().rg_free(po)
     lib().rg_free(pn)
     return off, nbrs, ep.value
+
+
+def build_schedule(nb, batch=0):
+    """rg_build_schedule: the batch sizes phase 3 runs in (what the oracle's scheduled build takes)."""
+    n = C.c_uint32()
+    check(lib().rg_build_schedule(C.c_uint32(nb), C.c_uint32(batch), None, C.c_uint32(0), C.byref(n)))
+    out = np.zeros(max(n.value, 1), np.uint32)
+    check(lib().rg_build_schedule(C.c_uint32(nb), C.c_uint32(batch), out.ctypes.data_as(C.c_void_p), C.c_uint32(out.size), C.byref(n)))
+    return out[: n.value]

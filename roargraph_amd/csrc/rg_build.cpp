@@ -21,8 +21,11 @@
 // thread, recall of the search over the built index).  Out-of-range accesses the reference would perform on empty
 // candidate pools are guarded instead of replicated.
 //
-// Threads: one thread reproduces the reference's T=1 result deterministically; with more threads the same per-node
-// mutex scheme is used and, exactly like the reference, the result depends on scheduling.
+// Threads: one thread reproduces the reference's T=1 sequence.  More threads do NOT race on the lists as the reference's do
+// (its multi-threaded result depends on scheduling): phases 1 and 2 are replayed list by list in the one-thread
+// order (phase1_replay, phase2_windows), phase 3 runs in fixed batches over a frozen graph and links them in node order
+// (link_batch) -- one result for any thread count, on the host or with the GPU, equal to the oracle's restatement given
+// the same batch list (rg_build_schedule).
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -38,6 +41,12 @@
 #if defined(__x86_64__)
 #include <immintrin.h>
 #endif
+
+#include <climits>
+#include <linux/futex.h>
+#include <sys/syscall.h>
+#include <unistd.h>
+#include <sched.h>
 
 #include <hip/hip_runtime.h>
 
@@ -139,6 +148,7 @@ struct Builder {
     bool ep_known = false;
     float *d_base_pre = nullptr;   // GPU-assisted build: the base goes up once, for the entry point and for phase 3
     std::vector<std::vector<uint32_t>> proj, supply;
+    std::vector<uint8_t> dirty;    // GPU phase 3: supply rows changed since the graph snapshot on the device was refreshed
     std::vector<std::mutex> locks;
     int threads = 1;
 
@@ -167,6 +177,42 @@ struct Builder {
             });
         for (auto &th : pool) th.join();
     }
+
+    // T persistent threads running fn(t, team) with a spinning barrier between their steps (phase 2 below has ~10^4 steps of
+    // a few microseconds each: thread creation per step would cost more than the steps)
+    struct Team {
+        int T;
+        std::atomic<int> arrived{0}, sense{0};
+        explicit Team(int t) : T(t) {}
+        void barrier(int &local) {
+            local ^= 1;
+            if (arrived.fetch_add(1, std::memory_order_acq_rel) == T - 1) {
+                arrived.store(0, std::memory_order_relaxed);
+                sense.store(local, std::memory_order_release);
+                if (T > 1) syscall(SYS_futex, reinterpret_cast<int *>(&sense), FUTEX_WAKE_PRIVATE, INT_MAX, nullptr, nullptr, 0);
+            } else {
+                // a short spin, then sleep in the kernel: the threads may outnumber the CPUs this process may use (a CPU quota
+                // makes spinning waiters starve the thread everybody waits for)
+                for (unsigned spins = 0; spins < 64 && sense.load(std::memory_order_acquire) != local; ++spins) {
+#if defined(__x86_64__)
+                    _mm_pause();
+#endif
+                }
+                while (sense.load(std::memory_order_acquire) != local)
+                    syscall(SYS_futex, reinterpret_cast<int *>(&sense), FUTEX_WAIT_PRIVATE, local ^ 1, nullptr, nullptr, 0);
+            }
+        }
+    };
+    static_assert(sizeof(std::atomic<int>) == sizeof(int), "the futex word is the atomic itself");
+    void run_team(const std::function<void(int, Team &)> &fn) {
+        Team team(std::max(1, threads));
+        if (team.T == 1) { fn(0, team); return; }
+        std::vector<std::thread> pool;
+        for (int t = 0; t < team.T; ++t) pool.emplace_back([&, t] { fn(t, team); });
+        for (auto &th : pool) th.join();
+    }
+    // which thread applies the reverse edges into list x: any fixed map gives the same graph, every list has ONE writer
+    static uint32_t owner_of(uint32_t x, uint32_t T) { return (uint32_t)(((uint64_t)(x * 2654435761u) * T) >> 32); }
 
     // occlusion scan shared by all prune routines: p survives if it is not yet chosen and no chosen r is closer to it
     // than p is to the pivot
@@ -272,6 +318,222 @@ struct Builder {
                 g[des] = copy;
             }
         }
+    }
+
+    // one step of add_reverse's loop on a list this thread owns (no lock: deterministic schedules give every list one writer)
+    void apply_insert(std::vector<uint32_t> &dn, uint32_t des, uint32_t src, uint32_t limit, bool phantoms) const {
+        if (has(dn, src)) return;
+        dn.push_back(src);
+        if (dn.size() > limit) prune_reverse(des, dn, phantoms);
+    }
+
+    // ---- deterministic multi-threaded forms of the three places where the reference's threads race on the lists ----------
+    // All three rest on one observation: a reverse-edge insertion (src -> des) reads and writes the list of `des` ONLY
+    // (prune_reverse scores des against its own list members).  So once it is known WHICH insertions reach a list and in what
+    // order, every list can be replayed on its own by one thread, and the outcome is the one-thread outcome -- for any
+    // number of threads, without locks.
+    //
+    // Phase 1 (:1059-1097).  The pruned list of training query sq depends on its knn row only (`lists`: [nq][M+1], length +
+    // ids, complete), so the whole event sequence of a list x is static: a WRITE by every query whose nearest base point
+    // is x, an INSERT (of that query's nearest point) by every query whose pruned list holds x, in query order.  A WRITE
+    // replaces the list, so x starts from its LAST write and replays the inserts of the later queries.
+    void phase1_replay(const uint32_t *knn, uint32_t nq, uint32_t kdim, const std::vector<uint32_t> &lists) {
+        const uint32_t W = M + 1, none = 0xffffffffu;
+        std::vector<uint32_t> last(nd, none);
+        for (uint32_t sq = 0; sq < nq; ++sq) last[knn[(size_t)sq * kdim]] = sq;
+        std::vector<uint32_t> cnt(nd, 0);
+        auto live = [&](uint32_t des, uint32_t sq) { return last[des] == none || sq > last[des]; };
+        parallel_for(nq, 4096, [&](uint32_t sq, int) {
+            const uint32_t *l = lists.data() + (size_t)sq * W;
+            for (uint32_t i = 0; i < l[0]; ++i)
+                if (live(l[1 + i], sq)) __atomic_fetch_add(&cnt[l[1 + i]], 1u, __ATOMIC_RELAXED);
+        });
+        std::vector<uint64_t> off((size_t)nd + 1, 0);
+        for (uint32_t x = 0; x < nd; ++x) { off[x + 1] = off[x] + cnt[x]; cnt[x] = 0; }
+        std::vector<uint32_t> ev(off[nd]);
+        parallel_for(nq, 4096, [&](uint32_t sq, int) {
+            const uint32_t *l = lists.data() + (size_t)sq * W;
+            for (uint32_t i = 0; i < l[0]; ++i) {
+                const uint32_t des = l[1 + i];
+                if (live(des, sq)) ev[off[des] + __atomic_fetch_add(&cnt[des], 1u, __ATOMIC_RELAXED)] = sq;
+            }
+        });
+        auto replay = [&](uint32_t x) {
+            if (last[x] == none && cnt[x] == 0) return;
+            std::vector<uint32_t> &dn = proj[x];
+            dn.clear();
+            if (last[x] != none) {
+                const uint32_t *l = lists.data() + (size_t)last[x] * W;
+                dn.assign(l + 1, l + 1 + l[0]);
+            }
+            uint32_t *e = ev.data() + off[x];
+            std::sort(e, e + cnt[x]);                         // query order (the fill above ran in parallel)
+            for (uint32_t i = 0; i < cnt[x]; ++i) apply_insert(dn, x, knn[(size_t)e[i] * kdim], M, false);
+        };
+        // the longest replays first (hubs take tens of thousands of inserts, one after another), then everything else
+        std::vector<uint32_t> heavy;
+        for (uint32_t x = 0; x < nd; ++x) if (cnt[x] >= 4096) heavy.push_back(x);
+        std::sort(heavy.begin(), heavy.end(), [&](uint32_t a, uint32_t b) { return cnt[a] > cnt[b] || (cnt[a] == cnt[b] && a < b); });
+        std::atomic<uint32_t> next_heavy(0), next_light(0);
+        if (timing) fprintf(stderr, "[rg_build]   phase 1: %zu reverse edges to replay, %zu lists with >= 4096 of them (the longest %u)\n",
+                            (size_t)off[nd], heavy.size(), heavy.empty() ? 0u : cnt[heavy[0]]);
+        run_team([&](int, Team &) {
+            for (;;) {
+                const uint32_t i = next_heavy.fetch_add(1);
+                if (i >= heavy.size()) break;
+                replay(heavy[i]);
+            }
+            for (;;) {
+                const uint32_t lo = next_light.fetch_add(256);
+                if (lo >= nd) break;
+                for (uint32_t x = lo; x < std::min(nd, lo + 256); ++x)
+                    if (cnt[x] < 4096) replay(x);
+            }
+        });
+    }
+
+    // Phase 2 (:1100-1107: for every node in order, insert it into the lists of its neighbours).  Node j reads its own list
+    // when its turn comes, and earlier turns may have changed that list -- but only turns of nodes i < j that held j in
+    // THEIR list, and (j being later) they can only hold j if they held it when the phase began.  So consecutive nodes
+    // are cut into windows in which no node is listed by an earlier node of the same window (pred[j] = the last i < j whose
+    // starting list holds j; j opens a new window if pred[j] is inside the current one): inside a window every node's list is
+    // still what it was when the window began, all their insertions are known, and each target list replays its own in
+    // source order -- the one-thread result exactly.
+    void phase2_windows() {
+        std::vector<uint32_t> pred(nd, 0);                // pred[j] = 1 + the last i < j whose list holds j (0: none)
+        parallel_for(nd, 4096, [&](uint32_t i, int) {
+            for (uint32_t j : proj[i])
+                if (j > i) {
+                    uint32_t cur = __atomic_load_n(&pred[j], __ATOMIC_RELAXED);
+                    while (cur < i + 1 && !__atomic_compare_exchange_n(&pred[j], &cur, i + 1, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+                }
+        });
+        std::vector<uint32_t> wend;                       // window ends
+        size_t maxw = 0;
+        for (uint32_t a = 0, j = 0; j <= nd; ++j)
+            if (j == nd || (pred[j] != 0 && pred[j] - 1 >= a)) {
+                if (j > a) { wend.push_back(j); maxw = std::max<size_t>(maxw, j - a); }
+                a = j;
+                if (j == nd) break;
+            }
+        std::vector<uint32_t>().swap(pred);
+        lap("phase 2 windows");
+        if (timing) fprintf(stderr, "[rg_build]   phase 2: %zu windows of independent nodes (mean %.0f, longest %zu)\n", wend.size(),
+                            wend.empty() ? 0.0 : (double)nd / wend.size(), maxw);
+        std::vector<uint32_t> ev_des(maxw * (size_t)M + 1), ev_src(maxw * (size_t)M + 1);
+        std::atomic<long long> st_events{0}, st_present{0}, st_pruned{0}, st_ns_apply{0}, st_ns_total{0};
+        run_team([&](int t, Team &team) {
+            int sense = 0;
+            const uint32_t T = (uint32_t)team.T;
+            std::vector<uint32_t> pre(maxw + 1);          // where each node's insertions start in the window's event list
+            uint32_t a = 0;
+            long long my_events = 0, my_present = 0, my_pruned = 0, my_ns = 0;
+            const auto t_begin = std::chrono::steady_clock::now();
+            for (size_t w = 0; w < wend.size(); ++w) {
+                const uint32_t b = wend[w], n = b - a;
+                pre[0] = 0;
+                for (uint32_t i = 0; i < n; ++i) pre[i + 1] = pre[i] + (uint32_t)proj[a + i].size();
+                for (uint32_t i = (uint32_t)t; i < n; i += T) {
+                    const std::vector<uint32_t> &l = proj[a + i];
+                    for (size_t k = 0; k < l.size(); ++k) { ev_des[pre[i] + k] = l[k]; ev_src[pre[i] + k] = a + i; }
+                }
+                team.barrier(sense);
+                const uint32_t ne = pre[n];
+                if (!timing) {
+                    for (uint32_t e = 0; e < ne; ++e)
+                        if (owner_of(ev_des[e], T) == (uint32_t)t) apply_insert(proj[ev_des[e]], ev_des[e], ev_src[e], M, false);
+                } else {
+                    const auto t0 = std::chrono::steady_clock::now();
+                    for (uint32_t e = 0; e < ne; ++e)
+                        if (owner_of(ev_des[e], T) == (uint32_t)t) {
+                            std::vector<uint32_t> &dn = proj[ev_des[e]];
+                            ++my_events;
+                            if (has(dn, ev_src[e])) { ++my_present; continue; }
+                            if (dn.size() >= M) ++my_pruned;
+                            apply_insert(dn, ev_des[e], ev_src[e], M, false);
+                        }
+                    my_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+                }
+                team.barrier(sense);
+                a = b;
+            }
+            if (timing) {
+                st_events += my_events; st_present += my_present; st_pruned += my_pruned; st_ns_apply += my_ns;
+                st_ns_total += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_begin).count();
+            }
+        });
+        if (timing) fprintf(stderr, "[rg_build]   phase 2: %lld insertions tried, %lld already present, %lld into a full list (pruned); thread time applying %.1f s of %.1f s\n",
+                            st_events.load(), st_present.load(), st_pruned.load(), st_ns_apply.load() * 1e-9, st_ns_total.load() * 1e-9);
+    }
+
+    // Linking a batch of phase 3 (:1209-1215 for nodes [b0, b0 + n), whose pruned lists `lists` ([n][M+1]) were all computed
+    // from the graph as it stood before the batch): node x's list is WRITTEN at its turn and takes INSERTs of the nodes whose
+    // pruned list holds x, in node order -- inserts of earlier nodes of the same batch into x are overwritten by x's write.
+    // Producers cut the batch into T consecutive slices and sort their insertions by owner; an owner walks the T slices in
+    // order, which is node order.
+    void link_batch(uint32_t b0, uint32_t n, const uint32_t *lists) {
+        const uint32_t W = M + 1;
+        const uint32_t T = (uint32_t)std::max(1, threads);
+        const auto t0 = timing ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
+        if (T == 1 || n < 8 * T) {                        // the definition: node by node
+            for (uint32_t i = 0; i < n; ++i) {
+                const uint32_t *l = lists + (size_t)i * W;
+                supply[b0 + i].assign(l + 1, l + 1 + l[0]);
+                if (!dirty.empty()) dirty[b0 + i] = 1;
+                for (uint32_t k = 0; k < l[0]; ++k) {
+                    apply_insert(supply[l[1 + k]], l[1 + k], b0 + i, 2 * M, true);
+                    if (!dirty.empty()) dirty[l[1 + k]] = 1;
+                }
+            }
+            if (timing) ns_reverse += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
+            return;
+        }
+        std::vector<std::vector<uint32_t>> bucket((size_t)T * T);   // [producer][owner]: (des, src) pairs
+        run_team([&](int t, Team &team) {
+            int sense = 0;
+            const uint32_t lo = (uint32_t)((uint64_t)n * t / T), hi = (uint32_t)((uint64_t)n * (t + 1) / T);
+            for (uint32_t i = lo; i < hi; ++i) {
+                const uint32_t *l = lists + (size_t)i * W;
+                for (uint32_t k = 0; k < l[0]; ++k) {
+                    std::vector<uint32_t> &bk = bucket[(size_t)t * T + owner_of(l[1 + k], T)];
+                    bk.push_back(l[1 + k]);
+                    bk.push_back(b0 + i);
+                }
+            }
+            team.barrier(sense);
+            for (uint32_t i = 0; i < n; ++i)              // the writes of the lists this thread owns
+                if (owner_of(b0 + i, T) == (uint32_t)t) {
+                    const uint32_t *l = lists + (size_t)i * W;
+                    supply[b0 + i].assign(l + 1, l + 1 + l[0]);
+                    if (!dirty.empty()) dirty[b0 + i] = 1;
+                }
+            for (uint32_t p = 0; p < T; ++p) {
+                const std::vector<uint32_t> &bk = bucket[(size_t)p * T + t];
+                for (size_t e = 0; e + 1 < bk.size(); e += 2) {
+                    const uint32_t des = bk[e], src = bk[e + 1];
+                    if (des >= b0 && des < b0 + n && src < des) continue;   // overwritten by des's own write
+                    apply_insert(supply[des], des, src, 2 * M, true);
+                    if (!dirty.empty()) dirty[des] = 1;                     // (one writer per row: its owner)
+                }
+            }
+        });
+        if (timing) ns_reverse += (long long)(std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count() * (double)T);
+    }
+
+    // the batches of phase 3 (also rg_build_schedule): `batch` nodes each if the caller fixed it; otherwise the first 2,048
+    // nodes one by one (the projection graph is barely connected before phase 3: searches from the entry point expand a
+    // handful of nodes), then batches of at most a quarter of what is linked, between 512 and B nodes
+    static std::vector<uint32_t> phase3_schedule(uint32_t nd, uint32_t batch) {
+        std::vector<uint32_t> s;
+        const uint32_t B = batch ? batch : std::max<uint32_t>(8192, std::min<uint32_t>(131072, nd / 24));
+        const uint32_t warm = batch ? 0u : std::min<uint32_t>(nd, 2048u);
+        s.assign(warm, 1u);
+        for (uint32_t b0 = warm, n = 0; b0 < nd; b0 += n) {
+            n = batch ? B : std::min(B, std::max<uint32_t>(512, b0 / 4));
+            n = std::min(n, nd - b0);
+            s.push_back(n);
+        }
+        return s;
     }
 
     // :1846-1940
@@ -383,17 +645,6 @@ struct Builder {
         }
     }
 
-    // a node's pruned list (from the GPU) takes the place of prune_search's result; the reverse edges follow as usual
-    void link_pruned(uint32_t node, const uint32_t *ids, uint32_t n) {
-        const auto t0 = timing ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
-        {
-            std::lock_guard<std::mutex> guard(locks[node]);
-            supply[node].assign(ids, ids + n);
-        }
-        add_reverse(supply, node, 2 * M, true);
-        if (timing) ns_reverse += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
-    }
-
     // Phase 3 with the n beam searches on the GPU (K1 in build mode), in batches: every node of a batch searches the
     // supply graph as it stood when the batch started (the reference's multi-threaded build sees a similarly racy
     // graph; at one thread it sees every earlier node's links -- so this variant is NOT the T=1 result, it is a valid
@@ -410,7 +661,8 @@ struct Builder {
         const uint32_t cap = (2 * L + 63) / 64 * 64;
         // batch schedule: a batch never exceeds a quarter of the nodes already linked (the graph changes fastest early
         // on, when a stale snapshot hurts most), between 2,048 and Bmax nodes; a fixed size if the caller gave one
-        const uint32_t B = gpu_batch ? gpu_batch : std::max<uint32_t>(8192, std::min<uint32_t>(131072, nd / 24));
+        const std::vector<uint32_t> sched = phase3_schedule(nd, gpu_batch);
+        const uint32_t B = *std::max_element(sched.begin(), sched.end());
         if (hipSetDevice(gpu_device) != hipSuccess) return fail("cannot select the build GPU");
         float *d_base = nullptr;
         uint2_pod *d_exp = nullptr;
@@ -423,9 +675,21 @@ struct Builder {
         uint32_t *d_have = nullptr, *h_have = nullptr, *d_out = nullptr, *h_out = nullptr;
         hipStream_t st = nullptr;
         hipEvent_t evA = nullptr, evB = nullptr;
+        // the graph snapshot on the device is refreshed with the rows that changed since the last batch (`dirty`), through
+        // two pinned staging buffers of CH rows (+ their row numbers) and a scatter kernel -- not with all nd rows from
+        // pageable memory every batch (10M nodes: 98 batches x 3.2 GB)
+        const uint32_t CH = std::min<uint32_t>(nd, 1u << 19);
+        uint32_t *h_stage[2] = {nullptr, nullptr}, *d_stage[2] = {nullptr, nullptr};
+        hipEvent_t evS[2] = {nullptr, nullptr};
+        bool stage_used[2] = {false, false};
+        std::vector<uint32_t> dl;
         bool ok = true;
+        for (int i = 0; i < 2 && ok; ++i)
+            ok = hipHostMalloc(&h_stage[i], (size_t)CH * (S + 1) * 4) == hipSuccess && hipMalloc(&d_stage[i], (size_t)CH * (S + 1) * 4) == hipSuccess &&
+                 hipEventCreate(&evS[i]) == hipSuccess;
+        dirty.assign(nd, 1);
         if (d_base_pre) { d_base = d_base_pre; d_base_pre = nullptr; }
-        else ok = hipMalloc(&d_base, (size_t)nd * stride * 4) == hipSuccess &&
+        else ok = ok && hipMalloc(&d_base, (size_t)nd * stride * 4) == hipSuccess &&
                   hipMemcpy(d_base, base, (size_t)nd * stride * 4, hipMemcpyHostToDevice) == hipSuccess;
         ok = ok && hipMalloc(&d_exp, (size_t)B * cap * 8) == hipSuccess && hipMalloc(&d_nexp, (size_t)B * 4) == hipSuccess &&
                   hipHostMalloc(&h_exp, (size_t)B * cap * 8) == hipSuccess && hipHostMalloc(&h_nexp, (size_t)B * 4) == hipSuccess &&
@@ -442,27 +706,49 @@ struct Builder {
         // The projection graph is barely connected before phase 3 (searches from the entry point expand a handful of
         // nodes), so the first nodes are linked one after another on the host, exactly as the reference does at one
         // thread; the GPU takes over once the graph is navigable, in batches of at most a quarter of what is linked.
-        const uint32_t warm = gpu_batch ? 0u : std::min<uint32_t>(nd, 2048u);
-        for (uint32_t node = 0; ok && node < warm; ++node) {
-            std::vector<Nb> expanded;
-            search_live(node, stamp[0], serial[0], expanded);
-            link_from_search(node, expanded);
-        }
+        size_t si = 0;
+        uint32_t warm = 0;
+        if (!gpu_batch)
+            for (; ok && si < sched.size() && sched[si] == 1; ++si, ++warm) {
+                std::vector<Nb> expanded;
+                search_live(warm, stamp[0], serial[0], expanded);
+                link_from_search(warm, expanded);
+            }
+        std::vector<uint32_t> lk((size_t)B * (M + 1));   // the batch's pruned lists, GPU's or host's, as link_batch wants them
         double t_snap = 0, t_gpu = 0, t_link = 0;
         uint32_t nbatches = 0;
+        size_t n_dirty = 0;
         auto since = [](std::chrono::steady_clock::time_point t0) { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); };
         auto t_b = std::chrono::steady_clock::now();
         if (timing) fprintf(stderr, "[rg_build]   phase 3 upload + warm-up  %8.2f s\n", since(t_mark));
-        for (uint32_t b0 = warm, n = 0; ok && b0 < nd; b0 += n) {
-            n = gpu_batch ? B : std::min(B, std::max<uint32_t>(512, b0 / 4));
-            n = std::min(n, nd - b0);
+        for (uint32_t b0 = warm, n = 0; ok && b0 < nd; b0 += n, ++si) {
+            n = sched[si];
             t_link += since(t_b); t_b = std::chrono::steady_clock::now();
-            parallel_for(nd, 4096, [&](uint32_t i, int) {
-                uint32_t *row = h_ell.data() + (size_t)i * S;
-                const std::vector<uint32_t> &l = supply[i];
-                row[0] = (uint32_t)l.size();
-                std::memcpy(row + 1, l.data(), l.size() * 4);
-            });
+            dl.clear();
+            for (uint32_t i = 0; i < nd; ++i) if (dirty[i]) { dl.push_back(i); dirty[i] = 0; }
+            n_dirty += dl.size();
+            for (size_t c0 = 0, ci = 0; ok && c0 < dl.size(); c0 += CH, ++ci) {
+                const int bi = (int)(ci & 1);
+                const uint32_t cn = (uint32_t)std::min<size_t>(CH, dl.size() - c0);
+                if (stage_used[bi]) ok = hipEventSynchronize(evS[bi]) == hipSuccess;   // its last upload has left the pinned buffer
+                if (!ok) break;
+                uint32_t *rows = h_stage[bi], *idx = h_stage[bi] + (size_t)CH * S;
+                parallel_for(cn, 4096, [&](uint32_t r, int) {
+                    const uint32_t i = dl[c0 + r];
+                    uint32_t *row = h_ell.data() + (size_t)i * S;
+                    const std::vector<uint32_t> &l = supply[i];
+                    row[0] = (uint32_t)l.size();
+                    std::memcpy(row + 1, l.data(), l.size() * 4);
+                    std::memcpy(rows + (size_t)r * S, row, (size_t)S * 4);
+                    idx[r] = i;
+                });
+                ok = hipMemcpyAsync(d_stage[bi], rows, (size_t)cn * S * 4, hipMemcpyHostToDevice, st) == hipSuccess &&
+                     hipMemcpyAsync(d_stage[bi] + (size_t)CH * S, idx, (size_t)cn * 4, hipMemcpyHostToDevice, st) == hipSuccess &&
+                     hipEventRecord(evS[bi], st) == hipSuccess &&
+                     build_index_update_rows(ix, d_stage[bi], d_stage[bi] + (size_t)CH * S, cn, st) == RG_OK;
+                stage_used[bi] = true;
+            }
+            if (!ok) break;
             t_snap += since(t_b); t_b = std::chrono::steady_clock::now();
             // the batch goes to the GPU in two halves over the same snapshot: the host links the first half while the
             // GPU searches the second (same semantics as one launch: every node of the batch searched the snapshot)
@@ -489,7 +775,7 @@ struct Builder {
                     good = hipMemcpyAsync(h_exp + (size_t)h0 * cap, d_exp + (size_t)h0 * cap, (size_t)hn * cap * 8, hipMemcpyDeviceToHost, st) == hipSuccess;
                 return good && hipEventRecord(ev, st) == hipSuccess;
             };
-            ok = ok && build_index_set_ell(ix, h_ell.data(), nullptr) == RG_OK && enqueue(0, nA, evA);
+            ok = ok && enqueue(0, nA, evA);
             if (ok && nB) ok = enqueue(nA, nB, evB);
             if (ok) ok = hipEventSynchronize(evA) == hipSuccess;
             if (!ok) break;
@@ -508,8 +794,9 @@ struct Builder {
                 const uint32_t node = b0 + i;
                 std::vector<Nb> expanded;
                 const uint32_t *po = gpu_prune ? h_out + (size_t)i * (M + 1) : nullptr;
+                uint32_t *dst = lk.data() + (size_t)i * (M + 1);
                 if (po && po[0] != 0xffffffffu && !gpu_verify) {
-                    link_pruned(node, po + 1, po[0]);
+                    std::memcpy(dst, po, (size_t)(po[0] + 1) * 4);
                     return;
                 }
                 if (h_nexp[i] > cap || (po && po[0] == 0xffffffffu && !want_exp)) {
@@ -538,13 +825,26 @@ struct Builder {
                         }
                     }
                 }
-                link_from_search(node, expanded);
+                // the host's pruning of this node's expansion list (shapes or nodes the kernel left to the host, or the check)
+                expanded.erase(std::remove_if(expanded.begin(), expanded.end(), [&](const Nb &x) { return x.id == node; }), expanded.end());
+                std::vector<uint32_t> pruned;
+                prune_search(expanded, node, pruned);
+                dst[0] = (uint32_t)pruned.size();
+                std::memcpy(dst + 1, pruned.data(), pruned.size() * 4);
             });
+            link_batch(b0 + h0, hn, lk.data() + (size_t)h0 * (M + 1));
             }
         }
         t_link += since(t_b);
-        if (timing) fprintf(stderr, "[rg_build]   phase 3: %u batches, snapshot %.2f s, upload + GPU search%s + download %.2f s, host linking %.2f s\n",
-                            nbatches, t_snap, gpu_prune ? " + GPU pruning" : "", t_gpu, t_link);
+        if (timing) fprintf(stderr, "[rg_build]   phase 3: %u batches, snapshot (%.1f M changed rows staged + uploaded) %.2f s, GPU search%s + download %.2f s, host linking %.2f s\n",
+                            nbatches, n_dirty * 1e-6, t_snap, gpu_prune ? " + GPU pruning" : "", t_gpu, t_link);
+        dirty.clear(); dirty.shrink_to_fit();
+        if (st) (void)hipStreamSynchronize(st);
+        for (int i = 0; i < 2; ++i) {
+            if (h_stage[i]) (void)hipHostFree(h_stage[i]);
+            if (d_stage[i]) (void)hipFree(d_stage[i]);
+            if (evS[i]) (void)hipEventDestroy(evS[i]);
+        }
         if (ix) rg_index_close(ix);
         if (d_base) (void)hipFree(d_base);
         if (d_exp) (void)hipFree(d_exp);
@@ -563,6 +863,47 @@ struct Builder {
         if (mismatches.load()) return fail("GPU phase 3: " + std::to_string(mismatches.load()) + " expansion lists differ from the host search");
         if (prune_mismatches.load()) return fail("GPU phase 3: " + std::to_string(prune_mismatches.load()) + " pruned lists differ from the host pruning");
         return true;
+    }
+
+    // Phase 3 on host threads, many of them: the batches of phase3_schedule, every node of a batch searching the graph as it
+    // stood when the batch began (a frozen flat copy), then link_batch -- what phase3_gpu does with the searches and the
+    // pruning on the host, so the two builders (and the oracle given the same schedule) write the same index.
+    void phase3_host_batched() {
+        const std::vector<uint32_t> sched = phase3_schedule(nd, 0);
+        const uint32_t S = 2 * M + 1;
+        std::vector<std::vector<uint32_t>> stamp(std::max(1, threads));
+        std::vector<uint32_t> serial(std::max(1, threads), 0);
+        size_t si = 0;
+        uint32_t b0 = 0;
+        for (; si < sched.size() && sched[si] == 1; ++si, ++b0) {
+            std::vector<Nb> expanded;
+            search_live(b0, stamp[0], serial[0], expanded);
+            link_from_search(b0, expanded);
+        }
+        if (b0 >= nd) return;
+        std::vector<uint32_t> ell((size_t)nd * S), lk;
+        for (; si < sched.size(); b0 += sched[si], ++si) {
+            const uint32_t n = sched[si];
+            parallel_for(nd, 4096, [&](uint32_t i, int) {
+                uint32_t *row = ell.data() + (size_t)i * S;
+                const std::vector<uint32_t> &l = supply[i];
+                row[0] = (uint32_t)l.size();
+                std::memcpy(row + 1, l.data(), l.size() * 4);
+            });
+            lk.resize((size_t)n * (M + 1));
+            parallel_for(n, 16, [&](uint32_t i, int t) {
+                const uint32_t node = b0 + i;
+                std::vector<Nb> expanded;
+                search_snapshot(node, ell.data(), S, stamp[t], serial[t], expanded);
+                expanded.erase(std::remove_if(expanded.begin(), expanded.end(), [&](const Nb &x) { return x.id == node; }), expanded.end());
+                std::vector<uint32_t> pruned;
+                prune_search(expanded, node, pruned);
+                uint32_t *dst = lk.data() + (size_t)i * (M + 1);
+                dst[0] = (uint32_t)pruned.size();
+                std::memcpy(dst + 1, pruned.data(), pruned.size() * 4);
+            });
+            link_batch(b0, n, lk.data());
+        }
     }
 
     // RG_BUILD_TIMING=1: per-phase wall times on stderr
@@ -645,39 +986,36 @@ struct Builder {
         };
         if (threads <= 1) {
             for (uint32_t sq = 0; sq < nq; ++sq) phase1_query(sq);   // the reference's order
-        } else {
-            // Training queries that share their nearest base point all rewrite that point's list (hubs collect thousands of
-            // them): one thread takes all queries of a base point, in query order, biggest groups first -- no two threads
-            // fight over the same list, and per base point the sequence is the one-thread sequence.
-            std::vector<uint32_t> order(nq);
-            for (uint32_t i = 0; i < nq; ++i) order[i] = i;
-            std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return knn[(size_t)a * kdim] < knn[(size_t)b * kdim]; });
-            std::vector<std::pair<uint32_t, uint32_t>> groups;   // [begin, end) in `order`
-            for (uint32_t i = 0; i < nq;) {
-                uint32_t j = i + 1;
-                while (j < nq && knn[(size_t)order[j] * kdim] == knn[(size_t)order[i] * kdim]) ++j;
-                groups.emplace_back(i, j);
-                i = j;
-            }
-            std::stable_sort(groups.begin(), groups.end(), [](const std::pair<uint32_t, uint32_t> &a, const std::pair<uint32_t, uint32_t> &b) {
-                return a.second - a.first > b.second - b.first;
+        } else if (std::min(kdim, Nq) > 0) {
+            // the one-thread result on many threads (phase1_replay): first every query's pruned list (the GPU's, or the host's
+            // for the queries the kernel left out / for the check), then each base point's list replayed on its own
+            const uint32_t n = std::min(kdim, Nq);
+            if (p1.empty()) p1.assign((size_t)nq * (M + 1), 0xffffffffu);
+            parallel_for(nq, 256, [&](uint32_t sq, int) {
+                uint32_t *po = p1.data() + (size_t)sq * (M + 1);
+                if (po[0] != 0xffffffffu && !gpu_verify) return;
+                const uint32_t *nn = knn + (size_t)sq * kdim;
+                const uint32_t tgt = nn[0];
+                for (uint32_t i = 0; i < n; ++i) prefetch_row(nn[i]);
+                std::vector<Nb> full;
+                for (uint32_t i = 0; i < n; ++i)
+                    if (nn[i] != tgt) full.push_back(Nb{nn[i], cmp(nn[i], tgt)});
+                std::vector<uint32_t> host_list;
+                prune_get_base(full, tgt, host_list);
+                if (po[0] != 0xffffffffu && (po[0] != host_list.size() || !std::equal(host_list.begin(), host_list.end(), po + 1)))
+                    p1_mismatches.fetch_add(1);
+                po[0] = (uint32_t)host_list.size();
+                std::memcpy(po + 1, host_list.data(), host_list.size() * 4);
             });
-            std::atomic<long long> ns_big{0};
-            parallel_for((uint32_t)groups.size(), 4, [&](uint32_t gi, int) {
-                const auto t0 = (timing && gi == 0) ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
-                for (uint32_t i = groups[gi].first; i < groups[gi].second; ++i) phase1_query(order[i]);
-                if (timing && gi == 0) ns_big = std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
-            });
-            if (timing && !groups.empty())
-                fprintf(stderr, "[rg_build]   phase 1: %zu base points are somebody's nearest, the most popular one of %u queries (%.2f s on its thread), "
-                                "10th %u, 100th %u\n", groups.size(), groups[0].second - groups[0].first, ns_big.load() * 1e-9,
-                        groups.size() > 9 ? groups[9].second - groups[9].first : 0u, groups.size() > 99 ? groups[99].second - groups[99].first : 0u);
+            lap("phase 1 pruning (host part)");
+            phase1_replay(knn, nq, kdim, p1);
         }
         lap("phase 1");
         if (p1_mismatches.load()) { gpu_error = "GPU phase 1: " + std::to_string(p1_mismatches.load()) + " pruned lists differ from the host pruning"; return false; }
         p1.clear(); p1.shrink_to_fit();
         // ---- phase 2 (:1100-1136)
-        parallel_for(nd, 100, [&](uint32_t node, int) { add_reverse(proj, node, M, false); });
+        if (threads <= 1) for (uint32_t node = 0; node < nd; ++node) add_reverse(proj, node, M, false);
+        else phase2_windows();
         lap("phase 2 reverse edges");
         parallel_for(nd, 2048, [&](uint32_t node, int) {
             if (proj[node].size() <= M) return;
@@ -695,14 +1033,16 @@ struct Builder {
         // ---- phase 3 (:1192-1220): connectivity enhancement -- beam search from the entry point towards every node
         if (gpu_device >= 0) {
             if (!phase3_gpu()) return false;
-        } else {
-            std::vector<std::vector<uint32_t>> stamp(std::max(1, threads));
-            std::vector<uint32_t> serial(std::max(1, threads), 0);
-            parallel_for(nd, 2048, [&](uint32_t node, int t) {
+        } else if (threads <= 1) {
+            std::vector<uint32_t> stamp;
+            uint32_t serial = 0;
+            for (uint32_t node = 0; node < nd; ++node) {     // the reference's one-thread sequence
                 std::vector<Nb> expanded;
-                search_live(node, stamp[t], serial[t], expanded);
+                search_live(node, stamp, serial, expanded);
                 link_from_search(node, expanded);
-            });
+            }
+        } else {
+            phase3_host_batched();
         }
         lap("phase 3");
         if (timing) fprintf(stderr, "[rg_build]   linking, thread-seconds: prune of the expansion list %.1f, reverse edges %.1f\n",
@@ -735,6 +1075,30 @@ struct Builder {
 }  // namespace
 }  // namespace rg
 
+// CPUs this process can actually run on at once: its affinity mask, cut by the cgroup CPU quota when there is one (a
+// container that shows 256 CPUs may be allowed 16 CPUs' worth of time; threads beyond that only take turns -- and turn
+// every barrier of the deterministic phases into a wait for the scheduler)
+static unsigned usable_cpus() {
+    unsigned n = std::max(1u, std::thread::hardware_concurrency());
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) n = std::max(1, CPU_COUNT(&set));
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {                   // cgroup v2: "<quota|max> <period>"
+        char q[32] = {0};
+        long long period = 0;
+        if (fscanf(f, "%31s %lld", q, &period) == 2 && period > 0 && strcmp(q, "max") != 0) {
+            const long long quota = atoll(q);
+            if (quota > 0) n = std::min<unsigned>(n, (unsigned)std::max<long long>(1, (quota + period - 1) / period));
+        }
+        fclose(f);
+    } else {
+        long long quota = -1, period = 0;                                    // cgroup v1
+        if (FILE *fq = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(fq, "%lld", &quota) != 1) quota = -1; fclose(fq); }
+        if (FILE *fp = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(fp, "%lld", &period) != 1) period = 0; fclose(fp); }
+        if (quota > 0 && period > 0) n = std::min<unsigned>(n, (unsigned)std::max<long long>(1, (quota + period - 1) / period));
+    }
+    return n;
+}
+
 static rg_status build_impl(const float *base, uint32_t nb, uint32_t dim, uint32_t stride, const uint32_t *knn_ids,
                             uint32_t nq, uint32_t knn_k, int metric, uint32_t M_sq, uint32_t M_pjbp, uint32_t L_pjpq,
                             uint32_t num_threads, int device, uint32_t batch, uint32_t *out_ep, uint64_t **out_offsets,
@@ -764,7 +1128,9 @@ static rg_status build_impl(const float *base, uint32_t nb, uint32_t dim, uint32
     b.avx512 = false;
 #endif
     b.M = M_pjbp; b.L = L_pjpq; b.Nq = M_sq;
+    // more than one thread: as many as asked for, but no more than can run at once (the result does not depend on the count)
     b.threads = (int)std::max<uint32_t>(1, num_threads);
+    if (b.threads > 1 && !getenv("RG_BUILD_THREADS_AS_GIVEN")) b.threads = (int)std::max(2u, std::min<unsigned>((unsigned)b.threads, usable_cpus()));
     b.gpu_device = device;
     b.gpu_batch = batch;
     b.gpu_verify = getenv("RG_BUILD_VERIFY") != nullptr;
@@ -827,4 +1193,12 @@ extern "C" rg_status rg_build_roargraph_gpu(const float *base, uint32_t nb, uint
         return rg::set_error(RG_ERR_DEVICE, "no HIP device visible: the gfx950 path cannot run (there is no CPU fallback)");
     return build_impl(base, nb, dim, stride, knn_ids, nq, knn_k, metric, M_sq, M_pjbp, L_pjpq, num_threads, device, batch,
                       out_ep, out_offsets, out_nbrs);
+}
+
+extern "C" rg_status rg_build_schedule(uint32_t nb, uint32_t batch, uint32_t *sizes, uint32_t cap, uint32_t *count) {
+    if (!count || (cap && !sizes)) return rg::set_error(RG_ERR_ARG, "null argument");
+    const std::vector<uint32_t> s = rg::Builder::phase3_schedule(nb, batch);
+    for (size_t i = 0; i < s.size() && i < cap; ++i) sizes[i] = s[i];
+    *count = (uint32_t)s.size();
+    return RG_OK;
 }

@@ -142,6 +142,7 @@ rg_status build_search_dev(rg_index *ix, uint32_t node0, uint32_t n, uint32_t L,
 rg_status build_index_create(const float *d_base, uint32_t nd, uint32_t dim, uint32_t stride, uint32_t ep, int metric,
                              int device, uint32_t ell_stride, rg_index **out);
 rg_status build_index_set_ell(rg_index *ix, const uint32_t *h_ell, void *stream);
+rg_status build_index_update_rows(rg_index *ix, const uint32_t *d_rows, const uint32_t *d_idx, uint32_t n, void *stream);
 // PruneProjectionBaseSearchCandidates (:1846-1940) of n expansion lists on the GPU (rg_build_prune.hip): d_have[i] = length +
 // ids of node i's projection list (row stride hs words), d_out[i] = length + pruned ids (row stride M + 1; length
 // 0xffffffff = left to the host).  Bit-identical to Builder::prune_search.

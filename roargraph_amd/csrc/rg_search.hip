@@ -1157,6 +1157,23 @@ rg_status build_index_set_ell(rg_index *ix, const uint32_t *h_ell, void *stream)
     return RG_OK;
 }
 
+// rows [idx[r]] of the ELL array <- rows[r] (the build's graph snapshot goes up as the rows that changed since the last one)
+__global__ void rg_ell_scatter_kernel(uint32_t *ell, const uint32_t *rows, const uint32_t *idx, uint32_t n, uint32_t S) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (size_t)n * S) return;
+    const uint32_t r = (uint32_t)(i / S), c = (uint32_t)(i % S);
+    ell[(size_t)idx[r] * S + c] = rows[i];
+}
+rg_status build_index_update_rows(rg_index *ix, const uint32_t *d_rows, const uint32_t *d_idx, uint32_t n, void *stream) {
+    if (n == 0) return RG_OK;
+    RG_HIP(hipSetDevice(ix->device));
+    const size_t words = (size_t)n * ix->ell_stride;
+    hipLaunchKernelGGL(rg_ell_scatter_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, (hipStream_t)stream, ix->d_ell, d_rows, d_idx, n,
+                       ix->ell_stride);
+    RG_HIP(hipGetLastError());
+    return RG_OK;
+}
+
 // host-form search in two halves (rg_search: one index; rg_search_sharded: one per replica, all in flight together)
 struct HostSearch {
     rg_index *ix = nullptr;

@@ -55,10 +55,55 @@ def test_small_build_properties_and_recall(rgb, oracle):
     gt = np_gt(query, base, 100)
     ids, _, _, _ = oracle.search(base, "ip", off, nbrs, ep, query, 10, 200, nthreads=4)
     assert oracle.recall(ids, gt, 10) > 0.95
-    # multi-threaded build: scheduling dependent like the reference, but the same quality
+    # multi-threaded build: phase 3 in batches (a different, fixed order), the same quality
     off8, nbrs8, ep8 = rgb.build_roargraph(base, knn, "ip", M_sq=100, M_pjbp=M, L_pjpq=200, num_threads=8)
     ids8, _, _, _ = oracle.search(base, "ip", off8, nbrs8, ep8, query, 10, 200, nthreads=4)
     assert ep8 == ep and np.diff(off8.astype(np.int64)).max() <= 2 * M and oracle.recall(ids8, gt, 10) > 0.95
+
+
+def structured(seed, nb, nt, d, metric, knn_k, r=6, dups=0):
+    """low-rank rows (hubs: a few base points are the nearest of thousands of training queries) + optional repeated rows"""
+    rng = np.random.default_rng(seed)
+    A = rng.standard_normal((r, d)).astype(np.float32)
+    base = rng.standard_normal((nb, r)).astype(np.float32) @ A + 0.05 * rng.standard_normal((nb, d)).astype(np.float32)
+    if dups:
+        base[rng.integers(0, nb, dups)] = base[rng.integers(0, nb, dups)]
+    train = (rng.standard_normal((nt, r)).astype(np.float32) * 0.5 + 0.3) @ A + 0.05 * rng.standard_normal((nt, d)).astype(np.float32)
+    knn = np.zeros((nt, knn_k), np.uint32)
+    for i in range(0, nt, 4096):
+        t = train[i:i + 4096].astype(np.float64)
+        b = base.astype(np.float64)
+        s = -(t @ b.T) if metric != "l2" else (t * t).sum(1)[:, None] - 2 * t @ b.T + (b * b).sum(1)[None]
+        knn[i:i + 4096] = np.argsort(s, axis=1, kind="stable")[:, :knn_k]
+    return base, knn
+
+
+@pytest.mark.parametrize("metric,nb,nt,d,knn_k,M,L,r,dups", [
+    ("ip", 3000, 20000, 16, 30, 6, 40, 6, 0),        # hubs: lists full, thousands of reverse edges into one list
+    ("l2", 3000, 20000, 16, 30, 6, 40, 6, 200),      # repeated rows: ties in distance
+    ("l2", 5000, 20000, 8, 30, 8, 40, 8, 0),         # full-rank: every list near its bound, ~150 windows in phase 2
+    ("cosine", 2600, 6000, 24, 40, 10, 60, 8, 50),
+    ("ip", 1500, 3000, 16, 20, 8, 40, 6, 0),         # <= 2,048 nodes: the schedule is all ones -> equals the one-thread build too
+])
+def test_many_threads_one_result_equal_to_the_oracle(rgb, oracle, metric, nb, nt, d, knn_k, M, L, r, dups):
+    """rg_build_roargraph with T > 1 is deterministic (round 3): phases 1 and 2 replay every list's reverse edges in the
+    one-thread order (Builder::phase1_replay, phase2_windows), phase 3 runs in the batches of rg_build_schedule over a frozen
+    graph and links them in node order (link_batch).  The index must equal, byte for byte and for every thread count,
+    the ORACLE's build given the same batch list (oracle/rg_oracle_build.c: plain sequential loops, searches of a batch
+    before its links) -- which for a schedule of ones is the reference's one-thread sequence."""
+    base, knn = structured(nb + d, nb, nt, d, metric, knn_k, r, dups)
+    sched = rgb.build_schedule(nb)
+    assert int(sched.sum()) == nb and (sched[: min(nb, 2048)] == 1).all()
+    oracle.use_avx512(True)
+    want = oracle.build_roargraph(base, knn, metric, knn_k, M, L, sched=sched)
+    oracle.use_avx512(False)
+    for T in (2, 5, 8):
+        got = rgb.build_roargraph(base, knn, metric, knn_k, M, L, num_threads=T)
+        assert got[2] == want[2], "entry point"
+        assert (got[0] == want[0]).all() and (got[1] == want[1]).all(), f"{T} threads: index differs from the oracle's"
+    if nb <= 2048:
+        one = rgb.build_roargraph(base, knn, metric, knn_k, M, L, num_threads=1)
+        assert (one[0] == want[0]).all() and (one[1] == want[1]).all()
 
 
 @pytest.mark.parametrize("metric,nb,nt,d,knn_k,M_sq,M,L", [("ip", 4000, 1500, 64, 100, 100, 20, 200), ("l2", 3000, 1000, 32, 50, 50, 16, 100),

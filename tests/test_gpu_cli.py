@@ -149,6 +149,34 @@ def test_gpu_assisted_build_one_node_at_a_time_equals_the_oracle_build(oracle, m
     assert (got[0] == want[0]).all() and (got[1] == want[1]).all(), "GPU-assisted build differs from the oracle's"
 
 
+@pytest.mark.parametrize("metric,d,nb,M,L,batch", [("ip", 200, 7000, 16, 120, 0), ("l2", 64, 6000, 12, 80, 0), ("ip", 200, 5000, 24, 150, 700)])
+def test_gpu_assisted_build_is_deterministic_and_equals_the_oracle_build(oracle, metric, d, nb, M, L, batch):
+    """rg_build_roargraph_gpu for any number of host threads: the GPU computes the pruned lists of phase 1 and the searches +
+    prunings of phase 3, the host replays the reverse edges list by list (phase1_replay, phase2_windows, link_batch).  The
+    index must equal the ORACLE's build given the batch list of rg_build_schedule(nb, batch) byte for byte -- with 1, 3 and 8
+    host threads -- and, for batch = 0, the all-host build at several threads."""
+    from roargraph_amd import build
+    rng = np.random.default_rng(nb + d)
+    r = 6
+    A = (rng.standard_normal((r, d)) / np.sqrt(r)).astype(np.float32)
+    base = (rng.standard_normal((nb, r)).astype(np.float32) @ A + 0.05 * rng.standard_normal((nb, d)).astype(np.float32))
+    base[rng.integers(0, nb, 100)] = base[rng.integers(0, nb, 100)]
+    train = ((0.3 + 0.5 * rng.standard_normal((9000, r))).astype(np.float32) @ A).astype(np.float32)
+    knn, _, _ = oracle.groundtruth_f64(base, train, metric, 60, nthreads=16)
+    sched = build.build_schedule(nb, batch)
+    assert int(sched.sum()) == nb
+    oracle.use_avx512(True)
+    want = oracle.build_roargraph(base, knn, metric, 60, M, L, sched=sched)
+    oracle.use_avx512(False)
+    for T in (1, 3, 8):
+        got = build.build_roargraph(base, knn, metric, 60, M, L, num_threads=T, device=0, batch=batch)
+        assert got[2] == want[2], "entry point"
+        assert (got[0] == want[0]).all() and (got[1] == want[1]).all(), f"GPU-assisted build, {T} host threads: differs from the oracle's"
+    if batch == 0:
+        host = build.build_roargraph(base, knn, metric, 60, M, L, num_threads=4)
+        assert (host[0] == want[0]).all() and (host[1] == want[1]).all(), "all-host build at 4 threads differs"
+
+
 @pytest.mark.parametrize("metric,d,M,L", [("ip", 200, 35, 500), ("l2", 512, 24, 150), ("ip", 104, 12, 100), ("l2", 200, 35, 300),
                                           ("ip", 200, 24, 600)])   # the last: lists longer than the kernel sorts -> host pruning
 def test_gpu_pruning_equals_host_pruning(oracle, monkeypatch, metric, d, M, L):
