@@ -320,6 +320,90 @@ struct Builder {
         }
     }
 
+    // prune_reverse (plain rule, :1526-1610) for a list that is pruned again and again -- phase 2 keeps the lists of popular base
+    // points at their bound, so EVERY further insertion re-prunes 36 candidates of which 35 were there the last time.  The
+    // cache keeps, for the first k entries of the list as it stands, their distance to the list's owner and to each other
+    // (the rule's `djk`), so a call computes only what involves the new entry; every value it uses is the value cmp()
+    // returns (cmp is symmetric bit for bit: a*b and (a-b)^2 commute), so the list that comes out is prune_reverse's.
+    // Layout: k, ids[cap], dx[cap], pair[cap][cap] as 32-bit words; kUnk marks a distance not computed yet (a genuine
+    // NaN of that pattern would just be recomputed every time).
+    static constexpr uint32_t kUnk = 0x7fc0dead;
+    static float unk() { float f; const uint32_t u = kUnk; std::memcpy(&f, &u, 4); return f; }
+    static bool is_unk(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u == kUnk; }
+    size_t pcache_words() const { const size_t cap = M + 1; return 1 + cap + cap + cap * cap; }
+    void prune_reverse_cached(uint32_t des, std::vector<uint32_t> &list, uint32_t *c, std::vector<float> &scratch) const {
+        const uint32_t cap = M + 1, m = (uint32_t)list.size();
+        if (m > cap) { c[0] = 0; prune_reverse(des, list, false); return; }
+        uint32_t *ids = c + 1;
+        float *dx = reinterpret_cast<float *>(c + 1 + cap), *pair = dx + cap;
+        uint32_t k = c[0];
+        if (k > m || std::memcmp(ids, list.data(), (size_t)k * 4) != 0) k = 0;
+        const float U = unk();
+        for (uint32_t i = k; i < m; ++i) {
+            ids[i] = list[i];
+            dx[i] = U;
+            for (uint32_t j = 0; j < m; ++j) pair[(size_t)i * cap + j] = pair[(size_t)j * cap + i] = U;
+        }
+        struct E { uint32_t id; float dist; uint32_t idx; };
+        E pq[64 + 8];
+        std::vector<E> big;
+        E *q = pq;
+        if (m > 64) { big.resize(m); q = big.data(); }
+        uint32_t n = 0;
+        for (uint32_t i = 0; i < m; ++i) {
+            if (is_unk(dx[i])) { prefetch_row(ids[i]); }
+        }
+        for (uint32_t i = 0; i < m; ++i) {
+            if (is_unk(dx[i])) dx[i] = cmp(des, ids[i]);
+            bool seen = false;
+            for (uint32_t j = 0; j < n; ++j) if (q[j].id == ids[i]) { seen = true; break; }
+            if (!seen) q[n++] = E{ids[i], dx[i], i};
+        }
+        uint32_t res[64 + 8];
+        std::vector<uint32_t> bigres;
+        uint32_t *r = res;
+        if (m > 64) { bigres.resize(m); r = bigres.data(); }
+        uint32_t nres = 0;
+        if (n) {
+            std::sort(q, q + n, [](const E &a, const E &b) { return a.dist < b.dist || (a.dist == b.dist && a.id < b.id); });
+            uint32_t start = 0;
+            if (q[start].id == des) ++start;
+            if (start < n) {
+                r[nres++] = q[start].idx;
+                while (nres < M && (++start) < n) {
+                    const E &p = q[start];
+                    bool occ = false;
+                    for (uint32_t t = 0; t < nres && !occ; ++t) {
+                        if (ids[r[t]] == p.id) { occ = true; break; }
+                        float &d = pair[(size_t)p.idx * cap + r[t]];
+                        if (is_unk(d)) { d = cmp(p.id, ids[r[t]]); pair[(size_t)r[t] * cap + p.idx] = d; }
+                        if (d < p.dist) occ = true;
+                    }
+                    if (!occ && p.id != des) r[nres++] = p.idx;
+                }
+                for (uint32_t i = 0; i < m && nres < M; ++i) {          // :1594-1598 top-up in the original list order
+                    bool in = false;
+                    for (uint32_t t = 0; t < nres; ++t) if (ids[r[t]] == ids[i]) { in = true; break; }
+                    if (!in) r[nres++] = i;
+                }
+            }
+        }
+        // the list that comes out, and the distances among its members carried over in its order
+        scratch.resize((size_t)nres * nres + 2 * (size_t)nres);
+        float *ndx = scratch.data(), *npair = ndx + nres;
+        uint32_t *nid = reinterpret_cast<uint32_t *>(npair + (size_t)nres * nres);
+        for (uint32_t a = 0; a < nres; ++a) {
+            nid[a] = ids[r[a]];
+            ndx[a] = dx[r[a]];
+            for (uint32_t b = 0; b < nres; ++b) npair[(size_t)a * nres + b] = pair[(size_t)r[a] * cap + r[b]];
+        }
+        list.assign(nid, nid + nres);
+        std::memcpy(ids, nid, (size_t)nres * 4);
+        std::memcpy(dx, ndx, (size_t)nres * 4);
+        for (uint32_t a = 0; a < nres; ++a) std::memcpy(pair + (size_t)a * cap, npair + (size_t)a * nres, (size_t)nres * 4);
+        c[0] = nres;
+    }
+
     // one step of add_reverse's loop on a list this thread owns (no lock: deterministic schedules give every list one writer)
     void apply_insert(std::vector<uint32_t> &dn, uint32_t des, uint32_t src, uint32_t limit, bool phantoms) const {
         if (has(dn, src)) return;
@@ -422,12 +506,30 @@ struct Builder {
                             wend.empty() ? 0.0 : (double)nd / wend.size(), maxw);
         std::vector<uint32_t> ev_des(maxw * (size_t)M + 1), ev_src(maxw * (size_t)M + 1);
         std::atomic<long long> st_events{0}, st_present{0}, st_pruned{0}, st_ns_apply{0}, st_ns_total{0};
+        // distance caches of the lists that get pruned (prune_reverse_cached), each touched by its owner thread only; at most
+        // 1.5 GB of them, first come first served (popular lists fill up first); RG_BUILD_NO_PRUNE_CACHE=1 turns them off
+        std::vector<uint32_t *> pc(nd, nullptr);
+        const size_t pc_words = pcache_words();
+        std::atomic<long long> pc_left{getenv("RG_BUILD_NO_PRUNE_CACHE") ? 0 : (long long)(1500000000ull / (pc_words * 4))};
+        auto insert_cached = [&](std::vector<uint32_t> &dn, uint32_t des, uint32_t src, std::vector<float> &scratch) {
+            if (has(dn, src)) return;
+            dn.push_back(src);
+            if (dn.size() <= M) return;
+            uint32_t *c = pc[des];
+            if (!c && pc_left.load(std::memory_order_relaxed) > 0 && pc_left.fetch_sub(1) > 0) {
+                c = pc[des] = new uint32_t[pc_words];
+                c[0] = 0;
+            }
+            if (c) prune_reverse_cached(des, dn, c, scratch);
+            else prune_reverse(des, dn, false);
+        };
         run_team([&](int t, Team &team) {
             int sense = 0;
             const uint32_t T = (uint32_t)team.T;
             std::vector<uint32_t> pre(maxw + 1);          // where each node's insertions start in the window's event list
             uint32_t a = 0;
             long long my_events = 0, my_present = 0, my_pruned = 0, my_ns = 0;
+            std::vector<float> scratch;
             const auto t_begin = std::chrono::steady_clock::now();
             for (size_t w = 0; w < wend.size(); ++w) {
                 const uint32_t b = wend[w], n = b - a;
@@ -441,7 +543,7 @@ struct Builder {
                 const uint32_t ne = pre[n];
                 if (!timing) {
                     for (uint32_t e = 0; e < ne; ++e)
-                        if (owner_of(ev_des[e], T) == (uint32_t)t) apply_insert(proj[ev_des[e]], ev_des[e], ev_src[e], M, false);
+                        if (owner_of(ev_des[e], T) == (uint32_t)t) insert_cached(proj[ev_des[e]], ev_des[e], ev_src[e], scratch);
                 } else {
                     const auto t0 = std::chrono::steady_clock::now();
                     for (uint32_t e = 0; e < ne; ++e)
@@ -450,7 +552,7 @@ struct Builder {
                             ++my_events;
                             if (has(dn, ev_src[e])) { ++my_present; continue; }
                             if (dn.size() >= M) ++my_pruned;
-                            apply_insert(dn, ev_des[e], ev_src[e], M, false);
+                            insert_cached(dn, ev_des[e], ev_src[e], scratch);
                         }
                     my_ns += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t0).count();
                 }
@@ -462,8 +564,10 @@ struct Builder {
                 st_ns_total += std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now() - t_begin).count();
             }
         });
-        if (timing) fprintf(stderr, "[rg_build]   phase 2: %lld insertions tried, %lld already present, %lld into a full list (pruned); thread time applying %.1f s of %.1f s\n",
-                            st_events.load(), st_present.load(), st_pruned.load(), st_ns_apply.load() * 1e-9, st_ns_total.load() * 1e-9);
+        size_t ncache = 0;
+        for (uint32_t *c : pc) if (c) { ++ncache; delete[] c; }
+        if (timing) fprintf(stderr, "[rg_build]   phase 2: %lld insertions tried, %lld already present, %lld into a full list (pruned; %zu lists with a distance cache); thread time applying %.1f s of %.1f s\n",
+                            st_events.load(), st_present.load(), st_pruned.load(), ncache, st_ns_apply.load() * 1e-9, st_ns_total.load() * 1e-9);
     }
 
     // Linking a batch of phase 3 (:1209-1215 for nodes [b0, b0 + n), whose pruned lists `lists` ([n][M+1]) were all computed
@@ -510,6 +614,9 @@ struct Builder {
             for (uint32_t p = 0; p < T; ++p) {
                 const std::vector<uint32_t> &bk = bucket[(size_t)p * T + t];
                 for (size_t e = 0; e + 1 < bk.size(); e += 2) {
+                    // the lists are scattered over the heap: ask for the vector header 16 insertions ahead, its storage 8 ahead
+                    if (e + 32 < bk.size()) __builtin_prefetch(&supply[bk[e + 32]], 0, 1);
+                    if (e + 16 < bk.size()) { const std::vector<uint32_t> &nx = supply[bk[e + 16]]; if (!nx.empty()) { __builtin_prefetch(nx.data(), 1, 1); __builtin_prefetch(nx.data() + 16, 1, 1); } }
                     const uint32_t des = bk[e], src = bk[e + 1];
                     if (des >= b0 && des < b0 + n && src < des) continue;   // overwritten by des's own write
                     apply_insert(supply[des], des, src, 2 * M, true);
