@@ -201,6 +201,7 @@ class Searcher:
         self.out = [dict(ids=torch.zeros((nq, k), dtype=torch.int32, device=dev), dists=torch.zeros((nq, k), dtype=torch.float32, device=dev),
                          cmps=torch.zeros(nq, dtype=torch.int32, device=dev), hops=torch.zeros(nq, dtype=torch.int32, device=dev)) for _ in self.qs]
         self.cursor = 0
+        self.depth_settled = {}
 
     def run(self, L, b=None):
         if b is None:
@@ -219,12 +220,21 @@ class Searcher:
         t = self.t
         for _ in range(settle):
             self.run(L); self.wait()
+        if L not in self.depth_settled or self.depth_settled[L] < reps:
+            # the timed launches below are enqueued back to back: the first time `reps` batches are in flight on the stream the
+            # library allocates the per-batch state of the 2nd, 3rd ... (a hipMalloc between the event records of that batch:
+            # 2.4 - 6.7 ms once) -- let that happen here
+            for _ in range(reps):
+                self.run(L)
+            self.wait()
+            self.depth_settled[L] = reps
         ev = [(t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)) for _ in range(reps)]
         used = []
         for a, b in ev:
             a.record(); used.append(self.run(L)); b.record()
         self.wait()
-        return float(np.mean([a.elapsed_time(b) for a, b in ev])), used
+        self.last_reps_ms = [a.elapsed_time(b) for a, b in ev]
+        return float(np.mean(self.last_reps_ms)), used
 
     def point(self, L, ms, used):
         """One row of the report: `used` = the batches the timing ran (their buffers hold the results at this L)."""
@@ -449,7 +459,16 @@ def main():
     sweep = []
     for L in sweep_Ls:
         ms, used = S.timed(L, reps=3 if L <= 500 else 2)
-        pt = S.point(L, ms, used)
+        if max(S.last_reps_ms) > 1.5 * min(S.last_reps_ms):
+            # one launch far off the others (seen once in the round: 7.7 ms among 1.0 ms launches at L_pq = 10 -- a host stall
+            # between the two event records of a batch, not kernel time): measure the point again and say so
+            first = list(S.last_reps_ms)
+            ms, used = S.timed(L, reps=5 if L <= 500 else 3, settle=1)
+            pt = S.point(L, ms, used)
+            pt["remeasured"] = {"first_attempt_ms": first, "second_attempt_ms": list(S.last_reps_ms)}
+        else:
+            pt = S.point(L, ms, used)
+        pt["ms_reps"] = [round(x, 4) for x in S.last_reps_ms]
         if args.visited == 2 and rank == 0:
             # what explains a point above the 6.29 TB/s streaming-copy ceiling: how few of the launch's row reads are first
             # touches, and how many go to rows a 256-MiB cache could hold (null: the launch ran on the exact words)
