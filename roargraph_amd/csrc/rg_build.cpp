@@ -35,6 +35,8 @@
 #include <cstring>
 #include <functional>
 #include <mutex>
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <thread>
 #include <vector>
@@ -1206,7 +1208,25 @@ static unsigned usable_cpus() {
     return n;
 }
 
+static rg_status build_body(const float *base, uint32_t nb, uint32_t dim, uint32_t stride, const uint32_t *knn_ids,
+                            uint32_t nq, uint32_t knn_k, int metric, uint32_t M_sq, uint32_t M_pjbp, uint32_t L_pjpq,
+                            uint32_t num_threads, int device, uint32_t batch, uint32_t *out_ep, uint64_t **out_offsets,
+                            uint32_t **out_nbrs);
+// nothing C++ leaves through the C ABI: the host side allocates O(nb) vectors and starts threads, both can fail
 static rg_status build_impl(const float *base, uint32_t nb, uint32_t dim, uint32_t stride, const uint32_t *knn_ids,
+                            uint32_t nq, uint32_t knn_k, int metric, uint32_t M_sq, uint32_t M_pjbp, uint32_t L_pjpq,
+                            uint32_t num_threads, int device, uint32_t batch, uint32_t *out_ep, uint64_t **out_offsets,
+                            uint32_t **out_nbrs) {
+    try {
+        return build_body(base, nb, dim, stride, knn_ids, nq, knn_k, metric, M_sq, M_pjbp, L_pjpq, num_threads, device, batch, out_ep,
+                          out_offsets, out_nbrs);
+    } catch (const std::bad_alloc &) {
+        return rg::set_error(RG_ERR_OOM, "out of host memory during the build");
+    } catch (const std::exception &e) {
+        return rg::set_error(RG_ERR_DEVICE, std::string("build failed: ") + e.what());
+    }
+}
+static rg_status build_body(const float *base, uint32_t nb, uint32_t dim, uint32_t stride, const uint32_t *knn_ids,
                             uint32_t nq, uint32_t knn_k, int metric, uint32_t M_sq, uint32_t M_pjbp, uint32_t L_pjpq,
                             uint32_t num_threads, int device, uint32_t batch, uint32_t *out_ep, uint64_t **out_offsets,
                             uint32_t **out_nbrs) {
