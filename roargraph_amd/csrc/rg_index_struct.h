@@ -48,6 +48,9 @@ struct SearchCtx {
     unsigned long long *d_scratch_stat = nullptr;   // status sink of launches nobody waits for (build mode, recounts)
     uint32_t *d_visited = nullptr, *d_epoch = nullptr;
     uint32_t slots = 0, vwords = 0;
+    // byte form of the exact visited set (look-ahead kernel form): one epoch byte per node and slot, its own epochs
+    uint32_t *d_vtags = nullptr, *d_epoch8 = nullptr;
+    uint32_t tslots = 0, twords = 0;
     uint32_t *d_qlog = nullptr, *d_qlog_n = nullptr;
     uint32_t qlog_nq = 0, logcap = 0, qlog_chunk = 0;
     uint32_t log_holds = 0;      // queries whose logs the last filter+log batch left in d_qlog (0: searched in sub-batches)
@@ -90,7 +93,8 @@ struct rg_index {
     // 2 = LDS filter + id log + exact distinct count (K4): everything bit-exact incl. cmps (default)
     int visited_mode = 2;
     int log_budget_kb = 16 << 20;  // HBM budget of the id logs per context (KiB, default 16 GiB = 32768 queries): larger batches are searched in sub-batches
-    int visited_budget_kb = 16 << 20;  // HBM budget of the exact visited words per context (KiB, default 16 GiB): caps the slots = the grid of a mode-0 launch
+    int visited_bytes = -1;   // look-ahead form: -1 / 1 = one epoch byte per node (marks are plain stores), 0 = the epoch-tagged words
+    int visited_budget_kb = 24 << 20;  // HBM budget of the exact visited words per context (KiB, default 24 GiB): caps the slots = the grid of a mode-0 launch
     int visited_uncached = 0;        // knob: exact visited words in 1 = uncached (MTYPE_UC), 2 = fine-grained device memory
     int log_cap_knob = 0;       // 0 = auto; tests force small logs to exercise the exact fallback
     int count_table_log2 = 15;  // K4 LDS table: at most 2^15 words = 128 KiB
@@ -121,6 +125,7 @@ struct rg_index {
     bool query_in_lds = false;   // K1: force the generic (query staged in LDS) instantiation for d = 200 / 512
     bool count_full_ids = false; // K4: force the full-id bucket form (the half-word form is used when the remainder fits)
     int filter_log2 = 0;    // VIS=1: log2 of the LDS filter's 16-bit entries; 0 = automatic (per launch)
+    int filter_fill = 1;    // automatic size only: the filter also takes the LDS the resident queries leave unused
     int num_cu = 256;
     size_t lds_per_cu = 160 * 1024;
     // ---- mutable state, all behind `mu`

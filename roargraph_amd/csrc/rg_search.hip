@@ -560,7 +560,7 @@ static void free_ctx(SearchCtx *cx) {
     if (cx->own) (void)hipStreamDestroy(cx->own);
     if (cx->h_pin) (void)hipHostFree(cx->h_pin);
     if (cx->d_front) (void)hipFree(cx->d_front);
-    void *bufs[] = {cx->d_counter, cx->d_scratch_stat, cx->d_visited, cx->d_epoch, cx->d_qlog, cx->d_qlog_n,
+    void *bufs[] = {cx->d_counter, cx->d_scratch_stat, cx->d_visited, cx->d_epoch, cx->d_vtags, cx->d_epoch8, cx->d_qlog, cx->d_qlog_n,
                     cx->d_q, cx->d_dist, cx->d_ids, cx->d_ch};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
@@ -665,21 +665,37 @@ static size_t stage_total_floats(const rg_index *ix, int R, bool bf) {   // the 
 }
 static size_t search_lds_bytes(const rg_index *ix, uint32_t L, int R, int mode, bool bf, int filter_auto) {
     size_t b = stage_total_floats(ix, R, bf) * 4 + (dimc_of(ix) ? 0 : (size_t)ix->dim * 4) + kCand * 4 + kCand * 4 + 2 * kWave * 4 + (size_t)L * 8;
-    if (mode != 0 || ix->exact_filter) b += 128 * 4 + std::max<size_t>(4, (size_t)2 << filter_log2_of(ix, filter_auto));
+    if (mode != 0 || ix->exact_filter) b += 128 * 4 + std::max<size_t>(16, (size_t)2 << filter_log2_of(ix, filter_auto));
     return (b + 15) / 16 * 16;
+}
+// bits of a filter entry for a table of `slots` entries: the x that share a slot are at most ceil(2^id_bits / slots)
+// consecutive values (rg_search_kernel.h: vf_hash), told apart by that many low bits
+static uint32_t filter_rem_bits(uint32_t id_bits, uint32_t slots) {
+    const uint64_t span = (((uint64_t)1 << id_bits) + slots - 1) / slots;
+    uint32_t r = 0;
+    while (((uint64_t)1 << r) < span) ++r;
+    return r;
 }
 
 // visited words of mode 0: slots x ceil(nd / 16) words per context (2.5 MB per slot at 10M nodes).  Grow-only; the slot
-// count (and with it the launch grid) is capped by "visited_budget_kb" (default 16 GiB per context), and an allocation
+// count (and with it the launch grid) is capped by "visited_budget_kb" (default 24 GiB per context), and an allocation
 // that fails returns RG_ERR_OOM without touching what the context already had -- the caller then runs the batch in the
 // filter + log form, which returns the same bits
-static uint32_t visited_slot_cap(const rg_index *ix) {
-    const size_t per = (size_t)((ix->nd + 15) / 16) * 4;
+// words per slot: ceil(nd / 16) epoch-tagged words, or -- byte form -- nd epoch bytes rounded up to whole 128-byte lines
+static uint32_t visited_words(const rg_index *ix, bool bytes) {
+    return bytes ? (uint32_t)(((size_t)ix->nd + 127) / 128 * 32) : (ix->nd + 15) / 16;
+}
+static uint32_t visited_slot_cap(const rg_index *ix, bool bytes) {
+    const size_t per = (size_t)visited_words(ix, bytes) * 4;
     return (uint32_t)std::max<size_t>(1, std::min<size_t>(0x7fffffffu, ((size_t)std::max(1, ix->visited_budget_kb) << 10) / std::max<size_t>(per, 1)));
 }
-static rg_status ensure_visited(rg_index *ix, SearchCtx *cx, uint32_t slots) {
-    const uint32_t vwords = (ix->nd + 15) / 16;
-    if (cx->slots >= slots && cx->vwords == vwords) return RG_OK;
+static rg_status ensure_visited(rg_index *ix, SearchCtx *cx, uint32_t slots, bool bytes, hipStream_t s) {
+    const uint32_t vwords = visited_words(ix, bytes);
+    uint32_t *&d_vis = bytes ? cx->d_vtags : cx->d_visited;
+    uint32_t *&d_ep = bytes ? cx->d_epoch8 : cx->d_epoch;
+    uint32_t &have_slots = bytes ? cx->tslots : cx->slots;
+    uint32_t &have_words = bytes ? cx->twords : cx->vwords;
+    if (have_slots >= slots && have_words == vwords) return RG_OK;
     uint32_t *nv = nullptr, *ne = nullptr;
     // knob "visited_uncached": the words in memory the L2 does not cache (MTYPE_UC) -- a test then moves a 32-byte sector
     // over the fabric instead of the 128-byte line the L2 fetches for a 4-byte word it will not see again
@@ -691,16 +707,18 @@ static rg_status ensure_visited(rg_index *ix, SearchCtx *cx, uint32_t slots) {
         if (nv) (void)hipFree(nv);
         return set_error(RG_ERR_OOM, "no room for the visited words of the exact form");
     }
-    if (cx->d_visited) (void)hipFree(cx->d_visited);
-    if (cx->d_epoch) (void)hipFree(cx->d_epoch);
-    cx->d_visited = nv;
-    cx->d_epoch = ne;
-    cx->slots = 0;
+    if (d_vis) (void)hipFree(d_vis);
+    if (d_ep) (void)hipFree(d_ep);
+    d_vis = nv;
+    d_ep = ne;
+    have_slots = 0;
     ++cx->allocs;
-    RG_HIP(hipMemset(cx->d_visited, 0, (size_t)slots * vwords * 4));
-    RG_HIP(hipMemset(cx->d_epoch, 0, (size_t)slots * 4));
-    cx->slots = slots;
-    cx->vwords = vwords;
+    // cleared ON THE LAUNCH STREAM: the host-form calls run on a non-blocking private stream, which a fill on the null stream
+    // does not hold back -- and recycled memory may hold the tags of an earlier context, whose epochs were the same small numbers
+    RG_HIP(hipMemsetAsync(d_vis, 0, (size_t)slots * vwords * 4, s));
+    RG_HIP(hipMemsetAsync(d_ep, 0, (size_t)slots * 4, s));
+    have_slots = slots;
+    have_words = vwords;
     return RG_OK;
 }
 
@@ -752,7 +770,11 @@ static rg_status launch_k1(rg_index *ix, SearchCtx *cx, int mode, const float *d
     if (lds > ix->lds_per_cu) return set_error(RG_ERR_ARG, "L_pq too large for the 160 KiB LDS of one CU");
     int wpc = (int)std::min<size_t>(ix->lds_per_cu / lds, 32);
     // few resident queries (wide beams): each keeps 32 rows in flight (8 register sets, about 190 VGPRs: 8 waves per CU)
-    if (ix->rows_per_pass <= 0 && dimc_of(ix) == 200 && !bf && wpc <= 8) { R = 8; lds = search_lds_bytes(ix, L, R, mode, bf, filter_auto); }
+    // The filter forms go there from 12 LDS-limited residents down (L_pq >= 300 at d = 200): eight queries with 32 rows in
+    // flight and the LDS of the other three or four in their filters (the fill below) re-read fewer rows than eleven with
+    // 16 rows and 2^12 entries -- profiles/r03/k1_ab_box19.jsonl: +1 % at L_pq = 300 - 500, +6 % at 700.
+    const int r8_from = (mode != 0 && ix->filter_fill && ix->filter_log2 <= 0 && ix->waves_per_cu <= 0) ? 12 : 8;
+    if (ix->rows_per_pass <= 0 && dimc_of(ix) == 200 && !bf && wpc <= r8_from) { R = 8; wpc = std::min(wpc, 8); lds = search_lds_bytes(ix, L, R, mode, bf, filter_auto); }
     if (ix->waves_per_cu > 0) wpc = std::min(wpc, ix->waves_per_cu);
     else wpc = std::min(wpc, 24);
     K1Launch c;
@@ -785,10 +807,35 @@ static rg_status launch_k1(rg_index *ix, SearchCtx *cx, int mode, const float *d
         if (st != RG_OK) return st;
         if (occ > 0) wpc = std::min(wpc, occ);
     }
+    // LDS visited filter, fill (round 3; knob "filter_fill": 1 = default, launches that fill the chip; 2 = every launch; 0 = off): the slot count need not be a power of two
+    // (rg_search_kernel.h: vf_hash), so the filter takes the LDS that the resident queries of this launch leave unused --
+    // the carve is the last region, the extra entries cost nothing.  The occupancy is asked again with the grown
+    // allocation (LDS is handed out in granules) and the filter trimmed until the resident count holds.
+    uint32_t vf_slots = (mode != 0 || ix->exact_filter) ? std::max(8u, 1u << filter_log2_of(ix, filter_auto)) : 8u;
+    if ((mode != 0 || ix->exact_filter) && ix->filter_fill && ix->filter_log2 <= 0 && wpc >= 1 && ((uint64_t)ix->num_cu * wpc <= nq || ix->filter_fill == 2)) {
+        const size_t per = (ix->lds_per_cu / (size_t)wpc) / 16 * 16;
+        size_t extra = per > lds ? per - lds : 0;
+        extra = std::min<size_t>(extra, ((size_t)1 << 16) > (size_t)vf_slots * 2 ? ((size_t)1 << 16) - (size_t)vf_slots * 2 : 0);   // <= 2^15 entries
+        for (int tries = 0; extra >= 16 && tries < 8; ++tries) {
+            int occ = 0;
+            c.occupancy = &occ;
+            c.lds = lds + extra;
+            SearchParams none{};
+            rg_status st = dispatch(none);
+            c.occupancy = nullptr;
+            if (st != RG_OK) return st;
+            if (occ >= wpc) break;
+            extra = extra > 512 ? (extra - 512) / 16 * 16 : 0;
+            if (tries == 7) extra = 0;
+        }
+        if (extra >= 16) { lds += extra; vf_slots += (uint32_t)(extra / 2); }
+        c.lds = lds;
+    }
     c.grid = (uint32_t)std::min<uint64_t>(nq, (uint64_t)ix->num_cu * wpc);
-    if (mode == 0) c.grid = std::min(c.grid, visited_slot_cap(ix));
+    const bool vbytes = c.vis == 2 && ix->visited_bytes != 0;
+    if (mode == 0) c.grid = std::min(c.grid, visited_slot_cap(ix, vbytes));
     if (mode == 0) {
-        rg_status st = ensure_visited(ix, cx, c.grid);
+        rg_status st = ensure_visited(ix, cx, c.grid, vbytes, s);
         if (st != RG_OK) return st;
     }
     RG_HIP(hipMemsetAsync(cx->d_counter, 0, 4, s));
@@ -797,7 +844,9 @@ static rg_status launch_k1(rg_index *ix, SearchCtx *cx, int mode, const float *d
     P.ell = ix->d_ell; P.ell_stride = ix->ell_stride; P.offsets = ix->d_offsets; P.nbrs = ix->d_nbrs;
     P.ep = ix->ep; P.queries = d_q; P.nq = nq; P.qstride = qstride; P.k = k; P.L = L;
     P.out_ids = d_ids; P.out_dists = d_dists; P.out_cmps = d_cmps; P.out_hops = d_hops;
-    P.visited = mode == 0 ? cx->d_visited : nullptr; P.vwords = cx->vwords; P.slot_epoch = cx->d_epoch;
+    P.visited = mode == 0 ? (vbytes ? cx->d_vtags : cx->d_visited) : nullptr;
+    P.vwords = vbytes ? cx->twords : cx->vwords; P.slot_epoch = vbytes ? cx->d_epoch8 : cx->d_epoch;
+    P.vbytes = vbytes ? 1u : 0u;
     P.counter = cx->d_counter; P.status = d_status;
     P.stage_floats = (uint32_t)stage_pass_floats(ix, bf);
     P.stage_total = (uint32_t)stage_total_floats(ix, R, bf);
@@ -811,7 +860,8 @@ static rg_status launch_k1(rg_index *ix, SearchCtx *cx, int mode, const float *d
     }
     P.diag = (uint32_t)ix->diag;
     P.qbase = qbase;
-    P.vf_slots_log2 = filter_log2_of(ix, filter_auto);
+    P.vf_slots = vf_slots;
+    P.vf_rem_bits = filter_rem_bits(id_bits_of(ix->nd), vf_slots);
     P.vf_front = (mode == 0 && ix->exact_filter) ? 1u : 0u;
     P.id_bits = id_bits_of(ix->nd);
     P.qlog = with_log ? cx->d_qlog : nullptr; P.logcap = cx->logcap; P.qlog_n = with_log ? cx->d_qlog_n : nullptr;
@@ -1383,17 +1433,21 @@ rg_status rg_index_set(rg_index *ix, const char *name, int value) {
     else if (!strcmp(name, "diag")) ix->diag = value;
     else if (!strcmp(name, "visited")) ix->visited_mode = value < 0 || value > 2 ? 2 : value;
     else if (!strcmp(name, "filter_log2")) ix->filter_log2 = value;
+    else if (!strcmp(name, "filter_fill")) ix->filter_fill = value;
     else if (!strcmp(name, "log_cap")) ix->log_cap_knob = value;
     else if (!strcmp(name, "log_budget_kb")) ix->log_budget_kb = value;
     else if (!strcmp(name, "visited_budget_kb")) ix->visited_budget_kb = value;
+    else if (!strcmp(name, "visited_bytes")) ix->visited_bytes = value;
     else if (!strcmp(name, "visited_uncached")) {
         if (value != ix->visited_uncached) {      // contexts re-allocate their words on the next exact-words launch
             std::lock_guard<std::mutex> lk(ix->mu);
             for (rg::SearchCtx *c : ix->ctxs) {
                 if (c->d_visited) (void)hipFree(c->d_visited);
                 if (c->d_epoch) (void)hipFree(c->d_epoch);
-                c->d_visited = c->d_epoch = nullptr;
-                c->slots = 0;
+                if (c->d_vtags) (void)hipFree(c->d_vtags);
+                if (c->d_epoch8) (void)hipFree(c->d_epoch8);
+                c->d_visited = c->d_epoch = c->d_vtags = c->d_epoch8 = nullptr;
+                c->slots = c->tslots = 0;
             }
         }
         ix->visited_uncached = value;
@@ -1478,8 +1532,12 @@ rg_status rg_search_prepare(rg_index *ix, void *stream, uint32_t nq, uint32_t L_
     if (ix->visited_mode == 2) st = rg::ensure_qlog(ix, cx, nq);
     if (st == RG_OK && ix->visited_mode != 1) {
         // the slots a wide-beam launch of the exact-words form uses (its grid): at most eight to ten resident queries per CU
-        const uint32_t slots = std::min(std::min<uint32_t>(nq, (uint32_t)ix->num_cu * (L_pq >= 700 ? 8u : 12u)), rg::visited_slot_cap(ix));
-        st = rg::ensure_visited(ix, cx, slots);
+        // (the look-ahead form, which wide beams use, keeps byte tags of its own: launch_k1)
+        const bool look = (ix->lookahead > 0 || (ix->lookahead < 0 && L_pq >= 1200 && rg::dimc_of(ix) == 200)) && rg::dimc_of(ix) && !ix->adj_dups &&
+                          !ix->multi_expand && ix->diag == 0;
+        const bool bytes = look && ix->visited_bytes != 0;
+        const uint32_t slots = std::min(std::min<uint32_t>(nq, (uint32_t)ix->num_cu * (L_pq >= 700 ? 8u : 12u)), rg::visited_slot_cap(ix, bytes));
+        st = rg::ensure_visited(ix, cx, slots, bytes, (hipStream_t)stream);
         if (st == RG_ERR_OOM && ix->visited_mode == 2) st = RG_OK;   // the default falls back to its filter + log form
     }
     const std::string msg = st != RG_OK ? rg_last_error() : "";

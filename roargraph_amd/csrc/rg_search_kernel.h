@@ -57,8 +57,10 @@ struct SearchParams {
     uint32_t stage_total;     // floats of the whole staging region (>= R * stage_floats; fast mode: >= one fp32 pass too)
     uint32_t qbase;           // index of queries[0] in the caller's batch (error reporting of chunked launches)
     uint32_t diag;            // diagnostics only (breaks parity): bit0 = skip the visited test
-    uint32_t vf_slots_log2;   // log2 of the LDS visited-filter size (16-bit entries)
-    uint32_t vf_front;        // VIS=0: 1 = the LDS filter screens the exact HBM words
+    uint32_t vf_slots;        // entries (16-bit) of the LDS visited filter: any multiple of 8 (powers of two included)
+    uint32_t vf_rem_bits;     // bits of an entry: the smallest r with 2^r >= ceil(2^id_bits / vf_slots), at most 15
+    uint32_t vf_front;        // VIS=0: 1 = the LDS filter screens the exact HBM words; VIS=2: 1 = the region is the bit screen
+    uint32_t vbytes;          // VIS=2: 1 = `visited` holds one epoch BYTE per node ([slots][4 * vwords] bytes) instead of the words
     uint32_t *qlog;           // VIS=1, optional: [nq][logcap] ids scored by each query (input of the exact distinct count)
     uint32_t logcap;
     uint32_t *qlog_n;         // [nq] number of ids scored (may exceed logcap: overflow)
@@ -511,9 +513,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
     // unaligned appends would turn into read-modify-writes at the memory side once the line has left L2)
     uint32_t *logbuf = reinterpret_cast<uint32_t *>(bm.ent + P.L);        // 128
     uint16_t *vtab = reinterpret_cast<uint16_t *>(logbuf + 128);
-    const uint32_t vf_rem_bits = P.id_bits > P.vf_slots_log2 ? P.id_bits - P.vf_slots_log2 : 0u;
+    const uint32_t vf_up = 32u - P.id_bits;   // hashed id -> top of the word (id_bits >= 1)
     const uint32_t vf_id_mask = P.id_bits >= 32u ? 0xffffffffu : ((1u << P.id_bits) - 1u);
-    const uint32_t vf_rem_mask = (1u << vf_rem_bits) - 1u;
+    const uint32_t vf_rem_mask = (1u << P.vf_rem_bits) - 1u;
 
     uint32_t *vmap = P.visited + (size_t)blockIdx.x * P.vwords;
     uint32_t epoch = EXACT ? P.slot_epoch[blockIdx.x] : 0u;
@@ -538,16 +540,16 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
         // new visited epoch (VisitedList::reset, visited_list_pool.h:20-26: ++curV, wipe on wrap)
         uint32_t etag = 0;
         if (EXACT) {
-            if (++epoch == 0x10000u) {
+            if (++epoch == ((LOOK && P.vbytes) ? 0x100u : 0x10000u)) {
                 for (uint32_t w = lane; w < P.vwords; w += kWave) vmap[w] = 0u;
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 epoch = 1;
             }
             etag = epoch << 16;
         }
-        if (VIS == 1 || P.vf_front) {
+        if (VIS == 1 || P.vf_front) {   // exact-match filter: every slot empty; LOOK: the screen's bits clear
             uint32_t *vt32 = reinterpret_cast<uint32_t *>(vtab);
-            for (uint32_t i = lane; i < (1u << P.vf_slots_log2) / 2u; i += kWave) vt32[i] = 0xffffffffu;
+            for (uint32_t i = lane; i < P.vf_slots / 2u; i += kWave) vt32[i] = LOOK ? 0u : 0xffffffffu;
         }
         wave_sync();
 
@@ -564,11 +566,31 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
             if constexpr (BF) gather_issue_bf<NB>(P.base_bf + (size_t)rid * P.stride_bf, act, reinterpret_cast<uint32_t *>(buf), lane);
             else gather_issue(P.base + (size_t)rid * P.stride, P.dim, act, buf, lane);
         };
-        // LDS filter slot / remainder of an id (bijective hash: odd multiplier mod 2^id_bits)
+        // LDS filter slot / remainder of an id.  x = bijective hash of the id (odd multiplier mod 2^id_bits); the slot is
+        // floor(x * slots / 2^id_bits), so the x that share a slot are at most ceil(2^id_bits / slots) <= 2^rem_bits
+        // CONSECUTIVE integers, which their low rem_bits bits tell apart: (slot, rem) <-> id is one to one for ANY slot
+        // count -- the filter takes whatever LDS the resident queries leave, not the power of two below it (a power of two
+        // gives slot = the top bits of x, rem = the rest)
         auto vf_hash = [&](uint32_t id, uint32_t &slot, uint16_t &rem) __attribute__((always_inline)) {
             const uint32_t x = (id * 0x9E3779B1u) & vf_id_mask;
-            slot = x >> vf_rem_bits;
+            slot = __umulhi(x << vf_up, P.vf_slots);
             rem = (uint16_t)(x & vf_rem_mask);
+        };
+        // LOOK form: the same LDS region is a one-hash bit screen in front of the exact words instead -- a bit is set when
+        // its node is marked, so a CLEAR bit proves "not visited yet" and the 128-byte line read of the word is not issued
+        // at all (a set bit proves nothing: the word decides).  No false "visited", so every output stays exact; what it
+        // saves is memory transactions: a wide beam tests 1.8 nodes per node it scores, and more than half of the tests
+        // are of nodes never met before.
+        uint32_t *bl32 = reinterpret_cast<uint32_t *>(vtab);
+        const uint32_t bl_bits = P.vf_slots * 16u;
+        const bool screen = LOOK && P.vf_front != 0u;
+        auto bl_maybe = [&](uint32_t id) __attribute__((always_inline)) -> bool {
+            const uint32_t p = __umulhi(id * 0x9E3779B1u, bl_bits);
+            return (bl32[p >> 5] >> (p & 31u)) & 1u;
+        };
+        auto bl_set = [&](uint32_t id) __attribute__((always_inline)) {
+            const uint32_t p = __umulhi(id * 0x9E3779B1u, bl_bits);
+            (void)__hip_atomic_fetch_or(&bl32[p >> 5], 1u << (p & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
         };
         // visited test-and-set of this lane's neighbour (:2378, :2385); same-hop duplicates are resolved by the atomic's
         // order (VIS = 0) or by the merge's de-duplication (VIS = 1)
@@ -601,19 +623,25 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
                 // the LDS filter in front of the exact words: a hit proves "visited" and saves the two atomics (most
                 // repeat encounters on indexes with locality); a miss goes to the words, which decide
                 bool known = false;
-                if (P.vf_front && keep) {
+                if (!LOOK && P.vf_front && keep) {
                     uint32_t slot; uint16_t rem;
                     vf_hash(id, slot, rem);
                     known = vtab[slot] == rem;
                     if (!known) vtab[slot] = rem;
                 }
-                if (!known) {
+                if (LOOK && P.vbytes) {                    // byte tags (general path of the LOOK form: long rows, shared first hop)
+                    uint8_t *t = reinterpret_cast<uint8_t *>(vmap) + id;
+                    fresh = __hip_atomic_load(t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (uint8_t)epoch;
+                    if (fresh) __hip_atomic_store(t, (uint8_t)epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next hop's tests leave without a wait of their own
+                } else if (!known) {
                     uint32_t *w = &vmap[id >> 4];
                     const uint32_t bit = 1u << (id & 15u);
                     atomicMax(w, etag);                    // stale epoch -> word becomes (epoch, no bits)
                     const uint32_t old = atomicOr(w, bit); // same address, same lane: ordered behind the max
                     fresh = !(old & bit);
                 }
+                if (screen && fresh) bl_set(id);
             }
             return fresh;
         };
@@ -847,6 +875,22 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
             auto words_of = [&](uint32_t fa, uint32_t fb, uint32_t &wa, uint32_t &wb) __attribute__((always_inline)) {
                 const uint32_t dg = readlane_u(fa, 0);
                 const uint32_t ia = (uint32_t)__shfl_down((int)fa, 1, 64) & idm;
+                if (screen || P.vbytes) {
+                    // only the lanes whose screen bit is set read their word; 0 = "stale epoch" = fresh for the others
+                    lds_fence();
+                    const bool ma = (uint32_t)lane < min(dg, 63u) && (!screen || bl_maybe(ia));
+                    const bool mb = dg > 63u && 63u + (uint32_t)lane < dg && (!screen || bl_maybe(fb & idm));
+                    wa = 0u; wb = 0u;
+                    if (P.vbytes) {
+                        const uint8_t *t = reinterpret_cast<const uint8_t *>(vmap);
+                        if (ma) wa = __hip_atomic_load(t + ia, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (mb) wb = __hip_atomic_load(t + (fb & idm), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    } else {
+                        if (ma) wa = __hip_atomic_load(&vmap[ia >> 4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (mb) wb = __hip_atomic_load(&vmap[(fb & idm) >> 4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    return;
+                }
                 wa = __hip_atomic_load(&vmap[((uint32_t)lane < min(dg, 63u) ? ia : 0u) >> 4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 wb = 0u;
                 if (dg > 63u) wb = __hip_atomic_load(&vmap[(63u + (uint32_t)lane < dg ? (fb & idm) : 0u) >> 4], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -877,25 +921,28 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
                 RG_PROF_CNT(5, deg); RG_PROF_CNT(6, hit ? 1 : 0);
                 const uint32_t wA = (uint32_t)__shfl_down((int)fa, 1, 64), idA = wA & idm, idB = fb & idm;
                 const bool haveA = (uint32_t)lane < min(deg, 63u), haveB = 63u + (uint32_t)lane < deg;
-                bool knownA = false, knownB = false;   // the LDS filter in front of the words: a hit proves "visited"
-                if (P.vf_front) {
-                    uint32_t slot; uint16_t rem;
-                    if (haveA && keeps(wA)) { vf_hash(idA, slot, rem); knownA = vtab[slot] == rem; if (!knownA) vtab[slot] = rem; }
-                    lds_fence();
-                    if (haveB && keeps(fb)) { vf_hash(idB, slot, rem); knownB = vtab[slot] == rem; if (!knownB) vtab[slot] = rem; }
-                }
                 const uint32_t bitA = 1u << (idA & 15u), bitB = 1u << (idB & 15u);
-                const bool freshA = haveA && !knownA && !((wa >> 16) == epoch && (wa & bitA));   // :2378
-                const bool freshB = haveB && !knownB && !((wb >> 16) == epoch && (wb & bitB));
+                // :2378 (a word / byte the screen spared reads 0, which no epoch equals)
+                const bool vb = P.vbytes != 0u;
+                const bool freshA = haveA && (vb ? wa != epoch : !((wa >> 16) == epoch && (wa & bitA)));
+                const bool freshB = haveB && (vb ? wb != epoch : !((wb >> 16) == epoch && (wb & bitB)));
+                if (vb) {                        // :2385 as a plain byte store: no line is fetched for it, none comes back
+                    uint8_t *t = reinterpret_cast<uint8_t *>(vmap);
+                    if (freshA) { __hip_atomic_store(t + idA, (uint8_t)epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (screen) bl_set(idA); }
+                    if (freshB) { __hip_atomic_store(t + idB, (uint8_t)epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (screen) bl_set(idB); }
+                } else {
                 if (freshA) {                    // :2385, fire and forget
                     uint32_t *w = &vmap[idA >> 4];
                     (void)__hip_atomic_fetch_max(w, etag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // stale epoch -> (epoch, no bits)
                     (void)__hip_atomic_fetch_or(w, bitA, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // same address: behind the max
+                    if (screen) bl_set(idA);
                 }
                 if (freshB) {
                     uint32_t *w = &vmap[idB >> 4];
                     (void)__hip_atomic_fetch_max(w, etag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     (void)__hip_atomic_fetch_or(w, bitB, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (screen) bl_set(idB);
+                }
                 }
                 const unsigned long long fmA = __ballot(freshA), fmB = __ballot(freshB);
                 const uint32_t nA = __popcll(fmA), n = nA + (uint32_t)__popcll(fmB);

@@ -69,6 +69,36 @@ def test_search_lds_filter_mode(rg, oracle, metric, d, nb, L, k, flt):
     ix.close()
 
 
+@pytest.mark.parametrize("metric,d,nb", [("ip", 200, 4000), ("l2", 24, 3000), ("l2", 512, 2000), ("ip", 24, 70000)])
+@pytest.mark.parametrize("wpc", [0, 13, 9, 7, 3])
+def test_filter_of_any_size(rg, oracle, metric, d, nb, wpc):
+    """filter_fill: the LDS visited filter takes the LDS the resident queries leave, so its slot count is whatever fits -- not a
+    power of two.  slot = floor(hash * slots / 2^id_bits), entry = the low bits of the hash: still one to one with the id, so
+    a hit still proves "visited" and every output stays the oracle's.  filter_fill = 2 fills on small batches too; the
+    resident count (waves_per_cu) varies what is left over, i.e. the slot count; a 70,000-node index has 17-bit ids (entries
+    of several bits over tables that are not a power of two).  In the look-ahead form of the exact words the same region is
+    a one-hash bit screen (a clear bit proves "not visited", the word is then not read): same outputs again."""
+    if nb > 10000:      # random 20-regular graph (repeats and self loops included)
+        from roargraph_amd import synth
+        base, q = synth.make_synth(5, nb, 40, d)
+        off, nbrs = synth.random_regular_csr(nb, 20)
+        ep = 17
+    else:
+        base, q, off, nbrs, ep = small_set(metric, nb, d, nq=100)
+    ix = rg.IndexBipartite.from_arrays(base, off, nbrs, ep, metric=metric)
+    ix.set("filter_fill", 2)
+    ix.set("waves_per_cu", wpc)
+    for L, k in ((10, 10), (100, 100), (700, 10), (1900, 10)):
+        want = oracle.search(base, metric, off, nbrs, ep, q, k, L, nthreads=4)
+        for visited, look in ((2, -1), (1, -1), (0, 0), (0, 1)):   # look-ahead form: the region is the bit screen of the words
+            ix.set("visited", visited)
+            ix.set("lookahead", look)
+            got = ix.SearchRoarGraph(q, k, L)
+            assert (got[3] == want[3]).all() and (got[0] == want[0]).all() and (bits(got[1]) == bits(want[1])).all(), (L, visited, look)
+            assert (got[2] == want[2]).all() if visited != 1 else (got[2] >= want[2]).all(), ("cmps", L, visited, look)
+    ix.close()
+
+
 @pytest.mark.parametrize("metric,d,nb", [("ip", 200, 4000), ("l2", 24, 3000), ("l2", 512, 2000), ("ip", 136, 2500)])
 @pytest.mark.parametrize("long_ep_row", [False, True])
 def test_shared_frontier_mode_is_exact(rg, oracle, metric, d, nb, long_ep_row):
@@ -154,10 +184,28 @@ def test_exact_words_forms(rg, oracle, metric, d, nb, lookahead, exact_filter):
         want = oracle.search(base, metric, off, nbrs, ep, q, k, L, nthreads=4)
         for rpp in ((8, 16, 32) if d == 200 else (8, 16)):
             ix.set("rows_per_pass", rpp)
-            for rep in range(2):        # the second call re-uses the slots' visited words under the next epochs
-                got = ix.SearchRoarGraph(q, k, L)
-                assert (got[2] == want[2]).all(), ("cmps", L, rpp, rep)
-                assert (got[3] == want[3]).all() and (got[0] == want[0]).all() and (bits(got[1]) == bits(want[1])).all(), (L, rpp, rep)
+            for vbytes in ((-1, 0) if lookahead else (-1,)):   # look-ahead form: one epoch byte per node (default) or the words
+                ix.set("visited_bytes", vbytes)
+                for rep in range(2):        # the second call re-uses the slots' visited words under the next epochs
+                    got = ix.SearchRoarGraph(q, k, L)
+                    assert (got[2] == want[2]).all(), ("cmps", L, rpp, vbytes, rep)
+                    assert (got[3] == want[3]).all() and (got[0] == want[0]).all() and (bits(got[1]) == bits(want[1])).all(), (L, rpp, vbytes, rep)
+    ix.close()
+
+
+def test_byte_tags_survive_the_epoch_wrap(rg, oracle):
+    """Byte form of the exact visited set (look-ahead kernel form): a slot's epoch is one byte, so its tags are wiped every 255
+    queries (VisitedList::reset, visited_list_pool.h:20-26).  Two slots (visited_budget_kb) serve 64 queries per call: twelve
+    calls take both slots through the wrap; every call must return the oracle's outputs."""
+    base, q, off, nbrs, ep = small_set("ip", 4000, 200)
+    ix = rg.IndexBipartite.from_arrays(base, off, nbrs, ep, metric="ip")
+    ix.set("visited", 0)
+    ix.set("lookahead", 1)
+    ix.set("visited_budget_kb", 8)      # 4000 tag bytes per slot (rounded to 4096): two slots
+    want = oracle.search(base, "ip", off, nbrs, ep, q, 10, 300, nthreads=4)
+    for call in range(12):
+        got = ix.SearchRoarGraph(q, 10, 300)
+        assert (got[2] == want[2]).all() and (got[3] == want[3]).all() and (got[0] == want[0]).all() and (bits(got[1]) == bits(want[1])).all(), call
     ix.close()
 
 
