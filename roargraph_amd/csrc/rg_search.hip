@@ -781,12 +781,14 @@ static rg_status launch_k1(rg_index *ix, SearchCtx *cx, int mode, const float *d
     c.R = R; c.vis = mode == 0 ? 0 : 1; c.dimc = dimc_of(ix); c.bf = bf; c.lds = lds;
     // exact words, look-ahead form (rg_search_kernel.h, VIS = 2): the register-staged instantiations over ELL rows that
     // name no node twice; never with the opt-in second expansion, whose two lists share one test phase.  Knob "lookahead":
-    // -1 (default) = from L_pq 1200 up, where it is the faster of the two forms of the exact words on the 10M bench index
-    // (profiles/r03/k1_forms_10m.txt: 50 - 54 vs 47 - 51 % of 8 TB/s at 2000, level at 1000, 4 - 8 % behind at 300 - 700: its
-    // plain-load tests spare the write-back of every word a returning atomic touches without changing, its two small
-    // reads per hop travel under the inserts and the pop -- but it issues more memory instructions per hop); 0 = never;
-    // 1 = always; 2 = always, without the early guess of the next adjacency row
-    const bool look_wanted = ix->lookahead > 0 || (ix->lookahead < 0 && L >= 1200 && dimc_of(ix) == 200);   // (measured at d = 200 only)
+    // -1 (default) = at d = 200 from L_pq 200 up; 0 = never; 1 = always; 2 = always, without the early guess of the next
+    // adjacency row.  With the word form of its tags (round 3, first version) it won from L_pq 1200 up only (50 - 54 vs 47 - 51 %
+    // of 8 TB/s at 2000, 4 - 8 % behind at 300 - 700: more memory instructions per hop); with one epoch BYTE per node -- marks
+    // are plain stores, no line is fetched for them -- and the LDS bit screen that spares the tests of never-marked nodes
+    // it is the faster form of the exact set at every beam width measured (profiles/r03/k1_ab_box20.jsonl, box21: 68.1 /
+    // 65.1 / 61.6 / 58.2 / 54.6 % of 8 TB/s at L_pq 500 / 700 / 1000 / 1500 / 2000 against 60.5 / 57.8 / 54.0 / 49.9 / 46.4 of the
+    // returning atomics on the same box).
+    const bool look_wanted = ix->lookahead > 0 || (ix->lookahead < 0 && L >= 200 && dimc_of(ix) == 200);   // (measured at d = 200 only)
     if (mode == 0 && look_wanted && !ix->adj_dups && !ix->multi_expand && !bf && !bp && ix->diag == 0 &&
         ((c.dimc == 200 && R >= 2) || (c.dimc == 512 && (R == 2 || R == 4))))
         c.vis = 2;
@@ -1533,7 +1535,7 @@ rg_status rg_search_prepare(rg_index *ix, void *stream, uint32_t nq, uint32_t L_
     if (st == RG_OK && ix->visited_mode != 1) {
         // the slots a wide-beam launch of the exact-words form uses (its grid): at most eight to ten resident queries per CU
         // (the look-ahead form, which wide beams use, keeps byte tags of its own: launch_k1)
-        const bool look = (ix->lookahead > 0 || (ix->lookahead < 0 && L_pq >= 1200 && rg::dimc_of(ix) == 200)) && rg::dimc_of(ix) && !ix->adj_dups &&
+        const bool look = (ix->lookahead > 0 || (ix->lookahead < 0 && L_pq >= 200 && rg::dimc_of(ix) == 200)) && rg::dimc_of(ix) && !ix->adj_dups &&
                           !ix->multi_expand && ix->diag == 0;
         const bool bytes = look && ix->visited_bytes != 0;
         const uint32_t slots = std::min(std::min<uint32_t>(nq, (uint32_t)ix->num_cu * (L_pq >= 700 ? 8u : 12u)), rg::visited_slot_cap(ix, bytes));
