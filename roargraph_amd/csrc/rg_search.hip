@@ -849,6 +849,7 @@ static rg_status launch_k1(rg_index *ix, SearchCtx *cx, int mode, const float *d
     P.visited = mode == 0 ? (vbytes ? cx->d_vtags : cx->d_visited) : nullptr;
     P.vwords = vbytes ? cx->twords : cx->vwords; P.slot_epoch = vbytes ? cx->d_epoch8 : cx->d_epoch;
     P.vbytes = vbytes ? 1u : 0u;
+    P.roll = ix->gather_roll ? 1u : 0u;
     P.counter = cx->d_counter; P.status = d_status;
     P.stage_floats = (uint32_t)stage_pass_floats(ix, bf);
     P.stage_total = (uint32_t)stage_total_floats(ix, R, bf);
@@ -1440,6 +1441,7 @@ rg_status rg_index_set(rg_index *ix, const char *name, int value) {
     else if (!strcmp(name, "log_budget_kb")) ix->log_budget_kb = value;
     else if (!strcmp(name, "visited_budget_kb")) ix->visited_budget_kb = value;
     else if (!strcmp(name, "visited_bytes")) ix->visited_bytes = value;
+    else if (!strcmp(name, "gather_roll")) ix->gather_roll = value != 0;
     else if (!strcmp(name, "visited_uncached")) {
         if (value != ix->visited_uncached) {      // contexts re-allocate their words on the next exact-words launch
             std::lock_guard<std::mutex> lk(ix->mu);

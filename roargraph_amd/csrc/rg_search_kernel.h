@@ -60,6 +60,7 @@ struct SearchParams {
     uint32_t vf_slots;        // entries (16-bit) of the LDS visited filter: any multiple of 8 (powers of two included)
     uint32_t vf_rem_bits;     // bits of an entry: the smallest r with 2^r >= ceil(2^id_bits / vf_slots), at most 15
     uint32_t vf_front;        // VIS=0: 1 = the LDS filter screens the exact HBM words; VIS=2: 1 = the region is the bit screen
+    uint32_t roll;            // register-staged gather: 1 = streamed (set j re-loaded as soon as it is scored), 0 = batch by batch
     uint32_t vbytes;          // VIS=2: 1 = `visited` holds one epoch BYTE per node ([slots][4 * vwords] bytes) instead of the words
     uint32_t *qlog;           // VIS=1, optional: [nq][logcap] ids scored by each query (input of the exact distinct count)
     uint32_t logcap;
@@ -686,7 +687,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
                 const uint32_t rid0 = cand_id[0];
                 const bool split = REM != 0 && P.tail_off != nullptr;
                 const uint32_t tix0 = split ? cand_x[0] : rid0;
-                auto batch = [&](uint32_t p0, auto first_batch) __attribute__((always_inline)) {
+                // STREAM (round 3, knob "gather_roll", default on): a hop with more than 4R fresh rows used to pay one memory
+                // latency per batch of R sets.  In the streamed form set j is re-loaded with the rows of pass p + R as soon
+                // as pass p has been scored out of it, so 4R rows stay in flight from the first pass of a hop to its last
+                // instead of draining at every batch boundary.  The loads of the steady-state loop are unconditional (passes
+                // beyond the list re-read row 0, as idle sets do), so the waits the compiler puts in front of every set stay
+                // exact counts; the last group is scored by an epilogue that loads nothing.
+                auto batch = [&](uint32_t p0, auto first_batch, auto stream) __attribute__((always_inline)) {
+                    constexpr bool STREAM = decltype(stream)::value;
                     constexpr int NV = GF == 1 ? DIMC / 16 : 1;
                     v4f rv[GF == 1 ? 1 : R][NFULL];
                     float rw[GF == 1 ? R : 1][NV];
@@ -717,6 +725,37 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
                         else t8[j] = 0.0f;
                     }
                     if constexpr (decltype(first_batch)::value) hook();
+                    if constexpr (STREAM) {
+                        for (; p0 + R < npass; p0 += R) {   // every pass of this group exists and has a successor set to load
+#pragma unroll
+                            for (int j = 0; j < R; ++j) {
+                                RG_PROF(6);
+                                float d;
+                                if constexpr (GF == 1) d = regs_score_q<L2, DIMC>(rw[j], t8[j], qr);
+                                else d = bounce_score_q<L2, DIMC>(stage, rv[j], t8[j], qr, lane);
+                                const uint32_t c = 4 * (p0 + j) + g;
+                                if (c < n && (lane & 15) == 0) cand_x[c] = __float_as_uint(d);
+                                lds_fence();
+                                RG_PROF(3);
+                                // pass p0 + R + j takes the registers over (scores land in cand_x[.. 4 (p0 + R)): the tail
+                                // slots of the passes still to be loaded are intact)
+                                const uint32_t c2 = 4 * (p0 + R + j) + g;
+                                const uint32_t rid2 = c2 < n ? cand_id[c2] : rid0;
+                                uint32_t tix2 = rid2;
+                                if constexpr (REM != 0) tix2 = split ? (c2 < n ? cand_x[c2] : tix0) : rid2;
+                                if constexpr (GF == 1) {
+                                    const float *src = P.base + (size_t)rid2 * P.stride + (lane & 15);
+#pragma unroll
+                                    for (int t = 0; t < NV; ++t) rw[j][t] = src[16 * t];
+                                } else {
+                                    const float *src = P.base + (size_t)rid2 * P.stride + 4 * jsrc;
+#pragma unroll
+                                    for (int b = 0; b < NFULL; ++b) rv[j][b] = *reinterpret_cast<const v4f *>(src + 64 * b);
+                                }
+                                if constexpr (REM != 0) t8[j] = P.tail_base[(size_t)tix2 * P.tail_stride + (lane & 7)];
+                            }
+                        }
+                    }
 #pragma unroll
                     for (int j = 0; j < R; ++j) {
                         if (p0 + j < npass) {
@@ -731,11 +770,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
                         }
                     }
                 };
-                if constexpr (decltype(hooked)::value) {
-                    batch(0u, std::true_type{});
-                    for (uint32_t p0 = R; p0 < npass; p0 += R) batch(p0, std::false_type{});
+                if (P.roll) {
+                    batch(0u, hooked, std::true_type{});
+                } else if constexpr (decltype(hooked)::value) {
+                    batch(0u, std::true_type{}, std::false_type{});
+                    for (uint32_t p0 = R; p0 < npass; p0 += R) batch(p0, std::false_type{}, std::false_type{});
                 } else {
-                    for (uint32_t p0 = 0; p0 < npass; p0 += R) batch(p0, std::false_type{});
+                    for (uint32_t p0 = 0; p0 < npass; p0 += R) batch(p0, std::false_type{}, std::false_type{});
                 }
             } else {
                 const uint32_t lpp = BF ? (uint32_t)NB : loads_per_pass(P.dim);

@@ -77,6 +77,9 @@ def make_case(seed):
         nbrs = np.concatenate(rows).astype(np.uint32) if nb else nbrs
     if seed >= 60:
         knobs.update(visited=0, lookahead=1, _csr=0, query_in_lds=0, rows_per_pass=int(rng.choice([0, 8, 16, 32])))
+    knobs["gather_roll"] = int(rng.random() < 0.5)          # (drawn last: the cases of earlier rounds keep their other draws)
+    knobs["visited_bytes"] = int(rng.choice([-1, -1, 0]))
+    knobs["filter_fill"] = int(rng.choice([1, 2, 2, 0]))
     return base, q, off, nbrs, ep, metric, k, L, knobs
 
 

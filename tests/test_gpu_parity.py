@@ -421,6 +421,34 @@ def test_wide_and_empty_adjacency_rows(rg, oracle, layout, monkeypatch):
     ix.close()
 
 
+@pytest.mark.parametrize("metric,d", [("ip", 200), ("l2", 200)])
+@pytest.mark.parametrize("gather_form", [1, 0])
+def test_rolled_gather_on_wide_hops(rg, oracle, metric, d, gather_form):
+    """gather_roll = 1 (eight register sets): a hop with more than 32 fresh rows fetches its second batch of rows set by set
+    behind the first instead of after it.  Rows of up to 126 distinct neighbours give hops of one to four batches, with every
+    remainder; all visited forms, both gather layouts, split rows on and off: every output is the oracle's."""
+    rng = np.random.default_rng(23)
+    nb = 3000
+    base = rng.standard_normal((nb, d)).astype(np.float32)
+    q = (rng.standard_normal((40, d)) * 0.5 + 0.3).astype(np.float32)
+    deg = rng.integers(1, 127, nb)
+    deg[0] = 126
+    off = np.zeros(nb + 1, np.uint64); off[1:] = np.cumsum(deg)
+    nbrs = np.concatenate([rng.choice(nb, int(k), replace=False) for k in deg]).astype(np.uint32)
+    ix = rg.IndexBipartite.from_arrays(base, off, nbrs, 0, metric=metric)
+    ix.set("gather_roll", 1)
+    ix.set("rows_per_pass", 32)
+    ix.set("gather_form", gather_form)
+    for L, k in ((20, 10), (300, 100)):
+        want = oracle.search(base, metric, off, nbrs, 0, q, k, L, nthreads=4)
+        for visited, look, split in ((2, -1, 1), (1, -1, 0), (0, 1, 1), (0, 0, 1), (0, 1, 0)):
+            ix.set("visited", visited); ix.set("lookahead", look); ix.set("split_rows", split)
+            got = ix.SearchRoarGraph(q, k, L)
+            assert (got[3] == want[3]).all() and (got[0] == want[0]).all() and (bits(got[1]) == bits(want[1])).all(), (L, visited, look, split)
+            assert (got[2] == want[2]).all() if visited != 1 else (got[2] >= want[2]).all(), ("cmps", L, visited, look, split)
+    ix.close()
+
+
 @pytest.mark.parametrize("metric", ["ip", "l2"])
 def test_ties_duplicate_edges_and_self_loops(rg, oracle, metric):
     """Exact distance ties (every base row appears four times), repeated edges, self-loops and a single-query batch: the
