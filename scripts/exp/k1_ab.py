@@ -32,6 +32,7 @@ ap.add_argument("--L", default="500,1000,2000")
 ap.add_argument("--nbatch", type=int, default=3)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--index-cache", default="")
+ap.add_argument("--pipelined", action="store_true")
 ap.add_argument("--configs", default="atomics:visited=0,lookahead=0;look:visited=0,lookahead=1")
 a = ap.parse_args()
 
@@ -91,12 +92,22 @@ for L in [int(x) for x in a.L.split(",")]:
             run(b, L)
         ix.search_wait(st)
         ms = []
-        for r in range(a.reps):
-            for b in range(len(qs)):
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(); run(b, L); e1.record()
+        if a.pipelined:     # the batches of a repetition enqueued back to back, one wait at the end (what bench.py times)
+            for r in range(a.reps):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for b in range(len(qs)):
+                    run(b, L)
                 ix.search_wait(st)
-                ms.append(e0.elapsed_time(e1))
+                torch.cuda.synchronize()
+                ms.append((time.perf_counter() - t0) * 1e3 / len(qs))
+        else:
+            for r in range(a.reps):
+                for b in range(len(qs)):
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record(); run(b, L); e1.record()
+                    ix.search_wait(st)
+                    ms.append(e0.elapsed_time(e1))
         snap = [(o["ids"].clone(), o["hp"].clone(), o["cm"].clone()) for o in outs]
         same = None
         if L in ref:
