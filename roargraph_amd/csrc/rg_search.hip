@@ -781,14 +781,16 @@ static rg_status launch_k1(rg_index *ix, SearchCtx *cx, int mode, const float *d
     c.R = R; c.vis = mode == 0 ? 0 : 1; c.dimc = dimc_of(ix); c.bf = bf; c.lds = lds;
     // exact words, look-ahead form (rg_search_kernel.h, VIS = 2): the register-staged instantiations over ELL rows that
     // name no node twice; never with the opt-in second expansion, whose two lists share one test phase.  Knob "lookahead":
-    // -1 (default) = at d = 200 from L_pq 200 up; 0 = never; 1 = always; 2 = always, without the early guess of the next
+    // -1 (default) = wherever the form is instantiated; 0 = never; 1 = always; 2 = always, without the early guess of the next
     // adjacency row.  With the word form of its tags (round 3, first version) it won from L_pq 1200 up only (50 - 54 vs 47 - 51 %
     // of 8 TB/s at 2000, 4 - 8 % behind at 300 - 700: more memory instructions per hop); with one epoch BYTE per node -- marks
     // are plain stores, no line is fetched for them -- and the LDS bit screen that spares the tests of never-marked nodes
     // it is the faster form of the exact set at every beam width measured (profiles/r03/k1_ab_box20.jsonl, box21: 68.1 /
     // 65.1 / 61.6 / 58.2 / 54.6 % of 8 TB/s at L_pq 500 / 700 / 1000 / 1500 / 2000 against 60.5 / 57.8 / 54.0 / 49.9 / 46.4 of the
     // returning atomics on the same box).
-    const bool look_wanted = ix->lookahead > 0 || (ix->lookahead < 0 && L >= 200 && dimc_of(ix) == 200);   // (measured at d = 200 only)
+    // (d = 512, webvid-2.5M shape, profiles/r03/k1_ab_box33_d512.jsonl: 90.3 / 89.3 / 87.5 / 82.2 / 76.9 / 69.5 % at L_pq 50 ... 2000
+    // against 86.7 / 86.2 / 84.3 / 80.2 / 76.4 / 67.5 of the returning atomics; d = 200 at L_pq 10 - 100: k1_ab_box28.jsonl)
+    const bool look_wanted = ix->lookahead != 0;
     if (mode == 0 && look_wanted && !ix->adj_dups && !ix->multi_expand && !bf && !bp && ix->diag == 0 &&
         ((c.dimc == 200 && R >= 2) || (c.dimc == 512 && (R == 2 || R == 4))))
         c.vis = 2;
@@ -999,7 +1001,7 @@ static rg_status search_dev(rg_index *ix, SearchCtx *cx, const float *d_q, uint3
         return st == RG_OK ? done() : fail(st);
     }
     // Adaptive default: both exact forms return the same bits.  When a batch showed the LDS filter re-scoring nodes
-    // wholesale at this beam width (performed > 1.3 x distinct: long searches on indexes with locality), the next batch
+    // at this beam width (performed > 1.08 x distinct: long searches on indexes with locality), the next batch
     // of that width runs on the exact HBM words as a timed trial; the faster form is kept from that width on (which one
     // wins depends on the index: the words of a 10M-node index are 10 GB of random atomics, those of a 2M-node index
     // mostly cache resident -- scripts/exp/visited_modes_real.py).
@@ -1111,7 +1113,9 @@ static rg_status finish_batches(rg_index *ix, SearchCtx *cx, hipStream_t s, uint
             const unsigned long long performed = b->h_stat[1], distinct = b->h_stat[2];
             {
                 std::lock_guard<std::mutex> lk(ix->mu);
-                if (distinct > 0 && (double)performed > 1.3 * (double)distinct && per_q > 0.0f && b->nq >= 1000 &&
+                // (round 3: from 8 % of re-scored nodes -- it was 30 % -- : with byte tags and the bit screen the exact set wins
+                // earlier, at d = 512 from L_pq 200 where the filter re-scores a sixth; a trial costs one batch in the other form)
+                if (distinct > 0 && (double)performed > 1.08 * (double)distinct && per_q > 0.0f && b->nq >= 1000 &&
                     b->L > ix->filter_ok_upto && b->L < ix->exact_from_L) {
                     ix->trial_L = b->L;      // next batch of this width: the exact words, timed
                     ix->filter_per_q = per_q;
@@ -1537,7 +1541,7 @@ rg_status rg_search_prepare(rg_index *ix, void *stream, uint32_t nq, uint32_t L_
     if (st == RG_OK && ix->visited_mode != 1) {
         // the slots a wide-beam launch of the exact-words form uses (its grid): at most eight to ten resident queries per CU
         // (the look-ahead form, which wide beams use, keeps byte tags of its own: launch_k1)
-        const bool look = (ix->lookahead > 0 || (ix->lookahead < 0 && L_pq >= 200 && rg::dimc_of(ix) == 200)) && rg::dimc_of(ix) && !ix->adj_dups &&
+        const bool look = ix->lookahead != 0 && rg::dimc_of(ix) && !ix->adj_dups &&
                           !ix->multi_expand && ix->diag == 0;
         const bool bytes = look && ix->visited_bytes != 0;
         const uint32_t slots = std::min(std::min<uint32_t>(nq, (uint32_t)ix->num_cu * (L_pq >= 700 ? 8u : 12u)), rg::visited_slot_cap(ix, bytes));
