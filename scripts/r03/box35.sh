@@ -16,4 +16,4 @@ for n in ("bench_webvid_shape","bench_laion_shape"):
         for p in d["L_pq_sweep"]: print("  ", p["L_pq"], round(p["qps"]), round(p["recall_at_10"],4), round(p["pct_of_8000"],1))
     except Exception as e: print(n, "no line:", e)
 PY
-tail -2 $OUT/webvid.err $OUT/laion.err
+tail -q -n 2 $OUT/webvid.err $OUT/laion.err
