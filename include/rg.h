@@ -104,7 +104,7 @@ rg_status rg_index_info(const rg_index *idx, uint32_t *nd, uint32_t *dim, uint32
  * "rows_per_pass" = 4 * (passes of 4 rows a query keeps in flight; 16 / 32 use register staging at d = 200).
  * "visited" selects how the visited set is kept:
  *   2 (default) LDS exact-match filter + per-query id log + exact distinct count: ids, dists, hops AND cmps bit-exact.
- *               Adaptive: once a batch shows the filter re-scoring > 30 % extra nodes at some L_pq (long searches on
+ *               Adaptive: once a batch shows the filter re-scoring > 8 % extra nodes at some L_pq (long searches on
  *               indexes with locality), the next batch of that L_pq is a timed trial of mode 0 and the faster of the two
  *               exact forms is kept from that L_pq on -- the same bits either way
  *   1           LDS filter only: ids, dists, hops bit-exact; cmps = evaluations performed (>= the reference's)

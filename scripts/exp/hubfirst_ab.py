@@ -34,6 +34,7 @@ ap.add_argument("--nbatch", type=int, default=4)
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--index-cache", default="")
 ap.add_argument("--only", default="", help="A or B: run one layout only (counter passes)")
+ap.add_argument("--knobs", default="", help="knob=value,... set on both indexes (e.g. visited=0,lookahead=1: the byte-tag exact set)")
 a = ap.parse_args()
 
 dev = torch.device("cuda", 0)
@@ -86,6 +87,8 @@ if a.only:
 res = {}
 for name, b_, o_, n_, e_, back in layouts:
     ix = IndexBipartite.from_device(b_, o_, n_, e_, metric="ip")
+    for kv in [x for x in a.knobs.split(",") if x]:
+        ix.set(kv.split("=")[0], int(kv.split("=")[1]))
     outs = [dict(ids=torch.zeros((a.nq, k), dtype=torch.int32, device=dev), ds=torch.zeros((a.nq, k), device=dev),
                  cm=torch.zeros(a.nq, dtype=torch.int32, device=dev), hp=torch.zeros(a.nq, dtype=torch.int32, device=dev)) for _ in qs]
     for L in [int(x) for x in a.L.split(",")]:
