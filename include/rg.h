@@ -120,7 +120,9 @@ rg_status rg_index_info(const rg_index *idx, uint32_t *nd, uint32_t *dim, uint32
  * instantiated), "filter_min_indeg" (the LDS filter keeps entries only for neighbours of at least this in-degree; default 2),
  * "count_in_k1" (beams up to this wide count their distinct ids inside the search kernel; default 40, 0 = never),
  * "log_early", "visited_budget_kb" (cap of the exact visited words per stream; default 24 GiB), "visited_uncached",
- * "visited_bytes" (look-ahead form: one epoch byte per node instead of the epoch-tagged words; default on), "filter_fill".
+ * "visited_bytes" (look-ahead form: one epoch byte per node instead of the epoch-tagged words; default on), "filter_fill"
+ * (the LDS visited filter takes the LDS the resident queries leave: any slot count; default on), "gather_roll" (streamed
+ * row gather; default on).
  * "shared_frontier" = 1 (opt-in, EXACT: every output stays bit-identical; SURVEY 8 f-4, third mode): every query of a batch
  * starts at the entry point, so the first expansion scores the same rows for all of them -- they are scored once for the
  * batch (rg_front_score_kernel, the exact routine) and the first hop of every query reads the scores.

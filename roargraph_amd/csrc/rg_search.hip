@@ -709,6 +709,9 @@ static rg_status ensure_visited(rg_index *ix, SearchCtx *cx, uint32_t slots, boo
     }
     if (d_vis) (void)hipFree(d_vis);
     if (d_ep) (void)hipFree(d_ep);
+    if (getenv("RG_TRACE_ALLOC"))   // where an allocation landed (the same launch differs by +- 5 % between two allocations of the tags)
+        fprintf(stderr, "[rg_search] visited %s: %u slots x %u words at %p (%.2f GiB)\n", bytes ? "byte tags" : "words", slots, vwords, (void *)nv,
+                (double)slots * vwords * 4 / (1u << 30));
     d_vis = nv;
     d_ep = ne;
     have_slots = 0;
