@@ -94,7 +94,6 @@ struct rg_index {
     int visited_mode = 2;
     int log_budget_kb = 16 << 20;  // HBM budget of the id logs per context (KiB, default 16 GiB = 32768 queries): larger batches are searched in sub-batches
     bool gather_roll = true;   // register-staged gather: streamed (set j re-loaded as soon as it is scored) instead of batch by batch
-    bool tag_reroll = false;   // opt-in: byte tags are allocated twice, both probed with random reads, the faster physical placement stays
     int visited_bytes = -1;   // look-ahead form: -1 / 1 = one epoch byte per node (marks are plain stores), 0 = the epoch-tagged words
     int visited_budget_kb = 24 << 20;  // HBM budget of the exact visited words per context (KiB, default 24 GiB): caps the slots = the grid of a mode-0 launch
     int visited_uncached = 0;        // knob: exact visited words in 1 = uncached (MTYPE_UC), 2 = fine-grained device memory

@@ -681,42 +681,6 @@ static uint32_t filter_rem_bits(uint32_t id_bits, uint32_t slots) {
 // count (and with it the launch grid) is capped by "visited_budget_kb" (default 24 GiB per context), and an allocation
 // that fails returns RG_ERR_OOM without touching what the context already had -- the caller then runs the batch in the
 // filter + log form, which returns the same bits
-// Placement probe of a tag buffer (round 3, knob "tag_reroll"): random byte reads all over the buffer, the access pattern of
-// the visited tests.  Two allocations of the same 19 GiB run the same launch 10 % apart (profiles/r03/k1_ab_box39_*,
-// alloc_modes_box42.jsonl: a property of the physical backing the driver hands out, stable for the life of the
-// allocation).  With the knob on the byte form draws twice, probes both and keeps the faster one; RG_TRACE_ALLOC=1 prints the
-// probe of every allocation.  OFF by default: on the one box where it was tried every draw was the good mode (profiles/r03/
-// k1_ab_box43_probe*), so whether the probe tells the modes apart is not established.
-__global__ void __launch_bounds__(256) rg_tag_probe_kernel(const uint8_t *__restrict__ buf, size_t bytes, uint32_t iters, uint32_t *__restrict__ sink) {
-    unsigned long long x = ((unsigned long long)blockIdx.x * blockDim.x + threadIdx.x + 1ull) * 0x9E3779B97F4A7C15ull;
-    uint32_t acc = 0;
-    for (uint32_t i = 0; i < iters; i += 4) {
-        size_t o[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            x = x * 6364136223846793005ull + 1442695040888963407ull;
-            o[u] = (size_t)((x >> 11) % bytes);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) acc += __builtin_nontemporal_load(buf + o[u]);
-    }
-    if (acc == 0xffffffffu) *sink = acc;
-}
-static float probe_tags(const uint32_t *buf, size_t bytes, uint32_t *d_sink, hipStream_t s) {
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) { (void)hipGetLastError(); if (e0) (void)hipEventDestroy(e0); return -1.0f; }
-    float best = -1.0f;
-    for (int r = 0; r < 3; ++r) {
-        (void)hipEventRecord(e0, s);
-        hipLaunchKernelGGL(rg_tag_probe_kernel, dim3(4096), dim3(256), 0, s, reinterpret_cast<const uint8_t *>(buf), bytes, 32u, d_sink);
-        (void)hipEventRecord(e1, s);
-        float ms = 0.0f;
-        if (hipEventSynchronize(e1) == hipSuccess && hipEventElapsedTime(&ms, e0, e1) == hipSuccess && r > 0) best = best < 0.0f ? ms : std::min(best, ms);
-    }
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    if (hipGetLastError() != hipSuccess) return -1.0f;
-    return best;
-}
 // words per slot: ceil(nd / 16) epoch-tagged words, or -- byte form -- nd epoch bytes rounded up to whole 128-byte lines
 static uint32_t visited_words(const rg_index *ix, bool bytes) {
     return bytes ? (uint32_t)(((size_t)ix->nd + 127) / 128 * 32) : (ix->nd + 15) / 16;
@@ -745,20 +709,6 @@ static rg_status ensure_visited(rg_index *ix, SearchCtx *cx, uint32_t slots, boo
     }
     if (d_vis) (void)hipFree(d_vis);
     if (d_ep) (void)hipFree(d_ep);
-    d_vis = nullptr; d_ep = nullptr;
-    // byte tags of a launch that fills the chip: a second draw, the faster of the two stays (see rg_tag_probe_kernel)
-    const size_t nbytes = (size_t)slots * vwords * 4;
-    if (bytes && !ix->visited_uncached && nbytes >= ((size_t)1 << 30) && (ix->tag_reroll || getenv("RG_TRACE_ALLOC"))) {
-        const float t1 = probe_tags(nv, nbytes, ne, s);
-        float t2 = -1.0f;
-        uint32_t *nv2 = nullptr;
-        if (ix->tag_reroll && t1 > 0.0f && hipMalloc(&nv2, nbytes) == hipSuccess) {
-            t2 = probe_tags(nv2, nbytes, ne, s);
-            if (t2 > 0.0f && t2 < 0.98f * t1) std::swap(nv, nv2);
-            (void)hipFree(nv2);
-        } else (void)hipGetLastError();
-        if (getenv("RG_TRACE_ALLOC")) fprintf(stderr, "[rg_search] tag placement probe: %.3f ms%s%.3f ms -> kept %p\n", t1, ix->tag_reroll ? ", second draw " : " (no second draw) ", t2, (void *)nv);
-    }
     if (getenv("RG_TRACE_ALLOC"))   // where an allocation landed (the same launch differs by +- 5 % between two allocations of the tags)
         fprintf(stderr, "[rg_search] visited %s: %u slots x %u words at %p (%.2f GiB)\n", bytes ? "byte tags" : "words", slots, vwords, (void *)nv,
                 (double)slots * vwords * 4 / (1u << 30));
@@ -1498,7 +1448,6 @@ rg_status rg_index_set(rg_index *ix, const char *name, int value) {
     else if (!strcmp(name, "log_budget_kb")) ix->log_budget_kb = value;
     else if (!strcmp(name, "visited_budget_kb")) ix->visited_budget_kb = value;
     else if (!strcmp(name, "visited_bytes")) ix->visited_bytes = value;
-    else if (!strcmp(name, "tag_reroll")) ix->tag_reroll = value != 0;
     else if (!strcmp(name, "gather_roll")) ix->gather_roll = value != 0;
     else if (!strcmp(name, "visited_uncached")) {
         if (value != ix->visited_uncached) {      // contexts re-allocate their words on the next exact-words launch
