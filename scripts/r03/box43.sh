@@ -1,4 +1,5 @@
 #!/bin/bash
+# (needs the build of commit b499955: the probe and its knob "tag_reroll" were removed afterwards -- DESIGN 8)
 # round 3, forty-third box: does the placement probe of a tag allocation (random byte reads) tell the two modes apart, and does
 # drawing twice and keeping the faster one pin the good mode?  Every configuration below re-allocates the tags.
 R=${GRAFT_REPO_ROOT:-/root/repo}
