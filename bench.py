@@ -438,6 +438,10 @@ def main():
         off = torch.arange(0, args.nb + 1, dtype=torch.int64, device=dev) * args.deg
         ep = 0
         graph_desc = "random out-degree-%d graph (recall is meaningless on it)" % args.deg
+    # the setup phase (ground truth of the training queries, construction) went through torch's caching allocator, which keeps
+    # what it is given; the library allocates with hipMalloc -- hand the cached blocks back first, so that its large buffers
+    # (adjacency, split rows, id logs, the 19 GiB of visited tags of a wide beam) are cut from whole memory, not from the gaps
+    torch.cuda.empty_cache()
     index = IndexBipartite.from_device(base, off, nbrs, ep, metric=args.metric)
     for kv in [x for x in args.set.split(",") if x]:
         kname, kval = kv.split("=")
@@ -456,6 +460,7 @@ def main():
         groundtruth.gt_shard_dev(base, qb, args.metric, 100, 0, ti_q, tv_q, stream=stream); torch.cuda.synchronize()
         gts.append(ti_q.cpu().numpy().view(np.uint32).copy())
     del ti_q, tv_q
+    torch.cuda.empty_cache()
     S = Searcher(torch, index, qs, args.k, args.dim, stream, gts)
 
     # ---- L_pq sweep (every rank runs it: it also settles the adaptive default; rank 0 reports) -------------------------
