@@ -165,7 +165,8 @@ rg_status rg_search_dev(rg_index *idx, const float *d_queries, uint32_t nq, uint
                         void *stream);
 rg_status rg_search_wait(rg_index *idx, void *stream);
 /* Optional: allocate now what batches of up to nq queries at beam widths up to L_pq will need on `stream` (the id logs of
- * the default visited mode, the visited words of the exact form), so that the first search does not pay for it.  Plays
+ * the default visited mode; the visited tags of the exact form where a launch will use them: visited = 0, or a beam width
+ * from which the adaptive default already chose the exact set), so that the first search does not pay for it.  Plays
  * the part of InitVisitedListPool(num_threads) (index_bipartite.h:133; tests/test_search_roargraph.cpp:173), which the
  * reference calls before its timed loop.  Never required: searches allocate on first use. */
 rg_status rg_search_prepare(rg_index *idx, void *stream, uint32_t nq, uint32_t L_pq);
@@ -173,8 +174,9 @@ rg_status rg_search_prepare(rg_index *idx, void *stream, uint32_t nq, uint32_t L
  * `stream` left behind -- it must have run in the default visited mode in one piece and have been waited for --
  * the number of distance evaluations the launch performed (re-scored rows included: each is a row read) and the number
  * of DISTINCT base rows among them.  distinct / evaluations is the share of a launch's row reads that are first touches,
- * i.e. that no cache can have served from an earlier read of the same launch.  d_row_counts (optional, device, one
- * zero-initialised counter per base row) receives how often each row was read: the popularity distribution. */
+ * i.e. that no cache can have served from an earlier read of the same launch.  d_row_counts (optional, device; the
+ * caller provides nd zero-initialised counters, one per base row -- the call cannot check the size) receives how often each
+ * row was read: the popularity distribution.  The kernels run on `stream`; the call returns when they have finished. */
 rg_status rg_search_reuse_stats(rg_index *idx, void *stream, uint64_t *evaluations, uint64_t *distinct_rows,
                                 uint32_t *d_row_counts);
 

@@ -11,6 +11,9 @@
 //   --devices 0 1 ...   one index replica per listed GPU, the query batch split between them (host buffers in the timed
 //                       region: rg_search_sharded); --device is ignored when this is given
 //   --fast_bf16 1       opt-in non-parity mode of the library (default 0 = the reference's results bit for bit)
+//   --steady 1          a seventh stdout column QPS_steady: a later pass over the same queries, after the device path has
+//                       settled on one of its two exact visited forms for this beam width (default 0 = the reference's
+//                       six columns, test_search_roargraph.cpp:190, and one timed pass per L_pq)
 #include <hip/hip_runtime.h>
 
 #include <chrono>
@@ -49,6 +52,7 @@ int main(int argc, char **argv) {
     a.add("device", false, "HIP device index", "0");
     a.add("devices", false, "several HIP devices: one index replica each, queries sharded (rg_search_sharded)", "");
     a.add("fast_bf16", false, "1 = opt-in NON-parity mode: bf16 traversal + exact fp32 re-rank (rg.h)", "0");
+    a.add("steady", false, "1 = extra stdout column QPS_steady (two more passes per L_pq); default: the reference's six columns", "0");
     if (!a.parse(argc, argv)) return -1;
     if (a.help()) { a.usage(std::cout); return 0; }
 
@@ -121,10 +125,13 @@ int main(int argc, char **argv) {
     uint32_t L_max = k;
     for (const std::string &ls : a.list("L_pq")) L_max = std::max<uint32_t>(L_max, (uint32_t)std::strtoul(ls.c_str(), nullptr, 10));
     if (replicas.size() == 1) CK(rg_search_prepare(index, nullptr, q_pts, L_max));
-    // Columns: the reference's six (QPS = its protocol: 100 warm-up queries, then ONE timed pass over the query file,
-    // :198-213), plus QPS_steady = a later pass over the same queries, after the device path has settled on one of its two
-    // exact visited forms for this beam width (same results either way; RG_TRACE_ADAPTIVE=1 shows the decisions)
-    std::cout << "L_pq" << "\t\tQPS" << "\t\t\tavg_visited" << "\tmean_latency" << "\trecall@" << k << "\tavg_hops" << "\tQPS_steady" << std::endl;
+    // Columns: the reference's six (:190; QPS = its protocol: 100 warm-up queries, then ONE timed pass over the query file,
+    // :198-213).  --steady 1 adds QPS_steady = a later pass over the same queries, after the device path has settled on one
+    // of its two exact visited forms for this beam width (same results either way; RG_TRACE_ADAPTIVE=1 shows the decisions)
+    const bool steady = a.u("steady") != 0;
+    std::cout << "L_pq" << "\t\tQPS" << "\t\t\tavg_visited" << "\tmean_latency" << "\trecall@" << k << "\tavg_hops";
+    if (steady) std::cout << "\tQPS_steady";
+    std::cout << std::endl;
     for (const std::string &ls : a.list("L_pq")) {
         const uint32_t L_pq = (uint32_t)std::strtoul(ls.c_str(), nullptr, 10);
         if (k > L_pq) { std::cout << "L_pq must greater or equal than k" << std::endl; return 1; }
@@ -139,13 +146,15 @@ int main(int argc, char **argv) {
                                  cmps.data(), hops.data()));
             auto t1 = std::chrono::high_resolution_clock::now();
             ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
-            CK(rg_search_sharded(replicas.data(), (int)replicas.size(), query, q_pts, q_stride, k, L_pq, res.data(), dist_h.data(),
-                                 cmps.data(), hops.data()));
-            auto t2 = std::chrono::high_resolution_clock::now();
-            CK(rg_search_sharded(replicas.data(), (int)replicas.size(), query, q_pts, q_stride, k, L_pq, res.data(), dist_h.data(),
-                                 cmps.data(), hops.data()));
-            auto t3 = std::chrono::high_resolution_clock::now();
-            ms_steady = std::chrono::duration<double, std::milli>(t3 - t2).count();
+            if (steady) {
+                CK(rg_search_sharded(replicas.data(), (int)replicas.size(), query, q_pts, q_stride, k, L_pq, res.data(), dist_h.data(),
+                                     cmps.data(), hops.data()));
+                auto t2 = std::chrono::high_resolution_clock::now();
+                CK(rg_search_sharded(replicas.data(), (int)replicas.size(), query, q_pts, q_stride, k, L_pq, res.data(), dist_h.data(),
+                                     cmps.data(), hops.data()));
+                auto t3 = std::chrono::high_resolution_clock::now();
+                ms_steady = std::chrono::duration<double, std::milli>(t3 - t2).count();
+            }
         } else {
             CK(rg_search_dev(index, d_q, warm, q_stride, k, L_pq, d_ids, d_dist, d_cmps, d_hops, nullptr));   // :198-201
             CK(rg_search_wait(index, nullptr));
@@ -157,14 +166,16 @@ int main(int argc, char **argv) {
             HK(hipMemcpy(res.data(), d_ids, res.size() * 4, hipMemcpyDeviceToHost));
             HK(hipMemcpy(cmps.data(), d_cmps, cmps.size() * 4, hipMemcpyDeviceToHost));
             HK(hipMemcpy(hops.data(), d_hops, hops.size() * 4, hipMemcpyDeviceToHost));
-            // steady state: one more untimed pass (where the adaptive default may try its other exact form), then a timed one
-            CK(rg_search_dev(index, d_q, q_pts, q_stride, k, L_pq, d_ids, d_dist, d_cmps, d_hops, nullptr));
-            CK(rg_search_wait(index, nullptr));
-            auto t2 = std::chrono::high_resolution_clock::now();
-            CK(rg_search_dev(index, d_q, q_pts, q_stride, k, L_pq, d_ids, d_dist, d_cmps, d_hops, nullptr));
-            CK(rg_search_wait(index, nullptr));
-            auto t3 = std::chrono::high_resolution_clock::now();
-            ms_steady = std::chrono::duration<double, std::milli>(t3 - t2).count();
+            if (steady) {
+                // steady state: one more untimed pass (where the adaptive default may try its other exact form), then a timed one
+                CK(rg_search_dev(index, d_q, q_pts, q_stride, k, L_pq, d_ids, d_dist, d_cmps, d_hops, nullptr));
+                CK(rg_search_wait(index, nullptr));
+                auto t2 = std::chrono::high_resolution_clock::now();
+                CK(rg_search_dev(index, d_q, q_pts, q_stride, k, L_pq, d_ids, d_dist, d_cmps, d_hops, nullptr));
+                CK(rg_search_wait(index, nullptr));
+                auto t3 = std::chrono::high_resolution_clock::now();
+                ms_steady = std::chrono::duration<double, std::milli>(t3 - t2).count();
+            }
         }
         const float qps = (float)q_pts / ((float)ms / 1000.0f);
         const float recall = rg_recall(q_pts, k, gt_dim, res.data(), gt_ids);
@@ -173,7 +184,9 @@ int main(int argc, char **argv) {
         avg_cmps /= q_pts;
         avg_hops /= (float)q_pts;
         std::cout << L_pq << "\t\t" << qps << "\t\t" << avg_cmps << "\t\t" << ((float)ms / q_pts) << "\t\t" << recall
-                  << "\t\t" << avg_hops << "\t\t" << ((float)q_pts / ((float)ms_steady / 1000.0f)) << std::endl;
+                  << "\t\t" << avg_hops;
+        if (steady) std::cout << "\t\t" << ((float)q_pts / ((float)ms_steady / 1000.0f));
+        std::cout << std::endl;
         if (evaluation_out.is_open())
             evaluation_out << L_pq << "," << qps << "," << avg_cmps << "," << ((float)ms / q_pts) << "," << recall << ","
                            << avg_hops << std::endl;

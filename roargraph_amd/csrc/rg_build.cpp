@@ -38,6 +38,7 @@
 #include <new>
 #include <stdexcept>
 #include <string>
+#include <exception>
 #include <thread>
 #include <vector>
 #if defined(__x86_64__)
@@ -163,31 +164,63 @@ struct Builder {
     }
     static bool has(const std::vector<uint32_t> &v, uint32_t x) { return std::find(v.begin(), v.end(), x) != v.end(); }
 
+    // An exception on a worker thread (bad_alloc from a list that grows, a vector of a pruning rule) would reach
+    // std::terminate on a std::thread, and a worker that died would leave its team mates in the barrier.  Workers catch; the
+    // first exception is kept, the others are told to stop (the loop's counter is pushed past its end, the team's barrier is
+    // poisoned), and the caller's thread rethrows after the join -- build_impl turns it into a status.
+    // RG_BUILD_FAULT=<n> (tests only): the n-th multi-threaded region of a build throws std::bad_alloc on one of its worker threads
+    static bool fault_here() {
+        static const long at = getenv("RG_BUILD_FAULT") ? atol(getenv("RG_BUILD_FAULT")) : 0;
+        static std::atomic<long> region(0);
+        return at > 0 && region.fetch_add(1) + 1 == at;
+    }
+    struct FirstError {
+        std::mutex mu;
+        std::exception_ptr ep;
+        void keep(std::exception_ptr e) { std::lock_guard<std::mutex> lk(mu); if (!ep) ep = e; }
+        void rethrow() { if (ep) std::rethrow_exception(ep); }
+    };
     // static-chunk (phases 1, 2) or dynamic-chunk (phases 3-5) loops, as the reference's omp schedules
     void parallel_for(uint32_t n, uint32_t chunk, const std::function<void(uint32_t, int)> &fn) {
         if (threads <= 1) { for (uint32_t i = 0; i < n; ++i) fn(i, 0); return; }
         std::atomic<uint32_t> next(0);
+        std::atomic<bool> stop(false);
+        FirstError err;
+        const bool fault = fault_here();
         std::vector<std::thread> pool;
         for (int t = 0; t < threads; ++t)
             pool.emplace_back([&, t] {
-                for (;;) {
-                    const uint32_t lo = next.fetch_add(chunk);
-                    if (lo >= n) break;
-                    const uint32_t hi = std::min(n, lo + chunk);
-                    for (uint32_t i = lo; i < hi; ++i) fn(i, t);
+                try {
+                    if (fault && t == threads - 1) throw std::bad_alloc();
+                    for (;;) {
+                        const uint32_t lo = next.fetch_add(chunk);
+                        if (lo >= n || stop.load(std::memory_order_relaxed)) break;
+                        const uint32_t hi = std::min(n, lo + chunk);
+                        for (uint32_t i = lo; i < hi; ++i) fn(i, t);
+                    }
+                } catch (...) {
+                    err.keep(std::current_exception());
+                    stop.store(true, std::memory_order_relaxed);
                 }
             });
         for (auto &th : pool) th.join();
+        err.rethrow();
     }
 
     // T persistent threads running fn(t, team) with a spinning barrier between their steps (phase 2 below has ~10^4 steps of
     // a few microseconds each: thread creation per step would cost more than the steps)
+    struct TeamAborted {};     // thrown by barrier() once a team mate has failed
     struct Team {
         int T;
-        std::atomic<int> arrived{0}, sense{0};
+        std::atomic<int> arrived{0}, sense{0}, aborted{0};
         explicit Team(int t) : T(t) {}
+        void abort() {
+            aborted.store(1, std::memory_order_release);
+            syscall(SYS_futex, reinterpret_cast<int *>(&sense), FUTEX_WAKE_PRIVATE, INT_MAX, nullptr, nullptr, 0);
+        }
         void barrier(int &local) {
             local ^= 1;
+            if (aborted.load(std::memory_order_acquire)) throw TeamAborted();
             if (arrived.fetch_add(1, std::memory_order_acq_rel) == T - 1) {
                 arrived.store(0, std::memory_order_relaxed);
                 sense.store(local, std::memory_order_release);
@@ -200,8 +233,12 @@ struct Builder {
                     _mm_pause();
 #endif
                 }
-                while (sense.load(std::memory_order_acquire) != local)
-                    syscall(SYS_futex, reinterpret_cast<int *>(&sense), FUTEX_WAIT_PRIVATE, local ^ 1, nullptr, nullptr, 0);
+                while (sense.load(std::memory_order_acquire) != local) {
+                    if (aborted.load(std::memory_order_acquire)) throw TeamAborted();
+                    // (a bounded sleep: a team mate's abort() may land between the check above and the wait)
+                    struct timespec ts = {0, 2000000};
+                    syscall(SYS_futex, reinterpret_cast<int *>(&sense), FUTEX_WAIT_PRIVATE, local ^ 1, &ts, nullptr, 0);
+                }
             }
         }
     };
@@ -209,9 +246,23 @@ struct Builder {
     void run_team(const std::function<void(int, Team &)> &fn) {
         Team team(std::max(1, threads));
         if (team.T == 1) { fn(0, team); return; }
+        FirstError err;
+        const bool fault = fault_here();
         std::vector<std::thread> pool;
-        for (int t = 0; t < team.T; ++t) pool.emplace_back([&, t] { fn(t, team); });
+        for (int t = 0; t < team.T; ++t)
+            pool.emplace_back([&, t] {
+                try {
+                    if (fault && t == team.T - 1) throw std::bad_alloc();
+                    fn(t, team);
+                } catch (const TeamAborted &) {
+                    // a team mate failed: its exception is the one reported
+                } catch (...) {
+                    err.keep(std::current_exception());
+                    team.abort();
+                }
+            });
         for (auto &th : pool) th.join();
+        err.rethrow();
     }
     // which thread applies the reverse edges into list x: any fixed map gives the same graph, every list has ONE writer
     static uint32_t owner_of(uint32_t x, uint32_t T) { return (uint32_t)(((uint64_t)(x * 2654435761u) * T) >> 32); }

@@ -119,6 +119,8 @@ struct rg_index {
     uint32_t front_n = 0;
     bool log_early = true;       // knob: the id-log store of a hop leaves right behind the row loads (rg_search_kernel.h: expand)
     int count_in_k1 = -1;        // knob: beams up to this wide count their distinct ids inside K1 (-1 = 40, 0 = never: K4 counts)
+    int count_tail = -1;         // knob (round 4): the distinct counts are made in the tail of the launch, by the waves that found the work
+                                 // queue empty (-1 = every beam width, 0 = off, N = beams up to N wide); takes precedence over count_in_k1
     int gather_form = -1;        // register-staged K1: 0 = 16-byte loads + LDS bounce, otherwise compute-layout loads where instantiated
     int lookahead = -1;          // mode 0, knob "lookahead": -1 = automatic (by beam width), 0 = returning atomics, 1 = look-ahead form, 2 = look-ahead
                                  // form without the early guess (same results in every form; rg_search.hip: launch_k1)

@@ -285,10 +285,10 @@ __global__ void rg_base_to_bf16_kernel(const float *__restrict__ base, uint32_t 
     }
 }
 
-// CSR -> ELL ([deg, ids...] per node at a fixed stride), one wave per node.  *dups is set when a list of at most 63
-// neighbours names a node twice (the file format does not forbid it, index_bipartite.cpp:2097-2117; the reference's own
-// builds never produce it): the look-ahead form of K1 tests a hop's neighbours against the visited words in one step
-// and would score such a node twice, so those indexes keep the returning-atomic form, which orders the two tests.
+// CSR -> ELL ([deg, ids...] per node at a fixed stride), one wave per node.  *dups is set when a list -- of any length --
+// names a node twice (the file format does not forbid it, index_bipartite.cpp:2097-2117; the reference's own builds never
+// produce it): the look-ahead form of K1 tests a hop's neighbours against the visited tags in one step and would score
+// such a node twice, so those indexes keep the returning-atomic form, which orders the two tests.
 __global__ void rg_csr_to_ell_kernel(const uint64_t *offsets, const uint32_t *nbrs, uint32_t nd, uint32_t *ell,
                                      uint32_t ell_stride, uint32_t *dups) {
     const int lane = threadIdx.x & 63;
@@ -299,10 +299,20 @@ __global__ void rg_csr_to_ell_kernel(const uint64_t *offsets, const uint32_t *nb
         uint32_t *row = ell + (size_t)node * ell_stride;
         if (lane == 0) row[0] = deg;
         for (uint32_t j = lane; j < ell_stride - 1; j += 64) row[1 + j] = j < deg ? nbrs[o0 + j] : 0u;
-        if (deg <= 63u && deg > 1u) {
-            const uint32_t mine = (uint32_t)lane < deg ? nbrs[o0 + lane] : 0xffffffffu;
+        if (deg > 1u) {
+            // every degree (rows of 64 .. 126 neighbours take the look-ahead form's two-read step, longer ones its general
+            // path with plain byte tags: both test a whole chunk in one step): entry i against every entry before it, the
+            // row 64 entries at a time
             bool twice = false;
-            for (uint32_t j = 0; j < deg; ++j) twice = twice || ((uint32_t)lane > j && readlane_u(mine, (int)j) == mine);
+            for (uint32_t c0 = 0; c0 < deg; c0 += 64u) {
+                const uint32_t i = c0 + (uint32_t)lane;
+                const uint32_t mine = i < deg ? nbrs[o0 + i] : 0xffffffffu;
+                for (uint32_t b0 = 0; b0 <= c0; b0 += 64u) {
+                    const uint32_t other = b0 + (uint32_t)lane < deg ? nbrs[o0 + b0 + lane] : 0xffffffffu;
+                    const uint32_t nj = min(64u, deg - b0);
+                    for (uint32_t j = 0; j < nj; ++j) twice = twice || (i < deg && i > b0 + j && readlane_u(other, (int)j) == mine);
+                }
+            }
             if (__ballot(twice) != 0ull && lane == 0) atomicOr(dups, 1u);
         }
     }
@@ -730,11 +740,19 @@ struct BuildOut { uint2_pod *exp; uint32_t exp_cap, node0; uint32_t *nexp; };
 static unsigned long long *g_prof_buf = nullptr;   // [nq][16], set through rg_prof_buffer (instrumented build only)
 #endif
 
-// one K1 launch.  mode: 0 exact HBM visited words, 1 LDS filter (optionally logging the scored ids).
-static rg_status launch_k1(rg_index *ix, SearchCtx *cx, int mode, const float *d_q, uint32_t nq, uint32_t qstride, uint32_t k,
-                           uint32_t L, uint32_t *d_ids, float *d_dists, uint32_t *d_cmps, uint32_t *d_hops,
-                           const uint32_t *qlist, bool with_log, unsigned long long *d_status, hipStream_t s,
-                           const BuildOut *bp = nullptr, uint32_t qbase = 0, unsigned long long *d_totals = nullptr) {
+// what one K1 launch will look like: kernel form, LDS carve, grid.  Computed in ONE place for the launch itself and for
+// rg_search_prepare (which allocates the visited tags of exactly the grid the launch will use).
+struct K1Plan {
+    K1Launch c;
+    int R = 1;
+    bool bf = false;
+    uint32_t vf_slots = 8;
+    bool vbytes = false;      // c.vis == 2 with one epoch byte per node
+};
+
+static rg_status plan_k1(rg_index *ix, int mode, uint32_t nq, uint32_t L, bool with_log, bool build_mode, bool has_qlist, hipStream_t s, K1Plan *out) {
+    const bool bp = build_mode;
+    const bool qlist = has_qlist;
     // rows in flight per query: two passes of four pay on graphs with many fresh neighbours per hop (measured: +4 % at
     // out-degree 40, -4 % at 16, where the extra staging only costs resident queries)
     // A batch that leaves most wave slots empty is latency bound per query: LDS is plentiful then, so each query keeps
@@ -841,11 +859,37 @@ static rg_status launch_k1(rg_index *ix, SearchCtx *cx, int mode, const float *d
     c.grid = (uint32_t)std::min<uint64_t>(nq, (uint64_t)ix->num_cu * wpc);
     const bool vbytes = c.vis == 2 && ix->visited_bytes != 0;
     if (mode == 0) c.grid = std::min(c.grid, visited_slot_cap(ix, vbytes));
+    out->c = c; out->R = R; out->bf = bf; out->vf_slots = vf_slots; out->vbytes = vbytes;
+    return RG_OK;
+}
+
+// one K1 launch.  mode: 0 exact HBM visited words, 1 LDS filter (optionally logging the scored ids).
+static rg_status launch_k1(rg_index *ix, SearchCtx *cx, int mode, const float *d_q, uint32_t nq, uint32_t qstride, uint32_t k,
+                           uint32_t L, uint32_t *d_ids, float *d_dists, uint32_t *d_cmps, uint32_t *d_hops,
+                           const uint32_t *qlist, bool with_log, unsigned long long *d_status, hipStream_t s,
+                           const BuildOut *bp = nullptr, uint32_t qbase = 0, unsigned long long *d_totals = nullptr) {
+    K1Plan plan;
+    {
+        rg_status st = plan_k1(ix, mode, nq, L, with_log, bp != nullptr, qlist != nullptr, s, &plan);
+        if (st != RG_OK) return st;
+    }
+    const K1Launch &c = plan.c;
+    const int R = plan.R;
+    const bool bf = plan.bf, vbytes = plan.vbytes;
+    const uint32_t vf_slots = plan.vf_slots;
+    const size_t lds = c.lds;
+    const bool l2 = ix->metric == RG_METRIC_L2, ell = ix->d_ell != nullptr;
+    auto dispatch = [&](const SearchParams &sp) -> rg_status {
+        if (l2 && ell) return launch_search_l2_ell(sp, c, s);
+        if (l2) return launch_search_l2_csr(sp, c, s);
+        if (ell) return launch_search_ip_ell(sp, c, s);
+        return launch_search_ip_csr(sp, c, s);
+    };
     if (mode == 0) {
         rg_status st = ensure_visited(ix, cx, c.grid, vbytes, s);
         if (st != RG_OK) return st;
     }
-    RG_HIP(hipMemsetAsync(cx->d_counter, 0, 4, s));
+    RG_HIP(hipMemsetAsync(cx->d_counter, 0, 8, s));     // [0] work queue of the searches, [1] work queue of the tail counters
     SearchParams P;
     P.base = ix->d_base; P.stride = ix->stride; P.dim = ix->dim; P.nd = ix->nd;
     P.ell = ix->d_ell; P.ell_stride = ix->ell_stride; P.offsets = ix->d_offsets; P.nbrs = ix->d_nbrs;
@@ -888,17 +932,25 @@ static rg_status launch_k1(rg_index *ix, SearchCtx *cx, int mode, const float *d
     // millisecond or two), level at 50 - 60, 1 - 2 % behind from 80 up (one wave's CAS chains against K4's full workgroups).
     // The table takes the LDS from the merge scratch on (beam, log line, filter): the largest power of two of words whose
     // buckets + side table fit; remainders must fit 15 bits (indexes of up to 2^(tbits + 13) nodes).
+    // Round 4, knob "count_tail" (-1 = default: every beam width; 0 = off; N = beams up to N wide): the counts move into the TAIL
+    // of the launch (SearchParams::count_mode 2) -- a finished query publishes its log and goes on; waves that find the work
+    // queue empty count the published logs while the last queries are still being searched, in the slots that would idle.
     P.count_tbits = 0;
+    P.count_mode = 0;
+    P.count_head = cx->d_counter + 1;
     P.totals = d_totals;
-    if (with_log && d_totals && !qlist && !bp && ix->count_in_k1 != 0 && L <= (uint32_t)(ix->count_in_k1 < 0 ? 40 : ix->count_in_k1) &&
-        ix->count_table_auto && !ix->count_full_ids && ix->log_cap_knob <= 0) {
+    const bool count_ok = with_log && d_totals && !qlist && !bp && ix->count_table_auto && !ix->count_full_ids && ix->log_cap_knob <= 0;
+    const bool tail = count_ok && ix->count_tail != 0 && (ix->count_tail < 0 || L <= (uint32_t)ix->count_tail);
+    const bool inline_count = count_ok && !tail && ix->count_in_k1 != 0 && L <= (uint32_t)(ix->count_in_k1 < 0 ? 40 : ix->count_in_k1);
+    if (tail || inline_count) {
         const size_t fixed = (size_t)P.stage_total * 4 + (dimc_of(ix) ? 0 : (size_t)ix->dim * 4) + 2 * kCand * 4;   // in front of the merge scratch
         const size_t region = lds > fixed ? lds - fixed : 0;
         uint32_t tb = 0;
         for (uint32_t t = 8; t <= 13; ++t)
             if (((size_t)4 << t) + ((size_t)4 << (t - 3)) <= region) tb = t;
-        if (tb >= 8 && id_bits_of(ix->nd) <= tb - 2 + 15) P.count_tbits = tb;
+        if (tb >= 8 && id_bits_of(ix->nd) <= tb - 2 + 15) { P.count_tbits = tb; P.count_mode = tail ? 2u : 1u; }
     }
+    if (P.count_mode == 2u) RG_HIP(hipMemsetAsync(cx->d_qlog_n, 0xff, (size_t)nq * 4, s));   // kRunning: no query of this launch has finished
     P.id_mask = (ix->ell_tagged && !bp) ? 0x00ffffffu : 0xffffffffu;
     P.vf_min_indeg = (uint32_t)std::max(0, std::min(255, ix->filter_min_indeg));
 #ifdef RG_K1_PROF
@@ -1024,6 +1076,12 @@ static rg_status search_dev(rg_index *ix, SearchCtx *cx, const float *d_q, uint3
             }
             if (st != RG_ERR_OOM) return fail(st);
             b->mode = 2; b->timed = false; b->is_trial = false;   // no room for the words: the other exact form, same bits
+            {   // ... and remembered: the trial of this width is over (a multi-GiB hipMalloc that fails is not retried every batch)
+                std::lock_guard<std::mutex> lk(ix->mu);
+                ix->filter_ok_upto = std::max(ix->filter_ok_upto, L);
+                if (ix->trial_L == L) ix->trial_L = 0;
+                if (ix->exact_from_L <= L) ix->exact_from_L = 0xffffffffu;
+            }
         }
     }
     if (!exact_count) {
@@ -1468,6 +1526,7 @@ rg_status rg_index_set(rg_index *ix, const char *name, int value) {
     else if (!strcmp(name, "lookahead")) ix->lookahead = value;
     else if (!strcmp(name, "gather_form")) ix->gather_form = value;
     else if (!strcmp(name, "count_in_k1")) ix->count_in_k1 = value;
+    else if (!strcmp(name, "count_tail")) ix->count_tail = value;
     else if (!strcmp(name, "log_early")) ix->log_early = value != 0;
     else if (!strcmp(name, "shared_frontier")) ix->shared_frontier = value != 0;
     else if (!strcmp(name, "filter_min_indeg")) ix->filter_min_indeg = value;
@@ -1541,14 +1600,19 @@ rg_status rg_search_prepare(rg_index *ix, void *stream, uint32_t nq, uint32_t L_
     rg_status st = rg::acquire_ctx(ix, (hipStream_t)stream, false, &cx);
     if (st != RG_OK) return st;
     if (ix->visited_mode == 2) st = rg::ensure_qlog(ix, cx, nq);
-    if (st == RG_OK && ix->visited_mode != 1) {
-        // the slots a wide-beam launch of the exact-words form uses (its grid): at most eight to ten resident queries per CU
-        // (the look-ahead form, which wide beams use, keeps byte tags of its own: launch_k1)
-        const bool look = ix->lookahead != 0 && rg::dimc_of(ix) && !ix->adj_dups &&
-                          !ix->multi_expand && ix->diag == 0;
-        const bool bytes = look && ix->visited_bytes != 0;
-        const uint32_t slots = std::min(std::min<uint32_t>(nq, (uint32_t)ix->num_cu * (L_pq >= 700 ? 8u : 12u)), rg::visited_slot_cap(ix, bytes));
-        st = rg::ensure_visited(ix, cx, slots, bytes, (hipStream_t)stream);
+    // The exact set in HBM (one epoch byte per node and slot: nd bytes x the launch's grid, 19 GiB for a wide beam over 10M
+    // nodes) is allocated ahead only where a launch will use it: visited = 0, or -- adaptive default -- a beam width from
+    // which the exact set already won its timed trial.  A default-mode index that never leaves its filter + log form never
+    // pays for the tags; the first trial batch of a width allocates them itself (and is not used as a measurement).
+    uint32_t exact_from_L;
+    {
+        std::lock_guard<std::mutex> lk(ix->mu);
+        exact_from_L = ix->exact_from_L;
+    }
+    if (st == RG_OK && (ix->visited_mode == 0 || (ix->visited_mode == 2 && L_pq >= exact_from_L))) {
+        rg::K1Plan plan;      // the grid (= slots) and the tag form of exactly the launch rg_search_dev will make
+        st = rg::plan_k1(ix, 0, nq, L_pq, false, false, false, (hipStream_t)stream, &plan);
+        if (st == RG_OK) st = rg::ensure_visited(ix, cx, plan.c.grid, plan.vbytes, (hipStream_t)stream);
         if (st == RG_ERR_OOM && ix->visited_mode == 2) st = RG_OK;   // the default falls back to its filter + log form
     }
     const std::string msg = st != RG_OK ? rg_last_error() : "";
@@ -1560,30 +1624,49 @@ rg_status rg_search_prepare(rg_index *ix, void *stream, uint32_t nq, uint32_t L_
 rg_status rg_search_reuse_stats(rg_index *ix, void *stream, uint64_t *evaluations, uint64_t *distinct_rows, uint32_t *d_row_counts) {
     if (!ix || !evaluations || !distinct_rows) return set_error(RG_ERR_ARG, "null argument");
     RG_HIP(hipSetDevice(ix->device));
+    hipStream_t s = (hipStream_t)stream;
+    // the context whose logs are read is held like a host-form search holds its own (reserved: no other caller is handed
+    // it, so no search can re-allocate or overwrite the logs under the two kernels below)
     rg::SearchCtx *cx = nullptr;
     {
         std::lock_guard<std::mutex> lk(ix->mu);
         for (rg::SearchCtx *c : ix->ctxs)
-            if (c->key == (hipStream_t)stream && c->pending.empty() && c->d_qlog && c->log_holds) { cx = c; break; }
+            if (c->key == s && !c->reserved && c->pending.empty() && c->d_qlog && c->log_holds) { cx = c; break; }
+        if (cx) { cx->reserved = true; cx->keyed = true; }
     }
     if (!cx) return set_error(RG_ERR_ARG, "no id logs for this stream: the last batch on it must have run in the default visited mode "
                                           "(filter + log), in one piece, and have been waited for");
-    RG_HIP(hipStreamSynchronize((hipStream_t)stream));
+    auto done = [&](rg_status st, const std::string &msg) {
+        {
+            std::lock_guard<std::mutex> lk(ix->mu);
+            cx->reserved = false;
+            if (cx->pending.empty()) cx->keyed = false;
+        }
+        return st == RG_OK ? RG_OK : set_error(st, msg);
+    };
     const size_t words = ((size_t)ix->nd + 31) / 32;
     rg::DevBuf<uint32_t> bm;
     rg::DevBuf<unsigned long long> tot;
-    RG_HIP(bm.alloc(words));
-    RG_HIP(tot.alloc(2));
-    RG_HIP(hipMemset(bm.p, 0, words * 4));
-    RG_HIP(hipMemset(tot.p, 0, 16));
-    hipLaunchKernelGGL(rg::rg_log_mark_kernel, dim3(std::min<uint32_t>(cx->log_holds, 4096u)), dim3(256), 0, 0, cx->d_qlog, cx->logcap, cx->d_qlog_n,
-                       cx->log_holds, bm.p, tot.p, d_row_counts);
-    hipLaunchKernelGGL(rg::rg_bitmap_count_kernel, dim3(2048), dim3(256), 0, 0, bm.p, words, tot.p + 1);
-    unsigned long long h[2];
-    RG_HIP(hipMemcpy(h, tot.p, 16, hipMemcpyDeviceToHost));
+    if (bm.alloc(words) != hipSuccess || tot.alloc(2) != hipSuccess) { (void)hipGetLastError(); return done(RG_ERR_OOM, "no room for the row bitmap"); }
+    hipError_t e = hipMemsetAsync(bm.p, 0, words * 4, s);
+    if (e == hipSuccess) e = hipMemsetAsync(tot.p, 0, 16, s);
+    if (e == hipSuccess) {
+        // d_row_counts, when given: nd counters (rg.h), one per base row, incremented per read
+        hipLaunchKernelGGL(rg::rg_log_mark_kernel, dim3(std::min<uint32_t>(cx->log_holds, 4096u)), dim3(256), 0, s, cx->d_qlog, cx->logcap, cx->d_qlog_n,
+                           cx->log_holds, bm.p, tot.p, d_row_counts);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(rg::rg_bitmap_count_kernel, dim3(2048), dim3(256), 0, s, bm.p, words, tot.p + 1);
+        e = hipGetLastError();
+    }
+    unsigned long long h[2] = {0, 0};
+    if (e == hipSuccess) e = hipMemcpyAsync(h, tot.p, 16, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) return done(RG_ERR_DEVICE, std::string("rg_search_reuse_stats: ") + hipGetErrorString(e));
     *evaluations = h[0];
     *distinct_rows = h[1];
-    return RG_OK;
+    return done(RG_OK, "");
 }
 
 rg_status rg_search_wait(rg_index *ix, void *stream) {

@@ -90,6 +90,14 @@ struct SearchParams {
     // query can count itself when the query is over, in the LDS its beam and filter no longer need (K4's bucketed set,
     // count_tbits = log2 of its table words; 0 = off: K4 counts).  qlog_n[q] then carries kCountedBit and K4 skips the query.
     uint32_t count_tbits;
+    // count_mode (round 4): 1 = the wave counts its query's log at the END OF THE QUERY (narrow beams, round 3);
+    // 2 = IN THE TAIL OF THE LAUNCH: a finished query only publishes its log (qlog_n[q] = length, after the log's last store
+    // has been acknowledged), and waves that find the work queue empty -- the launch's tail, when more and more slots would
+    // idle -- turn into counters: they take published queries from a second queue (count_head), claim each with a CAS on
+    // qlog_n[q] and count it in their own LDS.  The exact cmps then costs the search nothing but its log stores; whatever
+    // is left uncounted when the kernel ends (overflowed logs, a full side table) is K4's, as before.
+    uint32_t count_mode;
+    uint32_t *count_head;         // count_mode 2: next published query to count (work queue of the counters)
     unsigned long long *totals;   // [2] evaluations performed / distinct nodes of the queries counted here (as K4 reports them)
     // shared frontier (third mode; opt-in knob "shared_frontier"): every query of a batch starts at the entry
     // point, so the first expansion scores the same deg(ep) rows for all of them.  front_scores[q][0] = compare(ep, q) and
@@ -382,12 +390,15 @@ __device__ __forceinline__ void beam_insert(Beam &bm, float cd, uint32_t cid, bo
 }
 
 constexpr uint32_t kCountedBit = 0x80000000u;   // qlog_n[q]: the distinct count of the query's log is already in out_cmps[q]
+constexpr uint32_t kClaimBit = 0x40000000u;     // qlog_n[q], count_mode 2: a wave is counting the log right now
+constexpr uint32_t kRunning = 0xffffffffu;      // qlog_n[q], count_mode 2: the query has not finished yet (set before the launch)
 
 // Exact number of DISTINCT ids among log[0, n) -- one wave, K4's half-word bucket set (rg_distinct_kernel<true>,
 // rg_search.hip) over `tab`: T = 2^tbits words of 8-slot buckets (16-bit remainders of the bijective hash id * odd mod
 // 2^id_bits, bucket = its top bits) + T/8 words of exact side table for ids whose bucket is full; logs above 5T/4 ids are
 // counted in hash partitions.  fail = the side table filled up (the query is then left to K4).
-__device__ __forceinline__ uint32_t wave_distinct_half(const uint32_t *__restrict__ log, uint32_t n, uint32_t *tab, uint32_t tbits,
+template <int NL = 4>
+__device__ __forceinline__ uint32_t wave_distinct_half(const uint32_t *log, uint32_t n, uint32_t *tab, uint32_t tbits,
                                                        uint32_t id_bits, int lane, bool &fail) {
     const uint32_t T = 1u << tbits, bbits = tbits - 2u, OV = T / 8u;
     uint32_t *side = tab + T;
@@ -399,16 +410,18 @@ __device__ __forceinline__ uint32_t wave_distinct_half(const uint32_t *__restric
     for (uint32_t p = 0; p < parts; ++p) {
         for (uint32_t i = (uint32_t)lane * 4u; i < T + OV; i += kWave * 4u) *reinterpret_cast<uint4 *>(tab + i) = make_uint4(~0u, ~0u, ~0u, ~0u);
         lds_fence();
-        for (uint32_t i0 = (uint32_t)lane; i0 < n; i0 += kWave * 4u) {
-            uint32_t v[4];   // four independent loads in flight, then the inserts
+        for (uint32_t i0 = (uint32_t)lane; i0 < n; i0 += kWave * (uint32_t)NL) {
+            uint32_t v[NL];   // NL independent loads in flight (the log may be another XCD's: agent-scope loads, past the L1 and the local L2's stale lines), then the inserts
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < NL; ++u) {
                 const uint32_t i = i0 + (uint32_t)u * kWave;
-                v[u] = i < n ? __hip_atomic_load(log + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;   // from the L2: the wave's own stores
+                v[u] = i < n ? __hip_atomic_load(log + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xffffffffu;
             }
+#pragma nounroll
+            for (int u = 0; u < NL; ++u) {   // one copy of the insert code: the values rotate through v[0]
+                const uint32_t id = v[0];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const uint32_t id = v[u];
+                for (int w = 0; w + 1 < NL; ++w) v[w] = v[w + 1];
                 if (id == 0xffffffffu) continue;
                 if (parts > 1u && ((id * 0x85EBCA6Bu) >> 16) % parts != p) continue;
                 const uint32_t h = (id * 0x9E3779B1u) & hmask;
@@ -522,10 +535,43 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
     uint32_t epoch = EXACT ? P.slot_epoch[blockIdx.x] : 0u;
     unsigned long long tot_n = 0, tot_d = 0;   // in-kernel distinct count: this slot's share of the batch totals
 
+    // count_mode 2: the distinct counts are made in the tail of the launch (see SearchParams::count_mode)
+    const bool tail_count = VIS == 1 && P.count_mode == 2u && P.qlog != nullptr && P.count_tbits != 0u && P.qlist == nullptr && P.out_exp == nullptr;
+    // claim a published query (qlog_n[q] = the length of its complete log) and count it in this wave's LDS, from the merge
+    // scratch on (the wave is between two queries or has none left: beam, log line and filter are free)
+    auto count_published = [&](uint32_t q) __attribute__((always_inline)) {
+        uint32_t n = 0;
+        if (lane == 0) n = __hip_atomic_load(&P.qlog_n[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        n = readlane_u(n, 0);
+        // still running (its own wave will count it: that wave finds the queue empty too) / claimed or counted / empty or overflowed (K4's)
+        if (n == kRunning || (n & (kCountedBit | kClaimBit)) || n == 0u || n > P.logcap) return;
+        uint32_t won = 0;
+        if (lane == 0) won = atomicCAS(&P.qlog_n[q], n, n | kClaimBit) == n ? 1u : 0u;
+        if (!readlane_u(won, 0)) return;
+        lds_fence();
+        bool bad = false;
+        const uint32_t distinct = wave_distinct_half<16>(P.qlog + (size_t)q * P.logcap, n, mscr, P.count_tbits, max(P.id_bits, P.count_tbits - 1u), lane, bad);
+        if (lane == 0) {
+            if (!bad) {
+                __hip_atomic_store(&P.out_cmps[q], distinct, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the reference's cmps (:2397 counts every node once)
+                __hip_atomic_store(&P.qlog_n[q], n | kCountedBit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                __hip_atomic_store(&P.qlog_n[q], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);          // K4 counts it
+            }
+        }
+        if (!bad) { tot_n += n; tot_d += distinct; }
+        lds_fence();
+    };
+    uint32_t nxt = 0;
+    bool have_nxt = false;     // count_mode 2: the work item fetched at the end of the previous query
     for (;;) {
         uint32_t qi = 0;
-        if (lane == 0) qi = atomicAdd(P.counter, 1u);
-        qi = readlane_u(qi, 0);
+        if (have_nxt) qi = nxt;
+        else {
+            if (lane == 0) qi = atomicAdd(P.counter, 1u);
+            qi = readlane_u(qi, 0);
+        }
+        have_nxt = false;
         if (qi >= P.nq) break;
         const bool cmps_only = P.qlist != nullptr;
         const bool build = P.out_exp != nullptr;
@@ -664,7 +710,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
                 lds_fence();
                 lbn -= kWave;
                 if ((uint32_t)lane < lbn) logbuf[lane] = rest;
-                if (pos + lane < P.logcap) qlog[pos + lane] = v;
+                // agent-scope store: the counter of this log may run on another XCD, whose L2 is not this one's
+                if (pos + lane < P.logcap) __hip_atomic_store(&qlog[pos + lane], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 lds_fence();
             }
         };
@@ -1142,7 +1189,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
         if (VIS == 1 && qlog && lbn) {   // tail of the id log
             lds_sync();
             const uint32_t pos = logn - lbn;
-            if ((uint32_t)lane < lbn && pos + lane < P.logcap) qlog[pos + lane] = logbuf[lane];
+            if ((uint32_t)lane < lbn && pos + lane < P.logcap) __hip_atomic_store(&qlog[pos + lane], logbuf[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
 #ifdef RG_K1_PROF
         RG_PROF(5);
@@ -1152,7 +1199,25 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
         }
 #endif
         uint32_t logn_out = logn;
-        if (VIS == 1 && qlog && P.count_tbits && logn <= P.logcap && logn > 0 && !cmps_only && !build) {
+        if (tail_count) {
+            // publish: the log is complete once its last store has been acknowledged; then the length; then -- with the
+            // length acknowledged too -- the next work item is fetched, so that a wave that finds the queue empty sees every
+            // length published before the query that emptied it was handed out
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) {
+                if (P.out_hops) P.out_hops[qi] = hops;
+                __hip_atomic_store(&P.qlog_n[qi], logn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0) nxt = atomicAdd(P.counter, 1u);
+            nxt = readlane_u(nxt, 0);
+            have_nxt = true;
+            // out_cmps[qi] is written by whoever counts the log (a wave of this launch, K4, or the recount of an overflowed log)
+            if (nxt >= P.nq) count_published(qi);    // nothing left to search: this wave counts its own query first
+            wave_sync();
+            continue;
+        }
+        if (VIS == 1 && qlog && P.count_mode == 1u && P.count_tbits && logn <= P.logcap && logn > 0 && !cmps_only && !build) {
             // the query is over: its log is complete (the tail stores above included) and the LDS from the merge scratch on
             // -- beam, log line, filter -- is free until the next query initialises it
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1173,6 +1238,16 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
             if (VIS == 1 && P.qlog_n) P.qlog_n[qi] = logn_out;
         }
         wave_sync();
+    }
+    if (tail_count) {
+        // the tail of the launch: published queries, in the order they were handed out (the early ones finished long ago)
+        for (;;) {
+            uint32_t q = 0;
+            if (lane == 0) q = atomicAdd(P.count_head, 1u);
+            q = readlane_u(q, 0);
+            if (q >= P.nq) break;
+            count_published(q);
+        }
     }
     if (VIS == 1 && tot_n && lane == 0) {
         atomicAdd(&P.totals[0], tot_n);

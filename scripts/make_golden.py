@@ -12,7 +12,10 @@ can check both the oracle and the HIP path against them.
                               (genuine queue + visited pool + distance, loop restated -- see oracle/ref_driver.cpp)
   G4 formats.npz              bytes of small .fbin / gt files (good and truncated) + what util.h's loaders said
 
-usage: python scripts/make_golden.py [g1 g2 g3 g3c g4]   (default: all)
+  G5 cli_table.json           the stdout header / row / CSV row FORMATS of tests/test_search_roargraph.cpp (:190, :231-236):
+                              the string literals of its stream statements evaluated, variables left as {name}
+
+usage: python scripts/make_golden.py [g1 g2 g3 g3c g4 g5]   (default: all)
 """
 import os
 import subprocess
@@ -161,13 +164,45 @@ def g4():
     np.savez_compressed(os.path.join(OUT, "formats.npz"), **out)
 
 
+def g5():
+    """What the reference's search CLI prints: its three stream statements (header :190, table row :231-232, CSV row
+    :233-236) evaluated -- string literals decoded, every variable left as a {placeholder}.  Output data, not source."""
+    import json
+    import re
+    src = open("/root/reference/tests/test_search_roargraph.cpp").read()
+
+    def stream_format(stmt):
+        parts = [x.strip() for x in stmt.split("<<")]
+        out = []
+        for x in parts[1:]:
+            if x in ("std::endl", "std::endl;"):
+                break
+            m = re.fullmatch(r'"((?:[^"\\]|\\.)*)"', x)
+            if m:
+                out.append(m.group(1).encode().decode("unicode_escape"))
+            else:
+                out.append("{%s}" % re.sub(r"[^A-Za-z0-9_/ ()]", "", x).strip())
+        return "".join(out)
+
+    def statement(anchor, start=0):
+        i = src.index(anchor, start)
+        j = src.index("std::endl;", i)
+        return " ".join(src[i:j + len("std::endl;")].split()), j
+    head, j = statement('std::cout << "L_pq"')
+    row, j = statement("std::cout << L_pq", j)
+    csv, j = statement("evaluation_out << L_pq", j)
+    out = {"source": "tests/test_search_roargraph.cpp:190,231-236", "header": stream_format(head), "row": stream_format(row),
+           "csv_row": stream_format(csv)}
+    json.dump(out, open(os.path.join(OUT, "cli_table.json"), "w"), indent=1)
+
+
 if __name__ == "__main__":
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
     if not po.have_ref():
         sys.exit("oracle/_ref/rg_ref is not available (needs /root/reference and an AVX-512 host)")
     os.makedirs(OUT, exist_ok=True)
     only = sys.argv[1:]
-    for name, fn in (("g1", g1), ("g2", g2), ("g3", g3), ("g3c", g3_cosine), ("g4", g4)):
+    for name, fn in (("g1", g1), ("g2", g2), ("g3", g3), ("g3c", g3_cosine), ("g4", g4), ("g5", g5)):
         if not only or name in only:
             fn()
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))

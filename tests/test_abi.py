@@ -3,6 +3,7 @@ goldens / oracle, and compute entry points FAIL LOUDLY without a GPU (no CPU fal
 import ctypes as C
 import os
 import re
+import sys
 
 import numpy as np
 import pytest
@@ -177,3 +178,35 @@ def test_product_never_touches_the_oracle():
     if os.path.exists(so):
         out = subprocess.run(["ldd", so], capture_output=True, text=True).stdout
         assert "oracle" not in out
+
+
+def test_cli_table_golden_is_current_and_the_twin_prints_it():
+    """tests/golden/cli_table.json holds the reference CLI's stdout header / row / CSV row formats (stream statements of
+    tests/test_search_roargraph.cpp:190,231-236 evaluated by scripts/make_golden.py g5).  Where the reference tree is
+    present (this container) the golden is regenerated and must be unchanged; everywhere, the twin's source must print the
+    header's pieces in the reference's order with nothing added by default (the seventh column sits behind --steady)."""
+    import json
+    import re
+    golden = os.path.join(ROOT, "tests", "golden", "cli_table.json")
+    fmt = json.load(open(golden))
+    if os.path.exists("/root/reference/tests/test_search_roargraph.cpp"):
+        sys.path.insert(0, os.path.join(ROOT, "scripts"))
+        import importlib
+        mg = importlib.import_module("make_golden")
+        import tempfile
+        keep = mg.OUT
+        with tempfile.TemporaryDirectory() as td:
+            mg.OUT = td
+            try:
+                mg.g5()
+            finally:
+                mg.OUT = keep
+            assert json.load(open(os.path.join(td, "cli_table.json"))) == fmt, "golden is stale: run scripts/make_golden.py g5"
+    assert fmt["header"].count("\t") == 8 and fmt["csv_row"].count(",") == 5
+    src = open(os.path.join(ROOT, "roargraph_amd", "cli", "test_search_roargraph.cpp")).read()
+    stmt = src[src.index('std::cout << "L_pq"'):]
+    stmt = stmt[:stmt.index(";")]
+    lits = "".join(x.encode().decode("unicode_escape") if x is not None else "{k}"
+                   for x in (m.group(1) if m.group(1) is not None else None
+                             for m in re.finditer(r'<<\s*(?:"((?:[^"\\]|\\.)*)"|k\b)', stmt)))
+    assert lits == fmt["header"], (lits, fmt["header"])

@@ -181,3 +181,34 @@ def test_build_cli_twin(tmp_path, oracle):
     from roargraph_amd import build
     o2, n2, e2 = build.build_roargraph(base, knn, "ip", 40, 12, 60, 1)
     assert ep == e2 and (off == o2).all() and (nbrs == n2).all()
+
+
+def test_a_failing_worker_thread_ends_the_build_with_a_status():
+    """An allocation that fails on a WORKER thread (the lists grow there) must come back as RG_ERR_OOM through the C ABI --
+    not std::terminate, not team mates left in the barrier.  RG_BUILD_FAULT=n makes the n-th multi-threaded region of a
+    build throw std::bad_alloc on one of its threads; every region of a small four-thread build is tried."""
+    code = r'''
+import sys, numpy as np
+sys.path.insert(0, %r)
+from roargraph_amd import build
+rng = np.random.default_rng(3)
+base = rng.standard_normal((1500, 32)).astype(np.float32)
+train = (rng.standard_normal((600, 32)) * 0.5 + 0.3).astype(np.float32)
+knn = np.argsort(-(train.astype(np.float64) @ base.T.astype(np.float64)), axis=1, kind="stable")[:, :40].astype(np.uint32)
+try:
+    build.build_roargraph(base, knn, "ip", M_sq=40, M_pjbp=12, L_pjpq=60, num_threads=4)
+    print("BUILT")
+except Exception as e:
+    print("ERROR", e)
+''' % ROOT
+    seen_fault = seen_built = False
+    for region in range(1, 40):
+        env = dict(os.environ, RG_BUILD_FAULT=str(region))
+        r = subprocess.run([os.sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+        assert r.returncode == 0, (region, r.stdout[-300:], r.stderr[-300:])
+        if "BUILT" in r.stdout:      # the build has fewer multi-threaded regions than this
+            seen_built = True
+            break
+        assert "ERROR" in r.stdout and "out of host memory" in r.stdout, (region, r.stdout, r.stderr[-300:])
+        seen_fault = True
+    assert seen_fault and seen_built

@@ -1,6 +1,8 @@
 """-m gpu: the C++ CLI twins (roargraph_amd/bin) against the oracle: same flags, same table/CSV columns as
 tests/test_search_roargraph.cpp:190,231-236, same gt file layout as compute_groundtruth (README.md:70-74)."""
+import json
 import os
+import re
 import subprocess
 
 import numpy as np
@@ -41,11 +43,25 @@ def test_compute_groundtruth_then_search_cli(bins, oracle, tmp_path):
                         "--projection_index_save_path", gf, "--L_pq", "20", "100", "--k", "10", "-T", "16",
                         "--evaluation_save_path", csv], capture_output=True, text=True)
     assert r.returncode == 0, r.stdout + r.stderr
-    assert "L_pq\t\tQPS\t\t\tavg_visited\tmean_latency\trecall@10\tavg_hops\tQPS_steady" in r.stdout
-    table = [l.split() for l in r.stdout.splitlines() if l.split() and l.split()[0] in ("20", "100")]
-    assert len(table) == 2 and all(len(t) == 7 and float(t[1]) > 0 and float(t[6]) > 0 for t in table), "first-pass and steady QPS"
+    # stdout table: the reference's header line, character for character, and its row format (tests/golden/cli_table.json =
+    # the stream statements of test_search_roargraph.cpp:190,231-232 evaluated by scripts/make_golden.py g5)
+    fmt = json.load(open(os.path.join(ROOT, "tests", "golden", "cli_table.json")))
+    lines = r.stdout.splitlines()
+    assert fmt["header"].format(k=10) in lines, "header line differs from the reference's"
+    row_re = re.compile("^" + re.sub(r"\\\{[^}]*\\\}", r"(?:[-+0-9.eE]+|nan|inf)", re.escape(fmt["row"]).replace("\\\t", "\t")) + "$")
+    table = [l for l in lines if l.split() and l.split()[0] in ("20", "100")]
+    assert len(table) == 2 and all(len(t.split("\t\t")) == 6 and float(t.split()[1]) > 0 for t in table), "six columns, as the reference"
+    assert all(row_re.match(t) for t in table), (fmt["row"], table)
     rows = [l.split(",") for l in open(csv).read().strip().splitlines()]
-    assert [int(x[0]) for x in rows] == [20, 100] and all(len(x) == 6 for x in rows)
+    assert [int(x[0]) for x in rows] == [20, 100] and all(len(x) == len(fmt["csv_row"].split(",")) == 6 for x in rows)
+    # --steady 1: the additive seventh column (a later pass, after the adaptive default has settled)
+    r7 = subprocess.run([os.path.join(bins, "test_search_roargraph"), "--data_type", "float", "--dist", "ip",
+                         "--base_data_path", bf, "--query_path", qf, "--gt_path", gtf,
+                         "--projection_index_save_path", gf, "--L_pq", "20", "--k", "10", "--steady", "1"], capture_output=True, text=True)
+    assert r7.returncode == 0, r7.stdout + r7.stderr
+    assert fmt["header"].format(k=10) + "\tQPS_steady" in r7.stdout.splitlines()
+    t7 = [l.split() for l in r7.stdout.splitlines() if l.split() and l.split()[0] == "20"]
+    assert len(t7) == 1 and len(t7[0]) == 7 and float(t7[0][6]) > 0
     for row in rows:
         L = int(row[0])
         ids, _, cmps, hops = oracle.search(base, metric, off, nbrs, ep, q, 10, L, nthreads=4)

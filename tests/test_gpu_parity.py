@@ -212,19 +212,34 @@ def test_byte_tags_survive_the_epoch_wrap(rg, oracle):
 @pytest.mark.parametrize("lookahead", [1, 0])
 def test_exact_words_on_rows_with_repeats_and_long_rows(rg, oracle, lookahead):
     """The file format allows a list to name a node twice (SURVEY C-10): the second occurrence must not be scored.  An
-    index with such a list is detected at open and keeps the returning-atomic form whatever the knob says; lists longer
-    than one 63-neighbour read take the general path inside the look-ahead form."""
+    index with such a list -- of ANY length: short, 64 .. 126 neighbours (the look-ahead form's two-read step), longer (its
+    general path) -- is detected at open and keeps the returning-atomic form whatever the knob says; lists longer than one
+    63-neighbour read take the general path inside the look-ahead form."""
     from roargraph_amd import io
     base, q, off, nbrs, ep = small_set("ip", 4000, 200)
     lists = [nbrs[int(off[i]):int(off[i + 1])].copy() for i in range(base.shape[0])]
     long_rows = dict((i, np.unique(np.concatenate([lists[i], np.arange(i + 1, i + 120, dtype=np.uint32) % 4000]))) for i in (ep, 17, 900))
-    for with_repeats in (False, True):
+    first = int(lists[ep][0])      # expanded by every query
+
+    def mid_row(i):                # 100 distinct neighbours, the 3rd named again at position 90 (both in the second read)
+        r = np.unique(np.concatenate([lists[i], np.arange(i + 1, i + 200, dtype=np.uint32) % 4000]))[:100].astype(np.uint32)
+        return np.concatenate([r[:90], r[2:3], r[90:]])
+
+    def very_long_row(i):          # 150 distinct neighbours, one named again beyond position 126
+        r = np.unique(np.concatenate([lists[i], np.arange(i + 1, i + 300, dtype=np.uint32) % 4000]))[:150].astype(np.uint32)
+        return np.concatenate([r[:140], r[70:71], r[140:]])
+
+    for with_repeats in (None, "short", "mid", "long"):
         ls = list(lists)
         for i, row in long_rows.items():
             ls[i] = row.astype(np.uint32)
-        if with_repeats:
+        if with_repeats == "short":
             ls[3] = np.concatenate([ls[3], ls[3][:2]]).astype(np.uint32)
-            ls[int(ls[ep][0])] = np.concatenate([ls[int(ls[ep][0])][:5], ls[int(ls[ep][0])][:5]]).astype(np.uint32)
+            ls[first] = np.concatenate([ls[first][:5], ls[first][:5]]).astype(np.uint32)
+        elif with_repeats == "mid":
+            ls[first] = mid_row(first)
+        elif with_repeats == "long":
+            ls[first] = very_long_row(first)
         o2, n2 = io.lists_to_csr(ls)
         ix = rg.IndexBipartite.from_arrays(base, o2, n2, ep, metric="ip")
         ix.set("visited", 0)
@@ -234,6 +249,7 @@ def test_exact_words_on_rows_with_repeats_and_long_rows(rg, oracle, lookahead):
             want = oracle.search(base, "ip", o2, n2, ep, q, k, L, nthreads=4)
             assert (got[2] == want[2]).all(), ("cmps", with_repeats, L)
             assert (got[3] == want[3]).all() and (got[0] == want[0]).all() and (bits(got[1]) == bits(want[1])).all()
+            assert all(len(set(r.tolist())) == k for r in got[0]), ("a result row names a node twice", with_repeats, L)
         ix.close()
 
 
