@@ -129,8 +129,22 @@ rg_status rg_index_info(const rg_index *idx, uint32_t *nd, uint32_t *dim, uint32
  * "multi_expand" = 1 is the second OPT-IN mode that is NOT parity (speculative multi-expansion): every
  * iteration pops the TWO closest unexpanded entries and expands both in one adjacency / visited / gather phase, whether or
  * not the second would have been the reference's next pop; twice the fresh neighbours per latency chain, a slightly
- * different visiting order (recall is reported beside it by bench.py). */
+ * different visiting order (recall is reported beside it by bench.py).
+ * Round-4 knobs, none of which changes a result: "lset" (-1 automatic / 0 never / N = beams up to N wide: the exact visited
+ * set in LDS of the default mode at narrow beams, rg_search_kernel.h VIS = 3), "lset_bytes" (tests: cap of that set's LDS
+ * region), "count_tail" (the distinct counts made in the tail of the launch; measured, off by default). */
 rg_status rg_index_set(rg_index *idx, const char *name, int value);
+/* Counters of the search path since the index was opened (diagnostics: which form the batches ran in).  Names:
+ * "batches_lset" / "batches_filter_log" / "batches_exact_hbm" / "batches_filter_only" (batches enqueued per form),
+ * "lset_left" (queries that outgrew their exact LDS set), "recounted" (queries whose cmps the host recounted). */
+rg_status rg_index_stat(const rg_index *idx, const char *name, uint64_t *value);
+/* Where the large buffers of the indexes on `device` live (diagnostics; no counterpart in the reference).  The library
+ * builds every buffer of 2 GiB and more from 1-GiB granules taken round robin over the memory classes of the device
+ * (csrc/rg_mem.hip: K1's random row reads and visited tests run 4 - 12 % faster when rows and tags are spread over the
+ * classes than when a plain allocation puts them into one).  buffers = balanced buffers made so far, plain = large
+ * requests that fell back to a plain allocation, classes = memory classes found, granules_per_class[4] = granules of the
+ * live buffers per class.  RG_BALANCED_ALLOC=0 in the environment turns the balancing off. */
+rg_status rg_mem_stats(int device, uint64_t *buffers, uint64_t *plain, uint32_t *classes, uint64_t *granules_per_class);
 
 /* ----------------------------------------------------------------- operator
  * Replaces: float Distance::compare(const float *a, const float *b, unsigned length) (distance.h:18;

@@ -10,6 +10,7 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <map>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -119,8 +120,12 @@ struct rg_index {
     uint32_t front_n = 0;
     bool log_early = true;       // knob: the id-log store of a hop leaves right behind the row loads (rg_search_kernel.h: expand)
     int count_in_k1 = -1;        // knob: beams up to this wide count their distinct ids inside K1 (-1 = 40, 0 = never: K4 counts)
-    int count_tail = -1;         // knob (round 4): the distinct counts are made in the tail of the launch, by the waves that found the work
-                                 // queue empty (-1 = every beam width, 0 = off, N = beams up to N wide); takes precedence over count_in_k1
+    int count_tail = 0;          // knob (round 4, measured and left off): the distinct counts are made in the tail of the launch, by the waves
+                                 // that found the work queue empty (0 = off, N = beams up to N wide); takes precedence over count_in_k1
+    int lset_bytes = 0;          // knob (tests): cap of the exact LDS set's region in bytes (0 = what the launch has)
+    int lset = -1;               // knob "lset" (round 4): default visited mode, narrow beams: the exact visited set in LDS (K1 VIS = 3: no id
+                                 // log, no K4, no de-duplicating inserts).  -1 = wherever a query's visits fit the LDS a launch can give it,
+                                 // 0 = never, N = beams up to N wide whatever the estimate says
     int gather_form = -1;        // register-staged K1: 0 = 16-byte loads + LDS bounce, otherwise compute-layout loads where instantiated
     int lookahead = -1;          // mode 0, knob "lookahead": -1 = automatic (by beam width), 0 = returning atomics, 1 = look-ahead form, 2 = look-ahead
                                  // form without the early guess (same results in every form; rg_search.hip: launch_k1)
@@ -138,6 +143,12 @@ struct rg_index {
     uint32_t exact_from_L = 0xffffffffu;
     uint32_t trial_L = 0, filter_ok_upto = 0;
     float filter_per_q = 0.0f;
+    // exact LDS set: nodes a query visits at a beam width (mean of the last counted batch), and the smallest width at which
+    // too many queries outgrew the set (the form is not used from there on)
+    std::map<uint32_t, float> evals_at;
+    uint32_t lset_bad_from = 0xffffffffu;
+    // counters (rg_index_stat)
+    uint64_t n_batches_lset = 0, n_batches_filter_log = 0, n_batches_exact_hbm = 0, n_batches_filter_only = 0, n_lset_left = 0, n_recounted = 0;
 };
 
 namespace rg {

@@ -1,0 +1,24 @@
+// rg_mem.h -- device memory for the large, randomly read buffers of an index, balanced over the memory classes of the
+// device (rg_mem.hip has the measurement and the method).
+#pragma once
+#include <cstddef>
+
+#include "rg.h"
+
+namespace rg {
+// bytes of device memory on `device` (the current device must be `device`).  2 GiB and more: 1-GiB granules of measured
+// class, taken round robin over the classes; less -- or wherever balancing is not possible -- a plain hipMalloc.
+// RG_ERR_OOM when not even that succeeds.  Contents are undefined.
+rg_status dev_alloc(int device, size_t bytes, void **out);
+template <typename T>
+inline rg_status dev_alloc_t(int device, size_t n, T **out) {
+    void *p = nullptr;
+    rg_status st = dev_alloc(device, n * sizeof(T), &p);
+    *out = static_cast<T *>(p);
+    return st;
+}
+// releases what dev_alloc returned (or any hipMalloc'ed pointer); null is fine
+void dev_free(void *p);
+// hands the pool's spare granules back to the device
+void dev_trim(int device);
+}  // namespace rg

@@ -1,0 +1,385 @@
+// rg_mem.hip -- device memory for the large, randomly read buffers of an index (base rows, split rows, adjacency, visited
+// tags, id logs), BALANCED OVER THE MEMORY CLASSES of the device.
+//
+// What was measured (round 4; scripts/exp/alloc_map*.hip, profiles/r04/alloc_map*.jsonl): the 288 GB of an MI355X fall into
+// three classes of physical memory, met in runs of 4 ... 100+ GiB along the order in which a process is handed memory.
+// K1's access mix -- random 768-byte rows plus random byte tests -- runs 10 % SLOWER when the rows and the tags lie in the
+// same class than when they lie in two (5.97 vs 5.43 ms in the probe), and fastest when each of them is spread over all
+// classes (5.23 ms); a row gather alone gains 4 % from being spread, byte tests alone 10 %.  "Conflict" is an equivalence
+// relation with exactly three classes, each a third of the device (one pairwise matrix over 17 chunks: profiles/r04/).  A
+// plain hipMalloc of 8 - 19 GiB comes out of one run, i.e. one class -- which one, relative to the buffer it is used with,
+// is the coin that round 3's "two modes, 10 % apart" tossed.  No allocation flag changes this (contiguous, VMM, first-in-
+// process: scripts/exp/alloc_place.hip); what does is WHERE the physical pages come from.
+//
+// So buffers of 2 GiB and more are built with the HIP virtual-memory API from granules of 1 GiB whose class is
+// measured (a 1-ms probe kernel against one representative granule per known class: slow = same class), taken round robin
+// over the classes.  While a request still lacks granules of some class and the walk keeps delivering a class it has
+// enough of, the granules are held aside and ballast is allocated to step over the run; ballast and held granules are
+// released before the call returns.  Every step can fail softly: no VMM, no second class found, no memory to walk -- the buffer is then a plain
+// hipMalloc, exactly what round 3 shipped.  RG_BALANCED_ALLOC=0 turns the whole thing off.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <map>
+#include <mutex>
+#include <vector>
+
+#include "rg.h"
+#include "rg_internal.h"
+#include "rg_mem.h"
+
+namespace rg {
+
+namespace {
+
+constexpr size_t kGranule = (size_t)1 << 30;
+constexpr size_t kMinBalanced = (size_t)2 << 30;      // smaller buffers: hipMalloc
+constexpr size_t kBallast = (size_t)8 << 30;          // step over a run of a class the request has enough of
+constexpr int kMaxClasses = 4;
+
+__device__ __forceinline__ uint32_t mixu(uint32_t x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+
+// the access mix of K1 in miniature: every wave reads 32 random 768-byte rows of granule A (eight passes of four in flight,
+// one dword per lane and step) and makes 64 random byte tests + 32 byte marks in its own slice of granule B, `steps` times
+__global__ void __launch_bounds__(64) rg_mem_probe_kernel(const float *__restrict__ rows, uint32_t nrows, uint8_t *tags, size_t slot_bytes,
+                                                          uint32_t steps, uint32_t seed, float *out) {
+    const int lane = threadIdx.x, g = lane >> 4, a = lane & 15;
+    uint8_t *my = tags + (size_t)blockIdx.x * slot_bytes;
+    float acc = 0.0f;
+    uint32_t s = mixu(seed ^ (blockIdx.x * 0x9E3779B1u));
+    for (uint32_t it = 0; it < steps; ++it) {
+        s = mixu(s + it);
+        const uint32_t t = mixu(s ^ (uint32_t)lane * 0x85EBCA6Bu);
+        const size_t off = (size_t)(((uint64_t)t * (uint64_t)slot_bytes) >> 32);
+        const uint8_t v = __hip_atomic_load(my + off, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lane & 1) __hip_atomic_store(my + off, (uint8_t)(it + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        acc += (float)v;
+        float r[8][12];
+#pragma unroll
+        for (int p = 0; p < 8; ++p) {
+            const uint32_t rid = (uint32_t)(((uint64_t)mixu(s ^ (uint32_t)(p * 4 + g + 1) * 0xC2B2AE35u) * nrows) >> 32);
+            const float *src = rows + (size_t)rid * 192 + a;
+#pragma unroll
+            for (int k = 0; k < 12; ++k) r[p][k] = src[16 * k];
+        }
+#pragma unroll
+        for (int p = 0; p < 8; ++p)
+#pragma unroll
+            for (int k = 0; k < 12; ++k) acc += r[p][k];
+    }
+    if (acc == 123.456f) out[0] = acc;
+}
+
+struct Granule {
+    hipMemGenericAllocationHandle_t h{};
+    void *va = nullptr;     // where it is mapped while it sits in the pool (probes read it there)
+    int cls = -1;
+};
+
+struct Buffer {
+    size_t bytes = 0;       // mapped size (a multiple of the granule)
+    std::vector<hipMemGenericAllocationHandle_t> handles;
+    int per_class[kMaxClasses] = {0, 0, 0, 0};
+};
+
+struct Pool {
+    std::mutex mu;
+    bool tried = false, usable = false;
+    hipMemAllocationProp prop{};
+    std::vector<Granule> reps;                 // one mapped granule per known class, never handed out
+    std::vector<Granule> spare[kMaxClasses];   // classified, mapped in the pool, free
+    float t_same = 0.0f;                       // probe time of two granules of one class
+    float *d_out = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    std::map<void *, Buffer> live;
+    // statistics (rg_mem_stats)
+    uint64_t n_buffers = 0, n_plain = 0, n_probes = 0, n_ballast = 0;
+};
+
+Pool g_pool[16];
+bool g_off = false, g_off_read = false, g_trace = false;
+
+bool off() {
+    if (!g_off_read) {
+        const char *e = getenv("RG_BALANCED_ALLOC");
+        g_off = e && atoi(e) == 0;
+        g_trace = getenv("RG_TRACE_ALLOC") != nullptr;
+        g_off_read = true;
+    }
+    return g_off;
+}
+
+bool map_at(void *va, size_t bytes, hipMemGenericAllocationHandle_t h, int device) {
+    if (hipMemMap(va, bytes, 0, h, 0) != hipSuccess) return false;
+    hipMemAccessDesc d{};
+    d.location.type = hipMemLocationTypeDevice;
+    d.location.id = device;
+    d.flags = hipMemAccessFlagsProtReadWrite;
+    if (hipMemSetAccess(va, bytes, &d, 1) != hipSuccess) { (void)hipMemUnmap(va, bytes); return false; }
+    return true;
+}
+
+bool new_granule(Pool &P, int device, Granule *g) {
+    if (hipMemCreate(&g->h, kGranule, &P.prop, 0) != hipSuccess) { (void)hipGetLastError(); return false; }
+    if (hipMemAddressReserve(&g->va, kGranule, kGranule, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipMemRelease(g->h); return false; }
+    if (!map_at(g->va, kGranule, g->h, device)) { (void)hipGetLastError(); (void)hipMemAddressFree(g->va, kGranule); (void)hipMemRelease(g->h); return false; }
+    g->cls = -1;
+    return true;
+}
+
+void drop_granule(Granule &g) {
+    if (g.va) { (void)hipMemUnmap(g.va, kGranule); (void)hipMemAddressFree(g.va, kGranule); }
+    (void)hipMemRelease(g.h);
+    g.va = nullptr;
+}
+
+// milliseconds of the probe with its rows in granule a and its tags in granule b (two timed launches behind a warm-up one)
+float probe(Pool &P, const Granule &a, const Granule &b) {
+    const uint32_t slots = 2048, steps = 64;
+    const uint32_t nrows = (uint32_t)(kGranule / 768);
+    const size_t slot_bytes = kGranule / slots;
+    ++P.n_probes;
+    hipLaunchKernelGGL(rg_mem_probe_kernel, dim3(slots), dim3(64), 0, 0, (const float *)a.va, nrows, (uint8_t *)b.va, slot_bytes, steps, 3u, P.d_out);
+    float best = 1e30f;
+    for (int r = 0; r < 2; ++r) {
+        (void)hipEventRecord(P.e0, 0);
+        hipLaunchKernelGGL(rg_mem_probe_kernel, dim3(slots), dim3(64), 0, 0, (const float *)a.va, nrows, (uint8_t *)b.va, slot_bytes, steps, 11u + r, P.d_out);
+        (void)hipEventRecord(P.e1, 0);
+        if (hipEventSynchronize(P.e1) != hipSuccess) return -1.0f;
+        float ms = 0.0f;
+        if (hipEventElapsedTime(&ms, P.e0, P.e1) != hipSuccess) return -1.0f;
+        best = std::min(best, ms);
+    }
+    return hipGetLastError() == hipSuccess ? best : -1.0f;
+}
+
+bool init_pool(Pool &P, int device) {
+    if (P.tried) return P.usable;
+    P.tried = true;
+    P.prop.type = hipMemAllocationTypePinned;
+    P.prop.location.type = hipMemLocationTypeDevice;
+    P.prop.location.id = device;
+    size_t gran = 0;
+    if (hipMemGetAllocationGranularity(&gran, &P.prop, hipMemAllocationGranularityRecommended) != hipSuccess || gran == 0 || kGranule % gran) {
+        (void)hipGetLastError();
+        return false;
+    }
+    if (hipMalloc(&P.d_out, 64) != hipSuccess || hipEventCreate(&P.e0) != hipSuccess || hipEventCreate(&P.e1) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    // calibration: three granules handed out one after the other; runs of a class are gigabytes long, so at least two of
+    // them share a class, and the slowest of the three pairs is a same-class pair
+    Granule g[3];
+    int n = 0;
+    for (; n < 3; ++n)
+        if (!new_granule(P, device, &g[n])) break;
+    if (n < 3) { for (int i = 0; i < n; ++i) drop_granule(g[i]); return false; }
+    for (int i = 0; i < 3; ++i) (void)hipMemsetAsync(g[i].va, 0, kGranule, 0);
+    const float t01 = probe(P, g[0], g[1]), t02 = probe(P, g[0], g[2]), t12 = probe(P, g[1], g[2]);
+    if (t01 <= 0 || t02 <= 0 || t12 <= 0) { for (int i = 0; i < 3; ++i) drop_granule(g[i]); return false; }
+    P.t_same = std::max(t01, std::max(t02, t12));
+    g[0].cls = 0;
+    P.reps.push_back(g[0]);
+    // the two others join the pool through the ordinary classification below
+    for (int i = 1; i < 3; ++i) {
+        const float t = i == 1 ? t01 : t02;
+        if (t >= 0.955f * P.t_same) { g[i].cls = 0; P.spare[0].push_back(g[i]); }
+        else { g[i].cls = 1; if (P.reps.size() == 1) P.reps.push_back(g[i]); else P.spare[1].push_back(g[i]); }
+    }
+    if (g_trace) fprintf(stderr, "[rg_mem] device %d: probe of one class %.3f ms (pairs %.3f %.3f %.3f)\n", device, P.t_same, t01, t02, t12);
+    P.usable = true;
+    return true;
+}
+
+// class of a fresh granule: the known class whose representative it conflicts with (probe within 4.5 % of the same-class
+// time), else a new class (it becomes that class's representative; *is_rep says so)
+int classify(Pool &P, Granule &g, bool *is_rep) {
+    *is_rep = false;
+    (void)hipMemsetAsync(g.va, 0, kGranule, 0);
+    int slowest = -1;
+    float ts = 0.0f;
+    for (size_t c = 0; c < P.reps.size(); ++c) {
+        const float t = probe(P, P.reps[c], g);
+        if (t <= 0) return -1;
+        if (t >= 0.955f * P.t_same) return (int)c;
+        if (t > ts) { ts = t; slowest = (int)c; }
+    }
+    if ((int)P.reps.size() < kMaxClasses - 1) { *is_rep = true; return (int)P.reps.size(); }
+    return slowest;
+}
+
+}  // namespace
+
+rg_status dev_alloc(int device, size_t bytes, void **out) {
+    *out = nullptr;
+    if (bytes == 0) bytes = 16;
+    auto plain = [&]() -> rg_status {
+        hipError_t e = hipMalloc(out, bytes);
+        if (e != hipSuccess) { (void)hipGetLastError(); return set_error(RG_ERR_OOM, std::string("hipMalloc of ") + std::to_string(bytes) + " bytes: " + hipGetErrorString(e)); }
+        return RG_OK;
+    };
+    if (bytes < kMinBalanced || off() || device < 0 || device >= 16) return plain();
+    Pool &P = g_pool[device];
+    std::lock_guard<std::mutex> lk(P.mu);
+    if (!init_pool(P, device)) { ++P.n_plain; return plain(); }
+    const size_t n = (bytes + kGranule - 1) / kGranule;
+    // what the buffer should get of each class: an equal share of every class the walk can reach -- three on this part
+    const int want_classes = 3;
+    const size_t share = (n + want_classes - 1) / want_classes;
+    std::vector<void *> ballast;
+    std::vector<Granule> held;      // granules of a class the request has enough of: kept until the walk is over, so that the walk moves on
+    size_t free_b = 0, total_b = 0;
+    (void)hipMemGetInfo(&free_b, &total_b);
+    // walk: new granules until every class has its share in the pool (or memory / patience runs out)
+    auto have = [&](int c) { return c < kMaxClasses ? P.spare[c].size() : 0; };
+    auto satisfied = [&]() {
+        size_t tot = 0;
+        int classes = 0;
+        for (int c = 0; c < kMaxClasses; ++c) { tot += std::min(have(c), share); classes += have(c) >= share ? 1 : 0; }
+        return classes >= want_classes && tot >= n;
+    };
+    size_t walked = 0;
+    int same_in_a_row = 0;
+    while (!satisfied()) {
+        (void)hipMemGetInfo(&free_b, &total_b);
+        size_t pooled = 0;
+        for (int c = 0; c < kMaxClasses; ++c) pooled += have(c);
+        if (free_b < 2 * kGranule + ((size_t)1 << 30)) break;                       // the device is full: take what there is
+        if (pooled >= n && walked > std::max<size_t>(n * kGranule * 4, (size_t)96 << 30)) break;   // enough granules, and a long walk found no more classes
+        Granule g;
+        if (!new_granule(P, device, &g)) break;
+        walked += kGranule;
+        bool is_rep = false;
+        const int c = classify(P, g, &is_rep);
+        if (c < 0) { drop_granule(g); break; }
+        g.cls = c;
+        if (is_rep) { P.reps.push_back(g); same_in_a_row = 0; continue; }
+        const bool surplus = have(c) >= share + 1;
+        if (surplus) {
+            // a run of a class this request has enough of: the granule is held aside (released, it would be the first memory the
+            // next hipMemCreate finds) and, from the second in a row, a stretch of the run is stepped over with ballast
+            held.push_back(g);
+            if (++same_in_a_row >= 2 && free_b > kBallast + n * kGranule + ((size_t)4 << 30)) {
+                void *b = nullptr;
+                if (hipMalloc(&b, kBallast) == hipSuccess) { ballast.push_back(b); walked += kBallast; ++P.n_ballast; }
+                else (void)hipGetLastError();
+                same_in_a_row = 0;
+            }
+            continue;
+        }
+        same_in_a_row = 0;
+        P.spare[c].push_back(g);
+    }
+    // take: round robin over the classes, the fullest class first when some run short
+    size_t pooled = 0;
+    for (int c = 0; c < kMaxClasses; ++c) pooled += have(c);
+    auto release_ballast = [&]() {
+        for (void *b : ballast) (void)hipFree(b);
+        ballast.clear();
+        for (Granule &g : held) drop_granule(g);
+        held.clear();
+    };
+    if (pooled < n) {     // not enough granules (memory): the plain buffer
+        release_ballast();
+        ++P.n_plain;
+        return plain();
+    }
+    void *va = nullptr;
+    if (hipMemAddressReserve(&va, n * kGranule, kGranule, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); release_ballast(); ++P.n_plain; return plain(); }
+    Buffer buf;
+    buf.bytes = n * kGranule;
+    std::vector<Granule> taken;
+    int c = 0;
+    for (size_t i = 0; i < n; ++i) {
+        int tries = 0;
+        while (have(c) == 0 && tries < kMaxClasses) { c = (c + 1) % kMaxClasses; ++tries; }
+        Granule g = P.spare[c].back();
+        P.spare[c].pop_back();
+        taken.push_back(g);
+        buf.per_class[c]++;
+        c = (c + 1) % kMaxClasses;
+    }
+    bool ok = true;
+    for (size_t i = 0; i < n && ok; ++i) {
+        Granule &g = taken[i];
+        (void)hipMemUnmap(g.va, kGranule);
+        (void)hipMemAddressFree(g.va, kGranule);
+        g.va = nullptr;
+        ok = map_at((char *)va + i * kGranule, kGranule, g.h, device);
+        if (ok) buf.handles.push_back(g.h);
+    }
+    if (!ok) {
+        (void)hipGetLastError();
+        for (size_t i = 0; i < buf.handles.size(); ++i) (void)hipMemUnmap((char *)va + i * kGranule, kGranule);
+        for (Granule &g : taken) (void)hipMemRelease(g.h);
+        (void)hipMemAddressFree(va, n * kGranule);
+        release_ballast();
+        ++P.n_plain;
+        return plain();
+    }
+    release_ballast();
+    // surplus granules go back to the device (a few stay for the next buffer of this open)
+    for (int k = 0; k < kMaxClasses; ++k)
+        while (P.spare[k].size() > 4) { drop_granule(P.spare[k].back()); P.spare[k].pop_back(); }
+    if (g_trace)
+        fprintf(stderr, "[rg_mem] %.2f GiB at %p: %d / %d / %d / %d granules of the classes, %zu classes known, walked %.1f GiB\n", (double)buf.bytes / (1u << 30), va,
+                buf.per_class[0], buf.per_class[1], buf.per_class[2], buf.per_class[3], P.reps.size(), (double)walked / (1u << 30));
+    P.live[va] = buf;
+    ++P.n_buffers;
+    *out = va;
+    return RG_OK;
+}
+
+void dev_free(void *p) {
+    if (!p) return;
+    for (int d = 0; d < 16; ++d) {
+        Pool &P = g_pool[d];
+        std::lock_guard<std::mutex> lk(P.mu);
+        auto it = P.live.find(p);
+        if (it == P.live.end()) continue;
+        Buffer &b = it->second;
+        (void)hipDeviceSynchronize();
+        for (size_t i = 0; i < b.handles.size(); ++i) {
+            (void)hipMemUnmap((char *)p + i * kGranule, kGranule);
+            (void)hipMemRelease(b.handles[i]);
+        }
+        (void)hipMemAddressFree(p, b.bytes);
+        P.live.erase(it);
+        return;
+    }
+    (void)hipFree(p);
+}
+
+void dev_trim(int device) {
+    if (device < 0 || device >= 16) return;
+    Pool &P = g_pool[device];
+    std::lock_guard<std::mutex> lk(P.mu);
+    for (int k = 0; k < kMaxClasses; ++k) {
+        for (Granule &g : P.spare[k]) drop_granule(g);
+        P.spare[k].clear();
+    }
+}
+
+}  // namespace rg
+
+extern "C" rg_status rg_mem_stats(int device, uint64_t *buffers, uint64_t *plain, uint32_t *classes, uint64_t *granules_per_class /* [4] */) {
+    if (device < 0 || device >= 16) return rg::set_error(RG_ERR_ARG, "device index out of range");
+    rg::Pool &P = rg::g_pool[device];
+    std::lock_guard<std::mutex> lk(P.mu);
+    if (buffers) *buffers = P.n_buffers;
+    if (plain) *plain = P.n_plain;
+    if (classes) *classes = (uint32_t)P.reps.size();
+    if (granules_per_class) {
+        for (int k = 0; k < 4; ++k) granules_per_class[k] = 0;
+        for (auto &kv : P.live)
+            for (int k = 0; k < 4; ++k) granules_per_class[k] += (uint64_t)kv.second.per_class[k];
+    }
+    return RG_OK;
+}

@@ -22,6 +22,7 @@
 #include "rg_internal.h"
 #include "rg_search_kernel.h"
 #include "rg_index_struct.h"
+#include "rg_mem.h"
 
 namespace rg {
 
@@ -484,7 +485,10 @@ static rg_status finish_graph(rg_index *ix, const uint64_t *d_off, const uint32_
     const double ell_bytes = (double)ix->nd * es * 4.0, csr_bytes = (double)ne * 4.0 + (double)ix->nd * 8.0;
     if (!ix->force_csr && (ell_bytes <= 2.5 * csr_bytes + (64 << 20) || ell_bytes <= 16.0 * (1ull << 30))) {
         ix->ell_stride = es;
-        RG_HIP(hipMalloc(&ix->d_ell, (size_t)ix->nd * es * 4));
+        {   // (large buffers: balanced over the memory classes of the device, rg_mem.hip)
+            rg_status as = dev_alloc_t(ix->device, (size_t)ix->nd * es, &ix->d_ell);
+            if (as != RG_OK) return as;
+        }
         RG_HIP(hipMemset(d_stat, 0, 4));
         hipLaunchKernelGGL(rg_csr_to_ell_kernel, dim3(4096), dim3(256), 0, 0, d_off, d_nb, ix->nd, ix->d_ell, es, d_stat);
         RG_HIP(hipDeviceSynchronize());
@@ -512,8 +516,8 @@ static rg_status finish_graph(rg_index *ix, const uint64_t *d_off, const uint32_
         if (ix->dim == 200 && ne + 1 < 0xffffffffull && !(env && atoi(env) == 0)) {
             ix->main_dim = 192; ix->tail_dim = 8;
             // optional: an index that cannot afford the copy (or whose kernels fail) searches the base itself
-            bool ok = hipMalloc(&ix->d_main, (size_t)ix->nd * ix->main_dim * 4) == hipSuccess &&
-                      hipMalloc(&ix->d_etail, (size_t)(ne + 1) * ix->tail_dim * 4) == hipSuccess &&
+            bool ok = dev_alloc_t(ix->device, (size_t)ix->nd * ix->main_dim, &ix->d_main) == RG_OK &&
+                      dev_alloc_t(ix->device, (size_t)(ne + 1) * ix->tail_dim, &ix->d_etail) == RG_OK &&
                       hipMalloc(&ix->d_tail_off, (size_t)ix->nd * 4) == hipSuccess;
             if (ok) {
                 hipLaunchKernelGGL(rg_split_main_kernel, dim3(8192), dim3(256), 0, 0, ix->d_base, ix->nd, ix->stride, ix->main_dim, ix->d_main);
@@ -524,8 +528,8 @@ static rg_status finish_graph(rg_index *ix, const uint64_t *d_off, const uint32_
             }
             if (!ok) {
                 (void)hipGetLastError();
-                if (ix->d_main) (void)hipFree(ix->d_main);
-                if (ix->d_etail) (void)hipFree(ix->d_etail);
+                dev_free(ix->d_main);
+                dev_free(ix->d_etail);
                 if (ix->d_tail_off) (void)hipFree(ix->d_tail_off);
                 ix->d_main = ix->d_etail = nullptr;
                 ix->d_tail_off = nullptr;
@@ -536,6 +540,23 @@ static rg_status finish_graph(rg_index *ix, const uint64_t *d_off, const uint32_
         RG_HIP(hipMalloc(&ix->d_nbrs, std::max<size_t>(ne * 4, 4)));
         RG_HIP(hipMemcpy(ix->d_offsets, d_off, ((size_t)ix->nd + 1) * 8, hipMemcpyDeviceToDevice));
         RG_HIP(hipMemcpy(ix->d_nbrs, d_nb, ne * 4, hipMemcpyDeviceToDevice));
+    }
+    // The rows K1 gathers: the split copy made above (d = 200) is balanced over the memory classes; a base the library
+    // loaded itself is too (rg_index_open_mem).  A CALLER's device base is one plain allocation -- one class -- so, where
+    // the searches will read it directly and the device has the room, the index keeps a balanced copy of its own
+    // (RG_COPY_BASE=0: never; the caller's buffer is then only read at open).
+    {
+        const size_t bytes = (size_t)ix->nd * ix->stride * 4;
+        const char *env = getenv("RG_COPY_BASE");
+        size_t free_b = 0, total_b = 0;
+        if (!ix->own_base && !ix->d_main && bytes >= ((size_t)2 << 30) && !(env && atoi(env) == 0) &&
+            hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 2 * bytes + ((size_t)8 << 30)) {
+            float *copy = nullptr;
+            if (dev_alloc_t(ix->device, (size_t)ix->nd * ix->stride, &copy) == RG_OK) {
+                if (hipMemcpy(copy, ix->d_base, bytes, hipMemcpyDeviceToDevice) == hipSuccess) { ix->d_base = copy; ix->own_base = true; }
+                else { (void)hipGetLastError(); dev_free(copy); }
+            }
+        }
     }
     {   // the shared frontier: the entry point and its neighbours, in adjacency order
         uint64_t o[2] = {0, 0};
@@ -570,10 +591,13 @@ static void free_ctx(SearchCtx *cx) {
     if (cx->own) (void)hipStreamDestroy(cx->own);
     if (cx->h_pin) (void)hipHostFree(cx->h_pin);
     if (cx->d_front) (void)hipFree(cx->d_front);
-    void *bufs[] = {cx->d_counter, cx->d_scratch_stat, cx->d_visited, cx->d_epoch, cx->d_vtags, cx->d_epoch8, cx->d_qlog, cx->d_qlog_n,
+    void *bufs[] = {cx->d_counter, cx->d_scratch_stat, cx->d_epoch, cx->d_epoch8, cx->d_qlog_n,
                     cx->d_q, cx->d_dist, cx->d_ids, cx->d_ch};
     for (void *p : bufs)
         if (p) (void)hipFree(p);
+    dev_free(cx->d_visited);
+    dev_free(cx->d_vtags);
+    dev_free(cx->d_qlog);
     delete cx;
 }
 
@@ -709,15 +733,17 @@ static rg_status ensure_visited(rg_index *ix, SearchCtx *cx, uint32_t slots, boo
     uint32_t *nv = nullptr, *ne = nullptr;
     // knob "visited_uncached": the words in memory the L2 does not cache (MTYPE_UC) -- a test then moves a 32-byte sector
     // over the fabric instead of the 128-byte line the L2 fetches for a 4-byte word it will not see again
-    const hipError_t ev = ix->visited_uncached ? hipExtMallocWithFlags(reinterpret_cast<void **>(&nv), (size_t)slots * vwords * 4,
-                                                                       ix->visited_uncached == 2 ? hipDeviceMallocFinegrained : hipDeviceMallocUncached)
-                                               : hipMalloc(&nv, (size_t)slots * vwords * 4);
-    if (ev != hipSuccess || hipMalloc(&ne, (size_t)slots * 4) != hipSuccess) {
+    // the old buffer goes first: at 10M nodes the tags of a wide-beam launch are 19 GiB, and the new buffer wants the memory
+    // (and the classes) the old one held
+    if (d_vis) { dev_free(d_vis); d_vis = nullptr; have_slots = 0; }
+    const bool ok_v = ix->visited_uncached ? hipExtMallocWithFlags(reinterpret_cast<void **>(&nv), (size_t)slots * vwords * 4,
+                                                                   ix->visited_uncached == 2 ? hipDeviceMallocFinegrained : hipDeviceMallocUncached) == hipSuccess
+                                           : dev_alloc_t(ix->device, (size_t)slots * vwords, &nv) == RG_OK;
+    if (!ok_v || hipMalloc(&ne, (size_t)slots * 4) != hipSuccess) {
         (void)hipGetLastError();
-        if (nv) (void)hipFree(nv);
+        dev_free(nv);
         return set_error(RG_ERR_OOM, "no room for the visited words of the exact form");
     }
-    if (d_vis) (void)hipFree(d_vis);
     if (d_ep) (void)hipFree(d_ep);
     if (getenv("RG_TRACE_ALLOC"))   // where an allocation landed (the same launch differs by +- 5 % between two allocations of the tags)
         fprintf(stderr, "[rg_search] visited %s: %u slots x %u words at %p (%.2f GiB)\n", bytes ? "byte tags" : "words", slots, vwords, (void *)nv,
@@ -748,9 +774,19 @@ struct K1Plan {
     bool bf = false;
     uint32_t vf_slots = 8;
     bool vbytes = false;      // c.vis == 2 with one epoch byte per node
+    uint32_t vs_side = 0;     // c.vis == 3: words of the side table behind the buckets (vf_slots = the buckets' entries then)
 };
 
-static rg_status plan_k1(rg_index *ix, int mode, uint32_t nq, uint32_t L, bool with_log, bool build_mode, bool has_qlist, hipStream_t s, K1Plan *out) {
+// entries + side-table ids of an exact LDS set cut from `bytes` of filter region (plan_k1 below makes the same split)
+static uint32_t lset_capacity_of(uint32_t bytes) {
+    const uint32_t side = std::max(16u, bytes / 32u);
+    return bytes > side * 4u ? (bytes - side * 4u) / 16u * 8u + side : 0u;
+}
+
+// mode: 0 exact visited set in HBM, 1 LDS filter, 3 exact set in LDS (lset_need: the nodes it should hold -- resident queries
+// are given up, down to ten per CU, until it does)
+static rg_status plan_k1(rg_index *ix, int mode, uint32_t nq, uint32_t L, bool with_log, bool build_mode, bool has_qlist, hipStream_t s, K1Plan *out,
+                         uint32_t lset_need = 0) {
     const bool bp = build_mode;
     const bool qlist = has_qlist;
     // rows in flight per query: two passes of four pay on graphs with many fresh neighbours per hop (measured: +4 % at
@@ -799,7 +835,7 @@ static rg_status plan_k1(rg_index *ix, int mode, uint32_t nq, uint32_t L, bool w
     if (ix->waves_per_cu > 0) wpc = std::min(wpc, ix->waves_per_cu);
     else wpc = std::min(wpc, 24);
     K1Launch c;
-    c.R = R; c.vis = mode == 0 ? 0 : 1; c.dimc = dimc_of(ix); c.bf = bf; c.lds = lds;
+    c.R = R; c.vis = mode == 0 ? 0 : mode == 3 ? 3 : 1; c.dimc = dimc_of(ix); c.bf = bf; c.lds = lds;
     // exact words, look-ahead form (rg_search_kernel.h, VIS = 2): the register-staged instantiations over ELL rows that
     // name no node twice; never with the opt-in second expansion, whose two lists share one test phase.  Knob "lookahead":
     // -1 (default) = wherever the form is instantiated; 0 = never; 1 = always; 2 = always, without the early guess of the next
@@ -816,6 +852,7 @@ static rg_status plan_k1(rg_index *ix, int mode, uint32_t nq, uint32_t L, bool w
         ((c.dimc == 200 && R >= 2) || (c.dimc == 512 && (R == 2 || R == 4))))
         c.vis = 2;
     c.gf = gather_form_of(ix, R, bf);
+    if (c.vis == 3 && c.gf != 1) return set_error(RG_ERR_ARG, "internal: the exact LDS set exists for the compute-layout instantiations only");
     const bool l2 = ix->metric == RG_METRIC_L2, ell = ix->d_ell != nullptr;
     auto dispatch = [&](const SearchParams &sp) -> rg_status {
         if (l2 && ell) return launch_search_l2_ell(sp, c, s);
@@ -838,27 +875,51 @@ static rg_status plan_k1(rg_index *ix, int mode, uint32_t nq, uint32_t L, bool w
     // allocation (LDS is handed out in granules) and the filter trimmed until the resident count holds.
     uint32_t vf_slots = (mode != 0 || ix->exact_filter) ? std::max(8u, 1u << filter_log2_of(ix, filter_auto)) : 8u;
     if ((mode != 0 || ix->exact_filter) && ix->filter_fill && ix->filter_log2 <= 0 && wpc >= 1 && ((uint64_t)ix->num_cu * wpc <= nq || ix->filter_fill == 2)) {
-        const size_t per = (ix->lds_per_cu / (size_t)wpc) / 16 * 16;
-        size_t extra = per > lds ? per - lds : 0;
-        extra = std::min<size_t>(extra, ((size_t)1 << 16) > (size_t)vf_slots * 2 ? ((size_t)1 << 16) - (size_t)vf_slots * 2 : 0);   // <= 2^15 entries
-        for (int tries = 0; extra >= 16 && tries < 8; ++tries) {
-            int occ = 0;
-            c.occupancy = &occ;
-            c.lds = lds + extra;
-            SearchParams none{};
-            rg_status st = dispatch(none);
-            c.occupancy = nullptr;
-            if (st != RG_OK) return st;
-            if (occ >= wpc) break;
-            extra = extra > 512 ? (extra - 512) / 16 * 16 : 0;
-            if (tries == 7) extra = 0;
+        for (;;) {
+            const size_t per = (ix->lds_per_cu / (size_t)wpc) / 16 * 16;
+            size_t extra = per > lds ? per - lds : 0;
+            extra = std::min<size_t>(extra, ((size_t)1 << 16) > (size_t)vf_slots * 2 ? ((size_t)1 << 16) - (size_t)vf_slots * 2 : 0);   // <= 2^15 entries
+            for (int tries = 0; extra >= 16 && tries < 8; ++tries) {
+                int occ = 0;
+                c.occupancy = &occ;
+                c.lds = lds + extra;
+                SearchParams none{};
+                rg_status st = dispatch(none);
+                c.occupancy = nullptr;
+                if (st != RG_OK) return st;
+                if (occ >= wpc) break;
+                extra = extra > 512 ? (extra - 512) / 16 * 16 : 0;
+                if (tries == 7) extra = 0;
+            }
+            // the exact LDS set wants room for what a query visits -- and at least 2^(id_bits - 15) buckets, so that a 16-bit entry
+            // can tell the ids of one bucket apart: one resident query less, and again, down to nine per CU (narrow beams lose
+            // nothing down there: profiles/r04/k1_ab_box5.jsonl, filter form at 10 / 12 / 15 residents)
+            if (mode == 3 && wpc > 9) {
+                const uint32_t bytes = (uint32_t)(vf_slots * 2 + extra), side = std::max(16u, bytes / 32u);
+                const uint32_t buckets = bytes > side * 4u ? (bytes - side * 4u) / 16u : 0u;
+                if ((lset_need && lset_capacity_of(bytes) < lset_need) || buckets == 0 || filter_rem_bits(id_bits_of(ix->nd), buckets) > 15u) { --wpc; continue; }
+            }
+            if (extra >= 16) { lds += extra; vf_slots += (uint32_t)(extra / 2); }
+            c.lds = lds;
+            break;
         }
-        if (extra >= 16) { lds += extra; vf_slots += (uint32_t)(extra / 2); }
-        c.lds = lds;
     }
     c.grid = (uint32_t)std::min<uint64_t>(nq, (uint64_t)ix->num_cu * wpc);
     const bool vbytes = c.vis == 2 && ix->visited_bytes != 0;
     if (mode == 0) c.grid = std::min(c.grid, visited_slot_cap(ix, vbytes));
+    out->vs_side = 0;
+    if (c.vis == 3) {
+        // the filter's region becomes the exact set: an eighth of its bytes the side table of full ids, the rest buckets of
+        // eight 16-bit entries
+        uint32_t bytes = vf_slots * 2u;
+        if (ix->lset_bytes > 0) bytes = std::min(bytes, std::max(64u, (uint32_t)ix->lset_bytes / 16u * 16u));   // (tests: a set that queries outgrow)
+        const uint32_t side = std::max(16u, bytes / 32u);
+        const uint32_t buckets = (bytes - side * 4u) / 16u;
+        vf_slots = buckets * 8u;
+        out->vs_side = side;
+        if (buckets == 0 || filter_rem_bits(id_bits_of(ix->nd), buckets) > 15u)
+            return set_error(RG_ERR_ARG, "internal: the exact LDS set does not fit this launch");
+    }
     out->c = c; out->R = R; out->bf = bf; out->vf_slots = vf_slots; out->vbytes = vbytes;
     return RG_OK;
 }
@@ -867,10 +928,11 @@ static rg_status plan_k1(rg_index *ix, int mode, uint32_t nq, uint32_t L, bool w
 static rg_status launch_k1(rg_index *ix, SearchCtx *cx, int mode, const float *d_q, uint32_t nq, uint32_t qstride, uint32_t k,
                            uint32_t L, uint32_t *d_ids, float *d_dists, uint32_t *d_cmps, uint32_t *d_hops,
                            const uint32_t *qlist, bool with_log, unsigned long long *d_status, hipStream_t s,
-                           const BuildOut *bp = nullptr, uint32_t qbase = 0, unsigned long long *d_totals = nullptr) {
+                           const BuildOut *bp = nullptr, uint32_t qbase = 0, unsigned long long *d_totals = nullptr, uint32_t *d_ovf = nullptr,
+                           uint32_t lset_need = 0) {
     K1Plan plan;
     {
-        rg_status st = plan_k1(ix, mode, nq, L, with_log, bp != nullptr, qlist != nullptr, s, &plan);
+        rg_status st = plan_k1(ix, mode, nq, L, with_log, bp != nullptr, qlist != nullptr, s, &plan, lset_need);
         if (st != RG_OK) return st;
     }
     const K1Launch &c = plan.c;
@@ -913,7 +975,11 @@ static rg_status launch_k1(rg_index *ix, SearchCtx *cx, int mode, const float *d
     P.diag = (uint32_t)ix->diag;
     P.qbase = qbase;
     P.vf_slots = vf_slots;
-    P.vf_rem_bits = filter_rem_bits(id_bits_of(ix->nd), vf_slots);
+    P.vf_rem_bits = filter_rem_bits(id_bits_of(ix->nd), c.vis == 3 ? vf_slots / 8u : vf_slots);
+    P.vs_side = plan.vs_side;
+    P.ovf_count = d_ovf; P.ovf_list = d_ovf ? d_ovf + 2 : nullptr;       // (the batch record's overflow list: count, K4 work counter, queries)
+    P.lset_left = d_totals ? d_totals + 2 : nullptr;
+    if (c.vis == 3 && (!d_ovf || !d_totals || !with_log)) return set_error(RG_ERR_ARG, "internal: the exact LDS set needs the batch's totals, overflow list and logs");
     P.vf_front = (mode == 0 && ix->exact_filter) ? 1u : 0u;
     P.id_bits = id_bits_of(ix->nd);
     P.qlog = with_log ? cx->d_qlog : nullptr; P.logcap = cx->logcap; P.qlog_n = with_log ? cx->d_qlog_n : nullptr;
@@ -940,15 +1006,16 @@ static rg_status launch_k1(rg_index *ix, SearchCtx *cx, int mode, const float *d
     P.count_head = cx->d_counter + 1;
     P.totals = d_totals;
     const bool count_ok = with_log && d_totals && !qlist && !bp && ix->count_table_auto && !ix->count_full_ids && ix->log_cap_knob <= 0;
-    const bool tail = count_ok && ix->count_tail != 0 && (ix->count_tail < 0 || L <= (uint32_t)ix->count_tail);
-    const bool inline_count = count_ok && !tail && ix->count_in_k1 != 0 && L <= (uint32_t)(ix->count_in_k1 < 0 ? 40 : ix->count_in_k1);
-    if (tail || inline_count) {
+    const bool tail = count_ok && mode != 3 && ix->count_tail > 0 && L <= (uint32_t)ix->count_tail;
+    const bool inline_count = count_ok && !tail && mode != 3 && ix->count_in_k1 != 0 && L <= (uint32_t)(ix->count_in_k1 < 0 ? 40 : ix->count_in_k1);
+    const bool lset_count = mode == 3 && with_log && !ix->count_full_ids;      // a query that outgrows the exact set counts its own short log
+    if (tail || inline_count || lset_count) {
         const size_t fixed = (size_t)P.stage_total * 4 + (dimc_of(ix) ? 0 : (size_t)ix->dim * 4) + 2 * kCand * 4;   // in front of the merge scratch
         const size_t region = lds > fixed ? lds - fixed : 0;
         uint32_t tb = 0;
         for (uint32_t t = 8; t <= 13; ++t)
             if (((size_t)4 << t) + ((size_t)4 << (t - 3)) <= region) tb = t;
-        if (tb >= 8 && id_bits_of(ix->nd) <= tb - 2 + 15) { P.count_tbits = tb; P.count_mode = tail ? 2u : 1u; }
+        if (tb >= 8 && id_bits_of(ix->nd) <= tb - 2 + 15) { P.count_tbits = tb; P.count_mode = mode == 3 ? 0u : tail ? 2u : 1u; }
     }
     if (P.count_mode == 2u) RG_HIP(hipMemsetAsync(cx->d_qlog_n, 0xff, (size_t)nq * 4, s));   // kRunning: no query of this launch has finished
     P.id_mask = (ix->ell_tagged && !bp) ? 0x00ffffffu : 0xffffffffu;
@@ -969,12 +1036,15 @@ static rg_status ensure_qlog(rg_index *ix, SearchCtx *cx, uint32_t nq) {
     const size_t budget = (size_t)std::max(1, ix->log_budget_kb) << 10;
     const uint32_t chunk = (uint32_t)std::max<size_t>(1, std::min<size_t>(nq, budget / ((size_t)cap * 4)));
     if (cx->d_qlog && cx->qlog_nq >= chunk && cx->logcap == cap) { cx->qlog_chunk = chunk; return RG_OK; }
-    if (cx->d_qlog) (void)hipFree(cx->d_qlog);
+    dev_free(cx->d_qlog);
     if (cx->d_qlog_n) (void)hipFree(cx->d_qlog_n);
     cx->d_qlog = cx->d_qlog_n = nullptr;
     cx->qlog_nq = 0;
     ++cx->allocs;
-    RG_HIP(hipMalloc(&cx->d_qlog, (size_t)chunk * cap * 4));
+    {
+        rg_status as = dev_alloc_t(ix->device, (size_t)chunk * cap, &cx->d_qlog);
+        if (as != RG_OK) return as;
+    }
     RG_HIP(hipMalloc(&cx->d_qlog_n, (size_t)chunk * 4));
     cx->qlog_nq = chunk;
     cx->qlog_chunk = chunk;
@@ -1003,7 +1073,7 @@ static rg_status search_dev(rg_index *ix, SearchCtx *cx, const float *d_q, uint3
     auto fail = [&](rg_status e) { cx->spare.push_back(b); return e; };
     b->q = d_q; b->nq = nq; b->qstride = qstride; b->k = k; b->L = L;
     b->ids = d_ids; b->dists = d_dists; b->cmps = d_cmps; b->hops = d_hops;
-    if (hipMemsetAsync(b->d_stat, 0xff, 8, s) != hipSuccess || hipMemsetAsync(b->d_stat + 1, 0, 16, s) != hipSuccess)
+    if (hipMemsetAsync(b->d_stat, 0xff, 8, s) != hipSuccess || hipMemsetAsync(b->d_stat + 1, 0, 24, s) != hipSuccess)
         return fail(set_error(RG_ERR_DEVICE, "hipMemsetAsync failed"));
     const bool fast = ix->fast_bf16 && ix->d_base_bf && dimc_of(ix);
     const bool exact_count = ix->visited_mode == 2 && d_cmps != nullptr && !fast;
@@ -1039,14 +1109,15 @@ static rg_status search_dev(rg_index *ix, SearchCtx *cx, const float *d_q, uint3
     }
     const uint32_t allocs0 = cx->allocs;
     auto done = [&]() -> rg_status {
-        b->h_stat[3] = 0;
+        b->h_stat[4] = 0;
         b->cold = cx->allocs != allocs0;
-        if (hipMemcpyAsync(b->h_stat, b->d_stat, 24, hipMemcpyDeviceToHost, s) != hipSuccess)
+        if (hipMemcpyAsync(b->h_stat, b->d_stat, 32, hipMemcpyDeviceToHost, s) != hipSuccess)      // status, two totals, queries that left the exact LDS set
             return fail(set_error(RG_ERR_DEVICE, "hipMemcpyAsync failed"));
-        if (b->counted && hipMemcpyAsync(b->h_stat + 3, b->d_ovf, 4, hipMemcpyDeviceToHost, s) != hipSuccess)
+        if (b->counted && hipMemcpyAsync(b->h_stat + 4, b->d_ovf, 4, hipMemcpyDeviceToHost, s) != hipSuccess)
             return fail(set_error(RG_ERR_DEVICE, "hipMemcpyAsync failed"));
         std::lock_guard<std::mutex> lk(ix->mu);
         cx->pending.push_back(b);
+        ++(b->mode == 3 ? ix->n_batches_lset : b->mode == 0 ? ix->n_batches_exact_hbm : b->counted ? ix->n_batches_filter_log : ix->n_batches_filter_only);
         return RG_OK;
     };
     // fast mode under the default visited mode: the exact words from the beam width on at which the parity batches (if
@@ -1054,6 +1125,38 @@ static rg_status search_dev(rg_index *ix, SearchCtx *cx, const float *d_q, uint3
     if (fast && ix->visited_mode == 2 && L >= exact_from_L) {
         st = launch_k1(ix, cx, 0, d_q, nq, qstride, k, L, d_ids, d_dists, d_cmps, d_hops, nullptr, false, b->d_stat, s);
         return st == RG_OK ? done() : fail(st);
+    }
+    // Narrow beams (round 4): the exact visited set in LDS (K1 VIS = 3).  What a query visits -- a few thousand nodes at
+    // L_pq <= 100 -- fits the LDS region the forgetful filter has, as eight-entry buckets of 16-bit remainders (K4's set, kept by
+    // the searching wave itself): nothing is scored twice, so cmps is exact as counted -- no id log to store, no K4 behind the
+    // launch, no de-duplicating inserts.  Used when the set can hold 1.6 x the nodes a query of this width visits (the mean of
+    // the last counted batch; 48 x L_pq before there is one), giving up resident queries down to ten per CU for it; a query
+    // that outgrows its set finishes in the forgetful form and counts its own short log (same bits); a width at which more
+    // than 3 % of the queries do is left to the forms below from then on.
+    if (exact_count && ix->lset != 0 && ix->filter_log2 <= 0 && ix->log_cap_knob <= 0 && !ix->multi_expand && ix->diag == 0 && dimc_of(ix)) {
+        uint32_t need, bad_from;
+        {
+            std::lock_guard<std::mutex> lk(ix->mu);
+            auto it = ix->evals_at.find(L);
+            need = (uint32_t)(1.6f * (it != ix->evals_at.end() ? it->second : 48.0f * (float)L));
+            bad_from = ix->lset_bad_from;
+        }
+        const bool forced = ix->lset > 0 && L <= (uint32_t)ix->lset;
+        if (forced || (ix->lset < 0 && L < bad_from && L <= 256u)) {
+            K1Plan plan;
+            rg_status ps = plan_k1(ix, 3, nq, L, true, false, false, s, &plan, need);
+            if (ps == RG_OK && (forced || plan.vf_slots + plan.vs_side >= need) && (st = ensure_qlog(ix, cx, nq)) == RG_OK && nq <= cx->qlog_chunk) {
+                if (hipMemsetAsync(b->d_ovf, 0, 8, s) != hipSuccess) return fail(set_error(RG_ERR_DEVICE, "hipMemsetAsync failed"));
+                b->mode = 3;
+                st = launch_k1(ix, cx, 3, d_q, nq, qstride, k, L, d_ids, d_dists, d_cmps, d_hops, nullptr, true, b->d_stat, s, nullptr, 0, b->d_stat + 1,
+                               b->d_ovf, need);
+                if (st != RG_OK) return fail(st);
+                cx->log_holds = 0;
+                b->counted = true;
+                return done();
+            }
+            if (st != RG_OK) return fail(st);
+        }
     }
     // Adaptive default: both exact forms return the same bits.  When a batch showed the LDS filter re-scoring nodes
     // at this beam width (performed > 1.08 x distinct: long searches on indexes with locality), the next batch
@@ -1085,6 +1188,7 @@ static rg_status search_dev(rg_index *ix, SearchCtx *cx, const float *d_q, uint3
         }
     }
     if (!exact_count) {
+        b->mode = ix->visited_mode == 0 ? 0 : 2;
         st = launch_k1(ix, cx, ix->visited_mode == 0 ? 0 : 1, d_q, nq, qstride, k, L, d_ids, d_dists, d_cmps, d_hops, nullptr, false,
                        b->d_stat, s);
         return st == RG_OK ? done() : fail(st);
@@ -1174,6 +1278,14 @@ static rg_status finish_batches(rg_index *ix, SearchCtx *cx, hipStream_t s, uint
             const unsigned long long performed = b->h_stat[1], distinct = b->h_stat[2];
             {
                 std::lock_guard<std::mutex> lk(ix->mu);
+                if (distinct > 0 && b->nq >= 64) ix->evals_at[b->L] = (float)((double)distinct / (double)b->nq);      // what the exact LDS set is sized by
+                if (b->mode == 3) {
+                    const unsigned long long left = b->h_stat[3];
+                    ix->n_lset_left += left;
+                    static const bool trace = getenv("RG_TRACE_ADAPTIVE") != nullptr;
+                    if (trace) fprintf(stderr, "[rg_search] batch L=%u nq=%u form=exact LDS set: %llu queries outgrew it\n", b->L, b->nq, left);
+                    if ((double)left > 0.03 * (double)b->nq && b->nq >= 64) ix->lset_bad_from = std::min(ix->lset_bad_from, b->L);
+                }
                 // (round 3: from 8 % of re-scored nodes -- it was 30 % -- : with byte tags and the bit screen the exact set wins
                 // earlier, at d = 512 from L_pq 200 where the filter re-scores a sixth; a trial costs one batch in the other form)
                 if (distinct > 0 && (double)performed > 1.08 * (double)distinct && per_q > 0.0f && b->nq >= 1000 &&
@@ -1182,7 +1294,8 @@ static rg_status finish_batches(rg_index *ix, SearchCtx *cx, hipStream_t s, uint
                     ix->filter_per_q = per_q;
                 }
             }
-            const uint32_t novf = (uint32_t)(b->h_stat[3] & 0xffffffffu);
+            const uint32_t novf = (uint32_t)(b->h_stat[4] & 0xffffffffu);
+            if (novf > 0) { std::lock_guard<std::mutex> lk(ix->mu); ix->n_recounted += novf; }
             if (novf > 0 && v == ~0ull && first == RG_OK) {
                 // logs that did not fit: recount those queries with the exact HBM visited words (only cmps is rewritten)
                 rg_status st = launch_k1(ix, cx, 0, b->q, novf, b->qstride, b->k, b->L, b->ids, b->dists, b->cmps, b->hops, b->d_ovf + 2,
@@ -1395,21 +1508,22 @@ void rg_index_close(rg_index *ix) {
     (void)hipSetDevice(ix->device);
     (void)hipDeviceSynchronize();
     for (rg::SearchCtx *cx : ix->ctxs) rg::free_ctx(cx);
-    if (ix->own_base && ix->d_base) (void)hipFree(ix->d_base);
+    if (ix->own_base) rg::dev_free(ix->d_base);
     if (ix->d_offsets) (void)hipFree(ix->d_offsets);
     if (ix->d_nbrs) (void)hipFree(ix->d_nbrs);
-    if (ix->d_ell) (void)hipFree(ix->d_ell);
+    rg::dev_free(ix->d_ell);
     if (ix->d_front_ids) (void)hipFree(ix->d_front_ids);
     rg::trace_stale("rg_index_close (after the frees)");
-    if (ix->d_base_bf) (void)hipFree(ix->d_base_bf);
-    if (ix->d_main) (void)hipFree(ix->d_main);
-    if (ix->d_etail) (void)hipFree(ix->d_etail);
+    rg::dev_free(ix->d_base_bf);
+    rg::dev_free(ix->d_main);
+    rg::dev_free(ix->d_etail);
     if (ix->d_tail_off) (void)hipFree(ix->d_tail_off);
     delete ix;
 }
 
-rg_status rg_index_open_dev(const float *d_base, uint32_t nd, uint32_t dim, uint32_t stride, const uint64_t *d_offsets,
-                            const uint32_t *d_nbrs, uint32_t ep, int metric, int device, rg_index **out) {
+// adopt_base: the base is a dev_alloc'ed buffer the index takes over (rg_index_open_mem); otherwise it stays the caller's
+static rg_status open_dev_impl(const float *d_base, uint32_t nd, uint32_t dim, uint32_t stride, const uint64_t *d_offsets,
+                               const uint32_t *d_nbrs, uint32_t ep, int metric, int device, bool adopt_base, rg_index **out) {
     if (!out || !d_base || !d_offsets) return set_error(RG_ERR_ARG, "null argument");
     if (metric != RG_METRIC_L2 && metric != RG_METRIC_IP && metric != RG_METRIC_COSINE)
         return set_error(RG_ERR_ARG, "Unknown distance type");
@@ -1420,12 +1534,22 @@ rg_status rg_index_open_dev(const float *d_base, uint32_t nd, uint32_t dim, uint
     rg_index *ix = new rg_index();
     ix->device = device; ix->metric = metric; ix->nd = nd; ix->dim = dim; ix->stride = stride; ix->ep = ep;
     ix->d_base = const_cast<float *>(d_base);
-    ix->own_base = false;
+    ix->own_base = adopt_base;
     if (const char *e = getenv("RG_FORCE_CSR")) ix->force_csr = atoi(e);
     st = rg::finish_graph(ix, d_offsets, d_nbrs);
-    if (st != RG_OK) { rg_index_close(ix); return st; }
+    if (st != RG_OK) {
+        if (adopt_base && ix->d_base == d_base) ix->own_base = false;     // the caller still owns what it passed in
+        rg_index_close(ix);
+        return st;
+    }
+    rg::dev_trim(device);
     *out = ix;
     return RG_OK;
+}
+
+rg_status rg_index_open_dev(const float *d_base, uint32_t nd, uint32_t dim, uint32_t stride, const uint64_t *d_offsets,
+                            const uint32_t *d_nbrs, uint32_t ep, int metric, int device, rg_index **out) {
+    return open_dev_impl(d_base, nd, dim, stride, d_offsets, d_nbrs, ep, metric, device, false, out);
 }
 
 rg_status rg_index_open_mem(const float *base, uint32_t nd, uint32_t dim, uint32_t stride, const uint64_t *offsets,
@@ -1436,8 +1560,12 @@ rg_status rg_index_open_mem(const float *base, uint32_t nd, uint32_t dim, uint32
     if (st != RG_OK) return st;
     // device copy at the aligned stride, zero padded (data_align, util.h:37-75); cosine rows are normalised first
     const uint32_t ad = rg::aligned_dim(dim);
-    rg::DevBuf<float> d_base;
-    RG_HIP(d_base.alloc((size_t)nd * ad));
+    struct Big {      // (balanced over the memory classes when it is large: rg_mem.hip)
+        float *p = nullptr;
+        ~Big() { rg::dev_free(p); }
+    } d_base;
+    st = rg::dev_alloc_t(device, (size_t)nd * ad, &d_base.p);
+    if (st != RG_OK) return st;
     if (metric == RG_METRIC_COSINE || ad != dim || ad != stride) {
         std::vector<float> tmp((size_t)nd * ad, 0.0f);
         for (size_t i = 0; i < nd; ++i) std::memcpy(tmp.data() + i * ad, base + i * (size_t)stride, (size_t)dim * 4);
@@ -1454,10 +1582,9 @@ rg_status rg_index_open_mem(const float *base, uint32_t nd, uint32_t dim, uint32
     RG_HIP(hipMemcpy(d_off.p, offsets, ((size_t)nd + 1) * 8, hipMemcpyHostToDevice));
     RG_HIP(hipMemcpy(d_nb.p, nbrs, ne * 4, hipMemcpyHostToDevice));
     rg_index *ix = nullptr;
-    st = rg_index_open_dev(d_base.p, nd, ad, ad, d_off.p, d_nb.p, ep, metric, device, &ix);
+    st = open_dev_impl(d_base.p, nd, ad, ad, d_off.p, d_nb.p, ep, metric, device, true, &ix);
     if (st != RG_OK) return st;
-    ix->own_base = true;
-    (void)d_base.release();   // now owned by the index
+    d_base.p = nullptr;       // now owned by the index
     *out = ix;
     return RG_OK;
 }
@@ -1511,9 +1638,9 @@ rg_status rg_index_set(rg_index *ix, const char *name, int value) {
         if (value != ix->visited_uncached) {      // contexts re-allocate their words on the next exact-words launch
             std::lock_guard<std::mutex> lk(ix->mu);
             for (rg::SearchCtx *c : ix->ctxs) {
-                if (c->d_visited) (void)hipFree(c->d_visited);
+                rg::dev_free(c->d_visited);
                 if (c->d_epoch) (void)hipFree(c->d_epoch);
-                if (c->d_vtags) (void)hipFree(c->d_vtags);
+                rg::dev_free(c->d_vtags);
                 if (c->d_epoch8) (void)hipFree(c->d_epoch8);
                 c->d_visited = c->d_epoch = c->d_vtags = c->d_epoch8 = nullptr;
                 c->slots = c->tslots = 0;
@@ -1527,6 +1654,8 @@ rg_status rg_index_set(rg_index *ix, const char *name, int value) {
     else if (!strcmp(name, "gather_form")) ix->gather_form = value;
     else if (!strcmp(name, "count_in_k1")) ix->count_in_k1 = value;
     else if (!strcmp(name, "count_tail")) ix->count_tail = value;
+    else if (!strcmp(name, "lset_bytes")) ix->lset_bytes = value;
+    else if (!strcmp(name, "lset")) { ix->lset = value; std::lock_guard<std::mutex> lk(ix->mu); ix->lset_bad_from = 0xffffffffu; }
     else if (!strcmp(name, "log_early")) ix->log_early = value != 0;
     else if (!strcmp(name, "shared_frontier")) ix->shared_frontier = value != 0;
     else if (!strcmp(name, "filter_min_indeg")) ix->filter_min_indeg = value;
@@ -1537,7 +1666,10 @@ rg_status rg_index_set(rg_index *ix, const char *name, int value) {
         if (value && !ix->d_base_bf) {
             if (hipSetDevice(ix->device) != hipSuccess) return set_error(RG_ERR_DEVICE, "cannot select the index device");
             ix->stride_bf = (ix->dim + 127u) / 128u * 128u;
-            RG_HIP(hipMalloc(&ix->d_base_bf, (size_t)ix->nd * ix->stride_bf * 2));
+            {
+                rg_status as = rg::dev_alloc_t(ix->device, (size_t)ix->nd * ix->stride_bf, &ix->d_base_bf);
+                if (as != RG_OK) return as;
+            }
             hipLaunchKernelGGL(rg::rg_base_to_bf16_kernel, dim3(ix->num_cu * 8), dim3(256), 0, 0, ix->d_base, ix->nd, ix->dim, ix->stride,
                                ix->d_base_bf, ix->stride_bf);
             RG_HIP(hipGetLastError());
@@ -1548,6 +1680,20 @@ rg_status rg_index_set(rg_index *ix, const char *name, int value) {
     else if (!strcmp(name, "count_table_log2")) { ix->count_table_log2 = value > 0 ? value : 15; ix->count_table_auto = value <= 0; }
     else if (!strcmp(name, "count_full_ids")) ix->count_full_ids = value != 0;
     else return set_error(RG_ERR_ARG, "unknown knob");
+    return RG_OK;
+}
+
+rg_status rg_index_stat(const rg_index *ixc, const char *name, uint64_t *value) {
+    if (!ixc || !name || !value) return set_error(RG_ERR_ARG, "null argument");
+    rg_index *ix = const_cast<rg_index *>(ixc);
+    std::lock_guard<std::mutex> lk(ix->mu);
+    if (!strcmp(name, "batches_lset")) *value = ix->n_batches_lset;
+    else if (!strcmp(name, "batches_filter_log")) *value = ix->n_batches_filter_log;
+    else if (!strcmp(name, "batches_exact_hbm")) *value = ix->n_batches_exact_hbm;
+    else if (!strcmp(name, "batches_filter_only")) *value = ix->n_batches_filter_only;
+    else if (!strcmp(name, "lset_left")) *value = ix->n_lset_left;
+    else if (!strcmp(name, "recounted")) *value = ix->n_recounted;
+    else return set_error(RG_ERR_ARG, "unknown counter");
     return RG_OK;
 }
 

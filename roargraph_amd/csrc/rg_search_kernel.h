@@ -97,7 +97,15 @@ struct SearchParams {
     // qlog_n[q] and count it in their own LDS.  The exact cmps then costs the search nothing but its log stores; whatever
     // is left uncounted when the kernel ends (overflowed logs, a full side table) is K4's, as before.
     uint32_t count_mode;
-    uint32_t *count_head;         // count_mode 2: next published query to count (work queue of the counters)
+    uint32_t *count_head;
+    // VIS = 3, the EXACT set in LDS (round 4): the filter region holds vf_slots 16-bit entries in buckets of eight
+    // (ds_read_b128 sees a bucket) + vs_side words of full ids for nodes whose bucket is full.  Nothing is ever evicted, so
+    // no node is scored twice: cmps needs no log and no K4, the beam no de-duplication.  A query that outgrows the set goes
+    // on in the forgetful form from that hop on (log + de-duplicating inserts) and counts its short log itself at the end;
+    // lset_left counts such queries (the host stops using the form at a beam width where they are many).
+    uint32_t vs_side;
+    uint32_t *ovf_list, *ovf_count;     // VIS = 3: queries whose count could not be finished in the kernel (recounted by the host)
+    unsigned long long *lset_left;         // count_mode 2: next published query to count (work queue of the counters)
     unsigned long long *totals;   // [2] evaluations performed / distinct nodes of the queries counted here (as K4 reports them)
     // shared frontier (third mode; opt-in knob "shared_frontier"): every query of a batch starts at the entry
     // point, so the first expansion scores the same deg(ep) rows for all of them.  front_scores[q][0] = compare(ep, q) and
@@ -492,6 +500,12 @@ __device__ __forceinline__ uint32_t wave_distinct_half(const uint32_t *log, uint
 //      A first version fetched the guessed node's visited words under the gather: with half the guesses wrong the
 //      wasted sector reads cost more than the hits gained (profiles/r03/k1_ab_lookahead_10m.jsonl).
 //
+//   3  EXACT SET IN LDS (round 4; the compute-layout instantiations): eight-entry buckets of 16-bit remainders of a bijective
+//      id hash + a side table of full ids -- K4's set, kept by the searching wave itself in the region the filter has.
+//      Nothing is forgotten, so nothing is scored twice: cmps is exact as it is counted, without id log, K4 or
+//      de-duplicating inserts.  It holds what a narrow beam visits (a few thousand nodes in 10 KiB); a query that outgrows
+//      it finishes in the forgetful form and counts its short log itself (SearchParams::vs_side).
+//
 // GF: gather form of the register-staged instantiations
 //   0  rows fetched 16 bytes per lane (global_load_dwordx4), then bounced block by block through a 1-KiB LDS buffer into
 //      the layout the scoring routine reads (round 2)
@@ -504,8 +518,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
     static_assert(!BF || (DIMC != 0 && ELL), "fast mode: compile-time dimension, ELL adjacency");
     static_assert(GF == 0 || (DIMC != 0 && !BF), "compute-layout gather: register-staged instantiations");
     static_assert(VIS != 2 || (DIMC != 0 && ELL && !BF), "look-ahead form: register-staged gather over ELL rows");
-    constexpr bool EXACT = VIS != 1;   // visited words in HBM
+    static_assert(VIS != 3 || (DIMC != 0 && ELL && !BF), "exact LDS set: register-staged gather over ELL rows");
+    constexpr bool EXACT = VIS == 0 || VIS == 2;   // visited words in HBM
     constexpr bool LOOK = VIS == 2;
+    constexpr bool LSET = VIS == 3;                // exact visited set in LDS
+    constexpr bool LOGS = VIS == 1 || VIS == 3;    // forms that may log the ids they score
     constexpr int NB = (DIMC + 127) / 128;                                // fast mode: LDS-DMA instructions per bf16 row
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     const int lane = threadIdx.x;
@@ -534,6 +551,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
     uint32_t *vmap = P.visited + (size_t)blockIdx.x * P.vwords;
     uint32_t epoch = EXACT ? P.slot_epoch[blockIdx.x] : 0u;
     unsigned long long tot_n = 0, tot_d = 0;   // in-kernel distinct count: this slot's share of the batch totals
+    unsigned long long tot_left = 0;           // VIS = 3: queries of this slot that outgrew the exact set
 
     // count_mode 2: the distinct counts are made in the tail of the launch (see SearchParams::count_mode)
     const bool tail_count = VIS == 1 && P.count_mode == 2u && P.qlog != nullptr && P.count_tbits != 0u && P.qlist == nullptr && P.out_exp == nullptr;
@@ -578,7 +596,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
         const uint32_t tgt = P.tgt_base + qi;   // build mode: the node being linked is never scored (:1327)
         if (cmps_only) qi = P.qlist[qi];
         const float *query = P.queries + (size_t)qi * P.qstride;
-        uint32_t *qlog = (VIS == 1 && P.qlog) ? P.qlog + (size_t)qi * P.logcap : nullptr;
+        uint32_t *qlog = (LOGS && P.qlog) ? P.qlog + (size_t)qi * P.logcap : nullptr;
+        bool logging = VIS == 1;      // VIS = 3: from the hop on at which the query outgrew the exact set
+        bool left = false;            // VIS = 3: some lane found no room for its node (set by visit_set)
         uint32_t logn = 0, lbn = 0;   // ids scored so far / ids waiting in logbuf
         RG_PROF_DECL;
         if constexpr (DIMC != 0) load_query_regs<DIMC>(query, qr, lane);
@@ -594,9 +614,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
             }
             etag = epoch << 16;
         }
-        if (VIS == 1 || P.vf_front) {   // exact-match filter: every slot empty; LOOK: the screen's bits clear
+        if (VIS == 1 || LSET || P.vf_front) {   // exact-match filter / exact set: every slot empty; LOOK: the screen's bits clear
             uint32_t *vt32 = reinterpret_cast<uint32_t *>(vtab);
-            for (uint32_t i = lane; i < P.vf_slots / 2u; i += kWave) vt32[i] = LOOK ? 0u : 0xffffffffu;
+            for (uint32_t i = lane; i < P.vf_slots / 2u + (LSET ? P.vs_side : 0u); i += kWave) vt32[i] = LOOK ? 0u : 0xffffffffu;
         }
         wave_sync();
 
@@ -648,7 +668,47 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
         };
         auto visit_set = [&](uint32_t id, bool have, bool keep) __attribute__((always_inline)) -> bool {
             bool fresh = false;
-            if (VIS == 1) {
+            if (LSET) {
+                // exact set: bucket = floor(x * buckets / 2^id_bits) of the bijective hash x, entry = the low bits of x that tell
+                // the x of one bucket apart (vf_hash with slots = buckets): (bucket, entry) <-> id.  Found -> visited.  Not
+                // found -> the first empty entry takes it (CAS on its word: two lanes of one hop that bring the same node
+                // meet here, and exactly one of them is fresh); a full bucket sends the node to the side table of full ids.
+                if (have) {
+                    uint32_t b; uint16_t rem;
+                    const uint32_t x = (id * 0x9E3779B1u) & vf_id_mask;
+                    b = __umulhi(x << vf_up, P.vf_slots >> 3);
+                    rem = (uint16_t)(x & vf_rem_mask);
+                    uint32_t *bk = reinterpret_cast<uint32_t *>(vtab) + 4u * b;
+                    for (;;) {
+                        const uint4 t = *reinterpret_cast<const uint4 *>(bk);
+                        const uint32_t w4[4] = {t.x, t.y, t.z, t.w};
+                        int e = 8;
+                        bool found = false;
+#pragma unroll
+                        for (int k2 = 7; k2 >= 0; --k2) {
+                            const uint32_t hv = (k2 & 1) ? w4[k2 >> 1] >> 16 : w4[k2 >> 1] & 0xffffu;
+                            found |= hv == (uint32_t)rem;
+                            if (hv == 0xffffu) e = k2;
+                        }
+                        if (found) break;
+                        if (e == 8) {      // bucket full: the side table (full ids, linear probing)
+                            uint32_t *side = reinterpret_cast<uint32_t *>(vtab) + (P.vf_slots >> 1);
+                            uint32_t slot = __umulhi(id * 0x85EBCA6Bu, P.vs_side), probes = 0;
+                            for (;;) {
+                                const uint32_t old = atomicCAS(&side[slot], 0xffffffffu, id);
+                                if (old == 0xffffffffu) { fresh = true; break; }
+                                if (old == id) break;
+                                if (++slot == P.vs_side) slot = 0;
+                                if (++probes >= P.vs_side) { fresh = true; left = true; break; }   // no room: scored, not remembered
+                            }
+                            break;
+                        }
+                        const uint32_t w = e < 2 ? t.x : e < 4 ? t.y : e < 6 ? t.z : t.w;
+                        const uint32_t nw = (e & 1) ? (w & 0x0000ffffu) | ((uint32_t)rem << 16) : (w & 0xffff0000u) | (uint32_t)rem;
+                        if (atomicCAS(&bk[e >> 1], w, nw) == w) { fresh = true; break; }
+                    }
+                }
+            } else if (VIS == 1) {
                 // exact-match lookup: a hit proves "visited"; a miss is treated as fresh (may re-score a node whose
                 // entry was overwritten -- harmless for the beam, see beam_insert<true>)
                 if (have) {
@@ -696,14 +756,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
         // 256-B store.  The store is issued where no gather is outstanding: in front of gathers it would sit at the head
         // of the vmcnt queue and put its completion latency on the critical path of the first counted wait.
         auto log_append = [&](uint32_t off, uint32_t n) __attribute__((always_inline)) {
-            if (VIS == 1 && qlog) {
+            if (LOGS && qlog) {
                 if ((uint32_t)lane < n) logbuf[lbn + lane] = cand_id[off + lane];
                 lbn += n;
             }
             logn += n;
         };
         auto log_flush = [&]() __attribute__((always_inline)) {
-            if (VIS == 1 && qlog && lbn >= (uint32_t)kWave) {
+            if (LOGS && qlog && lbn >= (uint32_t)kWave) {
                 lds_fence();
                 const uint32_t pos = logn - lbn;                       // ids already flushed (multiple of 64)
                 const uint32_t v = logbuf[lane], rest = logbuf[kWave + lane];
@@ -927,8 +987,16 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
                     else if (P.tail_off) cand_x[pos] = toff + c0 + lane;   // the neighbour's place in the adjacency order
                 }
                 lds_fence();
-                log_append(0, n);
-                cmps += n;                                                 // :2397
+                if constexpr (LSET) {
+                    // a lane found no room for its node: from this hop on the set is incomplete -- the ids scored are logged (this
+                    // hop's too: none of them was scored before), inserts de-duplicate, and the log's distinct ids join cmps at the end
+                    if (!logging && __any(left)) logging = true;
+                    if (logging) log_append(0, n);
+                    else cmps += n;                                        // :2397
+                } else {
+                    log_append(0, n);
+                    cmps += n;                                             // :2397
+                }
                 RG_PROF(2);
                 if (from_front) log_flush();
                 else
@@ -946,7 +1014,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
                 const uint32_t cid = (uint32_t)lane < n ? cand_id[lane] : 0u;
                 lds_fence();
                 RG_PROF(3);
-                beam_insert<VIS == 1>(bm, cd, cid, (uint32_t)lane < n, P.ep, lane, mscr RG_PROF_MERGE);
+                if constexpr (LSET) {
+                    if (logging) beam_insert<true>(bm, cd, cid, (uint32_t)lane < n, P.ep, lane, mscr RG_PROF_MERGE);
+                    else beam_insert<false>(bm, cd, cid, (uint32_t)lane < n, P.ep, lane, mscr RG_PROF_MERGE);
+                } else beam_insert<VIS == 1>(bm, cd, cid, (uint32_t)lane < n, P.ep, lane, mscr RG_PROF_MERGE);
                 RG_PROF(4);
             }
         };
@@ -1186,7 +1257,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
                 P.out_dists[(size_t)qi * P.k + i] = __uint_as_float(e.x);
             }
         }
-        if (VIS == 1 && qlog && lbn) {   // tail of the id log
+        if (LOGS && qlog && lbn) {   // tail of the id log
             lds_sync();
             const uint32_t pos = logn - lbn;
             if ((uint32_t)lane < lbn && pos + lane < P.logcap) __hip_atomic_store(&qlog[pos + lane], logbuf[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1199,6 +1270,27 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
         }
 #endif
         uint32_t logn_out = logn;
+        if (LSET && !cmps_only && !build) {
+            const uint32_t pre = cmps;
+            if (logging) {    // the query outgrew the exact set: cmps so far + the distinct ids of what was scored since
+                bool bad = true;
+                uint32_t distinct = 0;
+                if (qlog && P.count_tbits && logn <= P.logcap) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    lds_fence();
+                    distinct = wave_distinct_half(qlog, logn, mscr, P.count_tbits, max(P.id_bits, P.count_tbits - 1u), lane, bad);
+                    lds_fence();
+                }
+                if (!bad) cmps += distinct;
+                else {           // left to the host's exact recount (rg_search_wait)
+                    cmps += logn;
+                    if (lane == 0) P.ovf_list[atomicAdd(P.ovf_count, 1u)] = qi + P.qbase;
+                }
+                ++tot_left;
+            }
+            tot_n += (unsigned long long)pre + logn;
+            tot_d += cmps;
+        }
         if (tail_count) {
             // publish: the log is complete once its last store has been acknowledged; then the length; then -- with the
             // length acknowledged too -- the next work item is fetched, so that a wave that finds the queue empty sees every
@@ -1249,7 +1341,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
             count_published(q);
         }
     }
-    if (VIS == 1 && tot_n && lane == 0) {
+    if (LSET && tot_left && lane == 0) atomicAdd(P.lset_left, tot_left);
+    if (LOGS && tot_n && lane == 0) {
         atomicAdd(&P.totals[0], tot_n);
         atomicAdd(&P.totals[1], tot_d);
     }
@@ -1260,7 +1353,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
 // what the host decided for one launch (rg_search.hip: plan_k1)
 struct K1Launch {
     int R = 1;        // staging ring depth (passes of 4 rows in flight)
-    int vis = 1;      // 0 = exact HBM visited words, 1 = LDS filter, 2 = exact words, look-ahead form
+    int vis = 1;      // 0 = exact HBM visited words, 1 = LDS filter, 2 = exact words, look-ahead form, 3 = exact set in LDS
     int dimc = 0;     // compile-time dimension instantiation (0 = generic)
     bool bf = false;  // opt-in bf16 traversal
     int gf = 0;       // gather form of the register-staged instantiations: 0 = 16-byte loads + LDS bounce, 1 = compute layout
@@ -1315,6 +1408,7 @@ static rg_status launch_search_t(const SearchParams &P, const K1Launch &c, hipSt
 // compute-layout gather (GF = 1): d = 200 with four or eight register sets, d = 512 with two (k1_gf_ok, rg_search.hip)
 template <bool L2, bool ELL, int R, int DIMC>
 static rg_status launch_search_gf1(const SearchParams &P, const K1Launch &c, hipStream_t s) {
+    if (c.vis == 3) return launch_search_d<L2, ELL, R, 3, DIMC, false, 1>(P, c, s);      // exact set in LDS (these instantiations only)
     if (c.vis == 2) return launch_search_d<L2, ELL, R, 2, DIMC, false, 1>(P, c, s);
     return c.vis == 1 ? launch_search_d<L2, ELL, R, 1, DIMC, false, 1>(P, c, s) : launch_search_d<L2, ELL, R, 0, DIMC, false, 1>(P, c, s);
 }

@@ -97,6 +97,13 @@ class IndexBipartite:
     def set(self, name, value):
         check(lib().rg_index_set(self.handle, name.encode(), int(value)))
 
+    def stat(self, name):
+        """counters of the search path since open (rg_index_stat): batches_lset / batches_filter_log / batches_exact_hbm /
+        batches_filter_only, lset_left, recounted"""
+        v = C.c_uint64()
+        check(lib().rg_index_stat(self.handle, name.encode(), C.byref(v)))
+        return int(v.value)
+
     # ---- operator --------------------------------------------------------------------------------------
     def score_batch(self, query, ids):
         """out[i] = Distance::compare(base[ids[i]], query, dim)   (include/efanna2e/distance.h:18)"""

@@ -492,3 +492,34 @@ def test_ties_duplicate_edges_and_self_loops(rg, oracle, metric):
             if vis != 1:
                 assert (got[2] == want[2]).all()
     ix.close()
+
+
+@pytest.mark.parametrize("metric,d,nb", [("ip", 200, 4000), ("l2", 512, 2000)])
+@pytest.mark.parametrize("lset_bytes", [0, 2048, 256])
+def test_exact_set_in_lds(rg, oracle, metric, d, nb, lset_bytes):
+    """Default visited mode at narrow beams (round 4): the exact visited set in LDS (K1 VIS = 3) -- no id log, no K4, no
+    de-duplicating inserts; cmps exact as counted.  lset_bytes caps the set so that queries outgrow it: they finish in the
+    forgetful form and count their own log (2048 bytes: some queries; 256: every query, at once)."""
+    base, q, off, nbrs, ep = small_set(metric, nb, d)
+    ix = rg.IndexBipartite.from_arrays(base, off, nbrs, ep, metric=metric)
+    ix.set("lset", 100000)          # the form at every beam width, whatever the estimate says
+    ix.set("lset_bytes", lset_bytes)
+    for L, k in ((10, 10), (50, 10), (150, 100), (700, 10)):
+        for rep in range(2):
+            got = ix.SearchRoarGraph(q, k, L)
+            want = oracle.search(base, metric, off, nbrs, ep, q, k, L, nthreads=4)
+            assert (got[2] == want[2]).all(), ("cmps", L, lset_bytes, rep)
+            assert (got[3] == want[3]).all() and (got[0] == want[0]).all() and (bits(got[1]) == bits(want[1])).all(), (L, lset_bytes)
+    assert ix.stat("batches_lset") == 8 and ix.stat("batches_filter_log") == 0
+    if lset_bytes:
+        assert ix.stat("lset_left") > 0
+    # the automatic rule: the form where the estimate says the visits fit; a width at which queries outgrow the set is left
+    ix.set("lset", -1)
+    n0 = ix.stat("batches_lset")
+    for rep in range(3):
+        got = ix.SearchRoarGraph(q, 10, 20)
+        want = oracle.search(base, metric, off, nbrs, ep, q, 10, 20, nthreads=4)
+        assert (got[2] == want[2]).all() and (got[0] == want[0]).all()
+    if lset_bytes == 0:
+        assert ix.stat("batches_lset") == n0 + 3
+    ix.close()
