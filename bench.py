@@ -46,6 +46,9 @@ sys.path.insert(0, ROOT)
 
 # the reference's evaluation list (README.md:118) thinned to the points that shape the curve
 SWEEP_DEFAULT = "10,20,30,40,50,60,80,100,150,200,300,500,700,1000,1500,2000"
+# ... and the list itself, all 56 points (`--sweep readme`)
+SWEEP_README = ("10,15,20,25,30,35,40,45,50,55,60,65,70,75,80,85,90,95,100,105,110,115,120,125,130,135,140,145,150,155,160,165,170,175,180,185,"
+                "190,195,200,220,240,260,280,300,350,400,450,500,550,600,700,800,900,1000,1500,2000")
 
 
 def parse():
@@ -69,7 +72,14 @@ def parse():
     ap.add_argument("--train", type=int, default=0, help="training queries of the index build (default nb/5)")
     ap.add_argument("--L", type=int, default=0, help="beam width of the timed headline; 0 = the smallest L_pq of the sweep with recall@10 >= --target-recall")
     ap.add_argument("--target-recall", type=float, default=0.90)
-    ap.add_argument("--sweep", default=SWEEP_DEFAULT, help="comma list of L_pq values (empty = none)")
+    ap.add_argument("--sweep", default=SWEEP_DEFAULT, help="comma list of L_pq values (empty = none); `readme` = the reference's own 56-point "
+                    "evaluation list (README.md:118)")
+    ap.add_argument("--configs", default="rank128,webvid,laion", help="comma list of the side blocks of the default run, each a smaller build + search "
+                    "of its own with roofline and cpu_baseline (rank 0, N = 1): rank128 = a harder data set (latent rank 128: 0.9 recall "
+                    "needs a beam ten times as wide), webvid = BASELINE configs[4] end to end (2.5M x 512 IP: ground truth -> build -> "
+                    "search), laion = BASELINE configs[3] shape (d = 512 L2 top-100) at the size --laion-nb; empty = none")
+    ap.add_argument("--laion-nb", type=int, default=4_000_000, help="rows of the laion-shaped side block (the full 10M x 512 run: "
+                    "python bench.py --nb 10000000 --dim 512 --metric l2 --k 100 --configs '')")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall budget of each CPU baseline sample (0 = skip)")
     ap.add_argument("--visited", type=int, default=2,
                     help="2 = library default (LDS visited filter + id log + exact distinct count, adaptive to the exact HBM words; "
@@ -176,7 +186,9 @@ def pmc_traffic(key):
     separate --pmc FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE with the gfx950 x2 correction).  Counters cannot be read from
     inside the timed process, so the figure is reported only when a committed profile is of the workload being benched."""
     import glob
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "search_traffic*.json")), reverse=True):
+    paths = glob.glob(os.path.join(ROOT, "profiles", "**", "search_traffic*.json"), recursive=True)
+    # newest round first (profiles/r04/... before profiles/r03/final/...), inside a round the deepest ("final") first
+    for path in sorted(paths, key=lambda q: (os.path.relpath(q, ROOT).split(os.sep)[1], q.count(os.sep), q), reverse=True):
         try:
             t = json.load(open(path))
         except Exception:
@@ -247,11 +259,13 @@ class Searcher:
         used = sorted(set(used))
         mc = float(np.mean([self.out[b]["cmps"].float().mean().item() for b in used]))
         mh = float(np.mean([self.out[b]["hops"].float().mean().item() for b in used]))
-        rec = None
+        rec = rec_k = None
         if self.k >= 10 and all(self.gts[b] is not None for b in used):
             rec = float(np.mean([ixmod.recall(self.out[b]["ids"].cpu().numpy().view(np.uint32), self.gts[b], 10) for b in used]))
+            rk = getattr(self, "recall_k", 10)      # the reference's recall@k over all k results (test_search_roargraph.cpp:23-36)
+            rec_k = rec if rk == 10 else float(np.mean([ixmod.recall(self.out[b]["ids"].cpu().numpy().view(np.uint32), self.gts[b], rk) for b in used]))
         gbps = self.nq * mc * 4 * self.dim / (ms / 1e3) / 1e9
-        return {"L_pq": L, "qps": self.nq / (ms / 1e3), "ms_per_batch": ms, "recall_at_10": rec, "mean_evals": mc, "mean_hops": mh,
+        return {"L_pq": L, "qps": self.nq / (ms / 1e3), "ms_per_batch": ms, "recall_at_10": rec, "recall_at_k": rec_k, "mean_evals": mc, "mean_hops": mh,
                 "distinct_batches": len(used), "GBps": gbps, "pct_of_8000": 100.0 * gbps / 8000.0, "pct_of_6290": 100.0 * gbps / 6290.0}
 
 
@@ -274,6 +288,81 @@ def reuse_of_last_launch(torch, index, stream, nb, nq, dev, full=False):
                     # popularity: share of the launch's row reads that go to its H most read rows (H rows = H x 768 B)
                     "share_of_reads_to_top_rows": {str(h): float(cum[min(h, nb) - 1].item()) for h in (64, 1024, 16384, 131072, MALL_ROWS, 1048576)},
                     "rows_read_by_every_query": int((counts >= nq).sum().item())})
+    return out
+
+
+
+def side_config(torch, dev, stream, name, nb, dim, metric, k, rank_latent, ntrain, nq, Ls, target, cpu_seconds, steps, what):
+    """One smaller workload end to end inside the default run: data -> ground truth of the training queries (K2) ->
+    GPU-assisted RoarGraph construction -> a short L_pq sweep -> `steps` timed batches at the smallest L_pq reaching `target`
+    recall@10 (recall@k for the top-100 shape) -> the reference loop on 16 host threads over the same index and queries (ids
+    asserted equal).  Returns a block with its own `roofline` and `cpu_baseline`."""
+    from roargraph_amd import build, groundtruth, synth
+    from roargraph_amd.index import IndexBipartite
+    t_all = time.perf_counter()
+    base, train, q, desc = synth.make_device_set(dev, 1234, nb, ntrain, nq, dim, data="lowrank", rank=rank_latent, q_seed=99)
+    t0 = time.perf_counter()
+    ti, _ = groundtruth.groundtruth_distributed(base, 0, train, metric, 100)
+    torch.cuda.synchronize()
+    t_gt = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    h_off, h_nbrs, ep = build.build_roargraph(base.cpu().numpy(), ti.cpu().numpy().view(np.uint32), metric, 100, 35, 500,
+                                              num_threads=int(os.environ.get("RG_BENCH_BUILD_THREADS", min(128, os.cpu_count() or 1))), device=dev.index or 0)
+    t_build = time.perf_counter() - t0
+    del train, ti
+    off = torch.from_numpy(h_off.view(np.int64)).to(dev)
+    nbrs = torch.from_numpy(h_nbrs.view(np.int32)).to(dev)
+    torch.cuda.empty_cache()
+    index = IndexBipartite.from_device(base, off, nbrs, ep, metric=metric)
+    nbatch = 3
+    qs = [q] + [synth.make_device_set(dev, 1234, 1024, 0, nq, dim, data="lowrank", rank=rank_latent, q_seed=99 + 7919 * b)[2] for b in range(1, nbatch)]
+    gts = []
+    ti_q = torch.zeros((nq, 100), dtype=torch.int32, device=dev); tv_q = torch.zeros((nq, 100), device=dev)
+    t0 = time.perf_counter()
+    for qb in qs:
+        groundtruth.gt_shard_dev(base, qb, metric, 100, 0, ti_q, tv_q, stream=stream); torch.cuda.synchronize()
+        gts.append(ti_q.cpu().numpy().view(np.uint32).copy())
+    t_gtq = time.perf_counter() - t0
+    del ti_q, tv_q
+    S = Searcher(torch, index, qs, k, dim, stream, gts)
+    S.recall_k = k if k <= 100 else 10
+    sweep = []
+    for L in [x for x in Ls if x >= k]:
+        ms, used = S.timed(L, reps=2, settle=2)
+        sweep.append(S.point(L, ms, used))
+    ok = [p["L_pq"] for p in sweep if (p["recall_at_k"] or 0.0) >= target]
+    L_star = min(ok) if ok else max(p["L_pq"] for p in sweep)
+    ms, used = S.timed(L_star, reps=steps, settle=1)
+    head = S.point(L_star, ms, used)
+    forms = {n_: index.stat(n_) for n_ in ("batches_lset", "batches_filter_log", "batches_exact_hbm")}
+    S.run(L_star, 0); S.wait()
+    ids_head = S.out[0]["ids"].cpu().numpy().view(np.uint32).copy()
+    cpu = None
+    if cpu_seconds > 0:
+        try:
+            cpu = cpu_search_baseline(base.cpu().numpy(), h_off, h_nbrs, ep, qs[0].cpu().numpy(), ids_head, metric, k, L_star,
+                                      [min(16, os.cpu_count() or 1)], cpu_seconds)[0]
+            cpu["gpu_over_cpu"] = head["qps"] / cpu["value"] if cpu.get("value") else None
+        except AssertionError:
+            raise
+        except Exception as e:  # noqa: BLE001
+            cpu = {"value": None, "unit": "QPS", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
+    index.close()
+    alg = head["mean_evals"] * nq * 4.0 * dim
+    out = {"name": name, "what": what,
+           "workload": "base %dx%d fp32 %s (%s), %d training queries, own RoarGraph index (M_sq=100 M_pjbp=35 L_pjpq=500, avg degree %.1f), %d queries/batch "
+                       "(%d distinct batches), top-%d, L_pq=%d" % (nb, dim, metric, desc, ntrain, float(h_nbrs.size) / nb, nq, nbatch, k, L_star),
+           "metric": "QPS @ recall@%d >= %.2f" % (S.recall_k, target), "value": head["qps"], "unit": "queries/s",
+           "L_pq": L_star, "recall_at_k": head["recall_at_k"], "recall_k": S.recall_k, "mean_evals": head["mean_evals"], "mean_hops": head["mean_hops"],
+           "seconds": {"train_ground_truth": t_gt, "construction": t_build, "query_ground_truth": t_gtq, "block_total": time.perf_counter() - t_all},
+           "roofline": {"bound": "hbm", "achieved": head["GBps"], "peak": 8000.0, "unit": "GB/s", "frac": head["GBps"] / 8000.0,
+                        "kernel_ms_avg": ms, "algorithmic_bytes_per_launch": alg, "traffic": None,
+                        "frac_of_measured_stream_ceiling_6290": head["GBps"] / 6290.0},
+           "cpu_baseline": cpu, "kernel_forms_of_the_batches": forms,
+           "L_pq_sweep": [{"L_pq": p["L_pq"], "qps": p["qps"], "recall_at_k": p["recall_at_k"], "mean_evals": p["mean_evals"], "pct_of_8000": p["pct_of_8000"]}
+                          for p in sweep]}
+    del S, index, base, off, nbrs, qs
+    torch.cuda.empty_cache()
     return out
 
 
@@ -301,6 +390,8 @@ def self_launch(args):
 
 def main():
     args = parse()
+    if args.sweep == "readme":
+        args.sweep = SWEEP_README
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(args)
     import torch
@@ -483,6 +574,10 @@ def main():
             # what explains a point above the 6.29 TB/s streaming-copy ceiling: how few of the launch's row reads are first
             # touches, and how many go to rows a 256-MiB cache could hold (null: the launch ran on the exact words)
             ru = reuse_of_last_launch(torch, index, stream, args.nb, args.nq, dev)
+            if ru is None:     # narrow beams run on the exact LDS set (no id logs): one untimed launch in the logging form, for the statistics only
+                index.set("lset", 0); S.run(L, 0); S.wait()
+                ru = reuse_of_last_launch(torch, index, stream, args.nb, args.nq, dev)
+                index.set("lset", -1)
             pt["distinct_rows_frac"] = ru["distinct_rows_frac"] if ru else None
             pt["share_of_reads_to_rows_a_256MiB_cache_can_hold"] = ru["share_of_reads_to_top_%d_rows" % MALL_ROWS] if ru else None
         sweep.append(pt)
@@ -542,7 +637,14 @@ def main():
     # first touches: distinct base rows among the evaluations of one launch (the id logs of the default visited mode)
     reuse = None
     if args.visited == 2:
-        reuse = reuse_of_last_launch(torch, index, stream, args.nb, args.nq, dev, full=True) or {"unavailable": "the launch ran on the exact words: no id logs"}
+        reuse = reuse_of_last_launch(torch, index, stream, args.nb, args.nq, dev, full=True)
+        if reuse is None:      # the headline ran on the exact LDS set (no id logs): one untimed launch in the logging form, for the statistics only
+            index.set("lset", 0); S.run(L_star, 0); S.wait()
+            reuse = reuse_of_last_launch(torch, index, stream, args.nb, args.nq, dev, full=True)
+            index.set("lset", -1)
+            S.run(L_star, 0); S.wait()
+        reuse = reuse or {"unavailable": "the launch ran on the exact words: no id logs"}
+    forms_head = {n_: index.stat(n_) for n_ in ("batches_lset", "batches_filter_log", "batches_exact_hbm", "batches_filter_only", "lset_left", "recounted")}
     ids_head = S.out[0]["ids"].cpu().numpy().view(np.uint32).copy()
     # the exact HBM-visited form returns the same bits (parity between the two exact forms, checked every run)
     if args.visited != 0:
@@ -786,6 +888,34 @@ def main():
                     gt["cpu_baseline"] = {"value": None, "unit": "distances/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
             del gq
 
+    # ---- side blocks (rank 0, N = 1): three smaller workloads, each built and searched inside the run, each with its own roofline
+    # and cpu_baseline -- the headline's data set is the easiest of the family (latent rank 32), and BASELINE configs[3] / [4] are d = 512
+    side_blocks = []
+    n_query_batches = len(qs)
+    if rank == 0 and world == 1 and args.configs:
+        mem_stats_main = index.mem_stats()
+        index.close()
+        del S, index, base, off, nbrs, qs
+        torch.cuda.empty_cache()
+        defs = {
+            "rank128": dict(nb=2_500_000, dim=200, metric="ip", k=10, rank_latent=128, Ls=[50, 100, 200, 300, 500, 700, 1000],
+                            what="a harder data set of the headline's family: latent rank 128 instead of 32 (four times the intrinsic dimension), "
+                                 "2.5M x 200 IP, top-10"),
+            "webvid": dict(nb=2_500_000, dim=512, metric="ip", k=10, rank_latent=32, Ls=[10, 20, 30, 50, 100, 200, 500],
+                           what="BASELINE configs[4] shape, end to end in the run: webvid-2.5M-shaped 2.5M x 512 IP, ground truth of 500k training "
+                                "queries (K2) -> GPU-assisted RoarGraph construction -> search, top-10"),
+            "laion": dict(nb=args.laion_nb, dim=512, metric="l2", k=100, rank_latent=32, Ls=[100, 150, 200, 300, 500, 1000],
+                          what="BASELINE configs[3] shape at %d rows (the full 10M x 512 run takes the whole default budget by itself: --nb 10000000 "
+                               "--dim 512 --metric l2 --k 100): laion-shaped d = 512 L2, top-100, recall@100" % args.laion_nb),
+        }
+        for cname in [c for c in args.configs.split(",") if c]:
+            if cname not in defs:
+                raise SystemExit("--configs: unknown block %r (rank128, webvid, laion)" % cname)
+            d_ = defs[cname]
+            side_blocks.append(side_config(torch, dev, stream, cname, d_["nb"], d_["dim"], d_["metric"], d_["k"], d_["rank_latent"], d_["nb"] // 5, args.nq,
+                                           d_["Ls"], args.target_recall, min(args.cpu_seconds, 6.0), min(args.steps, 5), d_["what"]))
+    else:
+        mem_stats_main = index.mem_stats() if rank == 0 else None
     traffic, traffic_src = pmc_traffic(wl_key) if rank == 0 else (None, None)
     shape_name = {(10_000_000, 200, "ip"): "t2i-10M-shaped", (10_000_000, 512, "l2"): "laion-10M-shaped",
                   (2_500_000, 512, "ip"): "webvid-2.5M-shaped"}.get((args.nb, args.dim, args.metric), "%dx%d" % (args.nb, args.dim))
@@ -806,7 +936,7 @@ def main():
             "config": {"workload": "%s: base %dx%d fp32 %s, %d queries/GPU/step (a different seeded batch every step), top-%d, L_pq=%d, %s, %s (replicated per GPU)"
                                    % (shape_name, args.nb, args.dim, args.metric, args.nq, args.k, L_star, data_desc, graph_desc),
                        "parallelism": "query-sharded x%d, index replicated" % world,
-                       "distinct_query_batches": len(qs),
+                       "distinct_query_batches": n_query_batches,
                        "L_pq": L_star, "recall_at_10": head["recall_at_10"], "target_recall": args.target_recall,
                        "visited": {2: "default: lds-filter + id log + exact distinct count, adaptive to the exact HBM words where a timed "
                                       "trial finds them faster (ids/dists/hops/cmps bit-exact vs the HBM-visited mode, checked in this run)",
@@ -816,7 +946,15 @@ def main():
                        "setup_seconds": {"train_gt": t_gt, "build": t_build, "total_run": time.perf_counter() - t_all}},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
                          "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "rg_search_kernel (+ rg_distinct_kernel in visited mode 2)", "kernel_ms_avg": kavg * 1e3,
+                         # the two bounds of "how much of frac did HBM itself deliver" at the top level: frac_hbm_only = the
+                         # same base under a random graph (no row is read twice: every byte comes from HBM; L_pq = 500), the one
+                         # driver-timed point where the memory system's figure and HBM's coincide; frac_cache_served = the share of the
+                         # headline launch's row reads that go to rows an ideal 256-MiB cache could hold (measured from its id logs)
+                         "frac_hbm_only": worst["frac"] if worst else None,
+                         "frac_cache_served": reuse.get("share_of_reads_to_top_%d_rows" % MALL_ROWS) if reuse else None,
+                         "kernel": "rg_search_kernel (exact visited set in LDS: no second kernel)" if forms_head.get("batches_lset") else
+                                   "rg_search_kernel (+ rg_distinct_kernel in visited mode 2)", "kernel_ms_avg": kavg * 1e3,
+                         "kernel_forms_of_the_batches_so_far": forms_head,
                          "kernel_ms_avg_is": "HIP-event span of the timed region (first enqueue on the launch stream ... rg_search_wait "
                                              "returned) / steps",
                          "k1_ms_per_enqueue_on_launch_stream": float(np.mean(k1_on_stream_ms)),
@@ -850,6 +988,8 @@ def main():
             "non_parity_modes": fast,
             "exact_opt_in_modes": shared,
             "gt_build": gt,
+            "configs": side_blocks,
+            "device_memory": mem_stats_main,
         }
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -83,6 +83,11 @@ void rg_normalize_rows(float *data, size_t n, size_t stride, uint32_t dim);
  *           -> InitVisitedListPool(T)               (index_bipartite.h:133)
  * The index is immutable after open. */
 rg_status rg_index_open(const char *base_fbin, const char *index_path, int metric, int device, rg_index **out);
+/* SURVEY 8(b)'s lifecycle signature: one REPLICA per listed device (the search shards by queries, the index is replicated:
+ * SURVEY 8(e)); the two files are read once, every replica is uploaded from memory.  out[0 .. ndev) receives the replicas
+ * (all null when the call fails); they are searched together with rg_search_sharded and closed one by one.  An rg_index
+ * itself stays a single-device object: every device-form entry point takes one stream, which belongs to one device. */
+rg_status rg_index_open_multi(const char *base_fbin, const char *index_path, int metric, const int *devices, int ndev, rg_index **out);
 /* same from host memory (copied to HBM); offsets has nd+1 entries */
 rg_status rg_index_open_mem(const float *base, uint32_t nd, uint32_t dim, uint32_t stride, const uint64_t *offsets,
                             const uint32_t *nbrs, uint32_t ep, int metric, int device, rg_index **out);
@@ -103,8 +108,9 @@ rg_status rg_index_info(const rg_index *idx, uint32_t *nd, uint32_t *dim, uint32
  * ceil(degree/4) lines; costs nd * 768 + (edges + 1) * 32 bytes of HBM (environment RG_SPLIT_ROWS=0: never built).
  * "rows_per_pass" = 4 * (passes of 4 rows a query keeps in flight; 16 / 32 use register staging at d = 200).
  * "visited" selects how the visited set is kept:
- *   2 (default) LDS exact-match filter + per-query id log + exact distinct count: ids, dists, hops AND cmps bit-exact.
- *               Adaptive: once a batch shows the filter re-scoring > 8 % extra nodes at some L_pq (long searches on
+ *   2 (default) ids, dists, hops AND cmps bit-exact.  Narrow beams (what a query visits fits the LDS): the exact visited set in
+ *               LDS, nothing else (knob "lset").  Otherwise LDS exact-match filter + per-query id log + exact distinct count.
+ *               Adaptive: once a batch shows the filter re-scoring > 4 % extra nodes at some L_pq (long searches on
  *               indexes with locality), the next batch of that L_pq is a timed trial of mode 0 and the faster of the two
  *               exact forms is kept from that L_pq on -- the same bits either way
  *   1           LDS filter only: ids, dists, hops bit-exact; cmps = evaluations performed (>= the reference's)

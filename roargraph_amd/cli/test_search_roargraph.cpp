@@ -79,15 +79,13 @@ int main(int argc, char **argv) {
     for (const std::string &d : a.list("devices"))
         if (!d.empty()) devices.push_back((int)std::strtol(d.c_str(), nullptr, 10));
     const int device = devices.empty() ? (int)a.u("device") : devices[0];
-    rg_index *index = nullptr;
     std::cout << "Load graph index: " << a.str("projection_index_save_path") << std::endl;
-    CK(rg_index_open(a.str("base_data_path").c_str(), a.str("projection_index_save_path").c_str(), metric, device, &index));
-    std::vector<rg_index *> replicas{index};
-    for (size_t r = 1; r < devices.size(); ++r) {
-        rg_index *rep = nullptr;
-        CK(rg_index_open(a.str("base_data_path").c_str(), a.str("projection_index_save_path").c_str(), metric, devices[r], &rep));
-        replicas.push_back(rep);
-    }
+    // one replica per device (--devices) or the one index of --device: the files are read once (rg_index_open_multi)
+    std::vector<int> devs = devices.empty() ? std::vector<int>{device} : devices;
+    std::vector<rg_index *> replicas(devs.size(), nullptr);
+    CK(rg_index_open_multi(a.str("base_data_path").c_str(), a.str("projection_index_save_path").c_str(), metric, devs.data(), (int)devs.size(),
+                           replicas.data()));
+    rg_index *index = replicas[0];
     if (replicas.size() > 1) std::cout << "Index replicated on " << replicas.size() << " devices, queries sharded" << std::endl;
     uint32_t nd, dim, stride, ep, maxdeg;
     float avgdeg;

@@ -113,11 +113,27 @@ struct GtParams {
     uint32_t nseg, seg_rows;
     uint32_t *seg_ids;
     float *seg_vals;
+    // balanced form (round 4): the (query block x base tile) rectangle is cut into one equal stretch per resident workgroup;
+    // a stretch that crosses a block boundary is two work items.  items[i] = (query block, first row, rows, list the piece's
+    // top-K goes to), workgroup w runs items[item_first[w] .. item_first[w + 1]); null = the forms above (work counter)
+    const uint4 *items;
+    const uint32_t *item_first;
 };
 
 // the parameters of work item `item` = (query block, segment): the segment's rows, bias, id offset and output lists
 __device__ __forceinline__ GtParams gt_segment(const GtParams &P0, uint32_t item, uint32_t &qblk) {
     GtParams P = P0;
+    if (P0.items) {
+        const uint4 it = P0.items[item];
+        qblk = it.x;
+        P.base = P0.base + (size_t)it.y * P0.bstride;
+        P.nb = it.z;
+        if (P0.bias) P.bias = P0.bias + it.y;
+        P.id_base = P0.id_base + it.y;
+        P.out_ids = P0.seg_ids + (size_t)it.w * P0.nq * P0.K;
+        P.out_vals = P0.seg_vals + (size_t)it.w * P0.nq * P0.K;
+        return P;
+    }
     qblk = item / P0.nseg;
     if (P0.nseg > 1) {
         const uint32_t seg = item % P0.nseg, r0 = seg * P0.seg_rows;
@@ -196,11 +212,20 @@ __global__ void __launch_bounds__(512) rg_gt_kernel(GtParams P0) {
     const uint32_t ninstr = kq_chunk * (kNB / 64);                  // LDS-DMA wave instructions per chunk (2 per k-quad)
     const bool hi = lane >= 32;
 
+    uint32_t cursor = P0.items ? P0.item_first[blockIdx.x] : 0u;
+    const uint32_t cursor_end = P0.items ? P0.item_first[blockIdx.x + 1] : 0u;
     for (;;) {
-        if (tid == 0) flag[1] = atomicAdd(P0.counter, 1u);
-        __syncthreads();
-        const uint32_t item = flag[1];
-        __syncthreads();
+        uint32_t item;
+        if (P0.items) {                       // balanced form: this workgroup's own stretch
+            if (cursor >= cursor_end) break;
+            item = cursor++;
+            __syncthreads();
+        } else {
+            if (tid == 0) flag[1] = atomicAdd(P0.counter, 1u);
+            __syncthreads();
+            item = flag[1];
+            __syncthreads();
+        }
         uint32_t blk;
         const GtParams P = gt_segment(P0, item, blk);
         if ((uint64_t)blk * MQ >= P.nq) break;
@@ -380,11 +405,20 @@ __global__ void __launch_bounds__(256, WPS) rg_gt_rs_kernel(GtParams P0) {
     float *bias_l = reinterpret_cast<float *>(flag + 4);                         // [2][128] -|b|^2/2 of the tile's rows (L2)
     u64 *cand = P0.cand + (size_t)blockIdx.x * MQB * C;
 
+    uint32_t cursor = P0.items ? P0.item_first[blockIdx.x] : 0u;
+    const uint32_t cursor_end = P0.items ? P0.item_first[blockIdx.x + 1] : 0u;
     for (;;) {
-        if (tid == 0) flag[1] = atomicAdd(P0.counter, 1u);
-        __syncthreads();
-        const uint32_t item = flag[1];
-        __syncthreads();
+        uint32_t item;
+        if (P0.items) {                       // balanced form: this workgroup's own stretch
+            if (cursor >= cursor_end) break;
+            item = cursor++;
+            __syncthreads();
+        } else {
+            if (tid == 0) flag[1] = atomicAdd(P0.counter, 1u);
+            __syncthreads();
+            item = flag[1];
+            __syncthreads();
+        }
         uint32_t blk;
         const GtParams P = gt_segment(P0, item, blk);
         if ((uint64_t)blk * MQB >= P.nq) break;
@@ -613,6 +647,37 @@ __global__ void __launch_bounds__(256, WPS) rg_gt_rs_kernel(GtParams P0) {
     }
 }
 
+// the item table of the balanced form, made on the device (one thread: <= 2 * slots + nblocks items) so that the launch
+// needs no host-to-device copy on the compute stream; the host runs the same loop to size and validate it
+__host__ __device__ inline uint64_t gt_cut(uint32_t w, uint32_t slots, uint64_t per, uint64_t total, uint64_t tpb, uint64_t snap) {
+    if (w >= slots) return total;
+    uint64_t c = (uint64_t)w * per;
+    if (c > total) c = total;
+    const uint64_t r = c % tpb;
+    if (r != 0 && r < snap) c -= r;
+    else if (r != 0 && tpb - r < snap) c += tpb - r;
+    return c < total ? c : total;
+}
+__global__ void rg_gt_items_kernel(uint32_t slots, uint64_t per, uint64_t total, uint64_t tpb, uint64_t snap, uint32_t nb, uint4 *items, uint32_t *first) {
+    if (threadIdx.x || blockIdx.x) return;
+    uint32_t n = 0, cur_blk = 0xffffffffu, cur_list = 0;
+    for (uint32_t w = 0; w < slots; ++w) {
+        first[w] = n;
+        const uint64_t hi = gt_cut(w + 1, slots, per, total, tpb, snap);
+        for (uint64_t c = gt_cut(w, slots, per, total, tpb, snap); c < hi;) {
+            const uint32_t blk = (uint32_t)(c / tpb);
+            const uint64_t t0 = c % tpb, nt = (tpb - t0) < (hi - c) ? (tpb - t0) : (hi - c);
+            const uint32_t row0 = (uint32_t)(t0 * kNB);
+            const uint64_t rows64 = nt * kNB;
+            const uint32_t rows = rows64 < (uint64_t)nb - row0 ? (uint32_t)rows64 : nb - row0;
+            if (blk != cur_blk) { cur_blk = blk; cur_list = 0; }
+            items[n++] = make_uint4(blk, row0, rows, cur_list++);
+            c += nt;
+        }
+    }
+    first[slots] = n;
+}
+
 // bias[i] = -0.5 * |b_i|^2 (one 16-lane group per row)
 __global__ void rg_gt_bias_kernel(const float *base, uint32_t nb, uint32_t bstride, uint32_t dim, float *bias) {
     const uint32_t gid = (blockIdx.x * blockDim.x + threadIdx.x) >> 4, sub = threadIdx.x & 15;
@@ -719,7 +784,7 @@ namespace rg {
 
 void gt_workspace_free(GtWorkspace *ws) {
     if (!ws) return;
-    for (int i = 0; i < 7; ++i) {
+    for (int i = 0; i < 9; ++i) {
         if (ws->p[i]) (void)hipFree(ws->p[i]);
         ws->p[i] = nullptr; ws->cap[i] = 0;
     }
@@ -794,12 +859,51 @@ rg_status gt_shard_ws(const float *d_base, uint32_t nb, uint32_t bstride, const 
         nseg = (nb + seg_rows - 1) / seg_rows;
         if (nb - (nseg - 1) * seg_rows < K) nseg = 1, seg_rows = nb;   // the last segment must still hold K rows
     }
-    const uint32_t grid = std::min<uint32_t>(nblocks * nseg, slots);
+    uint32_t grid = std::min<uint32_t>(nblocks * nseg, slots);
+    // Balanced form (round 4).  The work is a rectangle of nblocks query blocks x tpb base tiles.  Equal work items handed out
+    // one by one leave workgroups idle whenever their number is not a multiple of the resident workgroups: 10,000 queries at
+    // d = 200 are 79 blocks x 6 segments = 474 items for 512 workgroups, and with the padding of the last block 0.916 of the
+    // chip does 0.88-efficient work (0.79 of the MFMA peak measured, against 0.88 at 65,536 queries = 512 blocks).  Instead
+    // the rectangle, walked block by block, is cut into `slots` stretches of equal length; a stretch that crosses a block
+    // boundary is two items (a cut closer than `snap` tiles to a block boundary moves onto it: every item keeps >= K rows).
+    // A block's pieces go to separate lists, merged by K3 -- at most lmax = 1024 / K lists, else the older forms stay.
+    uint32_t bal_lists = 0, bal_items = 0;
+    uint64_t bal_per = 0, bal_total = 0, bal_tpb = 0, bal_snap = 0;
+    if (!getenv("RG_GT_NOBALANCE")) {
+        const uint64_t tpb = (nb + kNB - 1) / kNB, total = tpb * nblocks;
+        const uint64_t per = (total + slots - 1) / slots;
+        const uint64_t snap = std::max<uint64_t>((K + kNB - 1) / kNB, 4);
+        // makespan of the older forms: rounds of equal items
+        const uint64_t items_old = (uint64_t)nblocks * nseg, tiles_item = (tpb + nseg - 1) / nseg;
+        const uint64_t span_old = (items_old + slots - 1) / slots * tiles_item;
+        if (total >= slots && per + snap < span_old - span_old / 32 && per > 2 * snap) {
+            // the loop of rg_gt_items_kernel, to size and validate the table
+            uint32_t n = 0, cur_blk = 0xffffffffu, cur_list = 0, max_list = 0;
+            bool ok = true;
+            for (uint32_t w = 0; w < slots; ++w) {
+                const uint64_t hi = gt_cut(w + 1, slots, per, total, tpb, snap);
+                for (uint64_t c = gt_cut(w, slots, per, total, tpb, snap); c < hi;) {
+                    const uint32_t blk = (uint32_t)(c / tpb);
+                    const uint64_t t0 = c % tpb, nt = std::min<uint64_t>(tpb - t0, hi - c);
+                    const uint32_t row0 = (uint32_t)(t0 * kNB), rows = (uint32_t)std::min<uint64_t>(nt * kNB, (uint64_t)nb - row0);
+                    if (blk != cur_blk) { cur_blk = blk; cur_list = 0; }
+                    max_list = std::max(max_list, ++cur_list);
+                    ok = ok && rows >= K;
+                    ++n;
+                    c += nt;
+                }
+            }
+            if (ok && max_list > 1 && (uint64_t)max_list * K <= 1024) {
+                bal_lists = max_list; bal_items = n; bal_per = per; bal_total = total; bal_tpb = tpb; bal_snap = snap;
+            }
+        }
+    }
+    if (bal_lists) { nseg = bal_lists; seg_rows = nb; grid = slots; }
     // scratch, released on every exit path (stream-ordered blocks) or kept for the next call (workspace)
     struct Scratch {
         hipStream_t s;
         GtWorkspace *ws;
-        void *p[7] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        void *p[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
         ~Scratch() { if (!ws) for (void *q : p) if (q) (void)hipFreeAsync(q, s); }
         hipError_t get(int i, size_t bytes) {
             bytes = std::max<size_t>(bytes, 64);
@@ -841,11 +945,23 @@ rg_status gt_shard_ws(const float *d_base, uint32_t nb, uint32_t bstride, const 
     P.counter = counter; P.BK = bk;
     P.diag = getenv("RG_GT_DIAG") ? (uint32_t)atoi(getenv("RG_GT_DIAG")) : 0u;
     P.nseg = nseg; P.seg_rows = seg_rows; P.seg_ids = nullptr; P.seg_vals = nullptr;
+    P.items = nullptr; P.item_first = nullptr;
     if (nseg > 1) {
         RG_HIP(scratch.get(3, (size_t)nseg * nq * K * 4));
         RG_HIP(scratch.get(4, (size_t)nseg * nq * K * 4));
         P.seg_ids = static_cast<uint32_t *>(scratch.p[3]);
         P.seg_vals = static_cast<float *>(scratch.p[4]);
+    }
+    if (bal_lists) {
+        // blocks cut into fewer pieces than bal_lists leave lists unwritten: every list starts as K entries that rank last
+        RG_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(P.seg_vals), (int)0xff800000u, (size_t)nseg * nq * K, s));   // -inf
+        RG_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(P.seg_ids), (int)0xffffffffu, (size_t)nseg * nq * K, s));
+        RG_HIP(scratch.get(7, (size_t)bal_items * sizeof(uint4)));
+        RG_HIP(scratch.get(8, ((size_t)slots + 1) * 4));
+        hipLaunchKernelGGL(rg_gt_items_kernel, dim3(1), dim3(1), 0, s, slots, bal_per, bal_total, bal_tpb, bal_snap, nb, static_cast<uint4 *>(scratch.p[7]),
+                           static_cast<uint32_t *>(scratch.p[8]));
+        P.items = static_cast<const uint4 *>(scratch.p[7]);
+        P.item_first = static_cast<const uint32_t *>(scratch.p[8]);
     }
     rg_status st;
     if (rs_tmw) {

@@ -103,13 +103,14 @@ struct Pool {
 };
 
 Pool g_pool[16];
-bool g_off = false, g_off_read = false, g_trace = false;
+bool g_off = false, g_off_read = false, g_trace = false, g_trace2 = false;
 
 bool off() {
     if (!g_off_read) {
         const char *e = getenv("RG_BALANCED_ALLOC");
         g_off = e && atoi(e) == 0;
         g_trace = getenv("RG_TRACE_ALLOC") != nullptr;
+        g_trace2 = g_trace && atoi(getenv("RG_TRACE_ALLOC")) >= 2;
         g_off_read = true;
     }
     return g_off;
@@ -257,7 +258,9 @@ rg_status dev_alloc(int device, size_t bytes, void **out) {
         if (!new_granule(P, device, &g)) break;
         walked += kGranule;
         bool is_rep = false;
+        if (g_trace2) fprintf(stderr, "[rg_mem]   granule at %p (free %.1f GiB, pooled %zu, held %zu, ballast %zu)\n", g.va, (double)free_b / (1u << 30), pooled, held.size(), ballast.size());
         const int c = classify(P, g, &is_rep);
+        if (g_trace2) fprintf(stderr, "[rg_mem]   -> class %d%s\n", c, is_rep ? " (new)" : "");
         if (c < 0) { drop_granule(g); break; }
         g.cls = c;
         if (is_rep) { P.reps.push_back(g); same_in_a_row = 0; continue; }
@@ -382,4 +385,43 @@ extern "C" rg_status rg_mem_stats(int device, uint64_t *buffers, uint64_t *plain
             for (int k = 0; k < 4; ++k) granules_per_class[k] += (uint64_t)kv.second.per_class[k];
     }
     return RG_OK;
+}
+
+// diagnostics (scripts/exp/mem_stress.py): `rounds` times, buffers of the given sizes are allocated, every page of each is
+// written and read back by a kernel, and all are freed again in a shuffled order.  Returns the number of mismatching words.
+__global__ void rg_mem_fill_kernel(uint32_t *p, size_t words, uint32_t tag) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (size_t)gridDim.x * blockDim.x) p[i] = tag ^ (uint32_t)i;
+}
+__global__ void rg_mem_check_kernel(const uint32_t *p, size_t words, uint32_t tag, unsigned long long *bad) {
+    unsigned long long mine = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (size_t)gridDim.x * blockDim.x) mine += p[i] != (tag ^ (uint32_t)i) ? 1u : 0u;
+    if (mine) atomicAdd(bad, mine);
+}
+extern "C" rg_status rg_mem_selftest(int device, const uint64_t *sizes, int nsizes, int rounds, uint64_t *mismatches) {
+    if (!sizes || nsizes <= 0 || !mismatches) return rg::set_error(RG_ERR_ARG, "null argument");
+    if (hipSetDevice(device) != hipSuccess) return rg::set_error(RG_ERR_DEVICE, "cannot select the device");
+    unsigned long long *d_bad = nullptr;
+    if (hipMalloc(&d_bad, 8) != hipSuccess) return rg::set_error(RG_ERR_OOM, "hipMalloc");
+    (void)hipMemset(d_bad, 0, 8);
+    rg_status st = RG_OK;
+    for (int r = 0; r < rounds && st == RG_OK; ++r) {
+        std::vector<void *> bufs((size_t)nsizes, nullptr);
+        for (int i = 0; i < nsizes && st == RG_OK; ++i) {
+            st = rg::dev_alloc(device, (size_t)sizes[i], &bufs[(size_t)i]);
+            if (st != RG_OK) break;
+            hipLaunchKernelGGL(rg_mem_fill_kernel, dim3(4096), dim3(256), 0, 0, (uint32_t *)bufs[(size_t)i], (size_t)sizes[i] / 4, 0x5bd1e995u * (uint32_t)(r * 131 + i + 1));
+        }
+        for (int i = 0; i < nsizes && st == RG_OK; ++i)
+            if (bufs[(size_t)i])
+                hipLaunchKernelGGL(rg_mem_check_kernel, dim3(4096), dim3(256), 0, 0, (const uint32_t *)bufs[(size_t)i], (size_t)sizes[i] / 4,
+                                   0x5bd1e995u * (uint32_t)(r * 131 + i + 1), d_bad);
+        if (hipDeviceSynchronize() != hipSuccess) st = rg::set_error(RG_ERR_DEVICE, "a self-test kernel failed");
+        for (int i = 0; i < nsizes; ++i) rg::dev_free(bufs[(size_t)((i * 7 + r) % nsizes)]), bufs[(size_t)((i * 7 + r) % nsizes)] = nullptr;
+        rg::dev_trim(device);
+    }
+    unsigned long long h = 0;
+    (void)hipMemcpy(&h, d_bad, 8, hipMemcpyDeviceToHost);
+    (void)hipFree(d_bad);
+    *mismatches = h;
+    return st;
 }

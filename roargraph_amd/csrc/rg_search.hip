@@ -1159,7 +1159,7 @@ static rg_status search_dev(rg_index *ix, SearchCtx *cx, const float *d_q, uint3
         }
     }
     // Adaptive default: both exact forms return the same bits.  When a batch showed the LDS filter re-scoring nodes
-    // at this beam width (performed > 1.08 x distinct: long searches on indexes with locality), the next batch
+    // at this beam width (performed > 1.04 x distinct: long searches on indexes with locality), the next batch
     // of that width runs on the exact HBM words as a timed trial; the faster form is kept from that width on (which one
     // wins depends on the index: the words of a 10M-node index are 10 GB of random atomics, those of a 2M-node index
     // mostly cache resident -- scripts/exp/visited_modes_real.py).
@@ -1266,7 +1266,9 @@ static rg_status finish_batches(rg_index *ix, SearchCtx *cx, hipStream_t s, uint
                 fprintf(stderr, "[rg_search] batch L=%u nq=%u form=%s%s%s: %.3f us/query\n", b->L, b->nq, b->mode == 0 ? "exact words" : "filter+log",
                         b->is_trial ? " (trial)" : "", b->cold ? " (cold: not a measurement)" : "", per_q * 1e3f);
             if (b->mode == 0 && b->is_trial && per_q > 0.0f) {   // verdict of the trial
-                if (per_q < 0.97f * ix->filter_per_q) ix->exact_from_L = std::min(ix->exact_from_L, b->L);
+                // (round 4: any measurable win -- with the tags spread over the memory classes the exact set is 2 - 13 % ahead from
+                // L_pq 500 up on the 10M bench index, and a verdict that asked for 3 % left the 500 point on the slower form)
+                if (per_q < 0.99f * ix->filter_per_q) ix->exact_from_L = std::min(ix->exact_from_L, b->L);
                 else ix->filter_ok_upto = std::max(ix->filter_ok_upto, b->L);
                 if (ix->trial_L == b->L) ix->trial_L = 0;
                 if (trace)
@@ -1286,9 +1288,9 @@ static rg_status finish_batches(rg_index *ix, SearchCtx *cx, hipStream_t s, uint
                     if (trace) fprintf(stderr, "[rg_search] batch L=%u nq=%u form=exact LDS set: %llu queries outgrew it\n", b->L, b->nq, left);
                     if ((double)left > 0.03 * (double)b->nq && b->nq >= 64) ix->lset_bad_from = std::min(ix->lset_bad_from, b->L);
                 }
-                // (round 3: from 8 % of re-scored nodes -- it was 30 % -- : with byte tags and the bit screen the exact set wins
+                // (round 4: from 4 % of re-scored nodes; round 3: 8 % -- it was 30 % -- : with byte tags and the bit screen the exact set wins
                 // earlier, at d = 512 from L_pq 200 where the filter re-scores a sixth; a trial costs one batch in the other form)
-                if (distinct > 0 && (double)performed > 1.08 * (double)distinct && per_q > 0.0f && b->nq >= 1000 &&
+                if (distinct > 0 && (double)performed > 1.04 * (double)distinct && per_q > 0.0f && b->nq >= 1000 &&
                     b->L > ix->filter_ok_upto && b->L < ix->exact_from_L) {
                     ix->trial_L = b->L;      // next batch of this width: the exact words, timed
                     ix->filter_per_q = per_q;
@@ -1606,6 +1608,30 @@ rg_status rg_index_open(const char *base_fbin, const char *index_path, int metri
     st = rg_index_open_mem(base, nb, dim, stride, off, nbrs, ep, metric, device, out);
     rg_free(base); rg_free(off); rg_free(nbrs);
     return st;
+}
+
+rg_status rg_index_open_multi(const char *base_fbin, const char *index_path, int metric, const int *devices, int ndev, rg_index **out) {
+    if (!base_fbin || !index_path || !devices || !out || ndev <= 0) return set_error(RG_ERR_ARG, "null argument");
+    for (int r = 0; r < ndev; ++r) out[r] = nullptr;
+    uint32_t nb = 0, dim = 0, stride = 0, nd = 0, ep = 0;
+    float *base = nullptr;
+    uint64_t *off = nullptr;
+    uint32_t *nbrs = nullptr;
+    rg_status st = rg_fbin_load(base_fbin, &nb, &dim, &stride, &base);      // the files are read once, every replica is uploaded from memory
+    if (st != RG_OK) return st;
+    st = rg_graph_load(index_path, &nd, &ep, &off, &nbrs);
+    if (st == RG_OK && nd != nb) st = set_error(RG_ERR_FORMAT, "index and base file disagree on the number of points");
+    std::string msg = st != RG_OK ? rg_last_error() : "";
+    for (int r = 0; r < ndev && st == RG_OK; ++r) {
+        st = rg_index_open_mem(base, nb, dim, stride, off, nbrs, ep, metric, devices[r], &out[r]);
+        if (st != RG_OK) msg = rg_last_error();
+    }
+    rg_free(base); rg_free(off); rg_free(nbrs);
+    if (st != RG_OK) {
+        for (int r = 0; r < ndev; ++r) { if (out[r]) rg_index_close(out[r]); out[r] = nullptr; }
+        return set_error(st, msg);
+    }
+    return RG_OK;
 }
 
 rg_status rg_index_info(const rg_index *ix, uint32_t *nd, uint32_t *dim, uint32_t *stride, uint32_t *ep,

@@ -97,6 +97,15 @@ class IndexBipartite:
     def set(self, name, value):
         check(lib().rg_index_set(self.handle, name.encode(), int(value)))
 
+    def mem_stats(self):
+        """rg_mem_stats of this index's device: balanced buffers made, large requests that fell back to plain allocations,
+        memory classes found, 1-GiB granules of the live buffers per class"""
+        nb, npl, nc = C.c_uint64(), C.c_uint64(), C.c_uint32()
+        per = (C.c_uint64 * 4)()
+        check(lib().rg_mem_stats(C.c_int(self.info()["device"]), C.byref(nb), C.byref(npl), C.byref(nc), per))
+        return {"balanced_buffers": int(nb.value), "plain_fallbacks": int(npl.value), "memory_classes_found": int(nc.value),
+                "GiB_of_live_buffers_per_class": [int(x) for x in per]}
+
     def stat(self, name):
         """counters of the search path since open (rg_index_stat): batches_lset / batches_filter_log / batches_exact_hbm /
         batches_filter_only, lset_left, recounted"""

@@ -105,3 +105,25 @@ def test_row_shards_are_balanced_and_owned_rows_partition_the_job():
     for nq, w, batch in ((210, 3, 64), (65536 * 2 + 5, 8, 0), (7, 2, 100), (64, 4, 64)):
         rows = np.concatenate([groundtruth.owned_rows(nq, w, r, batch) for r in range(w)])
         assert rows.shape[0] == nq and (np.sort(rows) == np.arange(nq)).all()
+
+
+def test_bench_plan_for_eight_gpus_at_the_10m_shape():
+    """A dry run of `bench.py --gpus 8` (no 8-GPU node was available to any round so far): per-rank query
+    batches, the row shards and owned query ranges of the training-query ground truth, the index broadcast, and the owner
+    rows of the gt_build leg -- every partition complete and disjoint, the loads equal to within one row."""
+    from roargraph_amd import dist as rgdist
+    from roargraph_amd import groundtruth
+    nb, nq, ntrain, gt_nq = 10_000_000, 10_000, 2_000_000, 262_144
+    p = rgdist.bench_plan(8, nb, nq, ntrain, gt_nq, avg_degree=14.6)
+    assert [s["first_batch_seed"] for s in p["search"]] == list(range(99, 107)) and all(s["queries_per_step"] == nq for s in p["search"])
+    rows = [tuple(t["base_rows"]) for t in p["train_truth"]]
+    assert rows[0][0] == 0 and rows[-1][1] == nb and all(a[1] == b[0] for a, b in zip(rows, rows[1:]))
+    assert {hi - lo for lo, hi in rows} == {1_250_000}
+    owned = [tuple(t["owned_queries"]) for t in p["train_truth"]]
+    assert owned[0][0] == 0 and owned[-1][1] == ntrain and all(a[1] == b[0] for a, b in zip(owned, owned[1:]))
+    assert sum(t["scores"] for t in p["train_truth"]) == nb * ntrain                     # 2e13 scores, an eighth each
+    assert all(t["all_to_all_send_bytes"] == ntrain * 100 * 8 * 7 // 8 for t in p["train_truth"])
+    assert p["index_broadcast_bytes"] == (nb + 1) * 8 + int(14.6 * nb) * 4 and p["replica_bytes_per_gpu"] < 12e9
+    assert sum(g["owned_rows"] for g in p["gt_build"]) == gt_nq and {g["owned_rows"] for g in p["gt_build"]} == {gt_nq // 8}
+    all_rows = np.concatenate([groundtruth.owned_rows(gt_nq, 8, r, 65536) for r in range(8)])
+    assert (np.sort(all_rows) == np.arange(gt_nq)).all()

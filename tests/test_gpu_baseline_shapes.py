@@ -157,3 +157,92 @@ def test_config4_gt_unit_norm_clustered_l2_k100(oracle):
     mi = torch.zeros_like(ids); mv = torch.zeros_like(vals)
     groundtruth.gt_merge_dev(parts_i, parts_v, 3, nq, K, "l2", mi, mv); torch.cuda.synchronize()
     assert torch.equal(mi, ids) and torch.equal(mv.view(torch.int32), vals.view(torch.int32))
+
+
+def _full_size_sample(oracle, ix, base, off, nbrs, ep, q, metric, cases, ns, knob_sets):
+    """every (k, L) of `cases` through the device form on the whole batch in every knob set, then the first `ns` queries
+    against the oracle over the same full-size inputs; all knob sets must agree on the whole batch bit for bit"""
+    import torch
+    dev = q.device
+    nq = q.shape[0]
+    outs = {}
+    for name, knobs in knob_sets:
+        for kn, v in knobs.items():
+            ix.set(kn, v)
+        for k, L in cases:
+            ids = torch.zeros((nq, k), dtype=torch.int32, device=dev); ds = torch.zeros((nq, k), device=dev)
+            cm = torch.zeros(nq, dtype=torch.int32, device=dev); hp = torch.zeros(nq, dtype=torch.int32, device=dev)
+            ix.search_dev(q, k, L, ids, ds, cm, hp); ix.search_wait()
+            outs[(name, k, L)] = tuple(x.cpu().numpy() for x in (ids, ds, cm, hp))
+    hb, hq = base.cpu().numpy(), q[:ns].cpu().numpy()
+    hoff, hn = off.cpu().numpy().view(np.uint64), nbrs.cpu().numpy().view(np.uint32)
+    for k, L in cases:
+        want = oracle.search(hb, metric, hoff, hn, ep, hq, k, L, nthreads=min(32, os.cpu_count() or 1))
+        first = knob_sets[0][0]
+        for name, _ in knob_sets:
+            got = tuple(x[:ns] for x in outs[(name, k, L)])
+            _search_equal((got[0].view(np.uint32), got[1], got[2].view(np.uint32), got[3].view(np.uint32)), want)
+            for a, b in zip(outs[(name, k, L)], outs[(first, k, L)]):
+                assert (a.view(np.uint32) == b.view(np.uint32)).all(), (name, k, L)
+    return outs
+
+
+def test_config4_10m_x_512_l2_top100_parity_sample(oracle):
+    """BASELINE configs[3] at full size: 10M x 512, squared L2, top-100 -- 96 queries of a 2,048-query batch at L_pq = 200 and
+    1000 against the oracle over the same 20.5 GB base, in the default visited mode, on the exact tags and on the filter
+    alone (ids / distances / hops; the whole batch equal between the forms).  The adjacency mixes uniformly random edges
+    with edges to nearby ids (nodes are met again and again), as in the d = 200 test above."""
+    import torch
+    from roargraph_amd.index import IndexBipartite
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev); g.manual_seed(20254)
+    nb, d, deg, nq, ns = 10_000_000, 512, 40, 2048, 96
+    base = torch.empty((nb, d), device=dev)
+    for s in range(0, nb, 1 << 19):
+        base[s:s + (1 << 19)].normal_(generator=g)
+    nbrs = torch.randint(0, nb, (nb, deg), dtype=torch.int64, device=dev, generator=g)
+    near = (torch.arange(nb, device=dev)[:, None] + torch.randint(-48, 49, (nb, deg // 2), device=dev, generator=g)).clamp_(0, nb - 1)
+    nbrs[:, : deg // 2] = near
+    del near
+    nbrs = nbrs.to(torch.int32).reshape(-1)
+    off = torch.arange(0, nb + 1, dtype=torch.int64, device=dev) * deg
+    q = torch.empty((nq, d), device=dev).normal_(generator=g) * 0.5 + 0.3
+    ix = IndexBipartite.from_device(base, off, nbrs, 4321, metric="l2")
+    _full_size_sample(oracle, ix, base, off, nbrs, 4321, q, "l2", ((100, 200), (100, 1000)), ns,
+                      (("default", {"visited": 2}), ("exact_tags", {"visited": 0})))
+    ix.close()
+
+
+def test_config5_2p5m_x_512_ip_product_built_index(oracle):
+    """BASELINE configs[4] at full size, over an index the product built: 2.5M x 512 inner product, ground truth of 500k training
+    queries (K2) -> GPU-assisted construction (M_sq = 100, M_pjbp = 35, L_pjpq = 500) -> 2,048 queries, top-10, L_pq = 50 and
+    500; the first 128 against the oracle over the same index, default mode and exact tags; the eval-side ground truth of those
+    128 against fp64."""
+    import torch
+    from roargraph_amd import build, groundtruth, synth
+    from roargraph_amd.index import IndexBipartite
+    dev = torch.device("cuda", 0)
+    nb, d, ntrain, nq, ns = 2_500_000, 512, 500_000, 2048, 128
+    base, train, q, _ = synth.make_device_set(dev, 77, nb, ntrain, nq, d, data="lowrank", rank=32, q_seed=5)
+    ti, _ = groundtruth.groundtruth_distributed(base, 0, train, "ip", 100)
+    torch.cuda.synchronize()
+    h_off, h_nbrs, ep = build.build_roargraph(base.cpu().numpy(), ti.cpu().numpy().view(np.uint32), "ip", 100, 35, 500,
+                                              num_threads=min(64, os.cpu_count() or 1), device=0)
+    del train, ti
+    deg = np.diff(h_off.astype(np.int64))
+    assert deg.max() <= 70 and deg.mean() > 8 and int(h_nbrs.max()) < nb
+    off = torch.from_numpy(h_off.view(np.int64)).to(dev)
+    nbrs = torch.from_numpy(h_nbrs.view(np.int32)).to(dev)
+    ix = IndexBipartite.from_device(base, off, nbrs, ep, metric="ip")
+    outs = _full_size_sample(oracle, ix, base, off, nbrs, ep, q, "ip", ((10, 50), (10, 500)), ns,
+                             (("default", {"visited": 2}), ("exact_tags", {"visited": 0})))
+    ix.close()
+    # recall of the sample against fp64 truth: a genuine index over structured data reaches 0.9 well before L_pq = 500
+    gi = torch.zeros((ns, 100), dtype=torch.int32, device=dev); gv = torch.zeros((ns, 100), device=dev)
+    groundtruth.gt_shard_dev(base, q[:ns].contiguous(), "ip", 100, 0, gi, gv); torch.cuda.synchronize()
+    hb, hq = base.cpu().numpy(), q[:ns].cpu().numpy()
+    ref_ids, _, ref_s = oracle.groundtruth_f64(hb, hq, "ip", 100, nthreads=min(32, os.cpu_count() or 1))
+    check_gt(hb, hq, "ip", 100, gi.cpu().numpy().view(np.uint32), gv.cpu().numpy(), ref_ids, ref_s)
+    from roargraph_amd import index as ixmod
+    rec = ixmod.recall(outs[("default", 10, 500)][0][:ns].view(np.uint32), ref_ids, 10)
+    assert rec > 0.95, rec
