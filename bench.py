@@ -78,6 +78,7 @@ def parse():
                     "of its own with roofline and cpu_baseline (rank 0, N = 1): rank128 = a harder data set (latent rank 128: 0.9 recall "
                     "needs a beam ten times as wide), webvid = BASELINE configs[4] end to end (2.5M x 512 IP: ground truth -> build -> "
                     "search), laion = BASELINE configs[3] shape (d = 512 L2 top-100) at the size --laion-nb; empty = none")
+    ap.add_argument("--side-nb", type=int, default=0, help="rows of EVERY side block (tests: small sets); 0 = their own sizes")
     ap.add_argument("--laion-nb", type=int, default=4_000_000, help="rows of the laion-shaped side block (the full 10M x 512 run: "
                     "python bench.py --nb 10000000 --dim 512 --metric l2 --k 100 --configs '')")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall budget of each CPU baseline sample (0 = skip)")
@@ -575,8 +576,12 @@ def main():
             # touches, and how many go to rows a 256-MiB cache could hold (null: the launch ran on the exact words)
             ru = reuse_of_last_launch(torch, index, stream, args.nb, args.nq, dev)
             if ru is None:     # narrow beams run on the exact LDS set (no id logs): one untimed launch in the logging form, for the statistics only
-                index.set("lset", 0); S.run(L, 0); S.wait()
-                ru = reuse_of_last_launch(torch, index, stream, args.nb, args.nq, dev)
+                index.set("lset", 0)
+                for _ in range(3):      # (a batch may be the adaptive default's timed trial of the exact tags: no logs either)
+                    S.run(L, 0); S.wait()
+                    ru = reuse_of_last_launch(torch, index, stream, args.nb, args.nq, dev)
+                    if ru is not None:
+                        break
                 index.set("lset", -1)
             pt["distinct_rows_frac"] = ru["distinct_rows_frac"] if ru else None
             pt["share_of_reads_to_rows_a_256MiB_cache_can_hold"] = ru["share_of_reads_to_top_%d_rows" % MALL_ROWS] if ru else None
@@ -639,8 +644,12 @@ def main():
     if args.visited == 2:
         reuse = reuse_of_last_launch(torch, index, stream, args.nb, args.nq, dev, full=True)
         if reuse is None:      # the headline ran on the exact LDS set (no id logs): one untimed launch in the logging form, for the statistics only
-            index.set("lset", 0); S.run(L_star, 0); S.wait()
-            reuse = reuse_of_last_launch(torch, index, stream, args.nb, args.nq, dev, full=True)
+            index.set("lset", 0)
+            for _ in range(3):
+                S.run(L_star, 0); S.wait()
+                reuse = reuse_of_last_launch(torch, index, stream, args.nb, args.nq, dev, full=True)
+                if reuse is not None:
+                    break
             index.set("lset", -1)
             S.run(L_star, 0); S.wait()
         reuse = reuse or {"unavailable": "the launch ran on the exact words: no id logs"}
@@ -912,6 +921,8 @@ def main():
             if cname not in defs:
                 raise SystemExit("--configs: unknown block %r (rank128, webvid, laion)" % cname)
             d_ = defs[cname]
+            if args.side_nb:
+                d_["nb"] = args.side_nb
             side_blocks.append(side_config(torch, dev, stream, cname, d_["nb"], d_["dim"], d_["metric"], d_["k"], d_["rank_latent"], d_["nb"] // 5, args.nq,
                                            d_["Ls"], args.target_recall, min(args.cpu_seconds, 6.0), min(args.steps, 5), d_["what"]))
     else:

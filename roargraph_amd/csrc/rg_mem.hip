@@ -23,6 +23,7 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -116,26 +117,78 @@ bool off() {
     return g_off;
 }
 
+// debugging knobs of the mapping path (round 4: stale translations after unmap were suspected): RG_MEM_NOVAFREE=1 never hands a
+// virtual range back (no range is ever mapped twice), RG_MEM_FENCE=1 synchronises the device around every map / unmap
+bool knob(const char *name) { const char *e = getenv(name); return e && atoi(e) != 0; }
+void va_unmap(void *va, size_t bytes) {
+    static const bool fence = knob("RG_MEM_FENCE");
+    if (fence) (void)hipDeviceSynchronize();
+    (void)hipMemUnmap(va, bytes);
+    if (fence) (void)hipDeviceSynchronize();
+}
+// Virtual ranges are NEVER handed back to the runtime.  Measured (scripts/exp/mem_stress.py, profiles/r04/mem_stress_*.log; HIP
+// 7.0.51831 on the GPU box): after hipMemAddressFree a later reservation can return the same range, and accesses through it
+// then reach the physical memory of the OLD mapping -- whole granules of a buffer read back another buffer's data, or the GPU
+// faults when that memory went back to the driver (4 of 4 stress runs; 0 of 4 when no range is ever freed; device
+// synchronisation around every map / unmap changes nothing).  RG_MEM_VA: "leak" (default) = a range is used once;
+// "reuse" = ranges of equal size are kept in a list of the library's own and mapped again (experiment);
+// "free" = hipMemAddressFree (the behaviour that corrupts: only to reproduce it).
+enum VaMode { kVaLeak, kVaReuse, kVaFree };
+VaMode va_mode() {
+    static const VaMode m = [] {
+        const char *e = getenv("RG_MEM_VA");
+        if (e && !strcmp(e, "reuse")) return kVaReuse;
+        if (e && !strcmp(e, "free")) return kVaFree;
+        return kVaLeak;
+    }();
+    return m;
+}
+std::mutex g_va_mu;
+std::map<size_t, std::vector<void *>> g_va_spare;
+uint64_t g_va_reserved = 0;        // bytes of virtual address space reserved so far (rg_mem_stats)
+void va_free(void *va, size_t bytes) {
+    if (va_mode() == kVaFree) (void)hipMemAddressFree(va, bytes);
+    else if (va_mode() == kVaReuse) { std::lock_guard<std::mutex> lk(g_va_mu); g_va_spare[bytes].push_back(va); }
+}
+bool va_reserve(void **va, size_t bytes) {
+    if (va_mode() == kVaReuse) {
+        std::lock_guard<std::mutex> lk(g_va_mu);
+        auto it = g_va_spare.find(bytes);
+        if (it != g_va_spare.end() && !it->second.empty()) { *va = it->second.back(); it->second.pop_back(); return true; }
+    }
+    {   // ranges are used once: a process that has gone through 64 TiB of them (hundreds of index opens) gets plain allocations from then on
+        std::lock_guard<std::mutex> lk(g_va_mu);
+        if (va_mode() == kVaLeak && g_va_reserved + bytes > ((uint64_t)64 << 40)) return false;
+    }
+    if (hipMemAddressReserve(va, bytes, kGranule, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); return false; }
+    std::lock_guard<std::mutex> lk(g_va_mu);
+    g_va_reserved += bytes;
+    return true;
+}
+
 bool map_at(void *va, size_t bytes, hipMemGenericAllocationHandle_t h, int device) {
+    static const bool fence = knob("RG_MEM_FENCE");
+    if (fence) (void)hipDeviceSynchronize();
     if (hipMemMap(va, bytes, 0, h, 0) != hipSuccess) return false;
     hipMemAccessDesc d{};
     d.location.type = hipMemLocationTypeDevice;
     d.location.id = device;
     d.flags = hipMemAccessFlagsProtReadWrite;
-    if (hipMemSetAccess(va, bytes, &d, 1) != hipSuccess) { (void)hipMemUnmap(va, bytes); return false; }
+    if (hipMemSetAccess(va, bytes, &d, 1) != hipSuccess) { va_unmap(va, bytes); return false; }
+    if (fence) (void)hipDeviceSynchronize();
     return true;
 }
 
 bool new_granule(Pool &P, int device, Granule *g) {
     if (hipMemCreate(&g->h, kGranule, &P.prop, 0) != hipSuccess) { (void)hipGetLastError(); return false; }
-    if (hipMemAddressReserve(&g->va, kGranule, kGranule, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); (void)hipMemRelease(g->h); return false; }
-    if (!map_at(g->va, kGranule, g->h, device)) { (void)hipGetLastError(); (void)hipMemAddressFree(g->va, kGranule); (void)hipMemRelease(g->h); return false; }
+    if (!va_reserve(&g->va, kGranule)) { (void)hipMemRelease(g->h); return false; }
+    if (!map_at(g->va, kGranule, g->h, device)) { (void)hipGetLastError(); va_free(g->va, kGranule); (void)hipMemRelease(g->h); return false; }
     g->cls = -1;
     return true;
 }
 
 void drop_granule(Granule &g) {
-    if (g.va) { (void)hipMemUnmap(g.va, kGranule); (void)hipMemAddressFree(g.va, kGranule); }
+    if (g.va) { va_unmap(g.va, kGranule); va_free(g.va, kGranule); }
     (void)hipMemRelease(g.h);
     g.va = nullptr;
 }
@@ -295,7 +348,7 @@ rg_status dev_alloc(int device, size_t bytes, void **out) {
         return plain();
     }
     void *va = nullptr;
-    if (hipMemAddressReserve(&va, n * kGranule, kGranule, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); release_ballast(); ++P.n_plain; return plain(); }
+    if (!va_reserve(&va, n * kGranule)) { release_ballast(); ++P.n_plain; return plain(); }
     Buffer buf;
     buf.bytes = n * kGranule;
     std::vector<Granule> taken;
@@ -312,17 +365,17 @@ rg_status dev_alloc(int device, size_t bytes, void **out) {
     bool ok = true;
     for (size_t i = 0; i < n && ok; ++i) {
         Granule &g = taken[i];
-        (void)hipMemUnmap(g.va, kGranule);
-        (void)hipMemAddressFree(g.va, kGranule);
+        va_unmap(g.va, kGranule);
+        va_free(g.va, kGranule);
         g.va = nullptr;
         ok = map_at((char *)va + i * kGranule, kGranule, g.h, device);
         if (ok) buf.handles.push_back(g.h);
     }
     if (!ok) {
         (void)hipGetLastError();
-        for (size_t i = 0; i < buf.handles.size(); ++i) (void)hipMemUnmap((char *)va + i * kGranule, kGranule);
+        for (size_t i = 0; i < buf.handles.size(); ++i) va_unmap((char *)va + i * kGranule, kGranule);
         for (Granule &g : taken) (void)hipMemRelease(g.h);
-        (void)hipMemAddressFree(va, n * kGranule);
+        va_free(va, n * kGranule);
         release_ballast();
         ++P.n_plain;
         return plain();
@@ -350,10 +403,10 @@ void dev_free(void *p) {
         Buffer &b = it->second;
         (void)hipDeviceSynchronize();
         for (size_t i = 0; i < b.handles.size(); ++i) {
-            (void)hipMemUnmap((char *)p + i * kGranule, kGranule);
+            va_unmap((char *)p + i * kGranule, kGranule);
             (void)hipMemRelease(b.handles[i]);
         }
-        (void)hipMemAddressFree(p, b.bytes);
+        va_free(p, b.bytes);
         P.live.erase(it);
         return;
     }

@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""K2 at query counts that do not fill the chip with whole query blocks: balanced work split (round 4) against equal items
+handed out by a counter (RG_GT_NOBALANCE=1).  One launch per (form, nq) over a 10M x d base, % of the 157.3 TFLOP/s fp32-MFMA peak."""
+import json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+import torch
+from roargraph_amd import groundtruth
+dev = torch.device("cuda", 0)
+d = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+nb = int(sys.argv[2]) if len(sys.argv) > 2 else 10_000_000
+nqs = [int(x) for x in (sys.argv[3] if len(sys.argv) > 3 else "10000,16384,30000,65536,100000").split(",")]
+metric = sys.argv[4] if len(sys.argv) > 4 else "ip"
+g = torch.Generator(device=dev); g.manual_seed(1)
+base = torch.empty((nb, d), device=dev)
+for s in range(0, nb, 1 << 20):
+    base[s:s + (1 << 20)].normal_(generator=g)
+K = 100
+for nq in nqs:
+    q = torch.empty((nq, d), device=dev).normal_(generator=g) * 0.5 + 0.3
+    ids = torch.zeros((nq, K), dtype=torch.int32, device=dev); vals = torch.zeros((nq, K), device=dev)
+    ref = None
+    for form, env in (("balanced", None), ("equal_items", "1")):
+        if env: os.environ["RG_GT_NOBALANCE"] = env
+        else: os.environ.pop("RG_GT_NOBALANCE", None)
+        groundtruth.gt_shard_dev(base, q, metric, K, 0, ids, vals); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        groundtruth.gt_shard_dev(base, q, metric, K, 0, ids, vals); torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        same = None if ref is None else bool(torch.equal(ref, ids))
+        ref = ids.clone() if ref is None else ref
+        print(json.dumps({"d": d, "nq": nq, "form": form, "seconds": round(dt, 4), "TFLOPs": round(2.0 * d * nq * nb / dt / 1e12, 2),
+                          "frac_of_157.3": round(2.0 * d * nq * nb / dt / 1e12 / 157.3, 4), "ids_equal_first_form": same}), flush=True)

@@ -274,11 +274,18 @@ def test_bench_one_gpu_small_run_reports_every_block():
     import json
     import sys
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--nb", "300000", "--nq", "1000", "--gt-nq", "65536",
-           "--cpu-seconds", "1", "--sweep", "20,100", "--no-worstcase", "--no-fast", "--config1-nb", "0"]
+           "--cpu-seconds", "1", "--sweep", "20,100", "--no-worstcase", "--no-fast", "--config1-nb", "0", "--configs", "webvid,laion", "--side-nb", "40000"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     d = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert d["n_gpus"] == 1 and d["config"]["distinct_query_batches"] == 6
+    # the side blocks (round 4): d = 512 IP end to end and d = 512 L2 top-100, each with its own roofline and cpu_baseline
+    assert [c["name"] for c in d["configs"]] == ["webvid", "laion"]
+    for c in d["configs"]:
+        assert c["value"] > 0 and 0.0 < c["roofline"]["frac"] and c["recall_at_k"] > 0.5 and c["cpu_baseline"]["value"] > 0
+        assert c["seconds"]["construction"] > 0 and c["seconds"]["train_ground_truth"] > 0
+    assert d["configs"][1]["recall_k"] == 100 and "l2" in d["configs"][1]["workload"]
+    assert d["roofline"]["frac_cache_served"] is not None and "frac_hbm_only" in d["roofline"]
     rf = d["roofline"]
     assert 0.0 < rf["frac"] and rf["distinct_rows_frac"] is not None and 0.0 < rf["distinct_rows_frac"] <= 1.0
     assert 0.0 < rf["cache_served_frac_ceiling"] <= 1.0 and rf["hbm_frac_floor"] is not None
@@ -307,7 +314,7 @@ def test_bench_on_the_reference_file_layout(tmp_path):
     io.write_fbin(str(tmp_path / "query.10k.fbin"), mk(700))
     io.write_fbin(str(tmp_path / "query.train.10M.fbin"), mk(20000))
     common = [sys.executable, os.path.join(ROOT, "bench.py"), "--data-root", str(tmp_path), "--steps", "2", "--warmup", "1", "--nq", "512",
-              "--gt-nq", "0", "--cpu-seconds", "0", "--sweep", "20,100", "--no-worstcase", "--no-fast", "--config1-nb", "0"]
+              "--gt-nq", "0", "--cpu-seconds", "0", "--sweep", "20,100", "--no-worstcase", "--no-fast", "--config1-nb", "0", "--configs", ""]
     r = subprocess.run(common + ["--index-cache", str(tmp_path / "g.npz")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     d1 = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
