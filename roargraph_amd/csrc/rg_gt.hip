@@ -876,7 +876,10 @@ rg_status gt_shard_ws(const float *d_base, uint32_t nb, uint32_t bstride, const 
         // makespan of the older forms: rounds of equal items
         const uint64_t items_old = (uint64_t)nblocks * nseg, tiles_item = (tpb + nseg - 1) / nseg;
         const uint64_t span_old = (items_old + slots - 1) / slots * tiles_item;
-        if (total >= slots && per + snap < span_old - span_old / 32 && per > 2 * snap) {
+        // (measured, scripts/exp/gt_small_batch.py: where the equal items fit ONE round the balanced form is 2 % behind -- an idle
+        // workgroup slot leaves its CU's MFMA pipes to the neighbour, and more pieces mean more cold thresholds -- 0.730 vs 0.746 of
+        // peak at 10,000 queries; with a partial second round it is 16 % ahead: 0.789 vs 0.681 at 100,000)
+        if (total >= slots && items_old > slots && per + snap < span_old - span_old / 8 && per > 2 * snap) {
             // the loop of rg_gt_items_kernel, to size and validate the table
             uint32_t n = 0, cur_blk = 0xffffffffu, cur_list = 0, max_list = 0;
             bool ok = true;

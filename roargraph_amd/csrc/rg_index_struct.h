@@ -122,6 +122,7 @@ struct rg_index {
     int count_in_k1 = -1;        // knob: beams up to this wide count their distinct ids inside K1 (-1 = 40, 0 = never: K4 counts)
     int count_tail = 0;          // knob (round 4, measured and left off): the distinct counts are made in the tail of the launch, by the waves
                                  // that found the work queue empty (0 = off, N = beams up to N wide); takes precedence over count_in_k1
+    bool adaptive = true;        // knob: 0 = the default visited mode never leaves (or tries to leave) its filter + log + K4 form for the exact tags
     int lset_bytes = 0;          // knob (tests): cap of the exact LDS set's region in bytes (0 = what the launch has)
     int lset = -1;               // knob "lset" (round 4): default visited mode, narrow beams: the exact visited set in LDS (K1 VIS = 3: no id
                                  // log, no K4, no de-duplicating inserts).  -1 = wherever a query's visits fit the LDS a launch can give it,

@@ -1163,7 +1163,7 @@ static rg_status search_dev(rg_index *ix, SearchCtx *cx, const float *d_q, uint3
     // of that width runs on the exact HBM words as a timed trial; the faster form is kept from that width on (which one
     // wins depends on the index: the words of a 10M-node index are 10 GB of random atomics, those of a 2M-node index
     // mostly cache resident -- scripts/exp/visited_modes_real.py).
-    if (exact_count && ix->filter_log2 <= 0) {
+    if (exact_count && ix->filter_log2 <= 0 && ix->adaptive) {
         if (!b->ev0 && (hipEventCreate(&b->ev0) != hipSuccess || hipEventCreate(&b->ev1) != hipSuccess))
             return fail(set_error(RG_ERR_DEVICE, "hipEventCreate failed"));
         const bool trial = trial_L == L && nq >= 1000;
@@ -1681,6 +1681,7 @@ rg_status rg_index_set(rg_index *ix, const char *name, int value) {
     else if (!strcmp(name, "count_in_k1")) ix->count_in_k1 = value;
     else if (!strcmp(name, "count_tail")) ix->count_tail = value;
     else if (!strcmp(name, "lset_bytes")) ix->lset_bytes = value;
+    else if (!strcmp(name, "adaptive")) ix->adaptive = value != 0;
     else if (!strcmp(name, "lset")) { ix->lset = value; std::lock_guard<std::mutex> lk(ix->mu); ix->lset_bad_from = 0xffffffffu; }
     else if (!strcmp(name, "log_early")) ix->log_early = value != 0;
     else if (!strcmp(name, "shared_frontier")) ix->shared_frontier = value != 0;
