@@ -36,6 +36,7 @@ for W in ${WORKLOADS:-head L500 L1000 L2000 worst}; do
   run ${W}_tcc "$B" --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum
 done
 # K2 at the two query counts VERDICT r3 #6 names (10,000 = the eval-side truth and every tail batch; 65,536 = a streamed batch)
+export GT_FORMS=default
 run gt_trace "python $R/scripts/exp/gt_small_batch.py 200 10000000 10000,65536" --kernel-trace --stats
 run gt_sq "python $R/scripts/exp/gt_small_batch.py 200 10000000 10000,65536" --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_MFMA
 run calib_fetch "python $R/scripts/exp/calib_fetch.py" --pmc FETCH_SIZE
