@@ -118,13 +118,6 @@ struct GtParams {
     // top-K goes to), workgroup w runs items[item_first[w] .. item_first[w + 1]); null = the forms above (work counter)
     const uint4 *items;
     const uint32_t *item_first;
-    // Shared thresholds (round 4; K2-RS with several lists per query): a query's pieces run on different workgroups, each
-    // with a cold threshold of its own -- six pieces sort six times the candidates of one pass over the rows.  gthr[q] = the
-    // best K-th score any piece of query q has reached so far, as an order-preserving uint one step BELOW it (a candidate
-    // that ties with it may still win on the id); pieces exchange it whenever they compact.  No candidate below it can be
-    // in the merged top-K (one piece alone already holds K at or above it), so a piece may end with fewer than K entries:
-    // the rest of its list is written as entries that rank last.  null = off.
-    uint32_t *gthr;
 };
 
 // the parameters of work item `item` = (query block, segment): the segment's rows, bias, id offset and output lists
@@ -527,13 +520,6 @@ __global__ void __launch_bounds__(256, WPS) rg_gt_rs_kernel(GtParams P0) {
                                 for (int qi = w; qi < MQB; qi += 4)
                                     if (cnt[qi] + kNB > (uint32_t)C) gt_compact_call<ITEMS>(cand + (size_t)qi * C, &cnt[qi], &thr[qi], P.K, lane);
                                 __syncthreads();
-                                if (P.gthr && tid < MQB && q0 + (uint32_t)tid < P.nq) {   // exchange with the other pieces of these queries
-                                    const float mine = thr[tid];
-                                    const uint32_t om = mine > -__builtin_inff() ? f2ord(mine) - 1u : 0u;
-                                    const uint32_t og = om ? max(atomicMax(&P.gthr[q0 + tid], om), om) : __hip_atomic_load(&P.gthr[q0 + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                    if (og > om) thr[tid] = ord2f(og);
-                                }
-                                if (P.gthr) __syncthreads();
                                 if (tid == 0) flag[0] = 0;
                                 if (kThrRegs) {
 #pragma unroll
@@ -650,11 +636,10 @@ __global__ void __launch_bounds__(256, WPS) rg_gt_rs_kernel(GtParams P0) {
             gt_compact<ITEMS>(cand + (size_t)qi * C, &cnt[qi], &thr[qi], P.K, lane);
             const uint32_t q = q0 + qi;
             if (q < P.nq) {
-                const uint32_t have = cnt[qi];     // < K only with shared thresholds: the other pieces hold the rest
                 for (uint32_t e = lane; e < P.K; e += 64) {
                     const u64 k = cand[(size_t)qi * C + e];
-                    P.out_ids[(size_t)q * P.K + e] = e < have ? (uint32_t)k + P.id_base : 0xffffffffu;
-                    P.out_vals[(size_t)q * P.K + e] = e < have ? key_value(k, true) : -__builtin_inff();
+                    P.out_ids[(size_t)q * P.K + e] = (uint32_t)k + P.id_base;
+                    P.out_vals[(size_t)q * P.K + e] = key_value(k, true);
                 }
             }
         }
@@ -799,7 +784,7 @@ namespace rg {
 
 void gt_workspace_free(GtWorkspace *ws) {
     if (!ws) return;
-    for (int i = 0; i < 10; ++i) {
+    for (int i = 0; i < 9; ++i) {
         if (ws->p[i]) (void)hipFree(ws->p[i]);
         ws->p[i] = nullptr; ws->cap[i] = 0;
     }
@@ -921,7 +906,7 @@ rg_status gt_shard_ws(const float *d_base, uint32_t nb, uint32_t bstride, const 
     struct Scratch {
         hipStream_t s;
         GtWorkspace *ws;
-        void *p[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        void *p[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
         ~Scratch() { if (!ws) for (void *q : p) if (q) (void)hipFreeAsync(q, s); }
         hipError_t get(int i, size_t bytes) {
             bytes = std::max<size_t>(bytes, 64);
@@ -963,12 +948,7 @@ rg_status gt_shard_ws(const float *d_base, uint32_t nb, uint32_t bstride, const 
     P.counter = counter; P.BK = bk;
     P.diag = getenv("RG_GT_DIAG") ? (uint32_t)atoi(getenv("RG_GT_DIAG")) : 0u;
     P.nseg = nseg; P.seg_rows = seg_rows; P.seg_ids = nullptr; P.seg_vals = nullptr;
-    P.items = nullptr; P.item_first = nullptr; P.gthr = nullptr;
-    if (nseg > 1 && rs_tmw && !getenv("RG_GT_NOSHARE")) {     // several pieces per query: they share their thresholds (GtParams::gthr)
-        RG_HIP(scratch.get(9, (size_t)nq * 4));
-        P.gthr = static_cast<uint32_t *>(scratch.p[9]);
-        RG_HIP(hipMemsetAsync(P.gthr, 0, (size_t)nq * 4, s));
-    }
+    P.items = nullptr; P.item_first = nullptr;
     if (nseg > 1) {
         RG_HIP(scratch.get(3, (size_t)nseg * nq * K * 4));
         RG_HIP(scratch.get(4, (size_t)nseg * nq * K * 4));

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""K2 at query counts that do not fill the chip with whole query blocks: shared thresholds between a query's pieces and the
-balanced work split (round 4) against the older forms (RG_GT_NOSHARE=1, RG_GT_NOBALANCE=1).  One launch per (form, nq) over a 10M x d base, % of the 157.3 TFLOP/s fp32-MFMA peak."""
+"""K2 at query counts that do not fill the chip with whole query blocks: the balanced work split (round 4) against equal items
+handed out by a counter (RG_GT_NOBALANCE=1).  One launch per (form, nq) over a 10M x d base, % of the 157.3 TFLOP/s fp32-MFMA peak."""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -20,8 +20,7 @@ for nq in nqs:
     q = torch.empty((nq, d), device=dev).normal_(generator=g) * 0.5 + 0.3
     ids = torch.zeros((nq, K), dtype=torch.int32, device=dev); vals = torch.zeros((nq, K), device=dev)
     ref = None
-    forms = (("default", {}), ("thresholds_not_shared", {"RG_GT_NOSHARE": "1"}), ("equal_items", {"RG_GT_NOBALANCE": "1"}),
-             ("equal_items_not_shared", {"RG_GT_NOBALANCE": "1", "RG_GT_NOSHARE": "1"}))
+    forms = (("default", {}), ("equal_items", {"RG_GT_NOBALANCE": "1"}))
     if os.environ.get("GT_FORMS"):       # (profiling: one form only)
         forms = tuple(f for f in forms if f[0] in os.environ["GT_FORMS"].split(","))
     for form, env in forms:

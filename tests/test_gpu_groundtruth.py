@@ -228,21 +228,20 @@ def test_balanced_work_split_equals_the_equal_items_form(oracle, metric, d, K, m
     nb = 100_000
     base = synth.make_synth(31, nb, 16, d)[0]
     tb = torch.from_numpy(base).to(dev)
-    # 80,000 queries: the balanced split; 300 queries: three blocks cut into ten row segments each -- the pieces of a query share
-    # their thresholds (a piece may end with fewer than K entries, the merge takes the rest from the others)
+    # 80,000 queries: the balanced split; 300 queries: three blocks cut into ten row segments each (the equal-items form either way)
     for nq in (80_000, 300):
         q = synth.make_synth(32, 16, nq, d)[1]
         tq = torch.from_numpy(q).to(dev)
         res = {}
-        for name, env in (("default", {}), ("equal_items", {"RG_GT_NOBALANCE": "1"}), ("not_shared", {"RG_GT_NOSHARE": "1", "RG_GT_NOBALANCE": "1"})):
-            for k_ in ("RG_GT_NOBALANCE", "RG_GT_NOSHARE"):
+        for name, env in (("default", {}), ("equal_items", {"RG_GT_NOBALANCE": "1"})):
+            for k_ in ("RG_GT_NOBALANCE",):
                 monkeypatch.delenv(k_, raising=False)
             for k_, v_ in env.items():
                 monkeypatch.setenv(k_, v_)
             ids = torch.zeros((nq, K), dtype=torch.int32, device=dev); vals = torch.zeros((nq, K), device=dev)
             groundtruth.gt_shard_dev(tb, tq, metric, K, 0, ids, vals); torch.cuda.synchronize()
             res[name] = (ids.cpu().numpy().view(np.uint32), vals.cpu().numpy())
-        for name in ("equal_items", "not_shared"):
+        for name in ("equal_items",):
             assert (res["default"][0] == res[name][0]).all(), (name, nq)
             assert (res["default"][1].view(np.uint32) == res[name][1].view(np.uint32)).all(), (name, nq)
         sel = np.arange(0, nq, 331 if nq > 1000 else 7)
