@@ -306,7 +306,7 @@ rg_status dev_alloc(int device, size_t bytes, void **out) {
         size_t pooled = 0;
         for (int c = 0; c < kMaxClasses; ++c) pooled += have(c);
         if (free_b < 2 * kGranule + ((size_t)1 << 30)) break;                       // the device is full: take what there is
-        if (pooled >= n && walked > std::max<size_t>(n * kGranule * 4, (size_t)96 << 30)) break;   // enough granules, and a long walk found no more classes
+        if (pooled + held.size() >= n && walked > std::max<size_t>(n * kGranule * 3, (size_t)64 << 30)) break;   // a long walk found no more classes: take what there is
         Granule g;
         if (!new_granule(P, device, &g)) break;
         walked += kGranule;
@@ -336,6 +336,15 @@ rg_status dev_alloc(int device, size_t bytes, void **out) {
     // take: round robin over the classes, the fullest class first when some run short
     size_t pooled = 0;
     for (int c = 0; c < kMaxClasses; ++c) pooled += have(c);
+    // a class the walk could not reach (or reach enough of) leaves the request short of its equal shares: the granules held
+    // aside fill it up -- a buffer of measured granules in unequal shares is still spread over what there is, a plain
+    // allocation is one run of one class (box 17, run 1: two classes reachable after an in-process build, four of six buffers
+    // fell back to plain and the wide beams ran in round 3's slow mode)
+    while (pooled < n && !held.empty()) {
+        P.spare[held.back().cls].push_back(held.back());
+        held.pop_back();
+        ++pooled;
+    }
     auto release_ballast = [&]() {
         for (void *b : ballast) (void)hipFree(b);
         ballast.clear();

@@ -832,6 +832,10 @@ static rg_status plan_k1(rg_index *ix, int mode, uint32_t nq, uint32_t L, bool w
     // 16 rows and 2^12 entries -- profiles/r03/k1_ab_box19.jsonl: +1 % at L_pq = 300 - 500, +6 % at 700.
     const int r8_from = (mode != 0 && ix->filter_fill && ix->filter_log2 <= 0 && ix->waves_per_cu <= 0) ? 12 : 8;
     if (ix->rows_per_pass <= 0 && dimc_of(ix) == 200 && !bf && wpc <= r8_from) { R = 8; wpc = std::min(wpc, 8); lds = search_lds_bytes(ix, L, R, mode, bf, filter_auto); }
+    // exact-tag form at middling beams (nine to twelve LDS-limited residents, L_pq 300 - 900 at d = 200): eight residents, the LDS of
+    // the others goes to the bit screen (more tests of never-marked nodes stay on the CU).  profiles/r04/k1_ab_box17_look_forms.jsonl,
+    // % of 8 TB/s at L_pq 300 / 500 / 700: 76.1 / 71.5 / 70.6 as planned before, 76.1 / 73.8 / 71.1 with eight residents
+    if (mode == 0 && dimc_of(ix) == 200 && !bf && !bp && ix->waves_per_cu <= 0 && ix->rows_per_pass <= 0 && R == 4 && wpc > 8 && wpc <= 12) wpc = 8;
     if (ix->waves_per_cu > 0) wpc = std::min(wpc, ix->waves_per_cu);
     else wpc = std::min(wpc, 24);
     K1Launch c;
