@@ -101,6 +101,7 @@ struct Pool {
     std::map<void *, Buffer> live;
     // statistics (rg_mem_stats)
     uint64_t n_buffers = 0, n_plain = 0, n_probes = 0, n_ballast = 0;
+    bool far_walk_failed = false;              // a 192-GiB walk did not find what a request lacked: later walks are short
 };
 
 Pool g_pool[16];
@@ -301,12 +302,21 @@ rg_status dev_alloc(int device, size_t bytes, void **out) {
     };
     size_t walked = 0;
     int same_in_a_row = 0;
+    // how far a walk may go: runs of one class are up to 100+ GiB long, so a request that lacks a class walks up to 192 GiB (the
+    // ballast step doubles while the run goes on: 8, 16, 32 GiB); once a walk of this process came back without the class, the
+    // later ones stop at 48 GiB (box 19: the third class was 70+ GiB away after an in-process build, and the first eight buffers
+    // were spread over two classes -- 65.8 / 58.0 % at L_pq 1000 / 2000 against 67.3 / 59.3 with three)
+    const size_t walk_limit = P.far_walk_failed ? (size_t)48 << 30 : (size_t)192 << 30;
+    size_t ballast_step = kBallast;
     while (!satisfied()) {
         (void)hipMemGetInfo(&free_b, &total_b);
         size_t pooled = 0;
         for (int c = 0; c < kMaxClasses; ++c) pooled += have(c);
-        if (free_b < 2 * kGranule + ((size_t)1 << 30)) break;                       // the device is full: take what there is
-        if (pooled + held.size() >= n && walked > std::max<size_t>(n * kGranule * 3, (size_t)64 << 30)) break;   // a long walk found no more classes: take what there is
+        if (free_b < ((size_t)16 << 30)) break;                                     // the device is nearly full (others may live on it): take what there is
+        if (pooled + held.size() >= n && walked > walk_limit) {   // a long walk found no more classes: take what there is
+            if (walk_limit > ((size_t)100 << 30)) P.far_walk_failed = true;
+            break;
+        }
         Granule g;
         if (!new_granule(P, device, &g)) break;
         walked += kGranule;
@@ -316,21 +326,23 @@ rg_status dev_alloc(int device, size_t bytes, void **out) {
         if (g_trace2) fprintf(stderr, "[rg_mem]   -> class %d%s\n", c, is_rep ? " (new)" : "");
         if (c < 0) { drop_granule(g); break; }
         g.cls = c;
-        if (is_rep) { P.reps.push_back(g); same_in_a_row = 0; continue; }
+        if (is_rep) { P.reps.push_back(g); same_in_a_row = 0; ballast_step = kBallast; continue; }
         const bool surplus = have(c) >= share + 1;
         if (surplus) {
             // a run of a class this request has enough of: the granule is held aside (released, it would be the first memory the
             // next hipMemCreate finds) and, from the second in a row, a stretch of the run is stepped over with ballast
             held.push_back(g);
-            if (++same_in_a_row >= 2 && free_b > kBallast + n * kGranule + ((size_t)4 << 30)) {
+            if (++same_in_a_row >= 2 && free_b > ballast_step + n * kGranule + ((size_t)8 << 30)) {
                 void *b = nullptr;
-                if (hipMalloc(&b, kBallast) == hipSuccess) { ballast.push_back(b); walked += kBallast; ++P.n_ballast; }
+                if (hipMalloc(&b, ballast_step) == hipSuccess) { ballast.push_back(b); walked += ballast_step; ++P.n_ballast; }
                 else (void)hipGetLastError();
                 same_in_a_row = 0;
+                ballast_step = std::min<size_t>(ballast_step * 2, (size_t)32 << 30);
             }
             continue;
         }
         same_in_a_row = 0;
+        ballast_step = kBallast;
         P.spare[c].push_back(g);
     }
     // take: round robin over the classes, the fullest class first when some run short

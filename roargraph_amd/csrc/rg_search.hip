@@ -779,7 +779,7 @@ struct K1Plan {
 
 // entries + side-table ids of an exact LDS set cut from `bytes` of filter region (plan_k1 below makes the same split)
 static uint32_t lset_capacity_of(uint32_t bytes) {
-    const uint32_t side = std::max(16u, bytes / 32u);
+    const uint32_t side = std::max(16u, bytes / 32u) & ~3u;      // whole buckets of four ids
     return bytes > side * 4u ? (bytes - side * 4u) / 16u * 8u + side : 0u;
 }
 
@@ -899,7 +899,7 @@ static rg_status plan_k1(rg_index *ix, int mode, uint32_t nq, uint32_t L, bool w
             // can tell the ids of one bucket apart: one resident query less, and again, down to eight per CU (narrow beams lose
             // nothing down there: profiles/r04/k1_ab_box13_residents.jsonl, L_pq 40 - 80 at 8 ... 15 residents)
             if (mode == 3 && wpc > 8) {
-                const uint32_t bytes = (uint32_t)(vf_slots * 2 + extra), side = std::max(16u, bytes / 32u);
+                const uint32_t bytes = (uint32_t)(vf_slots * 2 + extra), side = std::max(16u, bytes / 32u) & ~3u;
                 const uint32_t buckets = bytes > side * 4u ? (bytes - side * 4u) / 16u : 0u;
                 if ((lset_need && lset_capacity_of(bytes) < lset_need) || buckets == 0 || filter_rem_bits(id_bits_of(ix->nd), buckets) > 15u) { --wpc; continue; }
             }
@@ -917,7 +917,7 @@ static rg_status plan_k1(rg_index *ix, int mode, uint32_t nq, uint32_t L, bool w
         // eight 16-bit entries
         uint32_t bytes = vf_slots * 2u;
         if (ix->lset_bytes > 0) bytes = std::min(bytes, std::max(64u, (uint32_t)ix->lset_bytes / 16u * 16u));   // (tests: a set that queries outgrow)
-        const uint32_t side = std::max(16u, bytes / 32u);
+        const uint32_t side = std::max(16u, bytes / 32u) & ~3u;      // whole buckets of four ids
         const uint32_t buckets = (bytes - side * 4u) / 16u;
         vf_slots = buckets * 8u;
         out->vs_side = side;
@@ -1130,13 +1130,15 @@ static rg_status search_dev(rg_index *ix, SearchCtx *cx, const float *d_q, uint3
         st = launch_k1(ix, cx, 0, d_q, nq, qstride, k, L, d_ids, d_dists, d_cmps, d_hops, nullptr, false, b->d_stat, s);
         return st == RG_OK ? done() : fail(st);
     }
-    // Narrow beams (round 4): the exact visited set in LDS (K1 VIS = 3).  What a query visits -- a few thousand nodes at
-    // L_pq <= 100 -- fits the LDS region the forgetful filter has, as eight-entry buckets of 16-bit remainders (K4's set, kept by
+    // Narrow and middling beams (round 4): the exact visited set in LDS (K1 VIS = 3).  What a query visits -- a few thousand nodes
+    // at L_pq <= 100 -- fits the LDS region the forgetful filter has, as eight-entry buckets of 16-bit remainders (K4's set, kept by
     // the searching wave itself): nothing is scored twice, so cmps is exact as counted -- no id log to store, no K4 behind the
-    // launch, no de-duplicating inserts.  Used when the set can hold 1.75 x the nodes a query of this width visits (the mean of
-    // the last counted batch; 44 x L_pq before there is one), giving up resident queries down to eight per CU for it; a query
-    // that outgrows its set finishes in the forgetful form and counts its own short log (same bits); a width at which more
-    // than 3 % of the queries do is left to the forms below from then on.
+    // launch, no de-duplicating inserts.  The launch gives up resident queries, down to eight per CU, until the set holds 1.75 x the
+    // nodes a query of this width visits (the mean of the last counted batch; 44 x L_pq before there is one).  A query that
+    // outgrows its set finishes in the forgetful form and counts its own -- short -- log (same bits), and that is cheap enough
+    // for the form to stay ahead while the set still holds 0.8 x the mean visits: % of 8 TB/s on the 10M bench index, this form /
+    // filter + log + K4 / exact tags (profiles/r04/k1_ab_box21_lset_forced_wide.jsonl): L_pq 100 87.7 / 82.9 / 79.8, 150 85.1 /
+    // 80.6 / 79.0 (every query outgrows), 200 82.4 / 78.0 / 75.3, 300 74.3 / 77.1 / 77.1, 500 62.5 / 73.9 / 73.0.
     if (exact_count && ix->lset != 0 && ix->filter_log2 <= 0 && ix->log_cap_knob <= 0 && !ix->multi_expand && ix->diag == 0 && dimc_of(ix)) {
         uint32_t need, bad_from;
         {
@@ -1149,7 +1151,8 @@ static rg_status search_dev(rg_index *ix, SearchCtx *cx, const float *d_q, uint3
             bad_from = ix->lset_bad_from;
         }
         const bool forced = ix->lset > 0 && L <= (uint32_t)ix->lset;
-        if (forced || (ix->lset < 0 && L < bad_from && L <= 256u)) {
+        (void)bad_from;
+        if (forced || (ix->lset < 0 && L <= 512u)) {
             K1Plan plan;
             rg_status ps = plan_k1(ix, 3, nq, L, true, false, false, s, &plan, need);
             {
@@ -1158,7 +1161,9 @@ static rg_status search_dev(rg_index *ix, SearchCtx *cx, const float *d_q, uint3
                     fprintf(stderr, "[rg_search] exact LDS set at L=%u: need %u, plan %s, holds %u (grid %u = %u per CU, R=%d)\n", L, need, ps == RG_OK ? "ok" : rg_last_error(),
                             ps == RG_OK ? plan.vf_slots + plan.vs_side : 0u, plan.c.grid, plan.c.grid / (uint32_t)std::max(1, ix->num_cu), plan.R);
             }
-            if (ps == RG_OK && (forced || plan.vf_slots + plan.vs_side >= need) && (st = ensure_qlog(ix, cx, nq)) == RG_OK && nq <= cx->qlog_chunk) {
+            // (holds >= 0.8 x the mean visits = 0.457 x need)
+            if (ps == RG_OK && (forced || (double)(plan.vf_slots + plan.vs_side) >= 0.457 * (double)need) && (st = ensure_qlog(ix, cx, nq)) == RG_OK &&
+                nq <= cx->qlog_chunk) {
                 if (hipMemsetAsync(b->d_ovf, 0, 8, s) != hipSuccess) return fail(set_error(RG_ERR_DEVICE, "hipMemsetAsync failed"));
                 b->mode = 3;
                 st = launch_k1(ix, cx, 3, d_q, nq, qstride, k, L, d_ids, d_dists, d_cmps, d_hops, nullptr, true, b->d_stat, s, nullptr, 0, b->d_stat + 1,
@@ -1299,7 +1304,7 @@ static rg_status finish_batches(rg_index *ix, SearchCtx *cx, hipStream_t s, uint
                     ix->n_lset_left += left;
                     static const bool trace = getenv("RG_TRACE_ADAPTIVE") != nullptr;
                     if (trace) fprintf(stderr, "[rg_search] batch L=%u nq=%u form=exact LDS set: %llu queries outgrew it\n", b->L, b->nq, left);
-                    if ((double)left > 0.03 * (double)b->nq && b->nq >= 64) ix->lset_bad_from = std::min(ix->lset_bad_from, b->L);
+                    (void)left;      // (queries that outgrow their set are cheap: the capacity rule in search_dev decides, not their number)
                 }
                 // (round 4: from 4 % of re-scored nodes; round 3: 8 % -- it was 30 % -- : with byte tags and the bit screen the exact set wins
                 // earlier, at d = 512 from L_pq 200 where the filter re-scores a sixth; a trial costs one batch in the other form)

@@ -691,16 +691,30 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
                             if (hv == 0xffffu) e = k2;
                         }
                         if (found) break;
-                        if (e == 8) {      // bucket full: the side table (full ids, linear probing)
+                        if (e == 8) {
+                            // bucket full: the side table -- buckets of four full ids (one ds_read_b128 each), at most four of
+                            // them from the id's hash on.  A node is only ever placed within that reach, so a lookup that finds
+                            // it nowhere there has seen everything; no room within it = the query has outgrown its set.  (The
+                            // first version probed single words linearly: a full table cost a CAS round trip per word and
+                            // lookup -- the cliff of profiles/r04/k1_ab_box14_lset_plan.txt.)
                             uint32_t *side = reinterpret_cast<uint32_t *>(vtab) + (P.vf_slots >> 1);
-                            uint32_t slot = __umulhi(id * 0x85EBCA6Bu, P.vs_side), probes = 0;
-                            for (;;) {
-                                const uint32_t old = atomicCAS(&side[slot], 0xffffffffu, id);
-                                if (old == 0xffffffffu) { fresh = true; break; }
-                                if (old == id) break;
-                                if (++slot == P.vs_side) slot = 0;
-                                if (++probes >= P.vs_side) { fresh = true; left = true; break; }   // no room: scored, not remembered
+                            const uint32_t nsb = P.vs_side >> 2;
+                            uint32_t sb = __umulhi(id * 0x85EBCA6Bu, nsb);
+                            bool done = false;
+                            for (int pr = 0; pr < 4 && !done; ++pr) {
+                                uint32_t *sp = side + 4u * sb;
+                                for (;;) {
+                                    const uint4 sv = *reinterpret_cast<const uint4 *>(sp);
+                                    if (sv.x == id || sv.y == id || sv.z == id || sv.w == id) { done = true; break; }   // visited
+                                    const int se = sv.x == 0xffffffffu ? 0 : sv.y == 0xffffffffu ? 1 : sv.z == 0xffffffffu ? 2 : sv.w == 0xffffffffu ? 3 : 4;
+                                    if (se == 4) break;                                                              // full: the next bucket
+                                    const uint32_t old = atomicCAS(sp + se, 0xffffffffu, id);
+                                    if (old == 0xffffffffu) { fresh = true; done = true; break; }
+                                    if (old == id) { done = true; break; }                                           // another lane of this hop brought it
+                                }
+                                if (++sb == nsb) sb = 0;
                             }
+                            if (!done) { fresh = true; left = true; }      // no room: scored, not remembered
                             break;
                         }
                         const uint32_t w = e < 2 ? t.x : e < 4 ? t.y : e < 6 ? t.z : t.w;
