@@ -144,10 +144,8 @@ struct rg_index {
     uint32_t exact_from_L = 0xffffffffu;
     uint32_t trial_L = 0, filter_ok_upto = 0;
     float filter_per_q = 0.0f;
-    // exact LDS set: nodes a query visits at a beam width (mean of the last counted batch), and the smallest width at which
-    // too many queries outgrew the set (the form is not used from there on)
+    // exact LDS set: nodes a query visits at a beam width (mean of the last counted batch): what the set is sized by
     std::map<uint32_t, float> evals_at;
-    uint32_t lset_bad_from = 0xffffffffu;
     // counters (rg_index_stat)
     uint64_t n_batches_lset = 0, n_batches_filter_log = 0, n_batches_exact_hbm = 0, n_batches_filter_only = 0, n_lset_left = 0, n_recounted = 0;
 };

@@ -13,10 +13,10 @@
 //
 // So buffers of 2 GiB and more are built with the HIP virtual-memory API from granules of 1 GiB whose class is
 // measured (a 1-ms probe kernel against one representative granule per known class: slow = same class), taken round robin
-// over the classes.  While a request still lacks granules of some class and the walk keeps delivering a class it has
-// enough of, the granules are held aside and ballast is allocated to step over the run; ballast and held granules are
-// released before the call returns.  Every step can fail softly: no VMM, no second class found, no memory to walk -- the buffer is then a plain
-// hipMalloc, exactly what round 3 shipped.  RG_BALANCED_ALLOC=0 turns the whole thing off.
+// over the classes.  A request that lacks granules of some class walks on, granule by granule, keeping everything it
+// classifies in a pool that the buffers of one index open share; dev_trim hands the pool back.  Every step can fail softly:
+// no VMM, no second class found, no memory to walk -- the buffer is then a plain hipMalloc, exactly what round 3 shipped.
+// RG_BALANCED_ALLOC=0 turns the whole thing off.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -38,7 +38,6 @@ namespace {
 
 constexpr size_t kGranule = (size_t)1 << 30;
 constexpr size_t kMinBalanced = (size_t)2 << 30;      // smaller buffers: hipMalloc
-constexpr size_t kBallast = (size_t)8 << 30;          // step over a run of a class the request has enough of
 constexpr int kMaxClasses = 4;
 
 __device__ __forceinline__ uint32_t mixu(uint32_t x) {
@@ -101,7 +100,7 @@ struct Pool {
     std::map<void *, Buffer> live;
     // statistics (rg_mem_stats)
     uint64_t n_buffers = 0, n_plain = 0, n_probes = 0, n_ballast = 0;
-    bool far_walk_failed = false;              // a 192-GiB walk did not find what a request lacked: later walks are short
+    size_t walked_epoch = 0;                   // bytes walked since the pool was last trimmed
 };
 
 Pool g_pool[16];
@@ -288,11 +287,13 @@ rg_status dev_alloc(int device, size_t bytes, void **out) {
     // what the buffer should get of each class: an equal share of every class the walk can reach -- three on this part
     const int want_classes = 3;
     const size_t share = (n + want_classes - 1) / want_classes;
-    std::vector<void *> ballast;
-    std::vector<Granule> held;      // granules of a class the request has enough of: kept until the walk is over, so that the walk moves on
     size_t free_b = 0, total_b = 0;
-    (void)hipMemGetInfo(&free_b, &total_b);
-    // walk: new granules until every class has its share in the pool (or memory / patience runs out)
+    // Walk: new granules, one after the other, each classified, ALL kept in the pool -- until every class has its share there, or
+    // the pool has walked its budget since it was last trimmed.  The pool lives across the buffers of one index open (and is
+    // handed back by dev_trim at its end), so the four or five buffers of an open share one walk.  Runs of a class are 4 ...
+    // 100+ GiB long: a walk that stepped over stretches with ballast (first version) found a scarce class in some processes and
+    // not in others (boxes 19, 22: tags spread 12 / 0 / 8 over the classes, 65.6 / 57.5 % at L_pq 1000 / 2000 against 67.3 / 59.3);
+    // granule by granule nothing is skipped, at about 10 ms per GiB walked.
     auto have = [&](int c) { return c < kMaxClasses ? P.spare[c].size() : 0; };
     auto satisfied = [&]() {
         size_t tot = 0;
@@ -300,76 +301,34 @@ rg_status dev_alloc(int device, size_t bytes, void **out) {
         for (int c = 0; c < kMaxClasses; ++c) { tot += std::min(have(c), share); classes += have(c) >= share ? 1 : 0; }
         return classes >= want_classes && tot >= n;
     };
+    const size_t epoch_budget = (size_t)160 << 30;
     size_t walked = 0;
-    int same_in_a_row = 0;
-    // how far a walk may go: runs of one class are up to 100+ GiB long, so a request that lacks a class walks up to 192 GiB (the
-    // ballast step doubles while the run goes on: 8, 16, 32 GiB); once a walk of this process came back without the class, the
-    // later ones stop at 48 GiB (box 19: the third class was 70+ GiB away after an in-process build, and the first eight buffers
-    // were spread over two classes -- 65.8 / 58.0 % at L_pq 1000 / 2000 against 67.3 / 59.3 with three)
-    const size_t walk_limit = P.far_walk_failed ? (size_t)48 << 30 : (size_t)192 << 30;
-    size_t ballast_step = kBallast;
     while (!satisfied()) {
         (void)hipMemGetInfo(&free_b, &total_b);
         size_t pooled = 0;
         for (int c = 0; c < kMaxClasses; ++c) pooled += have(c);
         if (free_b < ((size_t)16 << 30)) break;                                     // the device is nearly full (others may live on it): take what there is
-        if (pooled + held.size() >= n && walked > walk_limit) {   // a long walk found no more classes: take what there is
-            if (walk_limit > ((size_t)100 << 30)) P.far_walk_failed = true;
-            break;
-        }
+        if (pooled >= n && P.walked_epoch >= epoch_budget) break;                   // a long walk did not find enough of some class: take what there is
         Granule g;
         if (!new_granule(P, device, &g)) break;
         walked += kGranule;
+        P.walked_epoch += kGranule;
         bool is_rep = false;
-        if (g_trace2) fprintf(stderr, "[rg_mem]   granule at %p (free %.1f GiB, pooled %zu, held %zu, ballast %zu)\n", g.va, (double)free_b / (1u << 30), pooled, held.size(), ballast.size());
         const int c = classify(P, g, &is_rep);
-        if (g_trace2) fprintf(stderr, "[rg_mem]   -> class %d%s\n", c, is_rep ? " (new)" : "");
+        if (g_trace2) fprintf(stderr, "[rg_mem]   granule at %p (free %.1f GiB, pooled %zu) -> class %d%s\n", g.va, (double)free_b / (1u << 30), pooled, c, is_rep ? " (new)" : "");
         if (c < 0) { drop_granule(g); break; }
         g.cls = c;
-        if (is_rep) { P.reps.push_back(g); same_in_a_row = 0; ballast_step = kBallast; continue; }
-        const bool surplus = have(c) >= share + 1;
-        if (surplus) {
-            // a run of a class this request has enough of: the granule is held aside (released, it would be the first memory the
-            // next hipMemCreate finds) and, from the second in a row, a stretch of the run is stepped over with ballast
-            held.push_back(g);
-            if (++same_in_a_row >= 2 && free_b > ballast_step + n * kGranule + ((size_t)8 << 30)) {
-                void *b = nullptr;
-                if (hipMalloc(&b, ballast_step) == hipSuccess) { ballast.push_back(b); walked += ballast_step; ++P.n_ballast; }
-                else (void)hipGetLastError();
-                same_in_a_row = 0;
-                ballast_step = std::min<size_t>(ballast_step * 2, (size_t)32 << 30);
-            }
-            continue;
-        }
-        same_in_a_row = 0;
-        ballast_step = kBallast;
+        if (is_rep) { P.reps.push_back(g); continue; }
         P.spare[c].push_back(g);
     }
-    // take: round robin over the classes, the fullest class first when some run short
     size_t pooled = 0;
     for (int c = 0; c < kMaxClasses; ++c) pooled += have(c);
-    // a class the walk could not reach (or reach enough of) leaves the request short of its equal shares: the granules held
-    // aside fill it up -- a buffer of measured granules in unequal shares is still spread over what there is, a plain
-    // allocation is one run of one class (box 17, run 1: two classes reachable after an in-process build, four of six buffers
-    // fell back to plain and the wide beams ran in round 3's slow mode)
-    while (pooled < n && !held.empty()) {
-        P.spare[held.back().cls].push_back(held.back());
-        held.pop_back();
-        ++pooled;
-    }
-    auto release_ballast = [&]() {
-        for (void *b : ballast) (void)hipFree(b);
-        ballast.clear();
-        for (Granule &g : held) drop_granule(g);
-        held.clear();
-    };
     if (pooled < n) {     // not enough granules (memory): the plain buffer
-        release_ballast();
         ++P.n_plain;
         return plain();
     }
     void *va = nullptr;
-    if (!va_reserve(&va, n * kGranule)) { release_ballast(); ++P.n_plain; return plain(); }
+    if (!va_reserve(&va, n * kGranule)) { ++P.n_plain; return plain(); }
     Buffer buf;
     buf.bytes = n * kGranule;
     std::vector<Granule> taken;
@@ -397,14 +356,10 @@ rg_status dev_alloc(int device, size_t bytes, void **out) {
         for (size_t i = 0; i < buf.handles.size(); ++i) va_unmap((char *)va + i * kGranule, kGranule);
         for (Granule &g : taken) (void)hipMemRelease(g.h);
         va_free(va, n * kGranule);
-        release_ballast();
         ++P.n_plain;
         return plain();
     }
-    release_ballast();
-    // surplus granules go back to the device (a few stay for the next buffer of this open)
-    for (int k = 0; k < kMaxClasses; ++k)
-        while (P.spare[k].size() > 4) { drop_granule(P.spare[k].back()); P.spare[k].pop_back(); }
+    // (what is left in the pool serves the next buffer; dev_trim hands it back)
     if (g_trace)
         fprintf(stderr, "[rg_mem] %.2f GiB at %p: %d / %d / %d / %d granules of the classes, %zu classes known, walked %.1f GiB\n", (double)buf.bytes / (1u << 30), va,
                 buf.per_class[0], buf.per_class[1], buf.per_class[2], buf.per_class[3], P.reps.size(), (double)walked / (1u << 30));
@@ -442,6 +397,7 @@ void dev_trim(int device) {
         for (Granule &g : P.spare[k]) drop_granule(g);
         P.spare[k].clear();
     }
+    P.walked_epoch = 0;
 }
 
 }  // namespace rg

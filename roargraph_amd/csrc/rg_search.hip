@@ -739,6 +739,7 @@ static rg_status ensure_visited(rg_index *ix, SearchCtx *cx, uint32_t slots, boo
     const bool ok_v = ix->visited_uncached ? hipExtMallocWithFlags(reinterpret_cast<void **>(&nv), (size_t)slots * vwords * 4,
                                                                    ix->visited_uncached == 2 ? hipDeviceMallocFinegrained : hipDeviceMallocUncached) == hipSuccess
                                            : dev_alloc_t(ix->device, (size_t)slots * vwords, &nv) == RG_OK;
+    dev_trim(ix->device);      // (the allocator's pool of classified granules goes back to the device)
     if (!ok_v || hipMalloc(&ne, (size_t)slots * 4) != hipSuccess) {
         (void)hipGetLastError();
         dev_free(nv);
@@ -1047,6 +1048,7 @@ static rg_status ensure_qlog(rg_index *ix, SearchCtx *cx, uint32_t nq) {
     ++cx->allocs;
     {
         rg_status as = dev_alloc_t(ix->device, (size_t)chunk * cap, &cx->d_qlog);
+        dev_trim(ix->device);
         if (as != RG_OK) return as;
     }
     RG_HIP(hipMalloc(&cx->d_qlog_n, (size_t)chunk * 4));
@@ -1140,7 +1142,7 @@ static rg_status search_dev(rg_index *ix, SearchCtx *cx, const float *d_q, uint3
     // filter + log + K4 / exact tags (profiles/r04/k1_ab_box21_lset_forced_wide.jsonl): L_pq 100 87.7 / 82.9 / 79.8, 150 85.1 /
     // 80.6 / 79.0 (every query outgrows), 200 82.4 / 78.0 / 75.3, 300 74.3 / 77.1 / 77.1, 500 62.5 / 73.9 / 73.0.
     if (exact_count && ix->lset != 0 && ix->filter_log2 <= 0 && ix->log_cap_knob <= 0 && !ix->multi_expand && ix->diag == 0 && dimc_of(ix)) {
-        uint32_t need, bad_from;
+        uint32_t need;
         {
             std::lock_guard<std::mutex> lk(ix->mu);
             auto it = ix->evals_at.find(L);
@@ -1148,10 +1150,8 @@ static rg_status search_dev(rg_index *ix, SearchCtx *cx, const float *d_q, uint3
             // and eleven residents, profiles/r04/k1_ab_box14_lset_plan.txt: full buckets send their nodes to the side table,
             // whose linear probes are CAS round trips)
             need = (uint32_t)(1.75f * (it != ix->evals_at.end() ? it->second : 44.0f * (float)L));
-            bad_from = ix->lset_bad_from;
         }
         const bool forced = ix->lset > 0 && L <= (uint32_t)ix->lset;
-        (void)bad_from;
         if (forced || (ix->lset < 0 && L <= 512u)) {
             K1Plan plan;
             rg_status ps = plan_k1(ix, 3, nq, L, true, false, false, s, &plan, need);
@@ -1304,7 +1304,6 @@ static rg_status finish_batches(rg_index *ix, SearchCtx *cx, hipStream_t s, uint
                     ix->n_lset_left += left;
                     static const bool trace = getenv("RG_TRACE_ADAPTIVE") != nullptr;
                     if (trace) fprintf(stderr, "[rg_search] batch L=%u nq=%u form=exact LDS set: %llu queries outgrew it\n", b->L, b->nq, left);
-                    (void)left;      // (queries that outgrow their set are cheap: the capacity rule in search_dev decides, not their number)
                 }
                 // (round 4: from 4 % of re-scored nodes; round 3: 8 % -- it was 30 % -- : with byte tags and the bit screen the exact set wins
                 // earlier, at d = 512 from L_pq 200 where the filter re-scores a sixth; a trial costs one batch in the other form)
@@ -1560,6 +1559,7 @@ static rg_status open_dev_impl(const float *d_base, uint32_t nd, uint32_t dim, u
     if (st != RG_OK) {
         if (adopt_base && ix->d_base == d_base) ix->own_base = false;     // the caller still owns what it passed in
         rg_index_close(ix);
+        rg::dev_trim(device);
         return st;
     }
     rg::dev_trim(device);
@@ -1700,7 +1700,7 @@ rg_status rg_index_set(rg_index *ix, const char *name, int value) {
     else if (!strcmp(name, "count_tail")) ix->count_tail = value;
     else if (!strcmp(name, "lset_bytes")) ix->lset_bytes = value;
     else if (!strcmp(name, "adaptive")) ix->adaptive = value != 0;
-    else if (!strcmp(name, "lset")) { ix->lset = value; std::lock_guard<std::mutex> lk(ix->mu); ix->lset_bad_from = 0xffffffffu; }
+    else if (!strcmp(name, "lset")) ix->lset = value;
     else if (!strcmp(name, "log_early")) ix->log_early = value != 0;
     else if (!strcmp(name, "shared_frontier")) ix->shared_frontier = value != 0;
     else if (!strcmp(name, "filter_min_indeg")) ix->filter_min_indeg = value;
@@ -1713,6 +1713,7 @@ rg_status rg_index_set(rg_index *ix, const char *name, int value) {
             ix->stride_bf = (ix->dim + 127u) / 128u * 128u;
             {
                 rg_status as = rg::dev_alloc_t(ix->device, (size_t)ix->nd * ix->stride_bf, &ix->d_base_bf);
+                rg::dev_trim(ix->device);
                 if (as != RG_OK) return as;
             }
             hipLaunchKernelGGL(rg::rg_base_to_bf16_kernel, dim3(ix->num_cu * 8), dim3(256), 0, 0, ix->d_base, ix->nd, ix->dim, ix->stride,

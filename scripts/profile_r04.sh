@@ -14,7 +14,7 @@ COMMON="--steps 8 --warmup 3 --cpu-seconds 0 --gt-nq 0 --no-fast --no-two-stream
 run() {  # name, command (quoted), rocprof args...
   local name=$1; local cmd=$2; shift; shift
   rm -rf /tmp/rp_$name
-  rocprofv3 "$@" -d /tmp/rp_$name -o s -- $cmd > $OUT/$name.log 2>&1
+  timeout 900 rocprofv3 "$@" -d /tmp/rp_$name -o s -- $cmd > $OUT/$name.log 2>&1      # (a PMC pass once hung for 47 minutes: every pass has its own limit)
   local db=$(ls /tmp/rp_$name/*.db 2>/dev/null | head -1)
   if [ -n "$db" ]; then python $R/scripts/rocprof_summary.py --json $OUT/$name.pmc.json $db > $OUT/$name.txt 2>&1; fi
   grep -h '^{' $OUT/$name.log > $OUT/$name.bench.json 2>/dev/null
@@ -35,11 +35,13 @@ for W in ${WORKLOADS:-head L500 L1000 L2000 worst}; do
   run ${W}_sq "$B" --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM
   run ${W}_tcc "$B" --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum
 done
+if [ -z "$SKIP_GT" ]; then
 # K2 at the two query counts VERDICT r3 #6 names (10,000 = the eval-side truth and every tail batch; 65,536 = a streamed batch)
 export GT_FORMS=default
 run gt_trace "python $R/scripts/exp/gt_small_batch.py 200 10000000 10000,65536" --kernel-trace --stats
-run gt_sq "python $R/scripts/exp/gt_small_batch.py 200 10000000 10000,65536" --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM SQ_INSTS_MFMA
+run gt_sq "python $R/scripts/exp/gt_small_batch.py 200 10000000 10000,65536" --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM
 run calib_fetch "python $R/scripts/exp/calib_fetch.py" --pmc FETCH_SIZE
 run calib_tcc "python $R/scripts/exp/calib_fetch.py" --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_BUBBLE_sum TCC_HIT_sum
+fi
 python $R/scripts/make_traffic_json.py $(for W in ${WORKLOADS:-head L500 L1000 L2000 worst}; do echo $OUT/$W; done) > $OUT/search_traffic.json 2> $OUT/make_traffic.err
 ls -la $OUT
