@@ -301,14 +301,16 @@ rg_status dev_alloc(int device, size_t bytes, void **out) {
         for (int c = 0; c < kMaxClasses; ++c) { tot += std::min(have(c), share); classes += have(c) >= share ? 1 : 0; }
         return classes >= want_classes && tot >= n;
     };
-    const size_t epoch_budget = (size_t)160 << 30;
+    // (the pool never holds more than half of what was free when the walk began: other processes may live on the device)
+    (void)hipMemGetInfo(&free_b, &total_b);
+    const size_t epoch_budget = std::min<size_t>((size_t)160 << 30, free_b / 2);
     size_t walked = 0;
     while (!satisfied()) {
         (void)hipMemGetInfo(&free_b, &total_b);
         size_t pooled = 0;
         for (int c = 0; c < kMaxClasses; ++c) pooled += have(c);
         if (free_b < ((size_t)16 << 30)) break;                                     // the device is nearly full (others may live on it): take what there is
-        if (pooled >= n && P.walked_epoch >= epoch_budget) break;                   // a long walk did not find enough of some class: take what there is
+        if (pooled >= n && (P.walked_epoch >= epoch_budget || pooled * kGranule >= epoch_budget)) break;   // a long walk did not find enough of some class: take what there is
         Granule g;
         if (!new_granule(P, device, &g)) break;
         walked += kGranule;
