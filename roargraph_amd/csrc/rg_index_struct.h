@@ -120,8 +120,6 @@ struct rg_index {
     uint32_t front_n = 0;
     bool log_early = true;       // knob: the id-log store of a hop leaves right behind the row loads (rg_search_kernel.h: expand)
     int count_in_k1 = -1;        // knob: beams up to this wide count their distinct ids inside K1 (-1 = 40, 0 = never: K4 counts)
-    int count_tail = 0;          // knob (round 4, measured and left off): the distinct counts are made in the tail of the launch, by the waves
-                                 // that found the work queue empty (0 = off, N = beams up to N wide); takes precedence over count_in_k1
     bool adaptive = true;        // knob: 0 = the default visited mode never leaves (or tries to leave) its filter + log + K4 form for the exact tags
     int lset_bytes = 0;          // knob (tests): cap of the exact LDS set's region in bytes (0 = what the launch has)
     int lset = -1;               // knob "lset" (round 4): default visited mode, narrow beams: the exact visited set in LDS (K1 VIS = 3: no id

@@ -956,7 +956,7 @@ static rg_status launch_k1(rg_index *ix, SearchCtx *cx, int mode, const float *d
         rg_status st = ensure_visited(ix, cx, c.grid, vbytes, s);
         if (st != RG_OK) return st;
     }
-    RG_HIP(hipMemsetAsync(cx->d_counter, 0, 8, s));     // [0] work queue of the searches, [1] work queue of the tail counters
+    RG_HIP(hipMemsetAsync(cx->d_counter, 0, 4, s));
     SearchParams P;
     P.base = ix->d_base; P.stride = ix->stride; P.dim = ix->dim; P.nd = ix->nd;
     P.ell = ix->d_ell; P.ell_stride = ix->ell_stride; P.offsets = ix->d_offsets; P.nbrs = ix->d_nbrs;
@@ -1003,26 +1003,20 @@ static rg_status launch_k1(rg_index *ix, SearchCtx *cx, int mode, const float *d
     // millisecond or two), level at 50 - 60, 1 - 2 % behind from 80 up (one wave's CAS chains against K4's full workgroups).
     // The table takes the LDS from the merge scratch on (beam, log line, filter): the largest power of two of words whose
     // buckets + side table fit; remainders must fit 15 bits (indexes of up to 2^(tbits + 13) nodes).
-    // Round 4, knob "count_tail" (-1 = default: every beam width; 0 = off; N = beams up to N wide): the counts move into the TAIL
-    // of the launch (SearchParams::count_mode 2) -- a finished query publishes its log and goes on; waves that find the work
-    // queue empty count the published logs while the last queries are still being searched, in the slots that would idle.
     P.count_tbits = 0;
     P.count_mode = 0;
-    P.count_head = cx->d_counter + 1;
     P.totals = d_totals;
     const bool count_ok = with_log && d_totals && !qlist && !bp && ix->count_table_auto && !ix->count_full_ids && ix->log_cap_knob <= 0;
-    const bool tail = count_ok && mode != 3 && ix->count_tail > 0 && L <= (uint32_t)ix->count_tail;
-    const bool inline_count = count_ok && !tail && mode != 3 && ix->count_in_k1 != 0 && L <= (uint32_t)(ix->count_in_k1 < 0 ? 40 : ix->count_in_k1);
+    const bool inline_count = count_ok && mode != 3 && ix->count_in_k1 != 0 && L <= (uint32_t)(ix->count_in_k1 < 0 ? 40 : ix->count_in_k1);
     const bool lset_count = mode == 3 && with_log && !ix->count_full_ids;      // a query that outgrows the exact set counts its own short log
-    if (tail || inline_count || lset_count) {
+    if (inline_count || lset_count) {
         const size_t fixed = (size_t)P.stage_total * 4 + (dimc_of(ix) ? 0 : (size_t)ix->dim * 4) + 2 * kCand * 4;   // in front of the merge scratch
         const size_t region = lds > fixed ? lds - fixed : 0;
         uint32_t tb = 0;
         for (uint32_t t = 8; t <= 13; ++t)
             if (((size_t)4 << t) + ((size_t)4 << (t - 3)) <= region) tb = t;
-        if (tb >= 8 && id_bits_of(ix->nd) <= tb - 2 + 15) { P.count_tbits = tb; P.count_mode = mode == 3 ? 0u : tail ? 2u : 1u; }
+        if (tb >= 8 && id_bits_of(ix->nd) <= tb - 2 + 15) { P.count_tbits = tb; P.count_mode = mode == 3 ? 0u : 1u; }
     }
-    if (P.count_mode == 2u) RG_HIP(hipMemsetAsync(cx->d_qlog_n, 0xff, (size_t)nq * 4, s));   // kRunning: no query of this launch has finished
     P.id_mask = (ix->ell_tagged && !bp) ? 0x00ffffffu : 0xffffffffu;
     P.vf_min_indeg = (uint32_t)std::max(0, std::min(255, ix->filter_min_indeg));
 #ifdef RG_K1_PROF
@@ -1697,7 +1691,6 @@ rg_status rg_index_set(rg_index *ix, const char *name, int value) {
     else if (!strcmp(name, "lookahead")) ix->lookahead = value;
     else if (!strcmp(name, "gather_form")) ix->gather_form = value;
     else if (!strcmp(name, "count_in_k1")) ix->count_in_k1 = value;
-    else if (!strcmp(name, "count_tail")) ix->count_tail = value;
     else if (!strcmp(name, "lset_bytes")) ix->lset_bytes = value;
     else if (!strcmp(name, "adaptive")) ix->adaptive = value != 0;
     else if (!strcmp(name, "lset")) ix->lset = value;

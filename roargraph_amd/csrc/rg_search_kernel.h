@@ -90,14 +90,10 @@ struct SearchParams {
     // query can count itself when the query is over, in the LDS its beam and filter no longer need (K4's bucketed set,
     // count_tbits = log2 of its table words; 0 = off: K4 counts).  qlog_n[q] then carries kCountedBit and K4 skips the query.
     uint32_t count_tbits;
-    // count_mode (round 4): 1 = the wave counts its query's log at the END OF THE QUERY (narrow beams, round 3);
-    // 2 = IN THE TAIL OF THE LAUNCH: a finished query only publishes its log (qlog_n[q] = length, after the log's last store
-    // has been acknowledged), and waves that find the work queue empty -- the launch's tail, when more and more slots would
-    // idle -- turn into counters: they take published queries from a second queue (count_head), claim each with a CAS on
-    // qlog_n[q] and count it in their own LDS.  The exact cmps then costs the search nothing but its log stores; whatever
-    // is left uncounted when the kernel ends (overflowed logs, a full side table) is K4's, as before.
+    // count_mode: 1 = the wave counts its query's log at the END OF THE QUERY (narrow beams of the filter + log form, round 3); 0 = K4 counts.
+    // (Round 4 tried the counts in the TAIL of the launch, by the waves that found the work queue empty: exact, and slower -- dynamic
+    // scheduling leaves no idle tail to hide them in)
     uint32_t count_mode;
-    uint32_t *count_head;
     // VIS = 3, the EXACT set in LDS (round 4): the filter region holds vf_slots 16-bit entries in buckets of eight
     // (ds_read_b128 sees a bucket) + vs_side words of full ids for nodes whose bucket is full.  Nothing is ever evicted, so
     // no node is scored twice: cmps needs no log and no K4, the beam no de-duplication.  A query that outgrows the set goes
@@ -105,7 +101,7 @@ struct SearchParams {
     // lset_left counts such queries (the host stops using the form at a beam width where they are many).
     uint32_t vs_side;
     uint32_t *ovf_list, *ovf_count;     // VIS = 3: queries whose count could not be finished in the kernel (recounted by the host)
-    unsigned long long *lset_left;         // count_mode 2: next published query to count (work queue of the counters)
+    unsigned long long *lset_left;
     unsigned long long *totals;   // [2] evaluations performed / distinct nodes of the queries counted here (as K4 reports them)
     // shared frontier (third mode; opt-in knob "shared_frontier"): every query of a batch starts at the entry
     // point, so the first expansion scores the same deg(ep) rows for all of them.  front_scores[q][0] = compare(ep, q) and
@@ -398,8 +394,6 @@ __device__ __forceinline__ void beam_insert(Beam &bm, float cd, uint32_t cid, bo
 }
 
 constexpr uint32_t kCountedBit = 0x80000000u;   // qlog_n[q]: the distinct count of the query's log is already in out_cmps[q]
-constexpr uint32_t kClaimBit = 0x40000000u;     // qlog_n[q], count_mode 2: a wave is counting the log right now
-constexpr uint32_t kRunning = 0xffffffffu;      // qlog_n[q], count_mode 2: the query has not finished yet (set before the launch)
 
 // Exact number of DISTINCT ids among log[0, n) -- one wave, K4's half-word bucket set (rg_distinct_kernel<true>,
 // rg_search.hip) over `tab`: T = 2^tbits words of 8-slot buckets (16-bit remainders of the bijective hash id * odd mod
@@ -553,43 +547,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
     unsigned long long tot_n = 0, tot_d = 0;   // in-kernel distinct count: this slot's share of the batch totals
     unsigned long long tot_left = 0;           // VIS = 3: queries of this slot that outgrew the exact set
 
-    // count_mode 2: the distinct counts are made in the tail of the launch (see SearchParams::count_mode)
-    const bool tail_count = VIS == 1 && P.count_mode == 2u && P.qlog != nullptr && P.count_tbits != 0u && P.qlist == nullptr && P.out_exp == nullptr;
-    // claim a published query (qlog_n[q] = the length of its complete log) and count it in this wave's LDS, from the merge
-    // scratch on (the wave is between two queries or has none left: beam, log line and filter are free)
-    auto count_published = [&](uint32_t q) __attribute__((always_inline)) {
-        uint32_t n = 0;
-        if (lane == 0) n = __hip_atomic_load(&P.qlog_n[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        n = readlane_u(n, 0);
-        // still running (its own wave will count it: that wave finds the queue empty too) / claimed or counted / empty or overflowed (K4's)
-        if (n == kRunning || (n & (kCountedBit | kClaimBit)) || n == 0u || n > P.logcap) return;
-        uint32_t won = 0;
-        if (lane == 0) won = atomicCAS(&P.qlog_n[q], n, n | kClaimBit) == n ? 1u : 0u;
-        if (!readlane_u(won, 0)) return;
-        lds_fence();
-        bool bad = false;
-        const uint32_t distinct = wave_distinct_half<16>(P.qlog + (size_t)q * P.logcap, n, mscr, P.count_tbits, max(P.id_bits, P.count_tbits - 1u), lane, bad);
-        if (lane == 0) {
-            if (!bad) {
-                __hip_atomic_store(&P.out_cmps[q], distinct, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // the reference's cmps (:2397 counts every node once)
-                __hip_atomic_store(&P.qlog_n[q], n | kCountedBit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            } else {
-                __hip_atomic_store(&P.qlog_n[q], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);          // K4 counts it
-            }
-        }
-        if (!bad) { tot_n += n; tot_d += distinct; }
-        lds_fence();
-    };
-    uint32_t nxt = 0;
-    bool have_nxt = false;     // count_mode 2: the work item fetched at the end of the previous query
     for (;;) {
         uint32_t qi = 0;
-        if (have_nxt) qi = nxt;
-        else {
-            if (lane == 0) qi = atomicAdd(P.counter, 1u);
-            qi = readlane_u(qi, 0);
-        }
-        have_nxt = false;
+        if (lane == 0) qi = atomicAdd(P.counter, 1u);
+        qi = readlane_u(qi, 0);
         if (qi >= P.nq) break;
         const bool cmps_only = P.qlist != nullptr;
         const bool build = P.out_exp != nullptr;
@@ -1305,24 +1266,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
             tot_n += (unsigned long long)pre + logn;
             tot_d += cmps;
         }
-        if (tail_count) {
-            // publish: the log is complete once its last store has been acknowledged; then the length; then -- with the
-            // length acknowledged too -- the next work item is fetched, so that a wave that finds the queue empty sees every
-            // length published before the query that emptied it was handed out
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0) {
-                if (P.out_hops) P.out_hops[qi] = hops;
-                __hip_atomic_store(&P.qlog_n[qi], logn, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0) nxt = atomicAdd(P.counter, 1u);
-            nxt = readlane_u(nxt, 0);
-            have_nxt = true;
-            // out_cmps[qi] is written by whoever counts the log (a wave of this launch, K4, or the recount of an overflowed log)
-            if (nxt >= P.nq) count_published(qi);    // nothing left to search: this wave counts its own query first
-            wave_sync();
-            continue;
-        }
         if (VIS == 1 && qlog && P.count_mode == 1u && P.count_tbits && logn <= P.logcap && logn > 0 && !cmps_only && !build) {
             // the query is over: its log is complete (the tail stores above included) and the LDS from the merge scratch on
             // -- beam, log line, filter -- is free until the next query initialises it
@@ -1344,16 +1287,6 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
             if (VIS == 1 && P.qlog_n) P.qlog_n[qi] = logn_out;
         }
         wave_sync();
-    }
-    if (tail_count) {
-        // the tail of the launch: published queries, in the order they were handed out (the early ones finished long ago)
-        for (;;) {
-            uint32_t q = 0;
-            if (lane == 0) q = atomicAdd(P.count_head, 1u);
-            q = readlane_u(q, 0);
-            if (q >= P.nq) break;
-            count_published(q);
-        }
     }
     if (LSET && tot_left && lane == 0) atomicAdd(P.lset_left, tot_left);
     if (LOGS && tot_n && lane == 0) {
