@@ -473,7 +473,11 @@ __global__ void __launch_bounds__(256, WPS) rg_gt_rs_kernel(GtParams P0) {
             const uint32_t lds_bias = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(lds_ptr_t *)bias_l);
             auto stream_bias = [&](uint32_t tile, uint32_t slot) __attribute__((always_inline)) {
                 if (P.bias && w < 2) {   // waves 0/1: rows 0-63 / 64-127 of the tile
-                    const uint32_t id = min(tile * kNB + 64u * (uint32_t)w + (uint32_t)lane, P.nb - 1u);
+                    // (the lane number is made HERE: a value carried into the loop is spilled at this register pressure, and the
+                    // reload of a spill waits for vmcnt(0) -- for every DMA in flight, once per tile)
+                    uint32_t ln;
+                    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+                    const uint32_t id = min(tile * kNB + 64u * (uint32_t)w + ln, P.nb - 1u);
                     const float *src = P.bias + id;
                     asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off"
                                  :: "s"(lds_bias + slot * 512u + 256u * (uint32_t)w), "v"(src) : "memory");
@@ -607,9 +611,14 @@ __global__ void __launch_bounds__(256, WPS) rg_gt_rs_kernel(GtParams P0) {
 #pragma unroll
                                         for (int n = 0; n < 4; ++n) {
                                             const uint32_t id = tile * kNB + 32 * n + (lane & 31);
-                                            if (acc[m][n][r] > t && id < P.nb) {
+                                            if (acc[m][n][r] > t && id < P.nb && !(P.diag & 8u)) {
                                                 const uint32_t slot = atomicAdd(&cnt[qi], 1u);
-                                                cand[(size_t)qi * C + slot] = make_key(acc[m][n][r], id, true);
+                                                // the buffer's address is made HERE from the kernel argument: hoisted out of the loop it
+                                                // is spilled, and the reload of a spill waits for vmcnt(0) -- i.e. for the DMA of the next
+                                                // chunk and for the previous candidate's store, on every candidate
+                                                __attribute__((address_space(1))) u64 *cb = (__attribute__((address_space(1))) u64 *)P0.cand;
+                                                asm volatile("" : "+s"(cb));
+                                                cb[((uint32_t)blockIdx.x * MQB + (uint32_t)qi) * (uint32_t)C + slot] = make_key(acc[m][n][r], id, true);
                                                 if (slot + 1 + kNB > (uint32_t)C) flag[0] = 1;
                                             }
                                         }
@@ -879,7 +888,7 @@ rg_status gt_shard_ws(const float *d_base, uint32_t nb, uint32_t bstride, const 
         // (measured, scripts/exp/gt_small_batch.py: where the equal items fit ONE round the balanced form is 2 % behind -- an idle
         // workgroup slot leaves its CU's MFMA pipes to the neighbour, and more pieces mean more cold thresholds -- 0.730 vs 0.746 of
         // peak at 10,000 queries; with a partial second round it is 16 % ahead: 0.789 vs 0.681 at 100,000)
-        if (total >= slots && items_old > slots && per + snap < span_old - span_old / 8 && per > 2 * snap) {
+        if (total >= slots && (getenv("RG_GT_BALANCE_ONE") || (items_old > slots && per + snap < span_old - span_old / 8)) && per > 2 * snap) {
             // the loop of rg_gt_items_kernel, to size and validate the table
             uint32_t n = 0, cur_blk = 0xffffffffu, cur_list = 0, max_list = 0;
             bool ok = true;
@@ -937,7 +946,8 @@ rg_status gt_shard_ws(const float *d_base, uint32_t nb, uint32_t bstride, const 
         bias = static_cast<float *>(scratch.p[0]);
         hipLaunchKernelGGL(rg_gt_bias_kernel, dim3((nb * 16 + 255) / 256), dim3(256), 0, s, d_base, nb, bstride, dim, bias);
     }
-    RG_HIP(scratch.get(1, (size_t)grid * mq * 64 * items * 8));
+    const int rs_items = (rs_tmw && dim == 200 && getenv("RG_GT_CAND") && atoi(getenv("RG_GT_CAND")) == 8) ? 8 : 4;
+    RG_HIP(scratch.get(1, (size_t)grid * mq * 64 * (rs_tmw ? rs_items : items) * 8));
     cand = static_cast<u64 *>(scratch.p[1]);
     RG_HIP(scratch.get(2, 64));
     counter = static_cast<uint32_t *>(scratch.p[2]);
@@ -969,14 +979,18 @@ rg_status gt_shard_ws(const float *d_base, uint32_t nb, uint32_t bstride, const 
     rg_status st;
     if (rs_tmw) {
         const size_t lds_rs = ((size_t)2 * rs_bk * kNB + 2 * rs_mqb + 8 + 256) * 4;
-#define RG_RS_LAUNCH(D, BKV, WPSV)                                                                                           \
+#define RG_RS_LAUNCH_I(D, BKV, WPSV, IT)                                                                                     \
     {                                                                                                                        \
-        auto kern = rg_gt_rs_kernel<D, BKV, 1, 4, WPSV>;                                                                     \
+        auto kern = rg_gt_rs_kernel<D, BKV, 1, IT, WPSV>;                                                                    \
         RG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rs)); \
         hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_rs, s, P);                                                       \
     }
+#define RG_RS_LAUNCH(D, BKV, WPSV) RG_RS_LAUNCH_I(D, BKV, WPSV, 4)
         switch (dim) {
-            case 200: RG_RS_LAUNCH(200, 40, 2) break;
+            case 200:
+                if (rs_items == 8) RG_RS_LAUNCH_I(200, 40, 2, 8)
+                else RG_RS_LAUNCH(200, 40, 2)
+                break;
             case 512: RG_RS_LAUNCH(512, 64, 1) break;
             case 96: RG_RS_LAUNCH(96, 48, 2) break;
             case 128: RG_RS_LAUNCH(128, 64, 2) break;
@@ -984,6 +998,7 @@ rg_status gt_shard_ws(const float *d_base, uint32_t nb, uint32_t bstride, const 
             default: RG_RS_LAUNCH(384, 64, 1) break;
         }
 #undef RG_RS_LAUNCH
+#undef RG_RS_LAUNCH_I
         st = hipGetLastError() == hipSuccess ? RG_OK : set_error(RG_ERR_DEVICE, "K2-RS launch failed");
     } else {
         st = mq == 128 ? launch_gt_items<128>(items, P, grid, lds, s) : launch_gt_items<64>(items, P, grid, lds, s);

@@ -730,11 +730,14 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
         // id log (VIS = 1): n ids from cand_id[off ..) join the LDS line buffer; a full 64-id line leaves as one aligned
         // 256-B store.  The store is issued where no gather is outstanding: in front of gathers it would sit at the head
         // of the vmcnt queue and put its completion latency on the critical path of the first counted wait.
-        auto log_append = [&](uint32_t off, uint32_t n) __attribute__((always_inline)) {
+        auto log_put = [&](uint32_t off, uint32_t n) __attribute__((always_inline)) {
             if (LOGS && qlog) {
                 if ((uint32_t)lane < n) logbuf[lbn + lane] = cand_id[off + lane];
                 lbn += n;
             }
+        };
+        auto log_append = [&](uint32_t off, uint32_t n) __attribute__((always_inline)) {
+            log_put(off, n);
             logn += n;
         };
         auto log_flush = [&]() __attribute__((always_inline)) {
@@ -966,8 +969,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
                     // a lane found no room for its node: from this hop on the set is incomplete -- the ids scored are logged (this
                     // hop's too: none of them was scored before), inserts de-duplicate, and the log's distinct ids join cmps at the end
                     if (!logging && __any(left)) logging = true;
-                    if (logging) log_append(0, n);
-                    else cmps += n;                                        // :2397
+                    // (both counters advance by a selected VALUE: written as "if (logging) logn += n; else cmps += n;" the compiler
+                    // sinks the two additions into one through a selected ADDRESS, which puts both counters in scratch memory --
+                    // a load, a vmcnt(0) and a store per hop)
+                    const uint32_t n_log = logging ? n : 0u;
+                    if (logging) log_put(0, n);
+                    logn += n_log;
+                    cmps += n - n_log;                                     // :2397
                 } else {
                     log_append(0, n);
                     cmps += n;                                             // :2397

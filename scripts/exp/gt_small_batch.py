@@ -15,16 +15,20 @@ g = torch.Generator(device=dev); g.manual_seed(1)
 base = torch.empty((nb, d), device=dev)
 for s in range(0, nb, 1 << 20):
     base[s:s + (1 << 20)].normal_(generator=g)
-K = 100
+K = int(os.environ.get("GT_K", "100"))
 for nq in nqs:
     q = torch.empty((nq, d), device=dev).normal_(generator=g) * 0.5 + 0.3
     ids = torch.zeros((nq, K), dtype=torch.int32, device=dev); vals = torch.zeros((nq, K), device=dev)
     ref = None
     forms = (("default", {}), ("equal_items", {"RG_GT_NOBALANCE": "1"}))
-    if os.environ.get("GT_FORMS"):       # (profiling: one form only)
-        forms = tuple(f for f in forms if f[0] in os.environ["GT_FORMS"].split(","))
+    if os.environ.get("GT_FORMS"):       # "default" / "equal_items", or "name:ENV=V,ENV=V;name2:..." (experiment switches of rg_gt.hip)
+        spec = os.environ["GT_FORMS"]
+        if ":" in spec:
+            forms = tuple((f.partition(":")[0], dict(kv.split("=") for kv in f.partition(":")[2].split(",") if kv)) for f in spec.split(";"))
+        else:
+            forms = tuple(f for f in forms if f[0] in spec.split(","))
     for form, env in forms:
-        for k_ in ("RG_GT_NOSHARE", "RG_GT_NOBALANCE"):
+        for k_ in ("RG_GT_NOSHARE", "RG_GT_NOBALANCE", "RG_GT_CAND", "RG_GT_BALANCE_ONE", "RG_GT_DIAG"):
             os.environ.pop(k_, None)
         os.environ.update(env)
         groundtruth.gt_shard_dev(base, q, metric, K, 0, ids, vals); torch.cuda.synchronize()
@@ -33,5 +37,5 @@ for nq in nqs:
         dt = time.perf_counter() - t0
         same = None if ref is None else bool(torch.equal(ref, ids))
         ref = ids.clone() if ref is None else ref
-        print(json.dumps({"d": d, "nq": nq, "form": form, "seconds": round(dt, 4), "TFLOPs": round(2.0 * d * nq * nb / dt / 1e12, 2),
+        print(json.dumps({"d": d, "K": K, "nq": nq, "form": form, "seconds": round(dt, 4), "TFLOPs": round(2.0 * d * nq * nb / dt / 1e12, 2),
                           "frac_of_157.3": round(2.0 * d * nq * nb / dt / 1e12 / 157.3, 4), "ids_equal_first_form": same}), flush=True)

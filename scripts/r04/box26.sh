@@ -4,8 +4,13 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/r04_box26
 mkdir -p $OUT
 cd $R
-timeout 1200 python scripts/exp/k1_ab.py --L 250,300,400,500 --index-cache /tmp/ix.npz --pipelined --nbatch 4 \
-  --configs "auto:visited=2;forced_w8:visited=2,lset=100000;forced_r8_w7:visited=2,lset=100000,rows_per_pass=32,waves_per_cu=7;forced_r8_w6:visited=2,lset=100000,rows_per_pass=32,waves_per_cu=6;forced_r4_w7:visited=2,lset=100000,waves_per_cu=7;forced_r4_w6:visited=2,lset=100000,waves_per_cu=6;look:visited=0;filter:visited=1" \
+# K2 at full fill with 1 / 2 / 4 / 6 / 8 row segments per query block (512 or 510 items for 512 workgroups): what a segment costs
+for K in 100 10; do
+  GT_K=$K GT_FORMS=default timeout 300 python scripts/exp/gt_small_batch.py 200 10000000 8192,10880,16384,32768,65536 > $OUT/gt_fill_K$K.jsonl 2> $OUT/gt_fill_K$K.err
+  cat $OUT/gt_fill_K$K.jsonl
+done
+timeout 1200 python scripts/exp/k1_ab.py --L 300,400,500 --index-cache /tmp/ix.npz --pipelined --nbatch 4 \
+  --configs "auto:visited=2;forced_w8:visited=2,lset=100000;forced_r8_w6:visited=2,lset=100000,rows_per_pass=32,waves_per_cu=6;forced_r4_w7:visited=2,lset=100000,waves_per_cu=7;forced_r4_w6:visited=2,lset=100000,waves_per_cu=6;look:visited=0;filter:visited=1" \
   > $OUT/k1_ab.jsonl 2> $OUT/k1_ab.err
 grep '^{"config' $OUT/k1_ab.jsonl | python -c "
 import sys, json
