@@ -385,8 +385,12 @@ __device__ __forceinline__ void glds_run(uint32_t lds_addr, const float *src) {
 // 128*TMW queries); LDS holds just the double-buffered base chunk, barriers are BK/2 * 8*TMW MFMAs apart (10k cycles at
 // d=200) and the base stream is shared by twice as many queries as in the LDS-resident form.  Everything in k is
 // unrolled at compile time (register arrays need static indices), hence the DIM template parameter.
-template <int DIM, int BK, int TMW, int ITEMS, int WPS>
+template <int DIM, int BK, int TMW, int ITEMS, int WPS, bool PROF = false>
 __global__ void __launch_bounds__(256, WPS) rg_gt_rs_kernel(GtParams P0) {
+    // PROF (RG_GT_PROF=1, d = 200 only): per-wave sums of s_memtime ticks spent in the tile filter, in
+    // its rare path and in compactions, with their counts, added to P0.counter[4 ..] (u64) by wave 0 of every workgroup
+    unsigned long long pf_filter = 0, pf_slow = 0, pf_compact = 0, pf_item = 0;
+    uint32_t pf_tiles = 0, pf_nslow = 0, pf_nev = 0, pf_ncand = 0;
     constexpr int C = 64 * ITEMS;
     constexpr int MQB = 128 * TMW;            // queries per workgroup
     constexpr int NKC = DIM / BK;             // k-chunks per base tile
@@ -424,6 +428,7 @@ __global__ void __launch_bounds__(256, WPS) rg_gt_rs_kernel(GtParams P0) {
         if ((uint64_t)blk * MQB >= P.nq) break;
         const uint32_t ntiles = (P.nb + kNB - 1) / kNB;
         const uint32_t q0 = blk * MQB;
+        const unsigned long long pf_t0 = PROF ? __builtin_amdgcn_s_memtime() : 0ull;
         // A operands of this wave's queries, all k, into registers
         float areg[DIM / 2][TMW];
 #pragma unroll
@@ -521,6 +526,8 @@ __global__ void __launch_bounds__(256, WPS) rg_gt_rs_kernel(GtParams P0) {
                             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                             __syncthreads();
                             if (c == 0 && flag[0]) {   // set by the previous tile's filter
+                                const unsigned long long pf_c0 = PROF ? __builtin_amdgcn_s_memtime() : 0ull;
+                                if (PROF) ++pf_nev;
                                 for (int qi = w; qi < MQB; qi += 4)
                                     if (cnt[qi] + kNB > (uint32_t)C) gt_compact_call<ITEMS>(cand + (size_t)qi * C, &cnt[qi], &thr[qi], P.K, lane);
                                 __syncthreads();
@@ -530,6 +537,7 @@ __global__ void __launch_bounds__(256, WPS) rg_gt_rs_kernel(GtParams P0) {
                                     for (int r = 0; r < 16; ++r) thr_r[0][r] = thr[qoff + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)];
                                 }
                                 __syncthreads();
+                                if (PROF) pf_compact += __builtin_amdgcn_s_memtime() - pf_c0;
                             }
                             // chunk after next -> the buffer this chunk was read from.  Its DMA instructions and the first
                             // fragments of the next chunk are issued BETWEEN the last quad's MFMAs (one per MFMA), so that
@@ -589,7 +597,12 @@ __global__ void __launch_bounds__(256, WPS) rg_gt_rs_kernel(GtParams P0) {
                     ++step;
                     if (c + 1 == NKC && !(P.diag & 2u)) {
                         // tile finished: threshold filter (no barrier here: the compaction check is at the next barrier)
-                        bool any_win = false;
+                        // (two instructions per accumulator row for the maximum -- fmaxf would canonicalise its inputs first -- and
+                        // the wave's verdict as an OR of ballots on the scalar unit: as "any_win |= mx > t" the compiler builds a
+                        // 16-bit mask per lane, a hundred vector instructions per tile)
+                        const unsigned long long pf_f0 = PROF ? __builtin_amdgcn_s_memtime() : 0ull;
+                        if (PROF) ++pf_tiles;
+                        uint64_t any_win = 0;
                         float mx[TMW][16];
 #pragma unroll
                         for (int m = 0; m < TMW; ++m)
@@ -597,10 +610,14 @@ __global__ void __launch_bounds__(256, WPS) rg_gt_rs_kernel(GtParams P0) {
                             for (int r = 0; r < 16; ++r) {
                                 const float t = kThrRegs ? thr_r[kThrRegs ? m : 0][r]
                                                          : thr[qoff + 32 * m + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)];
-                                mx[m][r] = fmaxf(fmaxf(acc[m][0][r], acc[m][1][r]), fmaxf(acc[m][2][r], acc[m][3][r]));
-                                any_win |= mx[m][r] > t;
+                                float m3;
+                                asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m3) : "v"(acc[m][0][r]), "v"(acc[m][1][r]), "v"(acc[m][2][r]));
+                                asm("v_max_f32 %0, %1, %2" : "=v"(mx[m][r]) : "v"(m3), "v"(acc[m][3][r]));
+                                any_win |= __builtin_amdgcn_ballot_w64(mx[m][r] > t);
                             }
                         if (any_win) {
+                            const unsigned long long pf_s0 = PROF ? __builtin_amdgcn_s_memtime() : 0ull;
+                            if (PROF) ++pf_nslow;
 #pragma unroll
                             for (int m = 0; m < TMW; ++m)
 #pragma unroll
@@ -620,11 +637,14 @@ __global__ void __launch_bounds__(256, WPS) rg_gt_rs_kernel(GtParams P0) {
                                                 asm volatile("" : "+s"(cb));
                                                 cb[((uint32_t)blockIdx.x * MQB + (uint32_t)qi) * (uint32_t)C + slot] = make_key(acc[m][n][r], id, true);
                                                 if (slot + 1 + kNB > (uint32_t)C) flag[0] = 1;
+                                                if (PROF) pf_ncand += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(true));
                                             }
                                         }
                                     }
                                 }
+                            if (PROF) pf_slow += __builtin_amdgcn_s_memtime() - pf_s0;
                         }
+                        if (PROF) pf_filter += __builtin_amdgcn_s_memtime() - pf_f0;
                     }
                     if (c + 1 == NKC) rowp = rowp_next;
                 };
@@ -640,6 +660,7 @@ __global__ void __launch_bounds__(256, WPS) rg_gt_rs_kernel(GtParams P0) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last tile's candidate stores
             __syncthreads();
         }
+        const unsigned long long pf_t1 = PROF ? __builtin_amdgcn_s_memtime() : 0ull;
         // final selection + output
         for (int qi = w; qi < MQB; qi += 4) {
             gt_compact<ITEMS>(cand + (size_t)qi * C, &cnt[qi], &thr[qi], P.K, lane);
@@ -653,6 +674,13 @@ __global__ void __launch_bounds__(256, WPS) rg_gt_rs_kernel(GtParams P0) {
             }
         }
         __syncthreads();
+        if (PROF) pf_item += pf_t1 - pf_t0;
+    }
+    if (PROF && w == 0 && lane == 0) {
+        unsigned long long *pf = reinterpret_cast<unsigned long long *>(P0.counter + 4);
+        atomicAdd(pf + 0, pf_item); atomicAdd(pf + 1, pf_filter); atomicAdd(pf + 2, pf_slow); atomicAdd(pf + 3, pf_compact);
+        atomicAdd(pf + 4, (unsigned long long)pf_tiles); atomicAdd(pf + 5, (unsigned long long)pf_nslow);
+        atomicAdd(pf + 6, (unsigned long long)pf_nev); atomicAdd(pf + 7, (unsigned long long)pf_ncand);
     }
 }
 
@@ -949,9 +977,10 @@ rg_status gt_shard_ws(const float *d_base, uint32_t nb, uint32_t bstride, const 
     const int rs_items = (rs_tmw && dim == 200 && getenv("RG_GT_CAND") && atoi(getenv("RG_GT_CAND")) == 8) ? 8 : 4;
     RG_HIP(scratch.get(1, (size_t)grid * mq * 64 * (rs_tmw ? rs_items : items) * 8));
     cand = static_cast<u64 *>(scratch.p[1]);
-    RG_HIP(scratch.get(2, 64));
+    RG_HIP(scratch.get(2, 128));
     counter = static_cast<uint32_t *>(scratch.p[2]);
-    RG_HIP(hipMemsetAsync(counter, 0, 4, s));
+    RG_HIP(hipMemsetAsync(counter, 0, 128, s));
+    const bool rs_prof = rs_tmw && dim == 200 && getenv("RG_GT_PROF");
     GtParams P;
     P.base = d_base; P.nb = nb; P.bstride = bstride; P.queries = d_queries; P.nq = nq; P.qstride = qstride; P.dim = dim;
     P.bias = bias; P.K = K; P.id_base = id_base; P.out_ids = ids_k2; P.out_vals = vals; P.cand = cand;
@@ -988,7 +1017,11 @@ rg_status gt_shard_ws(const float *d_base, uint32_t nb, uint32_t bstride, const 
 #define RG_RS_LAUNCH(D, BKV, WPSV) RG_RS_LAUNCH_I(D, BKV, WPSV, 4)
         switch (dim) {
             case 200:
-                if (rs_items == 8) RG_RS_LAUNCH_I(200, 40, 2, 8)
+                if (rs_prof) {
+                    auto kern = rg_gt_rs_kernel<200, 40, 1, 4, 2, true>;
+                    RG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rs));
+                    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_rs, s, P);
+                } else if (rs_items == 8) RG_RS_LAUNCH_I(200, 40, 2, 8)
                 else RG_RS_LAUNCH(200, 40, 2)
                 break;
             case 512: RG_RS_LAUNCH(512, 64, 1) break;
@@ -1000,6 +1033,15 @@ rg_status gt_shard_ws(const float *d_base, uint32_t nb, uint32_t bstride, const 
 #undef RG_RS_LAUNCH
 #undef RG_RS_LAUNCH_I
         st = hipGetLastError() == hipSuccess ? RG_OK : set_error(RG_ERR_DEVICE, "K2-RS launch failed");
+        if (rs_prof && st == RG_OK) {
+            unsigned long long h[8];
+            RG_HIP(hipStreamSynchronize(s));
+            RG_HIP(hipMemcpy(h, counter + 4, sizeof(h), hipMemcpyDeviceToHost));
+            // (wave 0 of every workgroup; clock ticks of 10 ns)
+            fprintf(stderr, "[rg_gt prof] grid %u nseg %u items/wg: item %.3f, filter %.3f (rare path %.3f), compactions %.3f [s_memtime ticks x 1e-5: read as shares of item]; per workgroup: tiles %.0f, rare-path tiles %.0f, "
+                            "compaction events %.0f, candidate stores (wave 0) %.0f\n", grid, nseg, h[0] * 1e-5 / grid, h[1] * 1e-5 / grid, h[2] * 1e-5 / grid, h[3] * 1e-5 / grid,
+                    (double)h[4] / grid, (double)h[5] / grid, (double)h[6] / grid, (double)h[7] / grid);
+        }
     } else {
         st = mq == 128 ? launch_gt_items<128>(items, P, grid, lds, s) : launch_gt_items<64>(items, P, grid, lds, s);
     }

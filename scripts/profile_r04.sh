@@ -29,19 +29,23 @@ for W in ${WORKLOADS:-head L500 L1000 L2000 worst}; do
     worst) A="--graph random --L 500";;
   esac
   B="python $R/bench.py $COMMON $A"
-  run ${W}_trace "$B" --kernel-trace --stats
-  run ${W}_fetch "$B" --pmc FETCH_SIZE
-  run ${W}_write "$B" --pmc WRITE_SIZE
-  run ${W}_sq "$B" --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM
-  run ${W}_tcc "$B" --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum
+  for PASS in ${PASSES:-trace fetch write sq tcc}; do
+    case $PASS in
+      trace) run ${W}_trace "$B" --kernel-trace --stats;;
+      fetch) run ${W}_fetch "$B" --pmc FETCH_SIZE;;
+      write) run ${W}_write "$B" --pmc WRITE_SIZE;;
+      sq) run ${W}_sq "$B" --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM;;
+      tcc) run ${W}_tcc "$B" --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum;;
+    esac
+  done
 done
 if [ -z "$SKIP_GT" ]; then
 # K2 at the two query counts VERDICT r3 #6 names (10,000 = the eval-side truth and every tail batch; 65,536 = a streamed batch)
 export GT_FORMS=default
 run gt_trace "python $R/scripts/exp/gt_small_batch.py 200 10000000 10000,65536" --kernel-trace --stats
-run gt_sq "python $R/scripts/exp/gt_small_batch.py 200 10000000 10000,65536" --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM
-run calib_fetch "python $R/scripts/exp/calib_fetch.py" --pmc FETCH_SIZE
-run calib_tcc "python $R/scripts/exp/calib_fetch.py" --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_BUBBLE_sum TCC_HIT_sum
+[ -z "$SKIP_GT_SQ" ] && run gt_sq "python $R/scripts/exp/gt_small_batch.py 200 10000000 10000,65536" --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM
+[ -z "$SKIP_CALIB" ] && run calib_fetch "python $R/scripts/exp/calib_fetch.py" --pmc FETCH_SIZE
+[ -z "$SKIP_CALIB" ] && run calib_tcc "python $R/scripts/exp/calib_fetch.py" --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_BUBBLE_sum TCC_HIT_sum
 fi
 python $R/scripts/make_traffic_json.py $(for W in ${WORKLOADS:-head L500 L1000 L2000 worst}; do echo $OUT/$W; done) > $OUT/search_traffic.json 2> $OUT/make_traffic.err
 ls -la $OUT
