@@ -934,11 +934,15 @@ static rg_status launch_k1(rg_index *ix, SearchCtx *cx, int mode, const float *d
                            uint32_t L, uint32_t *d_ids, float *d_dists, uint32_t *d_cmps, uint32_t *d_hops,
                            const uint32_t *qlist, bool with_log, unsigned long long *d_status, hipStream_t s,
                            const BuildOut *bp = nullptr, uint32_t qbase = 0, unsigned long long *d_totals = nullptr, uint32_t *d_ovf = nullptr,
-                           uint32_t lset_need = 0) {
+                           uint32_t lset_need = 0, bool lset_tags = false) {
     K1Plan plan;
     {
         rg_status st = plan_k1(ix, mode, nq, L, with_log, bp != nullptr, qlist != nullptr, s, &plan, lset_need);
         if (st != RG_OK) return st;
+    }
+    if (mode == 3 && lset_tags) {    // the set's overflow goes to the exact byte tags: one slot of tags per resident query
+        plan.vbytes = true;
+        plan.c.grid = std::min(plan.c.grid, visited_slot_cap(ix, true));
     }
     const K1Launch &c = plan.c;
     const int R = plan.R;
@@ -952,7 +956,7 @@ static rg_status launch_k1(rg_index *ix, SearchCtx *cx, int mode, const float *d
         if (ell) return launch_search_ip_ell(sp, c, s);
         return launch_search_ip_csr(sp, c, s);
     };
-    if (mode == 0) {
+    if (mode == 0 || (mode == 3 && lset_tags)) {
         rg_status st = ensure_visited(ix, cx, c.grid, vbytes, s);
         if (st != RG_OK) return st;
     }
@@ -962,7 +966,7 @@ static rg_status launch_k1(rg_index *ix, SearchCtx *cx, int mode, const float *d
     P.ell = ix->d_ell; P.ell_stride = ix->ell_stride; P.offsets = ix->d_offsets; P.nbrs = ix->d_nbrs;
     P.ep = ix->ep; P.queries = d_q; P.nq = nq; P.qstride = qstride; P.k = k; P.L = L;
     P.out_ids = d_ids; P.out_dists = d_dists; P.out_cmps = d_cmps; P.out_hops = d_hops;
-    P.visited = mode == 0 ? (vbytes ? cx->d_vtags : cx->d_visited) : nullptr;
+    P.visited = (mode == 0 || (mode == 3 && lset_tags)) ? (vbytes ? cx->d_vtags : cx->d_visited) : nullptr;
     P.vwords = vbytes ? cx->twords : cx->vwords; P.slot_epoch = vbytes ? cx->d_epoch8 : cx->d_epoch;
     P.vbytes = vbytes ? 1u : 0u;
     P.roll = ix->gather_roll ? 1u : 0u;
@@ -1146,7 +1150,10 @@ static rg_status search_dev(rg_index *ix, SearchCtx *cx, const float *d_q, uint3
             need = (uint32_t)(1.75f * (it != ix->evals_at.end() ? it->second : 44.0f * (float)L));
         }
         const bool forced = ix->lset > 0 && L <= (uint32_t)ix->lset;
-        if (forced || (ix->lset < 0 && L <= 512u)) {
+        // knob "lset_tags": where the set alone does not pay, the nodes it has no room for go to the exact byte tags in HBM
+        // (same kernel, P.visited set): exact without a log at any width whose beam leaves room for 512 buckets
+        const bool tags_ok = ix->lset_tags > 0 && !forced;
+        if (forced || (ix->lset < 0 && (L <= 512u || tags_ok))) {
             K1Plan plan;
             rg_status ps = plan_k1(ix, 3, nq, L, true, false, false, s, &plan, need);
             {
@@ -1156,16 +1163,20 @@ static rg_status search_dev(rg_index *ix, SearchCtx *cx, const float *d_q, uint3
                             ps == RG_OK ? plan.vf_slots + plan.vs_side : 0u, plan.c.grid, plan.c.grid / (uint32_t)std::max(1, ix->num_cu), plan.R);
             }
             // (holds >= 0.8 x the mean visits = 0.457 x need)
-            if (ps == RG_OK && (forced || (double)(plan.vf_slots + plan.vs_side) >= 0.457 * (double)need) && (st = ensure_qlog(ix, cx, nq)) == RG_OK &&
-                nq <= cx->qlog_chunk) {
+            const bool pure = forced || (L <= 512u && (double)(plan.vf_slots + plan.vs_side) >= 0.457 * (double)need);
+            const bool with_tags = !pure && tags_ok;
+            if (ps == RG_OK && (pure || with_tags) && (st = ensure_qlog(ix, cx, nq)) == RG_OK && nq <= cx->qlog_chunk) {
                 if (hipMemsetAsync(b->d_ovf, 0, 8, s) != hipSuccess) return fail(set_error(RG_ERR_DEVICE, "hipMemsetAsync failed"));
                 b->mode = 3;
                 st = launch_k1(ix, cx, 3, d_q, nq, qstride, k, L, d_ids, d_dists, d_cmps, d_hops, nullptr, true, b->d_stat, s, nullptr, 0, b->d_stat + 1,
-                               b->d_ovf, need);
+                               b->d_ovf, need, with_tags);
+                if (st == RG_ERR_OOM && with_tags) st = RG_OK, ps = RG_ERR_OOM;     // no room for the tags: the forms below
+                else {
                 if (st != RG_OK) return fail(st);
                 cx->log_holds = 0;
                 b->counted = true;
                 return done();
+                }
             }
             if (st != RG_OK) return fail(st);
         }
@@ -1692,6 +1703,7 @@ rg_status rg_index_set(rg_index *ix, const char *name, int value) {
     else if (!strcmp(name, "gather_form")) ix->gather_form = value;
     else if (!strcmp(name, "count_in_k1")) ix->count_in_k1 = value;
     else if (!strcmp(name, "lset_bytes")) ix->lset_bytes = value;
+    else if (!strcmp(name, "lset_tags")) ix->lset_tags = value;
     else if (!strcmp(name, "adaptive")) ix->adaptive = value != 0;
     else if (!strcmp(name, "lset")) ix->lset = value;
     else if (!strcmp(name, "log_early")) ix->log_early = value != 0;

@@ -543,7 +543,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
     const uint32_t vf_rem_mask = (1u << P.vf_rem_bits) - 1u;
 
     uint32_t *vmap = P.visited + (size_t)blockIdx.x * P.vwords;
-    uint32_t epoch = EXACT ? P.slot_epoch[blockIdx.x] : 0u;
+    // VIS = 3 with P.visited set ("lset_tags"): the nodes the exact LDS set has no room for go to the exact byte tags in HBM
+    // instead of being forgotten -- the form stays exact without a log, for beams whose visits outgrow the LDS
+    const bool ltags = LSET && P.visited != nullptr;
+    uint32_t epoch = (EXACT || ltags) ? P.slot_epoch[blockIdx.x] : 0u;
     unsigned long long tot_n = 0, tot_d = 0;   // in-kernel distinct count: this slot's share of the batch totals
     unsigned long long tot_left = 0;           // VIS = 3: queries of this slot that outgrew the exact set
 
@@ -567,8 +570,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
         if constexpr (BF) load_query_regs_bf<DIMC>(query, qb, lane);
         // new visited epoch (VisitedList::reset, visited_list_pool.h:20-26: ++curV, wipe on wrap)
         uint32_t etag = 0;
-        if (EXACT) {
-            if (++epoch == ((LOOK && P.vbytes) ? 0x100u : 0x10000u)) {
+        if (EXACT || ltags) {
+            if (++epoch == (((LOOK && P.vbytes) || ltags) ? 0x100u : 0x10000u)) {
                 for (uint32_t w = lane; w < P.vwords; w += kWave) vmap[w] = 0u;
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 epoch = 1;
@@ -675,7 +678,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
                                 }
                                 if (++sb == nsb) sb = 0;
                             }
-                            if (!done) { fresh = true; left = true; }      // no room: scored, not remembered
+                            if (!done && ltags) {                          // no room: the node's epoch byte in HBM decides and remembers
+                                uint8_t *t = reinterpret_cast<uint8_t *>(vmap) + id;
+                                fresh = __hip_atomic_load(t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (uint8_t)epoch;
+                                if (fresh) __hip_atomic_store(t, (uint8_t)epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            } else if (!done) { fresh = true; left = true; }      // no room: scored, not remembered
                             break;
                         }
                         const uint32_t w = e < 2 ? t.x : e < 4 ? t.y : e < 6 ? t.z : t.w;
@@ -1301,7 +1308,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
         atomicAdd(&P.totals[0], tot_n);
         atomicAdd(&P.totals[1], tot_d);
     }
-    if (EXACT && lane == 0) P.slot_epoch[blockIdx.x] = epoch;
+    if ((EXACT || ltags) && lane == 0) P.slot_epoch[blockIdx.x] = epoch;
 }
 
 // ------------------------------------------------------------------------------------------ launch plumbing
