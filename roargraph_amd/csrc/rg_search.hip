@@ -1152,8 +1152,12 @@ static rg_status search_dev(rg_index *ix, SearchCtx *cx, const float *d_q, uint3
         const bool forced = ix->lset > 0 && L <= (uint32_t)ix->lset;
         // knob "lset_tags": where the set alone does not pay, the nodes it has no room for go to the exact byte tags in HBM
         // (same kernel, P.visited set): exact without a log at any width whose beam leaves room for 512 buckets
+        // Measured on the 10M bench index (profiles/r04/k1_ab_box35_lset_tags.txt, % of 8 TB/s, this form / the default forms): L_pq 240
+        // 81.2 / 77.4 (the set holds 0.74 x the mean visits), 300 75.7 / 75.1 (0.60 x), 400 71.7 / 75.2 (0.45 x), 500 68.6 / 72.5, 1000 60.2 /
+        // 67.1 -- the tests behind the set are a dependent round trip per hop, which the look-ahead form of the tags hides; so the form is
+        // used (knob 1, default) where the set holds at least 0.6 x the mean visits, and everywhere with knob 2 (tests)
         const bool tags_ok = ix->lset_tags > 0 && !forced;
-        if (forced || (ix->lset < 0 && (L <= 512u || tags_ok))) {
+        if (forced || (ix->lset < 0 && (L <= 512u || ix->lset_tags >= 2))) {
             K1Plan plan;
             rg_status ps = plan_k1(ix, 3, nq, L, true, false, false, s, &plan, need);
             {
@@ -1164,7 +1168,7 @@ static rg_status search_dev(rg_index *ix, SearchCtx *cx, const float *d_q, uint3
             }
             // (holds >= 0.8 x the mean visits = 0.457 x need)
             const bool pure = forced || (L <= 512u && (double)(plan.vf_slots + plan.vs_side) >= 0.457 * (double)need);
-            const bool with_tags = !pure && tags_ok;
+            const bool with_tags = !pure && tags_ok && (ix->lset_tags >= 2 || (L <= 512u && (double)(plan.vf_slots + plan.vs_side) >= 0.343 * (double)need));
             if (ps == RG_OK && (pure || with_tags) && (st = ensure_qlog(ix, cx, nq)) == RG_OK && nq <= cx->qlog_chunk) {
                 if (hipMemsetAsync(b->d_ovf, 0, 8, s) != hipSuccess) return fail(set_error(RG_ERR_DEVICE, "hipMemsetAsync failed"));
                 b->mode = 3;

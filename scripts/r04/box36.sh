@@ -1,0 +1,11 @@
+#!/bin/bash
+# round 4, box 36: GPU suite + the 56-point sweep with the exact LDS set + tags form in the default rule (L_pq 230 - 290 on the bench index)
+R=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$R/gpurun_out/r04_box36
+mkdir -p $OUT
+cd $R
+timeout 1500 python -m pytest tests -x -q -m gpu > $OUT/pytest.log 2>&1; grep -E "passed|failed" $OUT/pytest.log | tail -2
+timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > $OUT/smoke.log 2>&1; tail -1 $OUT/smoke.log
+RG_TRACE_ADAPTIVE=1 timeout 1500 python bench.py --gpus 1 --steps 20 --warmup 5 --sweep readme --configs "" --no-worstcase --no-fast --no-two-streams --cpu-seconds 0 --config1-nb 0 --gt-nq 0 > $OUT/bench_sweep_readme.json 2> $OUT/bench.err
+python scripts/show_bench.py $OUT/bench_sweep_readme.json | head -62 | awk '{printf "%s ", $0; if (NR%3==0) print ""}' | cut -c1-250
+grep "exact LDS set at" $OUT/bench.err | sort | uniq -c | sort -k7 | head -70 | cut -c1-160
