@@ -776,6 +776,8 @@ struct K1Plan {
     uint32_t vf_slots = 8;
     bool vbytes = false;      // c.vis == 2 with one epoch byte per node
     uint32_t vs_side = 0;     // c.vis == 3: words of the side table behind the buckets (vf_slots = the buckets' entries then)
+    bool ls_front = false;    // c.vis == 2: the same set layout in front of the screen, which is the bl_words behind it
+    uint32_t bl_words = 0;
 };
 
 // entries + side-table ids of an exact LDS set cut from `bytes` of filter region (plan_k1 below makes the same split)
@@ -925,6 +927,21 @@ static rg_status plan_k1(rg_index *ix, int mode, uint32_t nq, uint32_t L, bool w
         if (buckets == 0 || filter_rem_bits(id_bits_of(ix->nd), buckets) > 15u)
             return set_error(RG_ERR_ARG, "internal: the exact LDS set does not fit this launch");
     }
+    out->ls_front = false; out->bl_words = 0;
+    if (c.vis == 2 && vbytes && ix->exact_filter && ix->front_set != 0) {
+        // look-ahead form with byte tags: the front of the screen's region becomes an exact set (knob "front_set": its share of
+        // the region in percent, default 70) when the rest still gives the screen 64 words and the set has the 2^(id_bits - 15)
+        // buckets its 16-bit entries need
+        const uint32_t region = vf_slots * 2u;
+        const uint32_t set_bytes = (uint32_t)((uint64_t)region * (uint32_t)std::min(95, std::max(5, ix->front_set < 0 ? 70 : ix->front_set)) / 100u) / 16u * 16u;
+        const uint32_t side = std::max(16u, set_bytes / 32u) & ~3u;
+        const uint32_t buckets = set_bytes > side * 4u ? (set_bytes - side * 4u) / 16u : 0u;
+        const uint32_t blw = (region - set_bytes) / 4u;
+        if (buckets && filter_rem_bits(id_bits_of(ix->nd), buckets) <= 15u && blw >= 64u) {
+            out->ls_front = true; out->bl_words = blw; out->vs_side = side;
+            vf_slots = buckets * 8u;
+        }
+    }
     out->c = c; out->R = R; out->bf = bf; out->vf_slots = vf_slots; out->vbytes = vbytes;
     return RG_OK;
 }
@@ -984,7 +1001,8 @@ static rg_status launch_k1(rg_index *ix, SearchCtx *cx, int mode, const float *d
     P.diag = (uint32_t)ix->diag;
     P.qbase = qbase;
     P.vf_slots = vf_slots;
-    P.vf_rem_bits = filter_rem_bits(id_bits_of(ix->nd), c.vis == 3 ? vf_slots / 8u : vf_slots);
+    P.vf_rem_bits = filter_rem_bits(id_bits_of(ix->nd), (c.vis == 3 || plan.ls_front) ? vf_slots / 8u : vf_slots);
+    P.ls_front = plan.ls_front ? 1u : 0u; P.bl_words = plan.bl_words;
     P.vs_side = plan.vs_side;
     P.ovf_count = d_ovf; P.ovf_list = d_ovf ? d_ovf + 2 : nullptr;       // (the batch record's overflow list: count, K4 work counter, queries)
     P.lset_left = d_totals ? d_totals + 2 : nullptr;
@@ -1708,6 +1726,7 @@ rg_status rg_index_set(rg_index *ix, const char *name, int value) {
     else if (!strcmp(name, "count_in_k1")) ix->count_in_k1 = value;
     else if (!strcmp(name, "lset_bytes")) ix->lset_bytes = value;
     else if (!strcmp(name, "lset_tags")) ix->lset_tags = value;
+    else if (!strcmp(name, "front_set")) ix->front_set = value;
     else if (!strcmp(name, "adaptive")) ix->adaptive = value != 0;
     else if (!strcmp(name, "lset")) ix->lset = value;
     else if (!strcmp(name, "log_early")) ix->log_early = value != 0;

@@ -61,6 +61,8 @@ struct SearchParams {
     uint32_t vf_rem_bits;     // bits of an entry: the smallest r with 2^r >= ceil(2^id_bits / vf_slots), at most 15
     uint32_t vf_front;        // VIS=0: 1 = the LDS filter screens the exact HBM words; VIS=2: 1 = the region is the bit screen
     uint32_t roll;            // register-staged gather: 1 = streamed (set j re-loaded as soon as it is scored), 0 = batch by batch
+    uint32_t ls_front;        // VIS=2 with byte tags: 1 = the front of the LDS region is an exact set (vf_slots entries + vs_side words, as in VIS=3), the screen is the bl_words behind it
+    uint32_t bl_words;        // words of that screen
     uint32_t vbytes;          // VIS=2: 1 = `visited` holds one epoch BYTE per node ([slots][4 * vwords] bytes) instead of the words
     uint32_t *qlog;           // VIS=1, optional: [nq][logcap] ids scored by each query (input of the exact distinct count)
     uint32_t logcap;
@@ -580,7 +582,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
         }
         if (VIS == 1 || LSET || P.vf_front) {   // exact-match filter / exact set: every slot empty; LOOK: the screen's bits clear
             uint32_t *vt32 = reinterpret_cast<uint32_t *>(vtab);
-            for (uint32_t i = lane; i < P.vf_slots / 2u + (LSET ? P.vs_side : 0u); i += kWave) vt32[i] = LOOK ? 0u : 0xffffffffu;
+            const bool lsf = LOOK && P.ls_front != 0u;    // LOOK with the exact set in front: set + side empty, then the screen's bits clear
+            const uint32_t nset = P.vf_slots / 2u + ((LSET || lsf) ? P.vs_side : 0u);
+            for (uint32_t i = lane; i < nset; i += kWave) vt32[i] = (LOOK && !lsf) ? 0u : 0xffffffffu;
+            if (lsf) for (uint32_t i = lane; i < P.bl_words; i += kWave) vt32[nset + i] = 0u;
         }
         wave_sync();
 
@@ -612,8 +617,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
         // at all (a set bit proves nothing: the word decides).  No false "visited", so every output stays exact; what it
         // saves is memory transactions: a wide beam tests 1.8 nodes per node it scores, and more than half of the tests
         // are of nodes never met before.
-        uint32_t *bl32 = reinterpret_cast<uint32_t *>(vtab);
-        const uint32_t bl_bits = P.vf_slots * 16u;
+        // P.ls_front (round 4): the front of the region is an EXACT SET (the layout of VIS = 3: vf_slots entries + vs_side words), the
+        // screen the bl_words behind it.  A node the set holds needs no tag at all -- no mark stored, no line read when it is met
+        // again (the re-encounters are most of the tag lines a wide beam reads: 22 of 25 per hop at L_pq 500) -- and the tags and
+        // the screen keep only the nodes the set had no room for.
+        const bool fset = LOOK && P.ls_front != 0u;
+        uint32_t *bl32 = reinterpret_cast<uint32_t *>(vtab) + (fset ? P.vf_slots / 2u + P.vs_side : 0u);
+        const uint32_t bl_bits = fset ? P.bl_words * 32u : P.vf_slots * 16u;
         const bool screen = LOOK && P.vf_front != 0u;
         auto bl_maybe = [&](uint32_t id) __attribute__((always_inline)) -> bool {
             const uint32_t p = __umulhi(id * 0x9E3779B1u, bl_bits);
@@ -630,65 +640,69 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
         auto keeps = [&](uint32_t idw) __attribute__((always_inline)) -> bool {
             return idm == 0xffffffffu || (idw >> 24) >= P.vf_min_indeg;
         };
+        // exact set in LDS (VIS = 3; VIS = 2 with P.ls_front: in FRONT of the byte tags).  bucket = floor(x * buckets / 2^id_bits) of the
+        // bijective hash x, entry = the low bits of x that tell the x of one bucket apart (vf_hash with slots = buckets):
+        // (bucket, entry) <-> id.  Found -> visited.  Not found -> the first empty entry takes it (CAS on its word: two lanes of
+        // one hop that bring the same node meet here, and exactly one of them is fresh); a full bucket sends the node to the side
+        // table: buckets of four full ids (one ds_read_b128 each), at most four of them from the id's hash on.  A node is only
+        // ever placed within that reach, so a lookup that finds it nowhere there has seen everything; no room within it = the
+        // set cannot take the node.  (The first version probed single words linearly: a full table cost a CAS round trip per word
+        // and lookup -- the cliff of profiles/r04/k1_ab_box14_lset_plan.txt.)
+        // ls_visit: 0 = visited, 1 = inserted now (fresh), 2 = not in the set and no room for it.  ls_lookup: found or not.
+        auto ls_visit = [&](uint32_t id, bool insert) __attribute__((always_inline)) -> int {
+            const uint32_t x = (id * 0x9E3779B1u) & vf_id_mask;
+            const uint32_t b = __umulhi(x << vf_up, P.vf_slots >> 3);
+            const uint16_t rem = (uint16_t)(x & vf_rem_mask);
+            uint32_t *bk = reinterpret_cast<uint32_t *>(vtab) + 4u * b;
+            for (;;) {
+                const uint4 t = *reinterpret_cast<const uint4 *>(bk);
+                const uint32_t w4[4] = {t.x, t.y, t.z, t.w};
+                int e = 8;
+                bool found = false;
+#pragma unroll
+                for (int k2 = 7; k2 >= 0; --k2) {
+                    const uint32_t hv = (k2 & 1) ? w4[k2 >> 1] >> 16 : w4[k2 >> 1] & 0xffffu;
+                    found |= hv == (uint32_t)rem;
+                    if (hv == 0xffffu) e = k2;
+                }
+                if (found) return 0;
+                if (e == 8) {
+                    uint32_t *side = reinterpret_cast<uint32_t *>(vtab) + (P.vf_slots >> 1);
+                    const uint32_t nsb = P.vs_side >> 2;
+                    uint32_t sb = __umulhi(id * 0x85EBCA6Bu, nsb);
+                    for (int pr = 0; pr < 4; ++pr) {
+                        uint32_t *sp = side + 4u * sb;
+                        for (;;) {
+                            const uint4 sv = *reinterpret_cast<const uint4 *>(sp);
+                            if (sv.x == id || sv.y == id || sv.z == id || sv.w == id) return 0;                      // visited
+                            const int se = sv.x == 0xffffffffu ? 0 : sv.y == 0xffffffffu ? 1 : sv.z == 0xffffffffu ? 2 : sv.w == 0xffffffffu ? 3 : 4;
+                            if (se == 4) break;                                                              // full: the next bucket
+                            if (!insert) return 2;             // (a free entry in reach: the node is not in the set)
+                            const uint32_t old = atomicCAS(sp + se, 0xffffffffu, id);
+                            if (old == 0xffffffffu) return 1;
+                            if (old == id) return 0;                                                         // another lane of this hop brought it
+                        }
+                        if (++sb == nsb) sb = 0;
+                    }
+                    return 2;
+                }
+                if (!insert) return 2;
+                const uint32_t w = e < 2 ? t.x : e < 4 ? t.y : e < 6 ? t.z : t.w;
+                const uint32_t nw = (e & 1) ? (w & 0x0000ffffu) | ((uint32_t)rem << 16) : (w & 0xffff0000u) | (uint32_t)rem;
+                if (atomicCAS(&bk[e >> 1], w, nw) == w) return 1;
+            }
+        };
         auto visit_set = [&](uint32_t id, bool have, bool keep) __attribute__((always_inline)) -> bool {
             bool fresh = false;
             if (LSET) {
-                // exact set: bucket = floor(x * buckets / 2^id_bits) of the bijective hash x, entry = the low bits of x that tell
-                // the x of one bucket apart (vf_hash with slots = buckets): (bucket, entry) <-> id.  Found -> visited.  Not
-                // found -> the first empty entry takes it (CAS on its word: two lanes of one hop that bring the same node
-                // meet here, and exactly one of them is fresh); a full bucket sends the node to the side table of full ids.
                 if (have) {
-                    uint32_t b; uint16_t rem;
-                    const uint32_t x = (id * 0x9E3779B1u) & vf_id_mask;
-                    b = __umulhi(x << vf_up, P.vf_slots >> 3);
-                    rem = (uint16_t)(x & vf_rem_mask);
-                    uint32_t *bk = reinterpret_cast<uint32_t *>(vtab) + 4u * b;
-                    for (;;) {
-                        const uint4 t = *reinterpret_cast<const uint4 *>(bk);
-                        const uint32_t w4[4] = {t.x, t.y, t.z, t.w};
-                        int e = 8;
-                        bool found = false;
-#pragma unroll
-                        for (int k2 = 7; k2 >= 0; --k2) {
-                            const uint32_t hv = (k2 & 1) ? w4[k2 >> 1] >> 16 : w4[k2 >> 1] & 0xffffu;
-                            found |= hv == (uint32_t)rem;
-                            if (hv == 0xffffu) e = k2;
-                        }
-                        if (found) break;
-                        if (e == 8) {
-                            // bucket full: the side table -- buckets of four full ids (one ds_read_b128 each), at most four of
-                            // them from the id's hash on.  A node is only ever placed within that reach, so a lookup that finds
-                            // it nowhere there has seen everything; no room within it = the query has outgrown its set.  (The
-                            // first version probed single words linearly: a full table cost a CAS round trip per word and
-                            // lookup -- the cliff of profiles/r04/k1_ab_box14_lset_plan.txt.)
-                            uint32_t *side = reinterpret_cast<uint32_t *>(vtab) + (P.vf_slots >> 1);
-                            const uint32_t nsb = P.vs_side >> 2;
-                            uint32_t sb = __umulhi(id * 0x85EBCA6Bu, nsb);
-                            bool done = false;
-                            for (int pr = 0; pr < 4 && !done; ++pr) {
-                                uint32_t *sp = side + 4u * sb;
-                                for (;;) {
-                                    const uint4 sv = *reinterpret_cast<const uint4 *>(sp);
-                                    if (sv.x == id || sv.y == id || sv.z == id || sv.w == id) { done = true; break; }   // visited
-                                    const int se = sv.x == 0xffffffffu ? 0 : sv.y == 0xffffffffu ? 1 : sv.z == 0xffffffffu ? 2 : sv.w == 0xffffffffu ? 3 : 4;
-                                    if (se == 4) break;                                                              // full: the next bucket
-                                    const uint32_t old = atomicCAS(sp + se, 0xffffffffu, id);
-                                    if (old == 0xffffffffu) { fresh = true; done = true; break; }
-                                    if (old == id) { done = true; break; }                                           // another lane of this hop brought it
-                                }
-                                if (++sb == nsb) sb = 0;
-                            }
-                            if (!done && ltags) {                          // no room: the node's epoch byte in HBM decides and remembers
-                                uint8_t *t = reinterpret_cast<uint8_t *>(vmap) + id;
-                                fresh = __hip_atomic_load(t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (uint8_t)epoch;
-                                if (fresh) __hip_atomic_store(t, (uint8_t)epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            } else if (!done) { fresh = true; left = true; }      // no room: scored, not remembered
-                            break;
-                        }
-                        const uint32_t w = e < 2 ? t.x : e < 4 ? t.y : e < 6 ? t.z : t.w;
-                        const uint32_t nw = (e & 1) ? (w & 0x0000ffffu) | ((uint32_t)rem << 16) : (w & 0xffff0000u) | (uint32_t)rem;
-                        if (atomicCAS(&bk[e >> 1], w, nw) == w) { fresh = true; break; }
-                    }
+                    const int r = ls_visit(id, true);
+                    if (r == 1) fresh = true;
+                    else if (r == 2 && ltags) {                    // no room: the node's epoch byte in HBM decides and remembers
+                        uint8_t *t = reinterpret_cast<uint8_t *>(vmap) + id;
+                        fresh = __hip_atomic_load(t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (uint8_t)epoch;
+                        if (fresh) __hip_atomic_store(t, (uint8_t)epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    } else if (r == 2) { fresh = true; left = true; }      // no room: scored, not remembered
                 }
             } else if (VIS == 1) {
                 // exact-match lookup: a hit proves "visited"; a miss is treated as fresh (may re-score a node whose
@@ -719,10 +733,16 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
                     if (!known) vtab[slot] = rem;
                 }
                 if (LOOK && P.vbytes) {                    // byte tags (general path of the LOOK form: long rows, shared first hop)
-                    uint8_t *t = reinterpret_cast<uint8_t *>(vmap) + id;
-                    fresh = __hip_atomic_load(t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (uint8_t)epoch;
-                    if (fresh) __hip_atomic_store(t, (uint8_t)epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    const int r = fset ? ls_visit(id, true) : 2;
+                    if (r == 1) fresh = true;
+                    else if (r == 2) {
+                        uint8_t *t = reinterpret_cast<uint8_t *>(vmap) + id;
+                        fresh = __hip_atomic_load(t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != (uint8_t)epoch;
+                        if (fresh) __hip_atomic_store(t, (uint8_t)epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the next hop's tests leave without a wait of their own
+                    if (screen && fresh && r == 2) bl_set(id);
+                    return fresh;
                 } else if (!known) {
                     uint32_t *w = &vmap[id >> 4];
                     const uint32_t bit = 1u << (id & 15u);
@@ -1027,8 +1047,13 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
                 if (screen || P.vbytes) {
                     // only the lanes whose screen bit is set read their word; 0 = "stale epoch" = fresh for the others
                     lds_fence();
-                    const bool ma = (uint32_t)lane < min(dg, 63u) && (!screen || bl_maybe(ia));
-                    const bool mb = dg > 63u && 63u + (uint32_t)lane < dg && (!screen || bl_maybe(fb & idm));
+                    // (front set: a node it holds needs no tag; one it does not hold is tested whether or not the set will take it)
+                    bool ma = (uint32_t)lane < min(dg, 63u) && (!screen || bl_maybe(ia));
+                    bool mb = dg > 63u && 63u + (uint32_t)lane < dg && (!screen || bl_maybe(fb & idm));
+                    if (fset) {
+                        if (ma) ma = ls_visit(ia, false) != 0;
+                        if (mb) mb = ls_visit(fb & idm, false) != 0;
+                    }
                     wa = 0u; wb = 0u;
                     if (P.vbytes) {
                         const uint8_t *t = reinterpret_cast<const uint8_t *>(vmap);
@@ -1073,12 +1098,18 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
                 const uint32_t bitA = 1u << (idA & 15u), bitB = 1u << (idB & 15u);
                 // :2378 (a word / byte the screen spared reads 0, which no epoch equals)
                 const bool vb = P.vbytes != 0u;
-                const bool freshA = haveA && (vb ? wa != epoch : !((wa >> 16) == epoch && (wa & bitA)));
-                const bool freshB = haveB && (vb ? wb != epoch : !((wb >> 16) == epoch && (wb & bitB)));
+                // front set first: 0 = it holds the node (visited), 1 = it took the node now (fresh, no tag), 2 = the tags decide
+                int rA = 2, rB = 2;
+                if (fset) {
+                    if (haveA) rA = ls_visit(idA, true);
+                    if (haveB) rB = ls_visit(idB, true);
+                }
+                const bool freshA = haveA && (rA == 1 || (rA == 2 && (vb ? wa != epoch : !((wa >> 16) == epoch && (wa & bitA)))));
+                const bool freshB = haveB && (rB == 1 || (rB == 2 && (vb ? wb != epoch : !((wb >> 16) == epoch && (wb & bitB)))));
                 if (vb) {                        // :2385 as a plain byte store: no line is fetched for it, none comes back
                     uint8_t *t = reinterpret_cast<uint8_t *>(vmap);
-                    if (freshA) { __hip_atomic_store(t + idA, (uint8_t)epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (screen) bl_set(idA); }
-                    if (freshB) { __hip_atomic_store(t + idB, (uint8_t)epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (screen) bl_set(idB); }
+                    if (freshA && rA == 2) { __hip_atomic_store(t + idA, (uint8_t)epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (screen) bl_set(idA); }
+                    if (freshB && rB == 2) { __hip_atomic_store(t + idB, (uint8_t)epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (screen) bl_set(idB); }
                 } else {
                 if (freshA) {                    // :2385, fire and forget
                     uint32_t *w = &vmap[idA >> 4];

@@ -193,6 +193,34 @@ def test_exact_words_forms(rg, oracle, metric, d, nb, lookahead, exact_filter):
     ix.close()
 
 
+@pytest.mark.parametrize("metric,d,nb", [("ip", 200, 4000), ("l2", 512, 2000)])
+@pytest.mark.parametrize("front_set", [-1, 30, 90])
+def test_look_ahead_form_with_an_exact_set_in_front_of_the_tags(rg, oracle, metric, d, nb, front_set):
+    """Knob front_set (round 4): in the look-ahead byte-tag form the front of the LDS region is an exact set (the buckets of the
+    narrow-beam form); a node it holds needs no tag, the tags and the bit screen keep the nodes it had no room for.  Small and
+    large shares of the region, beams that fit the set and beams that outgrow it many times, repeated calls (the slots' epochs
+    advance), the wrap of the epoch byte with two slots: all four outputs bit-exact."""
+    base, q, off, nbrs, ep = small_set(metric, nb, d)
+    ix = rg.IndexBipartite.from_arrays(base, off, nbrs, ep, metric=metric)
+    ix.set("visited", 0)
+    ix.set("lookahead", 1)
+    ix.set("front_set", front_set)
+    for L, k in ((10, 10), (100, 100), (700, 10), (2000, 10)):
+        want = oracle.search(base, metric, off, nbrs, ep, q, k, L, nthreads=4)
+        for rpp in ((16, 32) if d == 200 else (8, 16)):
+            ix.set("rows_per_pass", rpp)
+            for rep in range(2):
+                got = ix.SearchRoarGraph(q, k, L)
+                assert (got[2] == want[2]).all(), ("cmps", L, rpp, rep)
+                assert (got[3] == want[3]).all() and (got[0] == want[0]).all() and (bits(got[1]) == bits(want[1])).all(), (L, rpp, rep)
+    ix.set("visited_budget_kb", 8)      # two slots: both pass the wrap of the epoch byte below
+    want = oracle.search(base, metric, off, nbrs, ep, q, 10, 300, nthreads=4)
+    for call in range(10):
+        got = ix.SearchRoarGraph(q, 10, 300)
+        assert (got[2] == want[2]).all() and (got[3] == want[3]).all() and (got[0] == want[0]).all() and (bits(got[1]) == bits(want[1])).all(), call
+    ix.close()
+
+
 def test_byte_tags_survive_the_epoch_wrap(rg, oracle):
     """Byte form of the exact visited set (look-ahead kernel form): a slot's epoch is one byte, so its tags are wiped every 255
     queries (VisitedList::reset, visited_list_pool.h:20-26).  Two slots (visited_budget_kb) serve 64 queries per call: twelve
