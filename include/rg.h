@@ -139,7 +139,8 @@ rg_status rg_index_info(const rg_index *idx, uint32_t *nd, uint32_t *dim, uint32
  * Round-4 knobs, none of which changes a result: "lset" (-1 automatic / 0 never / N = beams up to N wide: the exact visited
  * set in LDS of the default mode at narrow beams, rg_search_kernel.h VIS = 3), "lset_bytes" (tests: cap of that set's LDS
  * region), "lset_tags" (1, default: where that set alone no longer pays but still holds 0.6 x a query's visits, the nodes it has
- * no room for go to the exact byte tags in HBM; 2: wherever it fits; 0: never), "adaptive" (0: the
+ * no room for go to the exact byte tags in HBM; 2: wherever it fits; 0: never), "front_set" (look-ahead byte-tag form: -1, default =
+ * an exact set in front of the tags where it holds 0.4 x a query's visits, 0 never, N = N % of the LDS region always), "adaptive" (0: the
  * default mode keeps its filter + log form at every width -- bench.py's row-reuse statistics need the logs). */
 rg_status rg_index_set(rg_index *idx, const char *name, int value);
 /* Counters of the search path since the index was opened (diagnostics: which form the batches ran in).  Names:

@@ -122,7 +122,7 @@ struct rg_index {
     int count_in_k1 = -1;        // knob: beams up to this wide count their distinct ids inside K1 (-1 = 40, 0 = never: K4 counts)
     bool adaptive = true;        // knob: 0 = the default visited mode never leaves (or tries to leave) its filter + log + K4 form for the exact tags
     int lset_tags = 1;           // knob: 1 = where the exact LDS set alone does not pay but still holds 0.6 x the visits, its overflow goes to the exact byte tags (VIS = 3 + tags); 2 = wherever it fits (tests); 0 = never
-    int front_set = 0;           // knob: look-ahead byte-tag form with an exact set in front of the screen: 0 = no, -1 = 70 % of the region, N = N %
+    int front_set = -1;          // knob: look-ahead byte-tag form with an exact set in front of the screen: -1 = 85 % of the region where that holds 0.4 x a query's visits, 0 = never, N = N % always
     int lset_bytes = 0;          // knob (tests): cap of the exact LDS set's region in bytes (0 = what the launch has)
     int lset = -1;               // knob "lset" (round 4): default visited mode, narrow beams: the exact visited set in LDS (K1 VIS = 3: no id
                                  // log, no K4, no de-duplicating inserts).  -1 = wherever a query's visits fit the LDS a launch can give it,

@@ -929,15 +929,31 @@ static rg_status plan_k1(rg_index *ix, int mode, uint32_t nq, uint32_t L, bool w
     }
     out->ls_front = false; out->bl_words = 0;
     if (c.vis == 2 && vbytes && ix->exact_filter && ix->front_set != 0) {
-        // look-ahead form with byte tags: the front of the screen's region becomes an exact set (knob "front_set": its share of
-        // the region in percent, default 70) when the rest still gives the screen 64 words and the set has the 2^(id_bits - 15)
-        // buckets its 16-bit entries need
+        // look-ahead form with byte tags: the front of the screen's region becomes an exact set (knob "front_set": N = its share of
+        // the region in percent; -1, the default = 85 % where that holds at least 0.4 x the nodes a query of this width visits) when
+        // the rest still gives the screen 64 words and the set has the 2^(id_bits - 15) buckets its 16-bit entries need.
+        // Measured on the 10M bench index (profiles/r04/k1_ab_box38_front_set.txt; % of 8 TB/s, shares 50 / 70 / 85 % against the
+        // form without it): L_pq 300 72.7 / 79.5 / 80.9 against 76.1 (85 %: the set holds 0.51 x the visits), 400 75.4 / 75.0 / 74.8
+        // against 74.4 (0.38 x), 500 73.6 / 72.0 / 73.2 against 74.1 (0.30 x), 700 71.1 / 70.4 / 68.7 against 71.5: a node the set holds
+        // costs no tag store and no tag line when it is met again, but a full set makes every other test walk a bucket and the side
+        // table, and what the set takes the screen loses.
         const uint32_t region = vf_slots * 2u;
-        const uint32_t set_bytes = (uint32_t)((uint64_t)region * (uint32_t)std::min(95, std::max(5, ix->front_set < 0 ? 70 : ix->front_set)) / 100u) / 16u * 16u;
+        const uint32_t pct = (uint32_t)std::min(95, std::max(5, ix->front_set < 0 ? 85 : ix->front_set));
+        const uint32_t set_bytes = (uint32_t)((uint64_t)region * pct / 100u) / 16u * 16u;
         const uint32_t side = std::max(16u, set_bytes / 32u) & ~3u;
         const uint32_t buckets = set_bytes > side * 4u ? (set_bytes - side * 4u) / 16u : 0u;
         const uint32_t blw = (region - set_bytes) / 4u;
-        if (buckets && filter_rem_bits(id_bits_of(ix->nd), buckets) <= 15u && blw >= 64u) {
+        bool use = buckets && filter_rem_bits(id_bits_of(ix->nd), buckets) <= 15u && blw >= 64u;
+        if (use && ix->front_set < 0) {
+            float visits;
+            {
+                std::lock_guard<std::mutex> lk(ix->mu);
+                auto it = ix->evals_at.find(L);
+                visits = it != ix->evals_at.end() ? it->second : 44.0f * (float)L;
+            }
+            use = (float)(buckets * 8u + side) >= 0.4f * visits;
+        }
+        if (use) {
             out->ls_front = true; out->bl_words = blw; out->vs_side = side;
             vf_slots = buckets * 8u;
         }
