@@ -141,11 +141,14 @@ rg_status rg_index_info(const rg_index *idx, uint32_t *nd, uint32_t *dim, uint32
  * region), "lset_tags" (1, default: where that set alone no longer pays but still holds 0.6 x a query's visits, the nodes it has
  * no room for go to the exact byte tags in HBM; 2: wherever it fits; 0: never), "front_set" (look-ahead byte-tag form: -1, default =
  * an exact set in front of the tags where it holds 0.4 x a query's visits, 0 never, N = N % of the LDS region always), "adaptive" (0: the
- * default mode keeps its filter + log form at every width -- bench.py's row-reuse statistics need the logs). */
+ * default mode keeps its filter + log form at every width -- bench.py's row-reuse statistics need the logs), "hub_bits" (round 5:
+ * the look-ahead byte-tag form keeps an exact bitmap of the launch's hubs -- the nodes of highest in-degree per hashed position -- at the
+ * front of its LDS region: -1, default = sized by "hub_pct" (largest share of the region, percent, default 60), 0 = never, m = 2^m bits). */
 rg_status rg_index_set(rg_index *idx, const char *name, int value);
 /* Counters of the search path since the index was opened (diagnostics: which form the batches ran in).  Names:
  * "batches_lset" / "batches_filter_log" / "batches_exact_hbm" / "batches_filter_only" (batches enqueued per form),
- * "lset_left" (queries that outgrew their exact LDS set), "recounted" (queries whose cmps the host recounted). */
+ * "lset_left" (queries that outgrew their exact LDS set), "recounted" (queries whose cmps the host recounted), "hub_levels" (1: the
+ * adjacency carries hub levels), "hub_m_last" (log2 of the hub bitmap of the last search launch, 0 = none). */
 rg_status rg_index_stat(const rg_index *idx, const char *name, uint64_t *value);
 /* Where the large buffers of the indexes on `device` live (diagnostics; no counterpart in the reference).  The library
  * builds every buffer of 2 GiB and more from 1-GiB granules taken round robin over the memory classes of the device
@@ -154,6 +157,13 @@ rg_status rg_index_stat(const rg_index *idx, const char *name, uint64_t *value);
  * requests that fell back to a plain allocation, classes = memory classes found, granules_per_class[4] = granules of the
  * live buffers per class.  RG_BALANCED_ALLOC=0 in the environment turns the balancing off. */
 rg_status rg_mem_stats(int device, uint64_t *buffers, uint64_t *plain, uint32_t *classes, uint64_t *granules_per_class);
+/* The device adjacency of an index as the search kernel reads it (diagnostics, tests; no counterpart in the reference):
+ * [npts][*stride] words, word 0 of a row = its degree, then the neighbours: id in the low 24 bits and -- on indexes of up to 2^24
+ * nodes -- min(15, in-degree of the neighbour) in bits 24..27 and its hub level in bits 28..31 (knob "hub_bits": at 2^m bits the
+ * hub bitmap of a launch gives position p to the node of highest in-degree among those with (id * 0x9E3779B1) >> (32 - m) == p;
+ * level = the smallest such m, 8 .. 22, minus 8; 15 = never).  *nwords = npts * stride; host_out = NULL only reports the sizes.
+ * RG_ERR_ARG when the index keeps a CSR adjacency instead. */
+rg_status rg_index_debug_ell(const rg_index *idx, uint32_t *host_out, uint64_t *nwords, uint32_t *stride);
 
 /* ----------------------------------------------------------------- operator
  * Replaces: float Distance::compare(const float *a, const float *b, unsigned length) (distance.h:18;

@@ -123,6 +123,11 @@ struct rg_index {
     bool adaptive = true;        // knob: 0 = the default visited mode never leaves (or tries to leave) its filter + log + K4 form for the exact tags
     int lset_tags = 1;           // knob: 1 = where the exact LDS set alone does not pay but still holds 0.6 x the visits, its overflow goes to the exact byte tags (VIS = 3 + tags); 2 = wherever it fits (tests); 0 = never
     int front_set = -1;          // knob: look-ahead byte-tag form with an exact set in front of the screen: -1 = 85 % of the region where that holds 0.4 x a query's visits, 0 = never, N = N % always
+    bool hub_levels = false;     // ELL neighbour words carry the hub level of the neighbour in their top nibble (computed at open; RG_HUB_BITS=0: no)
+    int hub_bits = -1;           // knob: hub bitmap of the visited region: -1 = the look-ahead tag form takes one (size by "hub_pct"), 0 = never,
+                                 // m = 2^m bits whatever the region's size suggests (tests, experiments)
+    int hub_pct = -1;            // knob: largest share of the visited region the bitmap may take, percent (-1 = 60)
+    uint32_t hub_m_last = 0;     // statistics: log2 of the bitmap of the last search launch (0 = none)
     int lset_bytes = 0;          // knob (tests): cap of the exact LDS set's region in bytes (0 = what the launch has)
     int lset = -1;               // knob "lset" (round 4): default visited mode, narrow beams: the exact visited set in LDS (K1 VIS = 3: no id
                                  // log, no K4, no de-duplicating inserts).  -1 = wherever a query's visits fit the LDS a launch can give it,

@@ -324,14 +324,51 @@ __global__ void rg_csr_to_ell_kernel(const uint64_t *offsets, const uint32_t *nb
 __global__ void rg_indeg_kernel(const uint32_t *__restrict__ nbrs, uint64_t ne, uint32_t *__restrict__ indeg) {
     for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < ne; e += (size_t)gridDim.x * blockDim.x) atomicAdd(&indeg[nbrs[e]], 1u);
 }
-__global__ void rg_ell_tag_kernel(uint32_t *__restrict__ ell, uint32_t nd, uint32_t ell_stride, const uint32_t *__restrict__ indeg) {
+// top byte of a neighbour word: low nibble = min(15, in-degree of the neighbour) (admission rule of the LDS filter), high nibble =
+// its hub level (rg_search_kernel.h, SearchParams::hub_m; 15 = never a hub)
+__global__ void rg_ell_tag_kernel(uint32_t *__restrict__ ell, uint32_t nd, uint32_t ell_stride, const uint32_t *__restrict__ indeg,
+                                  const uint8_t *__restrict__ hub_lvl) {
     const size_t total = (size_t)nd * ell_stride;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
         const size_t row = i / ell_stride;
         const uint32_t j = (uint32_t)(i - row * ell_stride);
         if (j == 0 || j > ell[row * ell_stride]) continue;      // word 0 = degree; words beyond it are padding
         const uint32_t id = ell[i];
-        ell[i] = id | (min(255u, indeg[id]) << 24);
+        ell[i] = id | (min(15u, indeg[id]) << 24) | ((hub_lvl ? (uint32_t)hub_lvl[id] : 15u) << 28);
+    }
+}
+
+// ---- hub levels (round 5).  A visited bitmap of 2^m bits in LDS gives bit p to ONE node: the node of highest in-degree among those
+// whose hashed id falls on p = (id * 0x9E3779B1) >> (32 - m), the smaller id on a tie -- the node met most often per bit spent.
+// Positions nest over m, so the owner of a position at 2^m bits owns its position at every larger size; level = the smallest m
+// (kHubMinM ... kHubMaxM) at which the node owns a bit.  Key of a node: (in-degree, ~id), the largest key wins a position.
+constexpr uint32_t kHubMinM = 8, kHubMaxM = 22, kHubMult = 0x9E3779B1u;
+__global__ void rg_hub_key_kernel(const uint32_t *__restrict__ indeg, uint32_t nd, unsigned long long *__restrict__ finest) {
+    for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nd; v += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t dg = indeg[v];
+        if (dg == 0) continue;                                  // never met as a neighbour
+        atomicMax(&finest[((uint32_t)v * kHubMult) >> (32u - kHubMaxM)], ((unsigned long long)dg << 32) | (0xffffffffu - (uint32_t)v));
+    }
+}
+// tables of all sizes in one array: level m at words [2^m, 2^(m+1)); level m - 1 from level m
+__global__ void rg_hub_reduce_kernel(unsigned long long *__restrict__ tabs, uint32_t m) {
+    const uint32_t n = 1u << (m - 1u);
+    for (uint32_t p = blockIdx.x * blockDim.x + threadIdx.x; p < n; p += gridDim.x * blockDim.x) {
+        const unsigned long long a = tabs[(2u << (m - 1u)) + 2u * p], b = tabs[(2u << (m - 1u)) + 2u * p + 1u];
+        tabs[n + p] = a > b ? a : b;
+    }
+}
+__global__ void rg_hub_level_kernel(const uint32_t *__restrict__ indeg, uint32_t nd, const unsigned long long *__restrict__ tabs, uint8_t *__restrict__ lvl) {
+    for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nd; v += (size_t)gridDim.x * blockDim.x) {
+        const uint32_t dg = indeg[v];
+        uint32_t l = 15u;
+        if (dg) {
+            const unsigned long long key = ((unsigned long long)dg << 32) | (0xffffffffu - (uint32_t)v);
+            const uint32_t x = (uint32_t)v * kHubMult;
+            for (uint32_t m = kHubMinM; m <= kHubMaxM; ++m)
+                if (tabs[(1u << m) + (x >> (32u - m))] == key) { l = m - kHubMinM; break; }
+        }
+        lvl[v] = (uint8_t)l;
     }
 }
 
@@ -503,9 +540,21 @@ static rg_status finish_graph(rg_index *ix, const uint64_t *d_off, const uint32_
                     if (stale != hipSuccess && getenv("RG_TRACE_STALE")) fprintf(stderr, "[rg_index_open] stale HIP error before tagging: %s\n", hipGetErrorString(stale));
                 }
                 hipLaunchKernelGGL(rg_indeg_kernel, dim3(4096), dim3(256), 0, 0, d_nb, (uint64_t)ne, indeg.p);
-                hipLaunchKernelGGL(rg_ell_tag_kernel, dim3(8192), dim3(256), 0, 0, ix->d_ell, ix->nd, es, indeg.p);
+                // hub levels: 64 MB of position tables for a moment (optional: without them no node is a hub, RG_HUB_BITS=0: never)
+                DevBuf<unsigned long long> tabs;
+                DevBuf<uint8_t> lvl;
+                const char *henv = getenv("RG_HUB_BITS");
+                bool hubs = !(henv && atoi(henv) == 0) && tabs.alloc((size_t)2 << kHubMaxM) == hipSuccess && lvl.alloc(ix->nd) == hipSuccess &&
+                            hipMemset(tabs.p, 0, ((size_t)2 << kHubMaxM) * 8) == hipSuccess;
+                if (hubs) {
+                    hipLaunchKernelGGL(rg_hub_key_kernel, dim3(4096), dim3(256), 0, 0, indeg.p, ix->nd, tabs.p + ((size_t)1 << kHubMaxM));
+                    for (uint32_t m = kHubMaxM; m > kHubMinM; --m)
+                        hipLaunchKernelGGL(rg_hub_reduce_kernel, dim3(std::max(1u, std::min(4096u, (1u << (m - 1u)) / 256u))), dim3(256), 0, 0, tabs.p, m);
+                    hipLaunchKernelGGL(rg_hub_level_kernel, dim3(4096), dim3(256), 0, 0, indeg.p, ix->nd, tabs.p, lvl.p);
+                } else (void)hipGetLastError();
+                hipLaunchKernelGGL(rg_ell_tag_kernel, dim3(8192), dim3(256), 0, 0, ix->d_ell, ix->nd, es, indeg.p, hubs ? lvl.p : nullptr);
                 const hipError_t e1 = hipGetLastError(), e2 = hipDeviceSynchronize();
-                if (e1 == hipSuccess && e2 == hipSuccess) ix->ell_tagged = true;
+                if (e1 == hipSuccess && e2 == hipSuccess) { ix->ell_tagged = true; ix->hub_levels = hubs; }
                 else return set_error(RG_ERR_DEVICE, std::string("tagging the adjacency rows failed: ") + hipGetErrorString(e1 != hipSuccess ? e1 : e2));
             } else (void)hipGetLastError();
         }
@@ -778,6 +827,7 @@ struct K1Plan {
     uint32_t vs_side = 0;     // c.vis == 3: words of the side table behind the buckets (vf_slots = the buckets' entries then)
     bool ls_front = false;    // c.vis == 2: the same set layout in front of the screen, which is the bl_words behind it
     uint32_t bl_words = 0;
+    uint32_t hub_m = 0;       // log2 of the bits of the hub bitmap at the front of the visited region (0 = none)
 };
 
 // entries + side-table ids of an exact LDS set cut from `bytes` of filter region (plan_k1 below makes the same split)
@@ -914,6 +964,25 @@ static rg_status plan_k1(rg_index *ix, int mode, uint32_t nq, uint32_t L, bool w
     c.grid = (uint32_t)std::min<uint64_t>(nq, (uint64_t)ix->num_cu * wpc);
     const bool vbytes = c.vis == 2 && ix->visited_bytes != 0;
     if (mode == 0) c.grid = std::min(c.grid, visited_slot_cap(ix, vbytes));
+    // HUB BITS (round 5; rg_search_kernel.h, SearchParams::hub_m): the front of the visited region becomes an exact bitmap of the
+    // launch's hubs -- a power of two of bits, at most "hub_pct" percent of the region (default 60), between 2^10 and 2^19.  The
+    // look-ahead tag form takes it (a hub costs no tag line, no tag store and no screen bit).  The exact LDS set does not: a visited hub
+    // costs a bitmap about as many bits as a set entry costs, and the form's kernels have no register to spare.
+    out->hub_m = 0;
+    if (ix->hub_levels && ix->ell_tagged && ix->hub_bits != 0 && !bp && !bf && !qlist && ix->diag == 0 &&
+        c.vis == 2) {
+        const uint32_t region = vf_slots * 2u;
+        const uint32_t pct = (uint32_t)std::max(1, std::min(95, ix->hub_pct > 0 ? ix->hub_pct : 60));
+        uint32_t m = 0;
+        if (ix->hub_bits > 0) m = (uint32_t)std::max(8, std::min(19, ix->hub_bits));
+        else
+            for (uint32_t t = 19; t >= 10; --t)
+                if ((uint64_t)(1u << t) / 8u * 100u <= (uint64_t)region * pct) { m = t; break; }
+        if (m && (1u << m) / 8u + 64u <= region) {
+            out->hub_m = m;
+            vf_slots = (region - (1u << m) / 8u) / 2u;
+        }
+    }
     out->vs_side = 0;
     if (c.vis == 3) {
         // the filter's region becomes the exact set: an eighth of its bytes the side table of full ids, the rest buckets of
@@ -979,6 +1048,7 @@ static rg_status launch_k1(rg_index *ix, SearchCtx *cx, int mode, const float *d
     }
     const K1Launch &c = plan.c;
     const int R = plan.R;
+    if (!qlist && !bp) ix->hub_m_last = plan.hub_m;       // (statistics only)
     const bool bf = plan.bf, vbytes = plan.vbytes;
     const uint32_t vf_slots = plan.vf_slots;
     const size_t lds = c.lds;
@@ -1019,6 +1089,7 @@ static rg_status launch_k1(rg_index *ix, SearchCtx *cx, int mode, const float *d
     P.vf_slots = vf_slots;
     P.vf_rem_bits = filter_rem_bits(id_bits_of(ix->nd), (c.vis == 3 || plan.ls_front) ? vf_slots / 8u : vf_slots);
     P.ls_front = plan.ls_front ? 1u : 0u; P.bl_words = plan.bl_words;
+    P.hub_m = plan.hub_m; P.hub_words = plan.hub_m ? (1u << plan.hub_m) / 32u : 0u;
     P.vs_side = plan.vs_side;
     P.ovf_count = d_ovf; P.ovf_list = d_ovf ? d_ovf + 2 : nullptr;       // (the batch record's overflow list: count, K4 work counter, queries)
     P.lset_left = d_totals ? d_totals + 2 : nullptr;
@@ -1202,13 +1273,16 @@ static rg_status search_dev(rg_index *ix, SearchCtx *cx, const float *d_q, uint3
             }
             // (holds >= 0.8 x the mean visits = 0.457 x need)
             const bool pure = forced || (L <= 512u && (double)(plan.vf_slots + plan.vs_side) >= 0.457 * (double)need);
-            const bool with_tags = !pure && tags_ok && (ix->lset_tags >= 2 || (L <= 512u && (double)(plan.vf_slots + plan.vs_side) >= 0.343 * (double)need));
+            // (never over rows that name a node twice: two lanes of one hop that bring the same node and find no room in the set would both
+            // read a stale tag with a plain load and both call the node fresh -- the pure form settles them with its CAS or, once it
+            // logs, with de-duplicating inserts; the look-ahead form is kept off such rows for the same reason)
+            const bool with_tags = !pure && tags_ok && !ix->adj_dups && (ix->lset_tags >= 2 || (L <= 512u && (double)(plan.vf_slots + plan.vs_side) >= 0.343 * (double)need));
             if (ps == RG_OK && (pure || with_tags) && (st = ensure_qlog(ix, cx, nq)) == RG_OK && nq <= cx->qlog_chunk) {
                 if (hipMemsetAsync(b->d_ovf, 0, 8, s) != hipSuccess) return fail(set_error(RG_ERR_DEVICE, "hipMemsetAsync failed"));
                 b->mode = 3;
                 st = launch_k1(ix, cx, 3, d_q, nq, qstride, k, L, d_ids, d_dists, d_cmps, d_hops, nullptr, true, b->d_stat, s, nullptr, 0, b->d_stat + 1,
                                b->d_ovf, need, with_tags);
-                if (st == RG_ERR_OOM && with_tags) st = RG_OK, ps = RG_ERR_OOM;     // no room for the tags: the forms below
+                if (st == RG_ERR_OOM && with_tags) { st = RG_OK; ps = RG_ERR_OOM; b->mode = 2; }     // no room for the tags: the forms below
                 else {
                 if (st != RG_OK) return fail(st);
                 cx->log_holds = 0;
@@ -1743,6 +1817,8 @@ rg_status rg_index_set(rg_index *ix, const char *name, int value) {
     else if (!strcmp(name, "lset_bytes")) ix->lset_bytes = value;
     else if (!strcmp(name, "lset_tags")) ix->lset_tags = value;
     else if (!strcmp(name, "front_set")) ix->front_set = value;
+    else if (!strcmp(name, "hub_bits")) ix->hub_bits = value;
+    else if (!strcmp(name, "hub_pct")) ix->hub_pct = value;
     else if (!strcmp(name, "adaptive")) ix->adaptive = value != 0;
     else if (!strcmp(name, "lset")) ix->lset = value;
     else if (!strcmp(name, "log_early")) ix->log_early = value != 0;
@@ -1783,7 +1859,21 @@ rg_status rg_index_stat(const rg_index *ixc, const char *name, uint64_t *value) 
     else if (!strcmp(name, "batches_filter_only")) *value = ix->n_batches_filter_only;
     else if (!strcmp(name, "lset_left")) *value = ix->n_lset_left;
     else if (!strcmp(name, "recounted")) *value = ix->n_recounted;
+    else if (!strcmp(name, "hub_levels")) *value = ix->hub_levels ? 1 : 0;
+    else if (!strcmp(name, "hub_m_last")) *value = ix->hub_m_last;
     else return set_error(RG_ERR_ARG, "unknown counter");
+    return RG_OK;
+}
+
+rg_status rg_index_debug_ell(const rg_index *ix, uint32_t *host_out, uint64_t *nwords, uint32_t *stride) {
+    if (!ix || !nwords || !stride) return set_error(RG_ERR_ARG, "null argument");
+    if (!ix->d_ell) return set_error(RG_ERR_ARG, "the index keeps a CSR adjacency");
+    *nwords = (uint64_t)ix->nd * ix->ell_stride;
+    *stride = ix->ell_stride;
+    if (host_out) {
+        RG_HIP(hipSetDevice(ix->device));
+        RG_HIP(hipMemcpy(host_out, ix->d_ell, (size_t)*nwords * 4, hipMemcpyDeviceToHost));
+    }
     return RG_OK;
 }
 

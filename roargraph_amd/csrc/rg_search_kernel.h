@@ -111,6 +111,15 @@ struct SearchParams {
     // routine: same bits); the first hop reads them instead of gathering the rows.  null = off.
     const float *front_scores;
     uint32_t front_stride;
+    // HUB BITS (round 5; VIS = 2): the first hub_words words of the visited region are an EXACT bitmap of
+    // 2^hub_m bits for the "hubs" of that size -- per bit position p the node of highest in-degree among those with
+    // (id * 0x9E3779B1) >> (32 - hub_m) == p (ties: the smaller id).  Positions nest (the top m - 1 bits of the product are the top
+    // m bits shifted), so a node that owns its position at 2^m bits owns it at every larger size: the index stores, in the top
+    // nibble of every ELL neighbour word, 8 less than the smallest m at which the neighbour is a hub (15 = never), and a launch with
+    // 2^hub_m bits treats a neighbour as a hub iff 8 + nibble <= hub_m.  Two hubs never share a bit and no other node uses the
+    // bitmap, so the bit IS the node's visited flag: no tag line read, no tag store, no set entry, no screen bit for it -- and a
+    // third of all edges of the 10M bench index point into 1 % of its nodes.  0 = off.
+    uint32_t hub_m, hub_words;
     uint32_t log_early;       // VIS = 1: the id-log store of a hop is issued right behind the row loads (else after the scoring)
     uint32_t look;            // VIS = 2: 1 = fetch the predicted next pop's adjacency row and visited words early, 0 = no speculation
 #ifdef RG_K1_PROF
@@ -539,7 +548,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
     // id-log staging: ids are appended here and flushed to HBM 64 at a time (256-B aligned full-line stores; small
     // unaligned appends would turn into read-modify-writes at the memory side once the line has left L2)
     uint32_t *logbuf = reinterpret_cast<uint32_t *>(bm.ent + P.L);        // 128
-    uint16_t *vtab = reinterpret_cast<uint16_t *>(logbuf + 128);
+    uint32_t *hb32 = logbuf + 128;                                        // hub bitmap (P.hub_words words; none when hub_m == 0)
+    uint16_t *vtab = reinterpret_cast<uint16_t *>(hb32 + P.hub_words);
     const uint32_t vf_up = 32u - P.id_bits;   // hashed id -> top of the word (id_bits >= 1)
     const uint32_t vf_id_mask = P.id_bits >= 32u ? 0xffffffffu : ((1u << P.id_bits) - 1u);
     const uint32_t vf_rem_mask = (1u << P.vf_rem_bits) - 1u;
@@ -580,6 +590,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
             }
             etag = epoch << 16;
         }
+        if (LOOK && P.hub_m) for (uint32_t i = lane; i < P.hub_words; i += kWave) hb32[i] = 0u;     // no hub visited yet
         if (VIS == 1 || LSET || P.vf_front) {   // exact-match filter / exact set: every slot empty; LOOK: the screen's bits clear
             uint32_t *vt32 = reinterpret_cast<uint32_t *>(vtab);
             const bool lsf = LOOK && P.ls_front != 0u;    // LOOK with the exact set in front: set + side empty, then the screen's bits clear
@@ -638,7 +649,17 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
         // neighbour word of an adjacency row -> id, and whether the LDS filter keeps an entry for it (see id_mask)
         const uint32_t idm = P.id_mask;
         auto keeps = [&](uint32_t idw) __attribute__((always_inline)) -> bool {
-            return idm == 0xffffffffu || (idw >> 24) >= P.vf_min_indeg;
+            return idm == 0xffffffffu || ((idw >> 24) & 15u) >= P.vf_min_indeg;     // (low nibble of the top byte: min(15, in-degree))
+        };
+        // hub bits (SearchParams::hub_m): is the neighbour word's node a hub of this launch's bitmap / test-and-set of its bit
+        // (a returning LDS atomic: two lanes of one hop that bring the same hub -- rows that name a node twice -- get one "fresh")
+        auto hub_of = [&](uint32_t idw) __attribute__((always_inline)) -> bool {
+            return LOOK && P.hub_m != 0u && 8u + (idw >> 28) <= P.hub_m;
+        };
+        auto hub_visit = [&](uint32_t id) __attribute__((always_inline)) -> bool {
+            const uint32_t p = (id * 0x9E3779B1u) >> (32u - P.hub_m);
+            const uint32_t bit = 1u << (p & 31u);
+            return !(__hip_atomic_fetch_or(&hb32[p >> 5], bit, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) & bit);
         };
         // exact set in LDS (VIS = 3; VIS = 2 with P.ls_front: in FRONT of the byte tags).  bucket = floor(x * buckets / 2^id_bits) of the
         // bijective hash x, entry = the low bits of x that tell the x of one bucket apart (vf_hash with slots = buckets):
@@ -692,9 +713,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
                 if (atomicCAS(&bk[e >> 1], w, nw) == w) return 1;
             }
         };
-        auto visit_set = [&](uint32_t id, bool have, bool keep) __attribute__((always_inline)) -> bool {
+        auto visit_set = [&](uint32_t id, bool have, bool keep, bool hub) __attribute__((always_inline)) -> bool {
             bool fresh = false;
-            if (LSET) {
+            if (LOOK && hub) {
+                if (have) fresh = hub_visit(id);
+                if (LOOK && P.vbytes) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (as the tag path below leaves it)
+            } else if (LSET) {
                 if (have) {
                     const int r = ls_visit(id, true);
                     if (r == 1) fresh = true;
@@ -977,9 +1001,10 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
                     if (have) id = list[c0 + lane];
                 }
                 const bool keep = keeps(id);
+                const bool hub = ELL && hub_of(id);
                 if (ELL) id &= idm;
                 if (build && id == tgt) have = false;
-                const bool fresh = visit_set(id, have, keep);
+                const bool fresh = visit_set(id, have, keep, hub);
                 const unsigned long long fm = __ballot(fresh);
                 const uint32_t n = __popcll(fm);
                 RG_PROF_CNT(0, 1); RG_PROF_CNT(1, n);
@@ -1043,13 +1068,15 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
             // visited words of a row's neighbours: ids 0..62 sit in words 1..63 of the first read, ids 63.. in the second
             auto words_of = [&](uint32_t fa, uint32_t fb, uint32_t &wa, uint32_t &wb) __attribute__((always_inline)) {
                 const uint32_t dg = readlane_u(fa, 0);
-                const uint32_t ia = (uint32_t)__shfl_down((int)fa, 1, 64) & idm;
+                const uint32_t wsh = (uint32_t)__shfl_down((int)fa, 1, 64);   // (every lane takes part: never inside a short-circuit condition)
+                const uint32_t ia = wsh & idm;
                 if (screen || P.vbytes) {
                     // only the lanes whose screen bit is set read their word; 0 = "stale epoch" = fresh for the others
                     lds_fence();
                     // (front set: a node it holds needs no tag; one it does not hold is tested whether or not the set will take it)
-                    bool ma = (uint32_t)lane < min(dg, 63u) && (!screen || bl_maybe(ia));
-                    bool mb = dg > 63u && 63u + (uint32_t)lane < dg && (!screen || bl_maybe(fb & idm));
+                    // (a hub has no tag: its bit in the LDS bitmap is its visited flag)
+                    bool ma = (uint32_t)lane < min(dg, 63u) && !hub_of(wsh) && (!screen || bl_maybe(ia));
+                    bool mb = dg > 63u && 63u + (uint32_t)lane < dg && !hub_of(fb) && (!screen || bl_maybe(fb & idm));
                     if (fset) {
                         if (ma) ma = ls_visit(ia, false) != 0;
                         if (mb) mb = ls_visit(fb & idm, false) != 0;
@@ -1099,25 +1126,29 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
                 // :2378 (a word / byte the screen spared reads 0, which no epoch equals)
                 const bool vb = P.vbytes != 0u;
                 // front set first: 0 = it holds the node (visited), 1 = it took the node now (fresh, no tag), 2 = the tags decide
+                // hubs first: the bit of the LDS bitmap decides and remembers (3 = hub; no set entry, no tag, no screen bit)
                 int rA = 2, rB = 2;
+                bool fhA = false, fhB = false;
+                if (haveA && hub_of(wA)) { rA = 3; fhA = hub_visit(idA); }
+                if (haveB && hub_of(fb)) { rB = 3; fhB = hub_visit(idB); }
                 if (fset) {
-                    if (haveA) rA = ls_visit(idA, true);
-                    if (haveB) rB = ls_visit(idB, true);
+                    if (haveA && rA != 3) rA = ls_visit(idA, true);
+                    if (haveB && rB != 3) rB = ls_visit(idB, true);
                 }
-                const bool freshA = haveA && (rA == 1 || (rA == 2 && (vb ? wa != epoch : !((wa >> 16) == epoch && (wa & bitA)))));
-                const bool freshB = haveB && (rB == 1 || (rB == 2 && (vb ? wb != epoch : !((wb >> 16) == epoch && (wb & bitB)))));
+                const bool freshA = haveA && (rA == 3 ? fhA : (rA == 1 || (rA == 2 && (vb ? wa != epoch : !((wa >> 16) == epoch && (wa & bitA))))));
+                const bool freshB = haveB && (rB == 3 ? fhB : (rB == 1 || (rB == 2 && (vb ? wb != epoch : !((wb >> 16) == epoch && (wb & bitB))))));
                 if (vb) {                        // :2385 as a plain byte store: no line is fetched for it, none comes back
                     uint8_t *t = reinterpret_cast<uint8_t *>(vmap);
                     if (freshA && rA == 2) { __hip_atomic_store(t + idA, (uint8_t)epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (screen) bl_set(idA); }
                     if (freshB && rB == 2) { __hip_atomic_store(t + idB, (uint8_t)epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (screen) bl_set(idB); }
                 } else {
-                if (freshA) {                    // :2385, fire and forget
+                if (freshA && rA != 3) {         // :2385, fire and forget
                     uint32_t *w = &vmap[idA >> 4];
                     (void)__hip_atomic_fetch_max(w, etag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // stale epoch -> (epoch, no bits)
                     (void)__hip_atomic_fetch_or(w, bitA, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);    // same address: behind the max
                     if (screen) bl_set(idA);
                 }
-                if (freshB) {
+                if (freshB && rB != 3) {
                     uint32_t *w = &vmap[idB >> 4];
                     (void)__hip_atomic_fetch_max(w, etag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     (void)__hip_atomic_fetch_or(w, bitB, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1200,8 +1231,8 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
                     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
                     RG_PROF(1);
-                    const bool freshA = visit_set(idA, (uint32_t)lane < deg, keeps(wA));
-                    const bool freshB = visit_set(idB, (uint32_t)lane < deg2, keeps(wB));     // after A's marks: a common neighbour counts once
+                    const bool freshA = visit_set(idA, (uint32_t)lane < deg, keeps(wA), hub_of(wA));
+                    const bool freshB = visit_set(idB, (uint32_t)lane < deg2, keeps(wB), hub_of(wB));     // after A's marks: a common neighbour counts once
                     const unsigned long long fmA = __ballot(freshA), fmB = __ballot(freshB);
                     const uint32_t nA = __popcll(fmA), nB = __popcll(fmB);
                     const unsigned long long below = (1ull << lane) - 1ull;

@@ -77,7 +77,7 @@ for c in a.configs.split(";"):
     name, _, kv = c.partition(":")
     configs.append((name, [(x.split("=")[0], int(x.split("=")[1])) for x in kv.split(",") if x]))
 ALL_KNOBS = {"visited": 2, "lookahead": -1, "exact_filter": 1, "rows_per_pass": 0, "waves_per_cu": 0, "filter_log2": 0, "split_rows": 1,
-             "gather_form": -1, "filter_min_indeg": 2, "visited_uncached": 0, "count_in_k1": -1, "log_early": 1, "shared_frontier": 0, "filter_fill": 1, "visited_bytes": -1, "gather_roll": 1, "lset": -1, "adaptive": 1, "lset_tags": 1, "front_set": -1}
+             "gather_form": -1, "filter_min_indeg": 2, "visited_uncached": 0, "count_in_k1": -1, "log_early": 1, "shared_frontier": 0, "filter_fill": 1, "visited_bytes": -1, "gather_roll": 1, "lset": -1, "adaptive": 1, "lset_tags": 1, "front_set": -1, "hub_bits": -1, "hub_pct": -1}
 ref = {}
 for L in [int(x) for x in a.L.split(",")]:
     for name, kvs in configs:

@@ -571,3 +571,106 @@ def test_exact_set_in_lds_with_tags_behind_it(rg, oracle, metric, d, nb, lset_by
             assert (got[3] == want[3]).all() and (got[0] == want[0]).all() and (bits(got[1]) == bits(want[1])).all(), (L, lset_bytes)
     assert ix.stat("batches_lset") == 12 and ix.stat("batches_filter_log") == 0 and ix.stat("batches_exact_hbm") == 0
     ix.close()
+
+
+@pytest.mark.parametrize("metric,d,nb", [("ip", 200, 4000), ("l2", 512, 2000), ("ip", 24, 3000)])
+@pytest.mark.parametrize("hub_bits,front_set", [(8, 0), (10, 0), (12, -1), (14, 40), (-1, -1), (0, 0)])
+def test_hub_bits_in_front_of_the_tags(rg, oracle, metric, d, nb, hub_bits, front_set):
+    """Round 5, knob hub_bits: the front of the look-ahead form's LDS region is an exact bitmap of 2^m bits, one bit per position
+    of the hashed id, owned by the node of highest in-degree that falls on it (level stored in the top nibble of every ELL
+    neighbour word at open).  A hub's bit is its visited flag -- no tag, no set entry, no screen bit.  Every bitmap size a launch
+    can be given (2^8 bits: a handful of hubs; 2^14: most nodes of a small index are hubs), with and without the exact set
+    behind it, long rows (the form's general path), repeated calls, the epoch wrap of the tags: all four outputs bit-exact."""
+    base, q, off, nbrs, ep = small_set(metric, nb, d)
+    from roargraph_amd import io
+    lists = [nbrs[int(off[i]):int(off[i + 1])].copy() for i in range(base.shape[0])]
+    for i in (ep, 17, 900):      # rows of 64 .. 126 and of more than 126 neighbours: the two-read step and the general path
+        lists[i] = np.unique(np.concatenate([lists[i], np.arange(i + 1, i + (100 if i != 900 else 200), dtype=np.uint32) % nb])).astype(np.uint32)
+    off, nbrs = io.lists_to_csr(lists)
+    ix = rg.IndexBipartite.from_arrays(base, off, nbrs, ep, metric=metric)
+    assert ix.stat("hub_levels") == 1
+    ix.set("visited", 0)
+    ix.set("lookahead", 1)
+    ix.set("hub_bits", hub_bits)
+    ix.set("front_set", front_set)
+    dimc = d in (200, 512)       # the look-ahead form exists for the register-staged instantiations
+    for L, k in ((10, 10), (100, 100), (700, 10), (2000, 10)):
+        want = oracle.search(base, metric, off, nbrs, ep, q, k, L, nthreads=4)
+        for rpp in ((16, 32) if d == 200 else (8,)):
+            ix.set("rows_per_pass", rpp)
+            for rep in range(2):
+                got = ix.SearchRoarGraph(q, k, L)
+                assert (got[2] == want[2]).all(), ("cmps", L, rpp, rep)
+                assert (got[3] == want[3]).all() and (got[0] == want[0]).all() and (bits(got[1]) == bits(want[1])).all(), (L, rpp, rep)
+            if dimc and hub_bits > 0:      # (a forced size the launch's region cannot hold -- 2^14 bits beside a 2000-entry beam -- is dropped)
+                assert ix.stat("hub_m_last") in (0, hub_bits) and (L > 700 or ix.stat("hub_m_last") == hub_bits), (L, rpp)
+            if hub_bits == 0 or not dimc:
+                assert ix.stat("hub_m_last") == 0
+    if dimc:
+        ix.set("visited_budget_kb", 8)      # two slots: both pass the wrap of the epoch byte below
+        want = oracle.search(base, metric, off, nbrs, ep, q, 10, 300, nthreads=4)
+        for call in range(10):
+            got = ix.SearchRoarGraph(q, 10, 300)
+            assert (got[2] == want[2]).all() and (got[3] == want[3]).all() and (got[0] == want[0]).all() and (bits(got[1]) == bits(want[1])).all(), call
+    ix.close()
+
+
+def test_hub_levels_are_the_per_position_maxima_of_in_degree(rg, oracle):
+    """The hub level written at open (top nibble of the ELL neighbour words) against a numpy restatement of its definition: at
+    2^m bits, position p belongs to the node of largest (in-degree, -id) among those with (id * 0x9E3779B1) >> (32 - m) == p;
+    level = the smallest m in 8 .. 22 at which a node owns its position, minus 8 (15 = never)."""
+    import ctypes as C
+    from roargraph_amd._lib import check, lib
+    base, q, off, nbrs, ep = small_set("ip", 4000, 200)
+    ix = rg.IndexBipartite.from_arrays(base, off, nbrs, ep, metric="ip")
+    nd = base.shape[0]
+    indeg = np.bincount(nbrs, minlength=nd).astype(np.int64)
+    x = (np.arange(nd, dtype=np.uint64) * np.uint64(0x9E3779B1)) & np.uint64(0xffffffff)
+    key = (indeg << 32) | (0xffffffff - np.arange(nd, dtype=np.int64))
+    lvl = np.full(nd, 15, np.int64)
+    for m in range(22, 7, -1):
+        pos = (x >> np.uint64(32 - m)).astype(np.int64)
+        best = np.zeros(1 << m, np.int64)
+        np.maximum.at(best, pos, np.where(indeg > 0, key, 0))
+        own = (indeg > 0) & (best[pos] == key)
+        lvl[own] = m - 8
+    stride = C.c_uint32()
+    n = C.c_uint64()
+    check(lib().rg_index_debug_ell(ix.handle, None, C.byref(n), C.byref(stride)))
+    ell = np.zeros(n.value, np.uint32)
+    check(lib().rg_index_debug_ell(ix.handle, ell.ctypes.data_as(C.c_void_p), C.byref(n), C.byref(stride)))
+    ell = ell.reshape(nd, stride.value)
+    for v in range(0, nd, 7):
+        dg = int(ell[v, 0])
+        w = ell[v, 1:1 + dg]
+        ids = w & 0xffffff
+        assert (ids == nbrs[int(off[v]):int(off[v + 1])]).all()
+        assert ((w >> 28) == lvl[ids]).all() and (((w >> 24) & 15) == np.minimum(15, indeg[ids])).all(), v
+    ix.close()
+
+
+@pytest.mark.parametrize("lset_bytes", [256, 2048])
+def test_exact_set_with_tags_is_not_used_over_rows_with_repeats(rg, oracle, lset_bytes):
+    """the exact LDS set with the byte tags behind it tests a hop's neighbours lane-parallel; two lanes that bring the
+    same node and find no room in the set would both read a stale tag and both score it.  On an index whose rows name a node
+    twice the form must not be chosen (the pure set settles such lanes with its CAS, the logging form de-duplicates): forced
+    with lset_tags = 2 and a set every query outgrows, cmps and results stay the oracle's and no row names a node twice."""
+    from roargraph_amd import io
+    base, q, off, nbrs, ep = small_set("ip", 4000, 200)
+    lists = [nbrs[int(off[i]):int(off[i + 1])].copy() for i in range(base.shape[0])]
+    first = int(lists[ep][0])
+    lists[first] = np.concatenate([lists[first][:6], lists[first][:6], lists[first][6:]]).astype(np.uint32)
+    for i in range(0, 4000, 5):
+        lists[i] = np.concatenate([lists[i], lists[i][:3]]).astype(np.uint32)
+    o2, n2 = io.lists_to_csr(lists)
+    ix = rg.IndexBipartite.from_arrays(base, o2, n2, ep, metric="ip")
+    ix.set("lset_tags", 2)
+    ix.set("lset_bytes", lset_bytes)
+    for L, k in ((20, 10), (150, 100), (700, 10)):
+        want = oracle.search(base, "ip", o2, n2, ep, q, k, L, nthreads=4)
+        for rep in range(2):
+            got = ix.SearchRoarGraph(q, k, L)
+            assert (got[2] == want[2]).all(), ("cmps", L, rep)
+            assert (got[3] == want[3]).all() and (got[0] == want[0]).all() and (bits(got[1]) == bits(want[1])).all(), L
+            assert all(len(set(r.tolist())) == k for r in got[0])
+    ix.close()
