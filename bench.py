@@ -245,6 +245,8 @@ class Searcher:
             self.depth_settled[L] = reps
         ev = [(t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)) for _ in range(reps)]
         used = []
+        names = ("batches_lset", "batches_filter_log", "batches_exact_hbm", "batches_filter_only")
+        before = [self.ix.stat(n_) for n_ in names]
         e0, e1 = t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)
         e0.record()
         for a, b in ev:
@@ -254,6 +256,9 @@ class Searcher:
         # batches, on the launch stream or beside it, is done when the closing event is recorded) -- over the batches in it
         e1.record(); e1.synchronize()
         self.last_reps_ms = [a.elapsed_time(b) for a, b in ev]          # per enqueue, on the launch stream (K1 and what it waited for)
+        # which kernel form the timed launches ran in (counters of the library) and the hub bitmap of the last one
+        self.last_forms = {n_[8:]: self.ix.stat(n_) - b0 for n_, b0 in zip(names, before) if self.ix.stat(n_) - b0}
+        self.last_forms["hub_bits_log2"] = self.ix.stat("hub_m_last")
         return e0.elapsed_time(e1) / reps, used
 
     def point(self, L, ms, used):
@@ -646,6 +651,7 @@ def main():
         else:
             pt = S.point(L, ms, used)
         pt["ms_reps"] = [round(x, 4) for x in S.last_reps_ms]
+        pt["forms"] = dict(S.last_forms)
         if args.visited == 2 and rank == 0:
             # what explains a point above the 6.29 TB/s streaming-copy ceiling: how few of the launch's row reads are first
             # touches, and how many go to rows a 256-MiB cache could hold (null: the launch ran on the exact words)

@@ -143,7 +143,7 @@ rg_status rg_index_info(const rg_index *idx, uint32_t *nd, uint32_t *dim, uint32
  * an exact set in front of the tags where it holds 0.4 x a query's visits, 0 never, N = N % of the LDS region always), "adaptive" (0: the
  * default mode keeps its filter + log form at every width -- bench.py's row-reuse statistics need the logs), "hub_bits" (round 5:
  * the look-ahead byte-tag form keeps an exact bitmap of the launch's hubs -- the nodes of highest in-degree per hashed position -- at the
- * front of its LDS region: -1, default = sized by "hub_pct" (largest share of the region, percent, default 60), 0 = never, m = 2^m bits). */
+ * front of its LDS region: -1, default = sized by "hub_pct" (largest share of the region, percent; default 90, 60 at L_pq <= 420), 0 = never, m = 2^m bits). */
 rg_status rg_index_set(rg_index *idx, const char *name, int value);
 /* Counters of the search path since the index was opened (diagnostics: which form the batches ran in).  Names:
  * "batches_lset" / "batches_filter_log" / "batches_exact_hbm" / "batches_filter_only" (batches enqueued per form),

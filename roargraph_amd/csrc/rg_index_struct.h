@@ -126,7 +126,7 @@ struct rg_index {
     bool hub_levels = false;     // ELL neighbour words carry the hub level of the neighbour in their top nibble (computed at open; RG_HUB_BITS=0: no)
     int hub_bits = -1;           // knob: hub bitmap of the visited region: -1 = the look-ahead tag form takes one (size by "hub_pct"), 0 = never,
                                  // m = 2^m bits whatever the region's size suggests (tests, experiments)
-    int hub_pct = -1;            // knob: largest share of the visited region the bitmap may take, percent (-1 = 60)
+    int hub_pct = -1;            // knob: largest share of the visited region the bitmap may take, percent (-1 = 90; 60 at L_pq <= 420)
     uint32_t hub_m_last = 0;     // statistics: log2 of the bitmap of the last search launch (0 = none)
     int lset_bytes = 0;          // knob (tests): cap of the exact LDS set's region in bytes (0 = what the launch has)
     int lset = -1;               // knob "lset" (round 4): default visited mode, narrow beams: the exact visited set in LDS (K1 VIS = 3: no id

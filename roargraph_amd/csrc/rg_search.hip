@@ -748,7 +748,8 @@ static size_t stage_total_floats(const rg_index *ix, int R, bool bf) {   // the 
 }
 static size_t search_lds_bytes(const rg_index *ix, uint32_t L, int R, int mode, bool bf, int filter_auto) {
     size_t b = stage_total_floats(ix, R, bf) * 4 + (dimc_of(ix) ? 0 : (size_t)ix->dim * 4) + kCand * 4 + kCand * 4 + 2 * kWave * 4 + (size_t)L * 8;
-    if (mode != 0 || ix->exact_filter) b += 128 * 4 + std::max<size_t>(16, (size_t)2 << filter_log2_of(ix, filter_auto));
+    // (the 128-word id-log line exists in the forms that may log: the LDS filter and the exact LDS set, not the exact words)
+    if (mode != 0 || ix->exact_filter) b += (mode != 0 ? 128 * 4 : 0) + std::max<size_t>(16, (size_t)2 << filter_log2_of(ix, filter_auto));
     return (b + 15) / 16 * 16;
 }
 // bits of a filter entry for a table of `slots` entries: the x that share a slot are at most ceil(2^id_bits / slots)
@@ -965,14 +966,17 @@ static rg_status plan_k1(rg_index *ix, int mode, uint32_t nq, uint32_t L, bool w
     const bool vbytes = c.vis == 2 && ix->visited_bytes != 0;
     if (mode == 0) c.grid = std::min(c.grid, visited_slot_cap(ix, vbytes));
     // HUB BITS (round 5; rg_search_kernel.h, SearchParams::hub_m): the front of the visited region becomes an exact bitmap of the
-    // launch's hubs -- a power of two of bits, at most "hub_pct" percent of the region (default 60), between 2^10 and 2^19.  The
+    // launch's hubs -- a power of two of bits, at most "hub_pct" percent of the region (default 90; 60 at L_pq <= 420), between 2^10 and 2^19.  The
     // look-ahead tag form takes it (a hub costs no tag line, no tag store and no screen bit).  The exact LDS set does not: a visited hub
     // costs a bitmap about as many bits as a set entry costs, and the form's kernels have no register to spare.
     out->hub_m = 0;
     if (ix->hub_levels && ix->ell_tagged && ix->hub_bits != 0 && !bp && !bf && !qlist && ix->diag == 0 &&
         c.vis == 2) {
         const uint32_t region = vf_slots * 2u;
-        const uint32_t pct = (uint32_t)std::max(1, std::min(95, ix->hub_pct > 0 ? ix->hub_pct : 60));
+        // (measured on the 10M bench index, profiles/r05/k1_ab_box1_hub_bits.jsonl, box2: the larger bitmap wins wherever the exact set in
+        // front of the tags is not in play -- 75.6 against 74.1 % of 8 TB/s at L_pq 700 with 2^16 instead of 2^15 bits -- and loses
+        // a point where it is, L_pq 300 - 400)
+        const uint32_t pct = (uint32_t)std::max(1, std::min(95, ix->hub_pct > 0 ? ix->hub_pct : (ix->front_set == 0 || L > 420u) ? 90 : 60));
         uint32_t m = 0;
         if (ix->hub_bits > 0) m = (uint32_t)std::max(8, std::min(19, ix->hub_bits));
         else

@@ -548,7 +548,7 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
     // id-log staging: ids are appended here and flushed to HBM 64 at a time (256-B aligned full-line stores; small
     // unaligned appends would turn into read-modify-writes at the memory side once the line has left L2)
     uint32_t *logbuf = reinterpret_cast<uint32_t *>(bm.ent + P.L);        // 128
-    uint32_t *hb32 = logbuf + 128;                                        // hub bitmap (P.hub_words words; none when hub_m == 0)
+    uint32_t *hb32 = logbuf + (LOGS ? 128 : 0);                           // hub bitmap (P.hub_words words; none when hub_m == 0); forms that log nothing have no log line
     uint16_t *vtab = reinterpret_cast<uint16_t *>(hb32 + P.hub_words);
     const uint32_t vf_up = 32u - P.id_bits;   // hashed id -> top of the word (id_bits >= 1)
     const uint32_t vf_id_mask = P.id_bits >= 32u ? 0xffffffffu : ((1u << P.id_bits) - 1u);
@@ -1195,6 +1195,9 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(DIMC ==
                     if (!ev || bo < oe || (bo == oe && bi < en)) xn = bi;
                 }
                 // every mark of this hop has been acknowledged before the words of the next node are read
+                // (round 5: the same launch without this wait returns the same bits and runs level -- 80.4 / 78.3 / 70.3 / 60.2 against 80.3 /
+                // 78.3 / 69.8 / 60.2 % of 8 TB/s at L_pq 300 ... 2000, profiles/r05/k1_ab_box4_no_ack_wait.txt: the wait is covered by the
+                // early guess's row load, which the next step needs anyway; it stays)
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 bool words_out = false;
                 if (xn == NONE) la_node = NONE;

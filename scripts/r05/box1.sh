@@ -9,7 +9,7 @@ timeout 1500 python -m pytest tests/test_gpu_parity.py -x -q -k "hub or repeats 
 tail -5 $OUT/pytest_hub.log
 timeout 900 python -m pytest tests/test_gpu_cli.py -x -q -k "bench_one_gpu or bench_multi_rank" > $OUT/pytest_bench.log 2>&1
 tail -5 $OUT/pytest_bench.log
-timeout 1500 python scripts/exp/k1_ab.py --L 300,500,1000,2000 --nbatch 3 --reps 2 --index-cache /tmp/ix.npz \
+timeout 1500 python scripts/exp/k1_ab.py --L 200,300,400,500,700,1000,1500,2000 --nbatch 3 --reps 2 --index-cache /tmp/ix.npz \
   --configs "off:visited=0,lookahead=1,hub_bits=0;auto60:visited=0,lookahead=1;pct40:visited=0,lookahead=1,hub_pct=40;pct80:visited=0,lookahead=1,hub_pct=80;auto_nofs:visited=0,lookahead=1,front_set=0;off_nofs:visited=0,lookahead=1,hub_bits=0,front_set=0" \
   > $OUT/k1_ab_hub.jsonl 2> $OUT/k1_ab_hub.err
 cat $OUT/k1_ab_hub.jsonl
