@@ -246,6 +246,13 @@ rg_status rg_comm_init_rank(const void *id128, int rank, int world, int device, 
 rg_status rg_comm_init_local(const int *devices, int nranks, rg_comm **out);
 int rg_comm_uses_rccl(const rg_comm *comm);
 void rg_comm_destroy(rg_comm *comm);
+/* The exchange schedule of rg_groundtruth_rank as data (no GPU needed; the RCCL calls are issued from this very table):
+ * for rank `rank` of `world`, `nq` queries in batches of `batch` (0 = 65,536), ten words per (batch, peer):
+ *   batch, parity of its double buffer, q0, queries of the batch, peer, send_row0, send_rows (rows of the batch whose K-lists go
+ *   to the peer: elements [send_row0 * K, (send_row0 + send_rows) * K) of this rank's lists), recv_slot_row0, recv_rows (where the
+ *   peer's lists of the rows this rank owns arrive in its receive buffer, in rows), first global query row this rank owns.
+ * out = NULL only reports *n_words.  tests/test_dist_gloo.py plays the table for eight ranks against a pure-Python model. */
+rg_status rg_gt_exchange_plan(int world, int rank, uint32_t nq, uint32_t batch, uint32_t *out, uint64_t cap_words, uint64_t *n_words);
 rg_status rg_groundtruth_rank(rg_comm *comm, const float *d_base_shard, uint32_t nb_shard, uint32_t bstride, uint32_t id_base,
                               const float *queries, uint32_t nq, uint32_t qstride, uint32_t dim, int metric, uint32_t K,
                               uint32_t batch, uint32_t *out_ids, float *out_dists);

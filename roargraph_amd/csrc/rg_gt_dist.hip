@@ -138,6 +138,23 @@ static std::vector<std::pair<uint32_t, uint32_t>> ranges_of(uint32_t n, int worl
     return r;
 }
 
+// The exchange of one query batch, as rank `rank` sees it: for every peer j, the rows of its own K-lists that j owns go to j
+// (send_row0 / send_rows: rows of the batch, i.e. element offset send_row0 * K in d_ids / d_vals), and j's lists of the rows THIS
+// rank owns arrive in slot j of the receive buffer (recv_slot_row0 = j * per: element offset j * per * K in d_rids / d_rvals).
+// One function for the RCCL calls below and for rg_gt_exchange_plan (the schedule as data: tests drive it for eight ranks on a
+// box without a GPU).
+struct XferOp { uint32_t peer, send_row0, send_rows, recv_slot_row0, recv_rows; };
+static std::vector<XferOp> exchange_ops(int world, int rank, uint32_t nqb, uint32_t per) {
+    const auto own = ranges_of(nqb, world);
+    const uint32_t n_own = own[(size_t)rank].second - own[(size_t)rank].first;
+    std::vector<XferOp> ops;
+    for (int j = 0; j < world; ++j) {
+        const uint32_t jl = own[(size_t)j].first, jn = own[(size_t)j].second - jl;
+        ops.push_back({(uint32_t)j, jl, jn, (uint32_t)j * per, n_own});
+    }
+    return ops;
+}
+
 // where a rank's query batches come from and where its merged rows go (memory arrays or files)
 struct GtIo {
     std::function<rg_status(uint32_t q0, uint32_t n, float *dst, uint32_t dst_stride)> fill;      // rows -> pinned, zero padded
@@ -240,15 +257,15 @@ static rg_status gt_rank_body(rg_comm *cm, const float *d_base, uint32_t nb_shar
         } else {
             if (nc) {
                 RG_NCCL(nc->GroupStart());
-                for (int j = 0; j < world; ++j) {
-                    const uint32_t jl = own[(size_t)j].first, jn = own[(size_t)j].second - jl;
-                    if (jn) {
-                        RG_NCCL(nc->Send(B.d_ids[p] + (size_t)jl * K, (size_t)jn * K, ncclUint32, j, cm->nccl, B.s_comm));
-                        RG_NCCL(nc->Send(B.d_vals[p] + (size_t)jl * K, (size_t)jn * K, ncclFloat32, j, cm->nccl, B.s_comm));
+                for (const XferOp &op : exchange_ops(world, rank, nqb, per)) {
+                    const int j = (int)op.peer;
+                    if (op.send_rows) {
+                        RG_NCCL(nc->Send(B.d_ids[p] + (size_t)op.send_row0 * K, (size_t)op.send_rows * K, ncclUint32, j, cm->nccl, B.s_comm));
+                        RG_NCCL(nc->Send(B.d_vals[p] + (size_t)op.send_row0 * K, (size_t)op.send_rows * K, ncclFloat32, j, cm->nccl, B.s_comm));
                     }
-                    if (n_own) {
-                        RG_NCCL(nc->Recv(B.d_rids[p] + (size_t)j * per * K, (size_t)n_own * K, ncclUint32, j, cm->nccl, B.s_comm));
-                        RG_NCCL(nc->Recv(B.d_rvals[p] + (size_t)j * per * K, (size_t)n_own * K, ncclFloat32, j, cm->nccl, B.s_comm));
+                    if (op.recv_rows) {
+                        RG_NCCL(nc->Recv(B.d_rids[p] + (size_t)op.recv_slot_row0 * K, (size_t)op.recv_rows * K, ncclUint32, j, cm->nccl, B.s_comm));
+                        RG_NCCL(nc->Recv(B.d_rvals[p] + (size_t)op.recv_slot_row0 * K, (size_t)op.recv_rows * K, ncclFloat32, j, cm->nccl, B.s_comm));
                     }
                 }
                 RG_NCCL(nc->GroupEnd());
@@ -443,6 +460,26 @@ rg_status rg_comm_unique_id(void *id128) {
     ncclUniqueId id;
     RG_NCCL(nc->GetUniqueId(&id));
     std::memcpy(id128, id.internal, NCCL_UNIQUE_ID_BYTES);
+    return RG_OK;
+}
+
+rg_status rg_gt_exchange_plan(int world, int rank, uint32_t nq, uint32_t batch, uint32_t *out, uint64_t cap_words, uint64_t *n_words) {
+    if (world < 1 || rank < 0 || rank >= world || !n_words) return rg::set_error(RG_ERR_ARG, "rg_gt_exchange_plan: bad world / rank / null argument");
+    const uint32_t Qb = std::min<uint32_t>(std::max<uint32_t>(nq, 1u), batch ? batch : 65536u);
+    const uint32_t per = (Qb + (uint32_t)world - 1) / (uint32_t)world;
+    const uint32_t nbatch = nq ? (nq + Qb - 1) / Qb : 0;
+    uint64_t n = 0;
+    for (uint32_t b = 0; b < nbatch; ++b) {
+        const uint32_t q0 = b * Qb, nqb = std::min(Qb, nq - q0);
+        const auto own = rg::ranges_of(nqb, world);
+        for (const rg::XferOp &op : rg::exchange_ops(world, rank, nqb, per)) {
+            const uint32_t rec[10] = {b, b & 1u, q0, nqb, op.peer, op.send_row0, op.send_rows, op.recv_slot_row0, op.recv_rows, q0 + own[(size_t)rank].first};
+            if (out && n + 10 <= cap_words) memcpy(out + n, rec, sizeof rec);
+            n += 10;
+        }
+    }
+    *n_words = n;
+    if (out && n > cap_words) return rg::set_error(RG_ERR_ARG, "rg_gt_exchange_plan: output buffer too small");
     return RG_OK;
 }
 

@@ -127,3 +127,70 @@ def test_bench_plan_for_eight_gpus_at_the_10m_shape():
     assert sum(g["owned_rows"] for g in p["gt_build"]) == gt_nq and {g["owned_rows"] for g in p["gt_build"]} == {gt_nq // 8}
     all_rows = np.concatenate([groundtruth.owned_rows(gt_nq, 8, r, 65536) for r in range(8)])
     assert (np.sort(all_rows) == np.arange(gt_nq)).all()
+
+
+@pytest.mark.parametrize("world,nq,batch", [(8, 1000, 256), (8, 65536 + 77, 0), (3, 10, 4), (8, 5, 64), (2, 200, 64), (1, 33, 16)])
+def test_rccl_exchange_schedule_of_the_ground_truth_for_eight_ranks(world, nq, batch):
+    """the grouped ncclSend / ncclRecv exchange of rg_groundtruth_rank has never run between two real ranks (no round
+    had a multi-GPU node, RCCL refuses two ranks on one device).  The calls are issued from a table, rg_gt_exchange_plan, which needs no
+    GPU: here the tables of ALL ranks of a world are played against a pure-Python model -- every send has the matching receive
+    (peer, count), owners partition every batch, receive slots do not overlap and stay inside the buffer, the double-buffer
+    parity alternates -- and a full exchange + merge of random K-lists through the tables returns the global top-K."""
+    import ctypes as C
+    from roargraph_amd._lib import check, lib
+    K = 7
+
+    def plan(rank):
+        n = C.c_uint64()
+        check(lib().rg_gt_exchange_plan(world, rank, C.c_uint32(nq), C.c_uint32(batch), None, C.c_uint64(0), C.byref(n)))
+        out = np.zeros(n.value, np.uint32)
+        check(lib().rg_gt_exchange_plan(world, rank, C.c_uint32(nq), C.c_uint32(batch), out.ctypes.data_as(C.c_void_p), C.c_uint64(n.value), C.byref(n)))
+        return out.reshape(-1, 10)
+
+    plans = [plan(r) for r in range(world)]
+    Qb = min(max(nq, 1), batch or 65536)
+    per = (Qb + world - 1) // world
+    nbatch = (nq + Qb - 1) // Qb
+    assert all(p.shape[0] == nbatch * world for p in plans)
+    rng = np.random.default_rng(world * 1000 + nq)
+    # the model: every rank holds K-lists (score, id) of every query over its own shard; ids are globally unique
+    vals = rng.standard_normal((world, nq, K)).astype(np.float32)
+    vals = -np.sort(-vals, axis=2)
+    ids = (np.arange(world)[:, None, None] * 1_000_000 + rng.permutation(nq * K).reshape(nq, K)[None]).astype(np.uint32)
+    out_i = np.zeros((nq, K), np.uint32); out_v = np.zeros((nq, K), np.float32); written = np.zeros(nq, np.int32)
+    for b in range(nbatch):
+        q0, nqb = b * Qb, min(Qb, nq - b * Qb)
+        rows = [p[b * world:(b + 1) * world] for p in plans]
+        # the owners' ranges: balanced, contiguous, a partition of the batch (pure-Python model of ranges_of)
+        base_, extra = divmod(nqb, world)
+        want_own = [(j * base_ + min(j, extra), j * base_ + min(j, extra) + base_ + (1 if j < extra else 0)) for j in range(world)]
+        for r in range(world):
+            assert (rows[r][:, 0] == b).all() and (rows[r][:, 1] == (b & 1)).all() and (rows[r][:, 2] == q0).all() and (rows[r][:, 3] == nqb).all()
+            assert rows[r][:, 4].tolist() == list(range(world))
+            for j in range(world):
+                _, _, _, _, peer, s0, sn, rslot, rn, own0 = rows[r][j].tolist()
+                assert (s0, s0 + sn) == want_own[j], "rank %d sends rank %d the rows it owns" % (r, j)
+                assert rn == want_own[r][1] - want_own[r][0] and rslot == j * per and rslot + rn <= world * per
+                assert own0 == q0 + want_own[r][0]
+                # the matching call on the peer: j receives from r exactly what r sends to j
+                assert rows[j][r][8] == sn and rows[j][r][4] == r
+        # play the exchange: receive buffers [world * per rows], then the merge of the world lists per owned row
+        for r in range(world):
+            lo, hi = want_own[r]
+            if hi == lo:
+                continue
+            rb_i = np.zeros((world * per, K), np.uint32); rb_v = np.full((world * per, K), -np.inf, np.float32)
+            for j in range(world):         # what peer j sends to r lands in r's slot j
+                s0, sn = rows[j][r][5], rows[j][r][6]
+                slot, rn = rows[r][j][7], rows[r][j][8]
+                assert sn == rn
+                rb_i[slot:slot + rn] = ids[j, q0 + s0:q0 + s0 + sn]; rb_v[slot:slot + rn] = vals[j, q0 + s0:q0 + s0 + sn]
+            for t in range(hi - lo):
+                ci = np.concatenate([rb_i[j * per + t] for j in range(world)]); cv = np.concatenate([rb_v[j * per + t] for j in range(world)])
+                order = np.lexsort((ci, -cv))[:K]
+                out_i[q0 + lo + t] = ci[order]; out_v[q0 + lo + t] = cv[order]; written[q0 + lo + t] += 1
+    assert (written == 1).all(), "every query row is merged by exactly one rank"
+    for q in range(0, nq, max(1, nq // 50)):
+        ci, cv = ids[:, q].reshape(-1), vals[:, q].reshape(-1)
+        order = np.lexsort((ci, -cv))[:K]
+        assert (out_i[q] == ci[order]).all() and (out_v[q] == cv[order]).all()

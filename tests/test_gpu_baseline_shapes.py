@@ -9,6 +9,9 @@
             the oracle on the full-size base (a parity failure at 10M is a red test here, not a string in bench.py)
   config 4  LAION-shaped ground truth: unit-norm clustered embeddings, L2, K = 100, at 1M rows, where the rank-100 /
             rank-101 gap is of the order of the fp32 rounding of the ranking value
+  config 3  compute_groundtruth at its own size: 10M x 200 MIPS, K = 100 -- 10,000 queries over the whole base (the balanced work
+            split, thresholds and compactions of K2 at the size the bench runs), over one 1.25M-row shard with a non-zero id base
+            (what one of eight GPUs holds) and over eight shards + K3, a 256-query sample of each against fp64 brute force
 """
 import os
 
@@ -246,3 +249,45 @@ def test_config5_2p5m_x_512_ip_product_built_index(oracle):
     from roargraph_amd import index as ixmod
     rec = ixmod.recall(outs[("default", 10, 500)][0][:ns].view(np.uint32), ref_ids, 10)
     assert rec > 0.95, rec
+
+
+def test_config3_gt_10m_x_200_mips_k100_full_size(oracle):
+    """BASELINE configs[2] at full size on one GPU: K2 over 10M x 200 rows, MIPS, K = 100, 10,000 queries (474 work
+    items on 512 workgroups: the balanced split, threshold filter, candidate buffers and compactions all busy), the first 256
+    queries against the fp64 brute force of the checker over the same 8 GB base; one 1.25M-row shard with id_base = 3 x 1.25M (the
+    fourth of eight GPUs) against fp64 over that slice; eight shards + K3 == the one-shot lists bit for bit
+    (/root/reference/src/index_bipartite.cpp:2622-2642 is the consumer of these lists)."""
+    import torch
+    from roargraph_amd import groundtruth, synth
+    dev = torch.device("cuda", 0)
+    nb, d, nq, ns, K = 10_000_000, 200, 10_000, 256, 100
+    base, _, q, _ = synth.make_device_set(dev, 1234, nb, 0, nq, d, data="lowrank", rank=32, q_seed=4711)
+    ids = torch.zeros((nq, K), dtype=torch.int32, device=dev); vals = torch.zeros((nq, K), device=dev)
+    groundtruth.gt_shard_dev(base, q, "ip", K, 0, ids, vals); torch.cuda.synchronize()
+    hb, hq = base.cpu().numpy(), q[:ns].cpu().numpy()
+    nt = min(64, os.cpu_count() or 1)
+    ref_ids, _, ref_s = oracle.groundtruth_f64(hb, hq, "ip", K, nthreads=nt)
+    check_gt(hb, hq, "ip", K, ids[:ns].cpu().numpy().view(np.uint32), vals[:ns].cpu().numpy(), ref_ids, ref_s)
+    # one shard of eight, ids offset by its first row
+    shards = groundtruth.shard_rows(nb, 8)
+    lo, hi = shards[3]
+    assert lo == 3 * 1_250_000 and hi - lo == 1_250_000
+    si = torch.zeros((nq, K), dtype=torch.int32, device=dev); sv = torch.zeros((nq, K), device=dev)
+    groundtruth.gt_shard_dev(base[lo:hi], q, "ip", K, lo, si, sv); torch.cuda.synchronize()
+    r_ids, _, r_s = oracle.groundtruth_f64(hb[lo:hi], hq, "ip", K, nthreads=nt)
+    got = si[:ns].cpu().numpy().view(np.uint32)
+    assert got.min() >= lo and got.max() < hi
+    check_gt(hb[lo:hi], hq, "ip", K, got - np.uint32(lo), sv[:ns].cpu().numpy(), r_ids, r_s)
+    # eight shards + K3: the one-shot lists, bit for bit (ids and ranking values)
+    parts_i = torch.zeros((8, nq, K), dtype=torch.int32, device=dev); parts_v = torch.zeros((8, nq, K), device=dev)
+    for r, (a, b) in enumerate(shards):
+        groundtruth.gt_shard_dev(base[a:b], q, "ip", K, a, parts_i[r], parts_v[r])
+    assert torch.equal(parts_i[3], si) and torch.equal(parts_v[3].view(torch.int32), sv.view(torch.int32))
+    mi = torch.zeros_like(ids); mv = torch.zeros_like(vals)
+    groundtruth.gt_merge_dev(parts_i, parts_v, 8, nq, K, "ip", mi, mv); torch.cuda.synchronize()
+    same = mi == ids
+    if not bool(same.all()):      # rows may differ only inside exact fp32 ties of the ranking value (equal bits, ids swapped)
+        assert torch.equal(mv.view(torch.int32), vals.view(torch.int32)), "K3 over eight shards returned other values than one pass"
+        assert float(same.float().mean()) > 0.9999
+    else:
+        assert torch.equal(mv.view(torch.int32), vals.view(torch.int32))

@@ -308,6 +308,20 @@ print("RESULT rank %%d: ok rccl=%%d" %% (rank, 1))
         outs.append(o)
     res = [[l for l in o.splitlines() if l.startswith("RESULT")] for o in outs]
     print("\n".join(sum(res, [])))
+    # the record of what this runtime did: kept under gpurun_out/ (merged back by gpurun), copied to profiles/r05/
+    try:
+        rec_dir = os.path.join(root, "gpurun_out")
+        os.makedirs(rec_dir, exist_ok=True)
+        import torch
+        with open(os.path.join(rec_dir, "rccl_two_process.txt"), "w") as fh:
+            fh.write("two processes, rg_comm_unique_id + rg_comm_init_rank(rank, world = 2, device 0) on a box with %d GPU(s); torch %s, HIP %s\n"
+                     % (torch.cuda.device_count(), torch.__version__, torch.version.hip))
+            fh.write("\n".join(sum(res, [])) + "\n")
+            for r_, o in enumerate(outs):
+                extra = [l for l in o.splitlines() if not l.startswith("RESULT") and ("NCCL" in l or "RCCL" in l or "rccl" in l or "nccl" in l)][-6:]
+                fh.write("".join("rank %d output: %s\n" % (r_, l) for l in extra))
+    except OSError:
+        pass
     assert all(len(r) == 1 for r in res), outs
     ok = ["ok rccl" in r[0] for r in res]
     assert ok[0] == ok[1], res      # both joined, or both were refused
