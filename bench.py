@@ -1002,6 +1002,7 @@ def main():
         index.close()
         del S, index, base, off, nbrs, qs
         torch.cuda.empty_cache()
+        lib().rg_mem_release(local)      # the library's cache of freed buffers (the side blocks have other sizes)
         defs = {
             "rank128": dict(nb=2_500_000, dim=200, metric="ip", k=10, rank_latent=128, Ls=[50, 100, 200, 300, 500, 700, 1000],
                             what="a harder data set of the headline's family: latent rank 128 instead of 32 (four times the intrinsic dimension), "
@@ -1023,6 +1024,9 @@ def main():
                                            d_["Ls"], args.target_recall, min(args.cpu_seconds, 6.0), min(args.steps, 5), d_["what"]))
     else:
         mem_stats_main = index.mem_stats() if rank == 0 else None
+    if mem_stats_main and not mem_stats_main.get("placement_balanced", True):
+        print("[bench] WARNING: %d large buffer(s) of the index fell back to plain allocations (one memory class): wide beams run "
+              "up to 10 %% slower in that placement" % mem_stats_main.get("plain_allocs_of_this_index", -1), file=sys.stderr)
     traffic, traffic_src = pmc_traffic(wl_key) if rank == 0 else (None, None)
     shape_name = {(10_000_000, 200, "ip"): "t2i-10M-shaped", (10_000_000, 512, "l2"): "laion-10M-shaped",
                   (2_500_000, 512, "ip"): "webvid-2.5M-shaped"}.get((args.nb, args.dim, args.metric), "%dx%d" % (args.nb, args.dim))

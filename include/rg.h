@@ -148,7 +148,9 @@ rg_status rg_index_set(rg_index *idx, const char *name, int value);
 /* Counters of the search path since the index was opened (diagnostics: which form the batches ran in).  Names:
  * "batches_lset" / "batches_filter_log" / "batches_exact_hbm" / "batches_filter_only" (batches enqueued per form),
  * "lset_left" (queries that outgrew their exact LDS set), "recounted" (queries whose cmps the host recounted), "hub_levels" (1: the
- * adjacency carries hub levels), "hub_m_last" (log2 of the hub bitmap of the last search launch, 0 = none). */
+ * adjacency carries hub levels), "hub_m_last" (log2 of the hub bitmap of the last search launch, 0 = none), "placement_balanced"
+ * (1: every large buffer this index allocated so far -- rows, adjacency, visited tags, id logs -- is spread over the memory
+ * classes; 0: at least one fell back to a plain allocation, the slower placement), "plain_allocs" (how many). */
 rg_status rg_index_stat(const rg_index *idx, const char *name, uint64_t *value);
 /* Where the large buffers of the indexes on `device` live (diagnostics; no counterpart in the reference).  The library
  * builds every buffer of 2 GiB and more from 1-GiB granules taken round robin over the memory classes of the device
@@ -157,6 +159,14 @@ rg_status rg_index_stat(const rg_index *idx, const char *name, uint64_t *value);
  * requests that fell back to a plain allocation, classes = memory classes found, granules_per_class[4] = granules of the
  * live buffers per class.  RG_BALANCED_ALLOC=0 in the environment turns the balancing off. */
 rg_status rg_mem_stats(int device, uint64_t *buffers, uint64_t *plain, uint32_t *classes, uint64_t *granules_per_class);
+/* More of the same (round 5), vals[0 .. nvals): balanced buffers handed out, plain fallbacks, classes found, probe launches, wall time
+ * spent classifying granules (microseconds), bytes of virtual address space reserved so far (a range is used once: a runtime defect
+ * hands freed ranges back with stale translations), requests served from the cache of freed buffers, bytes cached, bytes live,
+ * classes a buffer is spread over.  A freed balanced buffer stays mapped and cached (RG_MEM_CACHE_GIB, default 64 GiB per device) and
+ * serves the next request of its size -- an index opened again reserves no new address space and runs no probe;
+ * rg_mem_release hands the cache (and the pool's spare granules) back to the device. */
+rg_status rg_mem_stats_ex(int device, uint64_t *vals, int nvals);
+rg_status rg_mem_release(int device);
 /* The device adjacency of an index as the search kernel reads it (diagnostics, tests; no counterpart in the reference):
  * [npts][*stride] words, word 0 of a row = its degree, then the neighbours: id in the low 24 bits and -- on indexes of up to 2^24
  * nodes -- min(15, in-degree of the neighbour) in bits 24..27 and its hub level in bits 28..31 (knob "hub_bits": at 2^m bits the

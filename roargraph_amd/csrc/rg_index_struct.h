@@ -128,6 +128,7 @@ struct rg_index {
                                  // m = 2^m bits whatever the region's size suggests (tests, experiments)
     int hub_pct = -1;            // knob: largest share of the visited region the bitmap may take, percent (-1 = 90; 60 at L_pq <= 420)
     uint32_t hub_m_last = 0;     // statistics: log2 of the bitmap of the last search launch (0 = none)
+    uint64_t n_plain_allocs = 0; // large buffers of this index that fell back to a plain allocation (one memory class: the slower placement)
     int lset_bytes = 0;          // knob (tests): cap of the exact LDS set's region in bytes (0 = what the launch has)
     int lset = -1;               // knob "lset" (round 4): default visited mode, narrow beams: the exact visited set in LDS (K1 VIS = 3: no id
                                  // log, no K4, no de-duplicating inserts).  -1 = wherever a query's visits fit the LDS a launch can give it,

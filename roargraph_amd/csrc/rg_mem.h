@@ -19,6 +19,9 @@ inline rg_status dev_alloc_t(int device, size_t n, T **out) {
 }
 // releases what dev_alloc returned (or any hipMalloc'ed pointer); null is fine
 void dev_free(void *p);
-// hands the pool's spare granules back to the device
+// hands the pool's spare granules back to the device (freed balanced buffers stay cached, mapped, for the next request of
+// their size: rg_mem_release hands those back too)
 void dev_trim(int device);
+// did the calling thread's last dev_alloc of 2 GiB or more fall back to a plain allocation (one memory class)?
+bool dev_last_plain();
 }  // namespace rg

@@ -20,6 +20,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -87,6 +88,11 @@ struct Buffer {
     std::vector<hipMemGenericAllocationHandle_t> handles;
     int per_class[kMaxClasses] = {0, 0, 0, 0};
 };
+// a freed balanced buffer, still mapped: the next request of (about) its size takes it as it is
+struct Cached {
+    void *va = nullptr;
+    Buffer buf;
+};
 
 struct Pool {
     std::mutex mu;
@@ -98,13 +104,31 @@ struct Pool {
     float *d_out = nullptr;
     hipEvent_t e0 = nullptr, e1 = nullptr;
     std::map<void *, Buffer> live;
-    // statistics (rg_mem_stats)
-    uint64_t n_buffers = 0, n_plain = 0, n_probes = 0, n_ballast = 0;
+    // BUFFER CACHE (round 5).  A virtual range can be used once (see va_reserve below), so a process that opens and closes indexes
+    // would go through address space without bound -- and pay the walk and its probes on every open.  A freed balanced buffer
+    // therefore stays as it is, mapped, in this list (up to RG_MEM_CACHE_GIB, default 64 GiB per device), and a later request of
+    // its size -- the same index opened again, the tags of the next context -- takes it whole: no new range, no probe, no remap.
+    // The cache goes back to the device when a request cannot be served otherwise, and through rg_mem_release.
+    std::vector<Cached> cache;
+    size_t cached_bytes = 0;
+    int want_classes = 3;                      // classes a buffer is spread over: three on MI355X; fewer once a full walk found fewer
+    // statistics (rg_mem_stats / rg_mem_stats_ex)
+    uint64_t n_buffers = 0, n_plain = 0, n_probes = 0, n_ballast = 0, n_cache_hits = 0;
+    double probe_ms = 0.0;                     // wall time spent classifying granules
     size_t walked_epoch = 0;                   // bytes walked since the pool was last trimmed
 };
 
 Pool g_pool[16];
 bool g_off = false, g_off_read = false, g_trace = false, g_trace2 = false;
+thread_local bool t_last_plain = false;       // dev_last_plain(): the calling thread's last large request fell back to hipMalloc
+
+size_t cache_cap_bytes() {
+    static const size_t cap = [] {
+        const char *e = getenv("RG_MEM_CACHE_GIB");
+        return (size_t)(e ? std::max(0, atoi(e)) : 64) << 30;
+    }();
+    return cap;
+}
 
 bool off() {
     if (!g_off_read) {
@@ -195,6 +219,8 @@ void drop_granule(Granule &g) {
 
 // milliseconds of the probe with its rows in granule a and its tags in granule b (two timed launches behind a warm-up one)
 float probe(Pool &P, const Granule &a, const Granule &b) {
+    struct Timer { Pool &P; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+                   ~Timer() { P.probe_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); } } timer{P};
     const uint32_t slots = 2048, steps = 64;
     const uint32_t nrows = (uint32_t)(kGranule / 768);
     const size_t slot_bytes = kGranule / slots;
@@ -269,23 +295,71 @@ int classify(Pool &P, Granule &g, bool *is_rep) {
     return slowest;
 }
 
+// (P.mu held) everything the pool holds beyond the live buffers goes back to the device: spare granules, cached buffers
+void release_spare(Pool &P) {
+    for (int k = 0; k < kMaxClasses; ++k) {
+        for (Granule &g : P.spare[k]) drop_granule(g);
+        P.spare[k].clear();
+    }
+    P.walked_epoch = 0;
+}
+void release_cache(Pool &P) {
+    if (P.cache.empty()) return;
+    (void)hipDeviceSynchronize();
+    for (Cached &c : P.cache) {
+        for (size_t i = 0; i < c.buf.handles.size(); ++i) {
+            va_unmap((char *)c.va + i * kGranule, kGranule);
+            (void)hipMemRelease(c.buf.handles[i]);
+        }
+        va_free(c.va, c.buf.bytes);
+    }
+    P.cache.clear();
+    P.cached_bytes = 0;
+}
+
 }  // namespace
+
+bool dev_last_plain() { return t_last_plain; }
 
 rg_status dev_alloc(int device, size_t bytes, void **out) {
     *out = nullptr;
     if (bytes == 0) bytes = 16;
+    t_last_plain = false;
+    Pool *Pp = (bytes >= kMinBalanced && !off() && device >= 0 && device < 16) ? &g_pool[device] : nullptr;
+    // the plain buffer.  Whatever the pool still holds goes back first (a request that the pool's own spare granules
+    // made impossible must not fail with the memory sitting in the pool)
     auto plain = [&]() -> rg_status {
+        if (Pp) { release_spare(*Pp); release_cache(*Pp); t_last_plain = true; }
         hipError_t e = hipMalloc(out, bytes);
         if (e != hipSuccess) { (void)hipGetLastError(); return set_error(RG_ERR_OOM, std::string("hipMalloc of ") + std::to_string(bytes) + " bytes: " + hipGetErrorString(e)); }
         return RG_OK;
     };
-    if (bytes < kMinBalanced || off() || device < 0 || device >= 16) return plain();
-    Pool &P = g_pool[device];
+    if (!Pp) return plain();
+    Pool &P = *Pp;
     std::lock_guard<std::mutex> lk(P.mu);
     if (!init_pool(P, device)) { ++P.n_plain; return plain(); }
     const size_t n = (bytes + kGranule - 1) / kGranule;
-    // what the buffer should get of each class: an equal share of every class the walk can reach -- three on this part
-    const int want_classes = 3;
+    {   // a cached buffer of this size (at most an eighth larger): taken as it is
+        int best = -1;
+        for (size_t i = 0; i < P.cache.size(); ++i) {
+            const size_t cn = P.cache[i].buf.bytes / kGranule;
+            if (cn >= n && cn <= n + std::max<size_t>(1, n / 8) && (best < 0 || cn < P.cache[(size_t)best].buf.bytes / kGranule)) best = (int)i;
+        }
+        if (best >= 0) {
+            Cached c = P.cache[(size_t)best];
+            P.cache.erase(P.cache.begin() + best);
+            P.cached_bytes -= c.buf.bytes;
+            P.live[c.va] = c.buf;
+            ++P.n_buffers; ++P.n_cache_hits;
+            if (g_trace) fprintf(stderr, "[rg_mem] %.2f GiB at %p: taken from the cache (%d / %d / %d / %d granules of the classes)\n", (double)c.buf.bytes / (1u << 30), c.va,
+                                 c.buf.per_class[0], c.buf.per_class[1], c.buf.per_class[2], c.buf.per_class[3]);
+            *out = c.va;
+            return RG_OK;
+        }
+    }
+    // what the buffer should get of each class: an equal share of every class the walk can reach -- three on this part (fewer once a
+    // whole walk has found fewer: a device or partition without the third class must not walk its budget on every request)
+    const int want_classes = P.want_classes;
     const size_t share = (n + want_classes - 1) / want_classes;
     size_t free_b = 0, total_b = 0;
     // Walk: new granules, one after the other, each classified, ALL kept in the pool -- until every class has its share there, or
@@ -305,12 +379,14 @@ rg_status dev_alloc(int device, size_t bytes, void **out) {
     (void)hipMemGetInfo(&free_b, &total_b);
     const size_t epoch_budget = std::min<size_t>((size_t)160 << 30, free_b / 2);
     size_t walked = 0;
+    bool budget_spent = false;
     while (!satisfied()) {
         (void)hipMemGetInfo(&free_b, &total_b);
         size_t pooled = 0;
         for (int c = 0; c < kMaxClasses; ++c) pooled += have(c);
+        if (free_b < ((size_t)16 << 30) && !P.cache.empty()) { release_cache(P); continue; }   // cached buffers are the first thing to give up
         if (free_b < ((size_t)16 << 30)) break;                                     // the device is nearly full (others may live on it): take what there is
-        if (pooled >= n && (P.walked_epoch >= epoch_budget || pooled * kGranule >= epoch_budget)) break;   // a long walk did not find enough of some class: take what there is
+        if (pooled >= n && (P.walked_epoch >= epoch_budget || pooled * kGranule >= epoch_budget)) { budget_spent = true; break; }   // a long walk did not find enough of some class: take what there is
         Granule g;
         if (!new_granule(P, device, &g)) break;
         walked += kGranule;
@@ -322,6 +398,14 @@ rg_status dev_alloc(int device, size_t bytes, void **out) {
         g.cls = c;
         if (is_rep) { P.reps.push_back(g); continue; }
         P.spare[c].push_back(g);
+    }
+    if (budget_spent) {   // the whole budget walked and some class never showed: aim for the classes there are from now on
+        int found = 0;
+        for (int c = 0; c < kMaxClasses; ++c) found += have(c) > 0 ? 1 : 0;
+        if (found >= 1 && found < P.want_classes) {
+            P.want_classes = found;
+            if (g_trace) fprintf(stderr, "[rg_mem] device %d: a full walk found %d class(es): buffers are spread over those from now on\n", device, found);
+        }
     }
     size_t pooled = 0;
     for (int c = 0; c < kMaxClasses; ++c) pooled += have(c);
@@ -356,7 +440,10 @@ rg_status dev_alloc(int device, size_t bytes, void **out) {
     if (!ok) {
         (void)hipGetLastError();
         for (size_t i = 0; i < buf.handles.size(); ++i) va_unmap((char *)va + i * kGranule, kGranule);
-        for (Granule &g : taken) (void)hipMemRelease(g.h);
+        for (Granule &g : taken) {
+            if (g.va) { va_unmap(g.va, kGranule); va_free(g.va, kGranule); g.va = nullptr; }   // (not moved yet: still mapped in the pool)
+            (void)hipMemRelease(g.h);
+        }
         va_free(va, n * kGranule);
         ++P.n_plain;
         return plain();
@@ -379,6 +466,13 @@ void dev_free(void *p) {
         auto it = P.live.find(p);
         if (it == P.live.end()) continue;
         Buffer &b = it->second;
+        if (P.cached_bytes + b.bytes <= cache_cap_bytes()) {     // kept mapped for the next request of its size
+            (void)hipDeviceSynchronize();                        // (nothing queued reads it any more when it is handed out again)
+            P.cache.push_back({p, b});
+            P.cached_bytes += b.bytes;
+            P.live.erase(it);
+            return;
+        }
         (void)hipDeviceSynchronize();
         for (size_t i = 0; i < b.handles.size(); ++i) {
             va_unmap((char *)p + i * kGranule, kGranule);
@@ -395,14 +489,34 @@ void dev_trim(int device) {
     if (device < 0 || device >= 16) return;
     Pool &P = g_pool[device];
     std::lock_guard<std::mutex> lk(P.mu);
-    for (int k = 0; k < kMaxClasses; ++k) {
-        for (Granule &g : P.spare[k]) drop_granule(g);
-        P.spare[k].clear();
-    }
-    P.walked_epoch = 0;
+    release_spare(P);
 }
 
 }  // namespace rg
+
+extern "C" rg_status rg_mem_release(int device) {
+    if (device < 0 || device >= 16) return rg::set_error(RG_ERR_ARG, "device index out of range");
+    if (hipSetDevice(device) != hipSuccess) return rg::set_error(RG_ERR_DEVICE, "cannot select the device");
+    rg::Pool &P = rg::g_pool[device];
+    std::lock_guard<std::mutex> lk(P.mu);
+    rg::release_spare(P);
+    rg::release_cache(P);
+    return RG_OK;
+}
+
+extern "C" rg_status rg_mem_stats_ex(int device, uint64_t *vals, int nvals) {
+    if (device < 0 || device >= 16 || !vals || nvals < 1) return rg::set_error(RG_ERR_ARG, "bad argument");
+    rg::Pool &P = rg::g_pool[device];
+    std::lock_guard<std::mutex> lk(P.mu);
+    uint64_t va = 0;
+    { std::lock_guard<std::mutex> lk2(rg::g_va_mu); va = rg::g_va_reserved; }
+    uint64_t live = 0;
+    for (auto &kv : P.live) live += kv.second.bytes;
+    const uint64_t all[10] = {P.n_buffers, P.n_plain, (uint64_t)P.reps.size(), P.n_probes, (uint64_t)(P.probe_ms * 1000.0), va, P.n_cache_hits,
+                              (uint64_t)P.cached_bytes, live, (uint64_t)P.want_classes};
+    for (int i = 0; i < nvals && i < 10; ++i) vals[i] = all[i];
+    return RG_OK;
+}
 
 extern "C" rg_status rg_mem_stats(int device, uint64_t *buffers, uint64_t *plain, uint32_t *classes, uint64_t *granules_per_class /* [4] */) {
     if (device < 0 || device >= 16) return rg::set_error(RG_ERR_ARG, "device index out of range");

@@ -525,6 +525,7 @@ static rg_status finish_graph(rg_index *ix, const uint64_t *d_off, const uint32_
         {   // (large buffers: balanced over the memory classes of the device, rg_mem.hip)
             rg_status as = dev_alloc_t(ix->device, (size_t)ix->nd * es, &ix->d_ell);
             if (as != RG_OK) return as;
+            ix->n_plain_allocs += dev_last_plain() ? 1 : 0;
         }
         RG_HIP(hipMemset(d_stat, 0, 4));
         hipLaunchKernelGGL(rg_csr_to_ell_kernel, dim3(4096), dim3(256), 0, 0, d_off, d_nb, ix->nd, ix->d_ell, es, d_stat);
@@ -565,9 +566,11 @@ static rg_status finish_graph(rg_index *ix, const uint64_t *d_off, const uint32_
         if (ix->dim == 200 && ne + 1 < 0xffffffffull && !(env && atoi(env) == 0)) {
             ix->main_dim = 192; ix->tail_dim = 8;
             // optional: an index that cannot afford the copy (or whose kernels fail) searches the base itself
-            bool ok = dev_alloc_t(ix->device, (size_t)ix->nd * ix->main_dim, &ix->d_main) == RG_OK &&
-                      dev_alloc_t(ix->device, (size_t)(ne + 1) * ix->tail_dim, &ix->d_etail) == RG_OK &&
-                      hipMalloc(&ix->d_tail_off, (size_t)ix->nd * 4) == hipSuccess;
+            bool ok = dev_alloc_t(ix->device, (size_t)ix->nd * ix->main_dim, &ix->d_main) == RG_OK;
+            ix->n_plain_allocs += ok && dev_last_plain() ? 1 : 0;
+            ok = ok && dev_alloc_t(ix->device, (size_t)(ne + 1) * ix->tail_dim, &ix->d_etail) == RG_OK;
+            ix->n_plain_allocs += ok && dev_last_plain() ? 1 : 0;
+            ok = ok && hipMalloc(&ix->d_tail_off, (size_t)ix->nd * 4) == hipSuccess;
             if (ok) {
                 hipLaunchKernelGGL(rg_split_main_kernel, dim3(8192), dim3(256), 0, 0, ix->d_base, ix->nd, ix->stride, ix->main_dim, ix->d_main);
                 hipLaunchKernelGGL(rg_split_tail_kernel, dim3(8192), dim3(256), 0, 0, ix->d_base, ix->stride, ix->main_dim, ix->tail_dim, d_nb,
@@ -602,6 +605,7 @@ static rg_status finish_graph(rg_index *ix, const uint64_t *d_off, const uint32_
             hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b > 2 * bytes + ((size_t)8 << 30)) {
             float *copy = nullptr;
             if (dev_alloc_t(ix->device, (size_t)ix->nd * ix->stride, &copy) == RG_OK) {
+                ix->n_plain_allocs += dev_last_plain() ? 1 : 0;
                 if (hipMemcpy(copy, ix->d_base, bytes, hipMemcpyDeviceToDevice) == hipSuccess) { ix->d_base = copy; ix->own_base = true; }
                 else { (void)hipGetLastError(); dev_free(copy); }
             }
@@ -789,6 +793,7 @@ static rg_status ensure_visited(rg_index *ix, SearchCtx *cx, uint32_t slots, boo
     const bool ok_v = ix->visited_uncached ? hipExtMallocWithFlags(reinterpret_cast<void **>(&nv), (size_t)slots * vwords * 4,
                                                                    ix->visited_uncached == 2 ? hipDeviceMallocFinegrained : hipDeviceMallocUncached) == hipSuccess
                                            : dev_alloc_t(ix->device, (size_t)slots * vwords, &nv) == RG_OK;
+    if (ok_v && !ix->visited_uncached && dev_last_plain()) { std::lock_guard<std::mutex> lk(ix->mu); ++ix->n_plain_allocs; }
     dev_trim(ix->device);      // (the allocator's pool of classified granules goes back to the device)
     if (!ok_v || hipMalloc(&ne, (size_t)slots * 4) != hipSuccess) {
         (void)hipGetLastError();
@@ -1155,6 +1160,7 @@ static rg_status ensure_qlog(rg_index *ix, SearchCtx *cx, uint32_t nq) {
     ++cx->allocs;
     {
         rg_status as = dev_alloc_t(ix->device, (size_t)chunk * cap, &cx->d_qlog);
+        if (as == RG_OK && dev_last_plain()) { std::lock_guard<std::mutex> lk(ix->mu); ++ix->n_plain_allocs; }
         dev_trim(ix->device);
         if (as != RG_OK) return as;
     }
@@ -1707,6 +1713,7 @@ rg_status rg_index_open_mem(const float *base, uint32_t nd, uint32_t dim, uint32
     } d_base;
     st = rg::dev_alloc_t(device, (size_t)nd * ad, &d_base.p);
     if (st != RG_OK) return st;
+    const bool base_plain = rg::dev_last_plain();
     if (metric == RG_METRIC_COSINE || ad != dim || ad != stride) {
         std::vector<float> tmp((size_t)nd * ad, 0.0f);
         for (size_t i = 0; i < nd; ++i) std::memcpy(tmp.data() + i * ad, base + i * (size_t)stride, (size_t)dim * 4);
@@ -1726,6 +1733,7 @@ rg_status rg_index_open_mem(const float *base, uint32_t nd, uint32_t dim, uint32
     st = open_dev_impl(d_base.p, nd, ad, ad, d_off.p, d_nb.p, ep, metric, device, true, &ix);
     if (st != RG_OK) return st;
     d_base.p = nullptr;       // now owned by the index
+    ix->n_plain_allocs += base_plain ? 1 : 0;
     *out = ix;
     return RG_OK;
 }
@@ -1837,6 +1845,7 @@ rg_status rg_index_set(rg_index *ix, const char *name, int value) {
             ix->stride_bf = (ix->dim + 127u) / 128u * 128u;
             {
                 rg_status as = rg::dev_alloc_t(ix->device, (size_t)ix->nd * ix->stride_bf, &ix->d_base_bf);
+                ix->n_plain_allocs += as == RG_OK && rg::dev_last_plain() ? 1 : 0;
                 rg::dev_trim(ix->device);
                 if (as != RG_OK) return as;
             }
@@ -1864,6 +1873,8 @@ rg_status rg_index_stat(const rg_index *ixc, const char *name, uint64_t *value) 
     else if (!strcmp(name, "lset_left")) *value = ix->n_lset_left;
     else if (!strcmp(name, "recounted")) *value = ix->n_recounted;
     else if (!strcmp(name, "hub_levels")) *value = ix->hub_levels ? 1 : 0;
+    else if (!strcmp(name, "placement_balanced")) *value = ix->n_plain_allocs == 0 ? 1 : 0;
+    else if (!strcmp(name, "plain_allocs")) *value = ix->n_plain_allocs;
     else if (!strcmp(name, "hub_m_last")) *value = ix->hub_m_last;
     else return set_error(RG_ERR_ARG, "unknown counter");
     return RG_OK;

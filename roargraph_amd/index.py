@@ -103,8 +103,14 @@ class IndexBipartite:
         nb, npl, nc = C.c_uint64(), C.c_uint64(), C.c_uint32()
         per = (C.c_uint64 * 4)()
         check(lib().rg_mem_stats(C.c_int(self.info()["device"]), C.byref(nb), C.byref(npl), C.byref(nc), per))
+        ex = (C.c_uint64 * 10)()
+        check(lib().rg_mem_stats_ex(C.c_int(self.info()["device"]), ex, 10))
         return {"balanced_buffers": int(nb.value), "plain_fallbacks": int(npl.value), "memory_classes_found": int(nc.value),
-                "GiB_of_live_buffers_per_class": [int(x) for x in per]}
+                "GiB_of_live_buffers_per_class": [int(x) for x in per],
+                # round 5: what the placement cost and whether this index got it (rg_mem_stats_ex, rg_index_stat)
+                "probe_launches": int(ex[3]), "probe_seconds": round(ex[4] / 1e6, 3), "GiB_of_address_space_reserved": round(ex[5] / 2 ** 30, 1),
+                "requests_served_from_cache": int(ex[6]), "GiB_cached": round(ex[7] / 2 ** 30, 1),
+                "placement_balanced": bool(self.stat("placement_balanced")), "plain_allocs_of_this_index": self.stat("plain_allocs")}
 
     def stat(self, name):
         """counters of the search path since open (rg_index_stat): batches_lset / batches_filter_log / batches_exact_hbm /

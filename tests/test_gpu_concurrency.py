@@ -130,3 +130,58 @@ def test_batches_in_flight_on_one_stream(oracle):
     assert (bufs[1][0].cpu().numpy() == 3).all() and (bufs[2][0].cpu().numpy() == 3).all()
     ix.search_wait()      # nothing pending any more
     ix.close()
+
+
+def test_fifty_opens_and_closes_reserve_no_new_address_space(oracle):
+    """the balanced allocator uses a virtual range once (a runtime defect hands freed ranges back with stale
+    translations), so a process that opens and closes indexes went through address space without bound and paid the placement probes
+    on every open.  Round 5: a freed balanced buffer stays mapped in a cache and serves the next request of its size.  Fifty opens
+    and closes of one index whose rows are a 3 GB balanced buffer: from the second open on no address space is reserved, no probe
+    runs, every open is served from the cache, the placement is reported balanced, and the searches return the same bits; the
+    cache goes back to the device on request."""
+    import ctypes as C
+    import torch
+    from roargraph_amd._lib import check, lib
+    from roargraph_amd.index import IndexBipartite
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev); g.manual_seed(77)
+    nb, d, deg, nq = 1_500_000, 512, 16, 256
+    base = torch.empty((nb, d), device=dev).normal_(generator=g)
+    nbrs = torch.randint(0, nb, (nb * deg,), dtype=torch.int32, device=dev, generator=g)
+    off = torch.arange(0, nb + 1, dtype=torch.int64, device=dev) * deg
+    q = torch.empty((nq, d), device=dev).normal_(generator=g)
+
+    def stats():
+        ex = (C.c_uint64 * 10)()
+        check(lib().rg_mem_stats_ex(0, ex, 10))
+        return [int(x) for x in ex]
+
+    first = None
+    va_after = []
+    for it in range(50):
+        ix = IndexBipartite.from_device(base, off, nbrs, 5, metric="l2")
+        assert ix.stat("placement_balanced") == 1 and ix.stat("plain_allocs") == 0
+        ids = torch.zeros((nq, 10), dtype=torch.int32, device=dev); ds = torch.zeros((nq, 10), device=dev)
+        cm = torch.zeros(nq, dtype=torch.int32, device=dev); hp = torch.zeros(nq, dtype=torch.int32, device=dev)
+        ix.search_dev(q, 10, 50, ids, ds, cm, hp); ix.search_wait()
+        got = (ids.cpu().numpy(), ds.cpu().numpy().view(np.uint32), cm.cpu().numpy(), hp.cpu().numpy())
+        if first is None:
+            first = got
+            ms = ix.mem_stats()
+            assert ms["balanced_buffers"] >= 1 and ms["plain_fallbacks"] == 0 and ms["placement_balanced"]
+        else:
+            assert all((a == b).all() for a, b in zip(got, first)), it
+        ix.close()
+        va_after.append(stats())
+    s1, s49 = va_after[1], va_after[49]
+    assert s49[5] == s1[5], "address space reserved grew between the 2nd and the 50th open: %r -> %r" % (s1[5], s49[5])
+    assert s49[3] == s1[3], "probes ran after the first opens"
+    assert s49[6] - s1[6] >= 48, "opens were not served from the cache"
+    assert s49[1] == 0 and s49[7] >= 3 * 2 ** 30            # nothing plain; the 3 GB buffer sits in the cache
+    check(lib().rg_mem_release(0))
+    assert stats()[7] == 0
+    # and after the release the next open builds its buffer again (new range, balanced)
+    ix = IndexBipartite.from_device(base, off, nbrs, 5, metric="l2")
+    assert ix.stat("placement_balanced") == 1 and stats()[5] > s49[5]
+    ix.close()
+    check(lib().rg_mem_release(0))
