@@ -79,7 +79,8 @@ def parse():
                     "needs a beam ten times as wide), webvid = BASELINE configs[4] end to end (2.5M x 512 IP: ground truth -> build -> "
                     "search), laion = BASELINE configs[3] shape (d = 512 L2 top-100) at the size --laion-nb; empty = none")
     ap.add_argument("--side-nb", type=int, default=0, help="rows of EVERY side block (tests: small sets); 0 = their own sizes")
-    ap.add_argument("--laion-nb", type=int, default=3_000_000, help="rows of the laion-shaped side block (the full 10M x 512 run: "
+    ap.add_argument("--rank128-nb", type=int, default=10_000_000, help="rows of the rank128 side block (default: the headline's size)")
+    ap.add_argument("--laion-nb", type=int, default=2_000_000, help="rows of the laion-shaped side block (the full 10M x 512 run: "
                     "python bench.py --nb 10000000 --dim 512 --metric l2 --k 100 --configs '')")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall budget of each CPU baseline sample (0 = skip)")
     ap.add_argument("--visited", type=int, default=2,
@@ -300,7 +301,7 @@ def reuse_of_last_launch(torch, index, stream, nb, nq, dev, full=False):
 
 
 
-def side_config(torch, dev, stream, name, nb, dim, metric, k, rank_latent, ntrain, nq, Ls, target, cpu_seconds, steps, what):
+def side_config(torch, dev, stream, name, nb, dim, metric, k, rank_latent, ntrain, nq, Ls, target, cpu_seconds, steps, what, frac_hbm_only=None):
     """One smaller workload end to end inside the default run: data -> ground truth of the training queries (K2) ->
     GPU-assisted RoarGraph construction -> a short L_pq sweep -> `steps` timed batches at the smallest L_pq reaching `target`
     recall@10 (recall@k for the top-100 shape) -> the reference loop on 16 host threads over the same index and queries (ids
@@ -343,8 +344,18 @@ def side_config(torch, dev, stream, name, nb, dim, metric, k, rank_latent, ntrai
     ms, used = S.timed(L_star, reps=steps, settle=1)
     head = S.point(L_star, ms, used)
     forms = {n_: index.stat(n_) for n_ in ("batches_lset", "batches_filter_log", "batches_exact_hbm")}
+    head_forms = dict(S.last_forms)
     S.run(L_star, 0); S.wait()
     ids_head = S.out[0]["ids"].cpu().numpy().view(np.uint32).copy()
+    # share of the headline launch's row reads that go to rows a 256-MiB cache can hold (one untimed launch in the logging form)
+    reuse = None
+    try:
+        index.set("lset", 0); index.set("adaptive", 0)
+        S.run(L_star, 0); S.wait()
+        reuse = reuse_of_last_launch(torch, index, stream, nb, nq, dev)
+        index.set("lset", -1); index.set("adaptive", 1)
+    except Exception:  # noqa: BLE001
+        reuse = None
     cpu = None
     if cpu_seconds > 0:
         try:
@@ -357,6 +368,8 @@ def side_config(torch, dev, stream, name, nb, dim, metric, k, rank_latent, ntrai
             cpu = {"value": None, "unit": "QPS", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
     index.close()
     alg = head["mean_evals"] * nq * 4.0 * dim
+    tr_, trs = pmc_traffic({"nb": nb, "dim": dim, "nq": nq, "k": k, "metric": metric, "data": "lowrank", "rank": rank_latent, "graph": "roargraph",
+                            "L": L_star, "visited": 2})
     out = {"name": name, "what": what, "nb": nb, "dim": dim,
            "workload": "base %dx%d fp32 %s (%s), %d training queries, own RoarGraph index (M_sq=100 M_pjbp=35 L_pjpq=500, avg degree %.1f), %d queries/batch "
                        "(%d distinct batches), top-%d, L_pq=%d" % (nb, dim, metric, desc, ntrain, float(h_nbrs.size) / nb, nq, nbatch, k, L_star),
@@ -364,7 +377,11 @@ def side_config(torch, dev, stream, name, nb, dim, metric, k, rank_latent, ntrai
            "L_pq": L_star, "recall_at_k": head["recall_at_k"], "recall_k": S.recall_k, "mean_evals": head["mean_evals"], "mean_hops": head["mean_hops"],
            "seconds": {"train_ground_truth": t_gt, "construction": t_build, "query_ground_truth": t_gtq, "block_total": time.perf_counter() - t_all},
            "roofline": {"bound": "hbm", "achieved": head["GBps"], "peak": 8000.0, "unit": "GB/s", "frac": head["GBps"] / 8000.0,
-                        "kernel_ms_avg": ms, "algorithmic_bytes_per_launch": alg, "traffic": None,
+                        "kernel_ms_avg": ms, "algorithmic_bytes_per_launch": alg, "traffic": tr_, "traffic_source": trs,
+                        "frac_hbm_only": frac_hbm_only,
+                        "frac_cache_served": reuse.get("share_of_reads_to_top_%d_rows" % MALL_ROWS) if reuse else None,
+                        "distinct_rows_frac": reuse.get("distinct_rows_frac") if reuse else None,
+                        "kernel_forms_of_the_timed_launches": head_forms,
                         "frac_of_measured_stream_ceiling_6290": head["GBps"] / 6290.0},
            "cpu_baseline": cpu, "kernel_forms_of_the_batches": forms,
            "L_pq_sweep": [{"L_pq": p["L_pq"], "qps": p["qps"], "recall_at_k": p["recall_at_k"], "mean_evals": p["mean_evals"], "pct_of_8000": p["pct_of_8000"]}
@@ -747,7 +764,7 @@ def main():
     kavg = float(np.mean(kernel_ms)) / 1e3
     alg_bytes = head["mean_evals"] * args.nq * 4.0 * args.dim
     achieved = alg_bytes / kavg / 1e9
-    wl_key = {"nb": args.nb, "dim": args.dim, "nq": args.nq, "k": args.k, "metric": args.metric, "data": args.data,
+    wl_key = {"nb": args.nb, "dim": args.dim, "nq": args.nq, "k": args.k, "metric": args.metric, "data": args.data, "rank": args.rank,
               "graph": "roargraph" if roar else "random", "L": L_star, "visited": args.visited}
 
     # ---- the boundary's host form (rg_search: host buffers in, host buffers out -- PCIe inclusive; never `value`) --------
@@ -897,7 +914,7 @@ def main():
         Sr = Searcher(torch, ixr, qs, args.k, args.dim, stream, None)
         msr, ur = Sr.timed(500, reps=min(5, args.steps), settle=2)
         pr = Sr.point(500, msr, ur)
-        tr_, trs = pmc_traffic({"nb": args.nb, "dim": args.dim, "nq": args.nq, "k": args.k, "metric": args.metric, "data": args.data,
+        tr_, trs = pmc_traffic({"nb": args.nb, "dim": args.dim, "nq": args.nq, "k": args.k, "metric": args.metric, "data": args.data, "rank": args.rank,
                                 "graph": "random", "L": 500, "visited": 2})
         worst = {"workload": "same base, random out-degree-%d graph, %d queries, top-%d, L_pq=500 (every neighbour fresh: pure random "
                              "%d-byte row reads; recall meaningless)" % (args.deg, args.nq, args.k, 4 * args.dim),
@@ -1004,9 +1021,11 @@ def main():
         torch.cuda.empty_cache()
         lib().rg_mem_release(local)      # the library's cache of freed buffers (the side blocks have other sizes)
         defs = {
-            "rank128": dict(nb=2_500_000, dim=200, metric="ip", k=10, rank_latent=128, Ls=[50, 100, 200, 300, 500, 700, 1000],
-                            what="a harder data set of the headline's family: latent rank 128 instead of 32 (four times the intrinsic dimension), "
-                                 "2.5M x 200 IP, top-10"),
+            # (round 5: at the headline's own size -- 10M x 200 -- so that the driver's clock sees the headline shape on data where
+            # recall 0.9 needs a four times wider beam and the index has more than twice the degree)
+            "rank128": dict(nb=args.rank128_nb, dim=200, metric="ip", k=10, rank_latent=128, Ls=[50, 100, 200, 300, 500, 1000],
+                            what="a harder data set of the headline's family and SIZE: latent rank 128 instead of 32 (four times the intrinsic "
+                                 "dimension), %d x 200 IP, top-10; frac_hbm_only = the headline block's random-graph figure (same base shape)" % args.rank128_nb),
             "webvid": dict(nb=2_500_000, dim=512, metric="ip", k=10, rank_latent=32, Ls=[10, 20, 30, 50, 100, 200, 500],
                            what="BASELINE configs[4] shape, end to end in the run: webvid-2.5M-shaped 2.5M x 512 IP, ground truth of 500k training "
                                 "queries (K2) -> GPU-assisted RoarGraph construction -> search, top-10"),
@@ -1021,7 +1040,8 @@ def main():
             if args.side_nb:
                 d_["nb"] = args.side_nb
             side_blocks.append(side_config(torch, dev, stream, cname, d_["nb"], d_["dim"], d_["metric"], d_["k"], d_["rank_latent"], d_["nb"] // 5, args.nq,
-                                           d_["Ls"], args.target_recall, min(args.cpu_seconds, 6.0), min(args.steps, 5), d_["what"]))
+                                           d_["Ls"], args.target_recall, min(args.cpu_seconds, 6.0), min(args.steps, 5), d_["what"],
+                                           frac_hbm_only=worst["frac"] if (worst and cname == "rank128" and d_["nb"] == args.nb and d_["dim"] == args.dim) else None))
     else:
         mem_stats_main = index.mem_stats() if rank == 0 else None
     if mem_stats_main and not mem_stats_main.get("placement_balanced", True):
@@ -1056,7 +1076,7 @@ def main():
                        "mean_evals_per_query": head["mean_evals"], "mean_hops": head["mean_hops"],
                        "setup_seconds": {"train_gt": t_gt, "build": t_build, "total_run": time.perf_counter() - t_all}},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-                         "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src,
+                         "frac": achieved / 8000.0, "traffic": traffic, "traffic_source": traffic_src, "traffic_key": wl_key,
                          # the two bounds of "how much of frac did HBM itself deliver" at the top level: frac_hbm_only = the
                          # same base under a random graph (no row is read twice: every byte comes from HBM; L_pq = 500), the one
                          # driver-timed point where the memory system's figure and HBM's coincide; frac_cache_served = the share of the

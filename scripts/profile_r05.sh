@@ -1,0 +1,52 @@
+#!/bin/bash
+# GPU box, round 5: rocprofv3 passes of the bench workloads at the round's code; text summaries under gpurun_out/prof_r05 for profiles/r05/.
+#   d = 200 (10M, genuine index built once into --index-cache): headline, L_pq 500 / 1000 / 2000 (look-ahead tags with the hub bitmap)
+#   d = 512: webvid (2.5M x 512 IP, L_pq 50), laion (2M x 512 L2 top-100, L_pq 150), worst512 (2.5M x 512 under a random graph, L_pq 500)
+#   trace        --kernel-trace --stats                 (average kernel durations)
+#   fetch/write  --pmc FETCH_SIZE / WRITE_SIZE          (fabric traffic; FETCH_SIZE x2 on gfx950)
+#   sq           --pmc SQ_* issue/wait counters          (where the wave cycles go)
+#   tcc          --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum
+R=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$R/gpurun_out/prof_r05
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+COMMON="--steps 8 --warmup 3 --cpu-seconds 0 --gt-nq 0 --no-fast --no-two-streams --no-worstcase --config1-nb 0 --sweep= --configs= ${BENCH_ARGS}"
+run() {  # name, command (quoted), rocprof args...
+  local name=$1; local cmd=$2; shift; shift
+  rm -rf /tmp/rp_$name
+  timeout 900 rocprofv3 "$@" -d /tmp/rp_$name -o s -- $cmd --full-out $OUT/$name.bench.json > $OUT/$name.log 2>&1      # (a PMC pass once hung for 47 minutes: every pass has its own limit)
+  local db=$(ls /tmp/rp_$name/*.db 2>/dev/null | head -1)
+  if [ -n "$db" ]; then python $R/scripts/rocprof_summary.py --json $OUT/$name.pmc.json $db > $OUT/$name.txt 2>&1; fi
+  rm -rf /tmp/rp_$name
+  grep -v "simple_timer\|SQLite3" $OUT/$name.log | tail -6 > $OUT/$name.log.tail; rm -f $OUT/$name.log
+}
+for W in ${WORKLOADS:-head L500 L1000 L2000 webvid laion worst512}; do
+  case $W in
+    head) A="--index-cache /tmp/bench_ix.npz --L ${L_STAR:-50}";;
+    L*) A="--index-cache /tmp/bench_ix.npz --L ${W#L}";;
+    webvid) A="--nb 2500000 --dim 512 --metric ip --k 10 --index-cache /tmp/webvid_ix.npz --L 50";;
+    laion) A="--nb 2000000 --dim 512 --metric l2 --k 100 --index-cache /tmp/laion_ix.npz --L 150";;
+    worst512) A="--nb 2500000 --dim 512 --metric ip --k 10 --graph random --L 500";;
+  esac
+  B="python $R/bench.py $COMMON $A"
+  # the first command of a workload builds its index into the cache (untimed by rocprof)
+  case $W in head|webvid|laion) $B --full-out $OUT/${W}_build.bench.json > $OUT/${W}_build.log 2>&1; tail -2 $OUT/${W}_build.log;; esac
+  for PASS in ${PASSES:-trace fetch write}; do
+    case $PASS in
+      trace) run ${W}_trace "$B" --kernel-trace --stats;;
+      fetch) run ${W}_fetch "$B" --pmc FETCH_SIZE;;
+      write) run ${W}_write "$B" --pmc WRITE_SIZE;;
+      sq) run ${W}_sq "$B" --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM;;
+      tcc) run ${W}_tcc "$B" --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum;;
+    esac
+  done
+  echo "== $W"; grep "rg_search_kernel" $OUT/${W}_trace.txt | head -2 | cut -c1-60,98-160
+done
+python $R/scripts/make_traffic_json.py $(for W in ${WORKLOADS:-head L500 L1000 L2000 webvid laion worst512}; do echo $OUT/$W; done) > $OUT/search_traffic.json 2> $OUT/make_traffic.err
+python - <<PY
+import json
+for e in json.load(open("$OUT/search_traffic.json")):
+    w=e["workload"]; print(w["nb"],w["dim"],w["graph"],"L",w["L"],"ms %.3f"%e["kernel_ms_avg_under_rocprof"],"alg %.1f GB"%(e["algorithmic_bytes_per_launch"]/1e9),"fetch %.1f write %.1f"%(e["fetch_bytes_corrected"]/1e9,e["write_bytes"]/1e9),"moved/alg %.3f"%e["moved_over_algorithmic"])
+PY
+cat $OUT/make_traffic.err
+ls $OUT | wc -l
