@@ -107,7 +107,7 @@ struct GtParams {
     u64 *cand;          // [grid][MQ][64*ITEMS]
     uint32_t *counter;
     uint32_t BK;
-    uint32_t diag;  // ablation switches for profiling only (wrong results): 1 no base streaming, 2 no epilogue, 4 no per-chunk barrier
+    uint32_t diag;  // ablation switches for profiling only (wrong results): 1 no base streaming, 2 no epilogue, 4 no per-chunk barrier; 16 (right results): mid-stream compaction by the bitonic sort instead of the selection
     // few query blocks for the chip: the base shard is also cut in nseg row segments, a work item is (query block, segment),
     // per-segment lists go to seg_ids / seg_vals [nseg][nq][K] and K3 merges them
     uint32_t nseg, seg_rows;
@@ -171,6 +171,91 @@ __device__ __forceinline__ void gt_compact(u64 *buf, uint32_t *cnt, float *thr, 
         *cnt = keep;
         *thr = n >= K ? key_value(kth, true) : -__builtin_inff();
     }
+}
+
+// Round 5: the mid-stream compaction as a SELECTION instead of a sort.  Between the tiles a query's buffer only has to shed
+// everything behind its K-th best and publish that value; the order of what stays does not matter until the item's final
+// gt_compact.  One wave, ITEMS keys per lane: the K-th smallest high word (the ranking value) by bisection between the
+// buffer's smallest and largest value with ballot counts -- a step is ITEMS compares + ballots on registers, no cross-lane
+// data movement, against the 33 exchange stages of the 256-key bitonic network; ties of the K-th value are settled on the low
+// word (the id) by a second bisection, in the rare buffers that have them; the survivors are packed with ballot prefix sums.
+// Exactly the K smallest keys stay (keys are unique: the low word is the row id).
+template <int ITEMS>
+__device__ __forceinline__ void gt_select(u64 *buf, uint32_t *cnt, float *thr, uint32_t K, int lane) {
+    const uint32_t n = *cnt;
+    if (n <= K) {      // nothing to shed (the threshold of a buffer that has just K entries is its worst)
+        if (n == K) {
+            uint32_t mx = 0;
+#pragma unroll
+            for (int it = 0; it < ITEMS; ++it) {
+                const uint32_t e = it * 64 + lane;
+                if (e < n) mx = max(mx, (uint32_t)(buf[e] >> 32));
+            }
+            for (int o = 32; o; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64));
+            if (lane == 0) *thr = ord2f(~mx);
+        }
+        return;
+    }
+    u64 key[ITEMS];
+    uint32_t h[ITEMS];
+    uint32_t lo = 0xffffffffu, hi = 0u;
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+        const uint32_t e = it * 64 + lane;
+        key[it] = e < n ? buf[e] : ~0ull;
+        h[it] = (uint32_t)(key[it] >> 32);
+        if (e < n) { lo = min(lo, h[it]); hi = max(hi, h[it]); }
+    }
+    for (int o = 32; o; o >>= 1) {
+        lo = min(lo, (uint32_t)__shfl_xor((int)lo, o, 64));
+        hi = max(hi, (uint32_t)__shfl_xor((int)hi, o, 64));
+    }
+    // smallest v with count(h <= v) >= K   (padding keys are ~0: above every real key, never counted below hi)
+    while (lo < hi) {
+        const uint32_t mid = lo + ((hi - lo) >> 1);
+        uint32_t c = 0;
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) c += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(h[it] <= mid && (uint32_t)(it * 64 + lane) < n));
+        if (c >= K) hi = mid; else lo = mid + 1u;
+    }
+    const uint32_t v = lo;
+    uint32_t c_less = 0, c_eq = 0;
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+        const bool live = (uint32_t)(it * 64 + lane) < n;
+        c_less += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(live && h[it] < v));
+        c_eq += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(live && h[it] == v));
+    }
+    uint32_t idmax = 0xffffffffu;       // keys with the K-th value stay up to this id
+    const uint32_t r = K - c_less;      // how many of them stay (1 <= r <= c_eq)
+    if (r < c_eq) {                     // ties at the K-th value: the r smallest ids
+        uint32_t l2 = 0u, h2 = 0xffffffffu;
+        while (l2 < h2) {
+            const uint32_t mid = l2 + ((h2 - l2) >> 1);
+            uint32_t c = 0;
+#pragma unroll
+            for (int it = 0; it < ITEMS; ++it)
+                c += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64((uint32_t)(it * 64 + lane) < n && h[it] == v && (uint32_t)key[it] <= mid));
+            if (c >= r) h2 = mid; else l2 = mid + 1u;
+        }
+        idmax = l2;
+    }
+    uint32_t base = 0;
+#pragma unroll
+    for (int it = 0; it < ITEMS; ++it) {
+        const bool keep = (uint32_t)(it * 64 + lane) < n && (h[it] < v || (h[it] == v && (uint32_t)key[it] <= idmax));
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
+        if (keep) buf[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = key[it];
+        base += (uint32_t)__popcll(m);
+    }
+    if (lane == 0) {
+        *cnt = K;
+        *thr = ord2f(~v);               // (make_key stores ~ord of the score: larger scores first)
+    }
+}
+template <int ITEMS>
+__device__ __attribute__((noinline)) void gt_select_call(u64 *buf, uint32_t *cnt, float *thr, uint32_t K, int lane) {
+    gt_select<ITEMS>(buf, cnt, thr, K, lane);
 }
 
 typedef __attribute__((address_space(3))) void lds_ptr_t;
@@ -529,7 +614,11 @@ __global__ void __launch_bounds__(256, WPS) rg_gt_rs_kernel(GtParams P0) {
                                 const unsigned long long pf_c0 = PROF ? __builtin_amdgcn_s_memtime() : 0ull;
                                 if (PROF) ++pf_nev;
                                 for (int qi = w; qi < MQB; qi += 4)
-                                    if (cnt[qi] + kNB > (uint32_t)C) gt_compact_call<ITEMS>(cand + (size_t)qi * C, &cnt[qi], &thr[qi], P.K, lane);
+                                    if (cnt[qi] + kNB > (uint32_t)C) {
+                                        // selection (round 5); RG_GT_DIAG=16: the bitonic sort of rounds 1 - 4 (same lists, A/B)
+                                        if (P.diag & 16u) gt_compact_call<ITEMS>(cand + (size_t)qi * C, &cnt[qi], &thr[qi], P.K, lane);
+                                        else gt_select_call<ITEMS>(cand + (size_t)qi * C, &cnt[qi], &thr[qi], P.K, lane);
+                                    }
                                 __syncthreads();
                                 if (tid == 0) flag[0] = 0;
                                 if (kThrRegs) {

@@ -40,10 +40,20 @@ for prefix in sys.argv[1:]:
         if wd:
             wb += 1024.0 * wd[1]["avg"]
     alg = line["roofline"]["algorithmic_bytes_per_launch"]
+    trace_ms = None      # average duration of that kernel in the --kernel-trace pass (the events of a bench run under rocprofv3 are inflated)
+    try:
+        short = kern[0].split("(")[0]
+        for ln in open(prefix + "_trace.txt"):
+            if ln.startswith(short[:60]) and "|" in ln:
+                trace_ms = float(ln.split("|")[3])
+                break
+    except Exception:  # noqa: BLE001
+        pass
     out.append({"workload": key, "kernels": kern, "fetch_bytes_corrected": fb, "write_bytes": wb,
                 "fetch_launches": fs[1]["launches"], "write_launches": ws[1]["launches"],
                 "algorithmic_bytes_per_launch": alg, "moved_over_algorithmic": (fb + wb) / alg if alg else None,
-                "kernel_ms_avg_under_rocprof": line["roofline"]["kernel_ms_avg"],
+                "kernel_ms_avg_in_the_kernel_trace": trace_ms,
+                "frac_of_8TBs_in_the_kernel_trace": alg / (trace_ms / 1e3) / 8e12 if trace_ms else None,
                 "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes over the bench command "
                           "(scripts/profile_r05.sh); KiB units; FETCH_SIZE x2 (gfx950)"})
 json.dump(out, sys.stdout, indent=1)

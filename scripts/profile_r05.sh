@@ -46,7 +46,7 @@ python $R/scripts/make_traffic_json.py $(for W in ${WORKLOADS:-head L500 L1000 L
 python - <<PY
 import json
 for e in json.load(open("$OUT/search_traffic.json")):
-    w=e["workload"]; print(w["nb"],w["dim"],w["graph"],"L",w["L"],"ms %.3f"%e["kernel_ms_avg_under_rocprof"],"alg %.1f GB"%(e["algorithmic_bytes_per_launch"]/1e9),"fetch %.1f write %.1f"%(e["fetch_bytes_corrected"]/1e9,e["write_bytes"]/1e9),"moved/alg %.3f"%e["moved_over_algorithmic"])
+    w=e["workload"]; print(w["nb"],w["dim"],w["graph"],"L",w["L"],"ms %.3f"%(e["kernel_ms_avg_in_the_kernel_trace"] or 0),"alg %.1f GB"%(e["algorithmic_bytes_per_launch"]/1e9),"fetch %.1f write %.1f"%(e["fetch_bytes_corrected"]/1e9,e["write_bytes"]/1e9),"moved/alg %.3f"%e["moved_over_algorithmic"])
 PY
 cat $OUT/make_traffic.err
 ls $OUT | wc -l
