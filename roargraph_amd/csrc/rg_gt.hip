@@ -118,25 +118,35 @@ struct GtParams {
     // top-K goes to), workgroup w runs items[item_first[w] .. item_first[w + 1]); null = the forms above (work counter)
     const uint4 *items;
     const uint32_t *item_first;
+    // QUOTA THRESHOLDS (round 5).  A query block whose base rows are cut into p pieces (segments / balanced stretches) is searched by p
+    // workgroups at once, each with the K-th best of ITS OWN rows as threshold -- the 100th best of a sixth of the base, where one
+    // pass over the whole base would by then be filtering with the 100th best of everything seen.  Piece i therefore also publishes
+    // u_i, the k_i-th best of its rows so far, k_i = ceil(K * rows_i / nb) (sum k_i >= K): every piece j holds at least k_j rows >=
+    // u_j, so at least K rows of the base are >= min_j u_j -- a lower bound of the final K-th best that any piece may filter with.
+    // quota_thr[(blk * nseg + piece) * MQB + query] (fp32 bits, -inf = nothing published yet); null = off (RG_GT_NOSHARE=1).
+    uint32_t *quota_thr;
 };
 
 // the parameters of work item `item` = (query block, segment): the segment's rows, bias, id offset and output lists
-__device__ __forceinline__ GtParams gt_segment(const GtParams &P0, uint32_t item, uint32_t &qblk) {
+__device__ __forceinline__ GtParams gt_segment(const GtParams &P0, uint32_t item, uint32_t &qblk, uint32_t &piece, uint32_t &npieces) {
     GtParams P = P0;
+    piece = 0; npieces = 1;
     if (P0.items) {
         const uint4 it = P0.items[item];
         qblk = it.x;
+        piece = it.w & 0xffffu; npieces = it.w >> 16;
         P.base = P0.base + (size_t)it.y * P0.bstride;
         P.nb = it.z;
         if (P0.bias) P.bias = P0.bias + it.y;
         P.id_base = P0.id_base + it.y;
-        P.out_ids = P0.seg_ids + (size_t)it.w * P0.nq * P0.K;
-        P.out_vals = P0.seg_vals + (size_t)it.w * P0.nq * P0.K;
+        P.out_ids = P0.seg_ids + (size_t)(it.w & 0xffffu) * P0.nq * P0.K;      // (w = list | pieces of the block << 16)
+        P.out_vals = P0.seg_vals + (size_t)(it.w & 0xffffu) * P0.nq * P0.K;
         return P;
     }
     qblk = item / P0.nseg;
     if (P0.nseg > 1) {
         const uint32_t seg = item % P0.nseg, r0 = seg * P0.seg_rows;
+        piece = seg; npieces = P0.nseg;
         P.base = P0.base + (size_t)r0 * P0.bstride;
         P.nb = min(P0.seg_rows, P0.nb - r0);
         if (P0.bias) P.bias = P0.bias + r0;
@@ -180,22 +190,26 @@ __device__ __forceinline__ void gt_compact(u64 *buf, uint32_t *cnt, float *thr, 
 // data movement, against the 33 exchange stages of the 256-key bitonic network; ties of the K-th value are settled on the low
 // word (the id) by a second bisection, in the rare buffers that have them; the survivors are packed with ballot prefix sums.
 // Exactly the K smallest keys stay (keys are unique: the low word is the row id).
+// quota thresholds of one query (GtParams::quota_thr): slots = the query's entry of piece 0, piece j's `pstride` words further
+struct QuotaRef {
+    uint32_t *slots = nullptr;     // null = off
+    uint32_t npieces = 0, piece = 0, pstride = 0, quota = 0;
+};
+// min over the pieces of what they published (-inf while some piece has published nothing); `mine` stands in for this piece's own slot
+__device__ __forceinline__ float quota_min(const QuotaRef &qr, float mine, int lane) {
+    float t = __builtin_inff();
+    if ((uint32_t)lane < qr.npieces)
+        t = (uint32_t)lane == qr.piece ? mine
+                                       : __uint_as_float(__hip_atomic_load(qr.slots + (size_t)lane * qr.pstride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    for (int o = 32; o; o >>= 1) t = fminf(t, __shfl_xor(t, o, 64));
+    return t;
+}
 template <int ITEMS>
-__device__ __forceinline__ void gt_select(u64 *buf, uint32_t *cnt, float *thr, uint32_t K, int lane) {
+__device__ __forceinline__ void gt_select(u64 *buf, uint32_t *cnt, float *thr, uint32_t K, int lane, uint32_t *q_slots, uint32_t q_pw, uint32_t q_quota,
+                                          uint32_t q_pstride) {
+    QuotaRef qr;      // (scalars at the call boundary: a struct by value goes through the stack)
+    qr.slots = q_slots; qr.npieces = q_pw & 0xffffu; qr.piece = q_pw >> 16; qr.quota = q_quota; qr.pstride = q_pstride;
     const uint32_t n = *cnt;
-    if (n <= K) {      // nothing to shed (the threshold of a buffer that has just K entries is its worst)
-        if (n == K) {
-            uint32_t mx = 0;
-#pragma unroll
-            for (int it = 0; it < ITEMS; ++it) {
-                const uint32_t e = it * 64 + lane;
-                if (e < n) mx = max(mx, (uint32_t)(buf[e] >> 32));
-            }
-            for (int o = 32; o; o >>= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, o, 64));
-            if (lane == 0) *thr = ord2f(~mx);
-        }
-        return;
-    }
     u64 key[ITEMS];
     uint32_t h[ITEMS];
     uint32_t lo = 0xffffffffu, hi = 0u;
@@ -210,52 +224,73 @@ __device__ __forceinline__ void gt_select(u64 *buf, uint32_t *cnt, float *thr, u
         lo = min(lo, (uint32_t)__shfl_xor((int)lo, o, 64));
         hi = max(hi, (uint32_t)__shfl_xor((int)hi, o, 64));
     }
-    // smallest v with count(h <= v) >= K   (padding keys are ~0: above every real key, never counted below hi)
-    while (lo < hi) {
-        const uint32_t mid = lo + ((hi - lo) >> 1);
-        uint32_t c = 0;
-#pragma unroll
-        for (int it = 0; it < ITEMS; ++it) c += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(h[it] <= mid && (uint32_t)(it * 64 + lane) < n));
-        if (c >= K) hi = mid; else lo = mid + 1u;
-    }
-    const uint32_t v = lo;
-    uint32_t c_less = 0, c_eq = 0;
-#pragma unroll
-    for (int it = 0; it < ITEMS; ++it) {
-        const bool live = (uint32_t)(it * 64 + lane) < n;
-        c_less += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(live && h[it] < v));
-        c_eq += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(live && h[it] == v));
-    }
-    uint32_t idmax = 0xffffffffu;       // keys with the K-th value stay up to this id
-    const uint32_t r = K - c_less;      // how many of them stay (1 <= r <= c_eq)
-    if (r < c_eq) {                     // ties at the K-th value: the r smallest ids
-        uint32_t l2 = 0u, h2 = 0xffffffffu;
-        while (l2 < h2) {
-            const uint32_t mid = l2 + ((h2 - l2) >> 1);
+    // smallest v in [l, r] with count(h <= v) >= k (needs n >= k; padding lanes are never counted)
+    auto kth_value = [&](uint32_t k, uint32_t l, uint32_t r) __attribute__((always_inline)) -> uint32_t {
+        while (l < r) {
+            const uint32_t mid = l + ((r - l) >> 1);
             uint32_t c = 0;
 #pragma unroll
-            for (int it = 0; it < ITEMS; ++it)
-                c += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64((uint32_t)(it * 64 + lane) < n && h[it] == v && (uint32_t)key[it] <= mid));
-            if (c >= r) h2 = mid; else l2 = mid + 1u;
+            for (int it = 0; it < ITEMS; ++it) c += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(h[it] <= mid && (uint32_t)(it * 64 + lane) < n));
+            if (c >= k) r = mid; else l = mid + 1u;
         }
-        idmax = l2;
-    }
-    uint32_t base = 0;
+        return l;
+    };
+    float own = -__builtin_inff();
+    uint32_t v = hi;
+    if (n > K) {
+        v = kth_value(K, lo, hi);
+        uint32_t c_less = 0, c_eq = 0;
 #pragma unroll
-    for (int it = 0; it < ITEMS; ++it) {
-        const bool keep = (uint32_t)(it * 64 + lane) < n && (h[it] < v || (h[it] == v && (uint32_t)key[it] <= idmax));
-        const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
-        if (keep) buf[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = key[it];
-        base += (uint32_t)__popcll(m);
+        for (int it = 0; it < ITEMS; ++it) {
+            const bool live = (uint32_t)(it * 64 + lane) < n;
+            c_less += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(live && h[it] < v));
+            c_eq += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(live && h[it] == v));
+        }
+        uint32_t idmax = 0xffffffffu;       // keys with the K-th value stay up to this id
+        const uint32_t r = K - c_less;      // how many of them stay (1 <= r <= c_eq)
+        if (r < c_eq) {                     // ties at the K-th value: the r smallest ids
+            uint32_t l2 = 0u, h2 = 0xffffffffu;
+            while (l2 < h2) {
+                const uint32_t mid = l2 + ((h2 - l2) >> 1);
+                uint32_t c = 0;
+#pragma unroll
+                for (int it = 0; it < ITEMS; ++it)
+                    c += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64((uint32_t)(it * 64 + lane) < n && h[it] == v && (uint32_t)key[it] <= mid));
+                if (c >= r) h2 = mid; else l2 = mid + 1u;
+            }
+            idmax = l2;
+        }
+        uint32_t base = 0;
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+            const bool keep = (uint32_t)(it * 64 + lane) < n && (h[it] < v || (h[it] == v && (uint32_t)key[it] <= idmax));
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(keep);
+            if (keep) buf[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = key[it];
+            base += (uint32_t)__popcll(m);
+        }
+        own = ord2f(~v);                    // (make_key stores ~ord of the score: larger scores first)
+    } else if (n == K) {
+        own = ord2f(~hi);
+    }
+    float t = own;
+    if (qr.slots) {
+        // this piece's k_i-th best so far (it only grows), published; then the bound every piece may use
+        float mine = -__builtin_inff();
+        if (n >= qr.quota) {
+            mine = ord2f(~kth_value(qr.quota, lo, v));
+            if (lane == 0) __hip_atomic_store(qr.slots + (size_t)qr.piece * qr.pstride, __float_as_uint(mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        t = fmaxf(own, quota_min(qr, mine, lane));
     }
     if (lane == 0) {
-        *cnt = K;
-        *thr = ord2f(~v);               // (make_key stores ~ord of the score: larger scores first)
+        if (n > K) *cnt = K;
+        *thr = fmaxf(*thr, t);              // (a threshold never loosens: the bound of an earlier event may have been the tighter one)
     }
 }
 template <int ITEMS>
-__device__ __attribute__((noinline)) void gt_select_call(u64 *buf, uint32_t *cnt, float *thr, uint32_t K, int lane) {
-    gt_select<ITEMS>(buf, cnt, thr, K, lane);
+__device__ __attribute__((noinline)) void gt_select_call(u64 *buf, uint32_t *cnt, float *thr, uint32_t K, int lane, uint32_t *q_slots, uint32_t q_pw,
+                                                         uint32_t q_quota, uint32_t q_pstride) {
+    gt_select<ITEMS>(buf, cnt, thr, K, lane, q_slots, q_pw, q_quota, q_pstride);
 }
 
 typedef __attribute__((address_space(3))) void lds_ptr_t;
@@ -312,7 +347,8 @@ __global__ void __launch_bounds__(512) rg_gt_kernel(GtParams P0) {
             __syncthreads();
         }
         uint32_t blk;
-        const GtParams P = gt_segment(P0, item, blk);
+        uint32_t piece, npieces;
+        const GtParams P = gt_segment(P0, item, blk, piece, npieces);
         if ((uint64_t)blk * MQ >= P.nq) break;
         const uint32_t ntiles = (P.nb + kNB - 1) / kNB;
         const uint32_t q0 = blk * MQ;
@@ -509,10 +545,18 @@ __global__ void __launch_bounds__(256, WPS) rg_gt_rs_kernel(GtParams P0) {
             __syncthreads();
         }
         uint32_t blk;
-        const GtParams P = gt_segment(P0, item, blk);
+        uint32_t piece, npieces;
+        const GtParams P = gt_segment(P0, item, blk, piece, npieces);
         if ((uint64_t)blk * MQB >= P.nq) break;
         const uint32_t ntiles = (P.nb + kNB - 1) / kNB;
         const uint32_t q0 = blk * MQB;
+        // quota thresholds of this item's piece (GtParams::quota_thr): k_i = ceil(K * rows of the piece / rows of the shard).  Parked in
+        // LDS (flag[2], flag[3]) and read back in the rare event path: carried in registers through the tile loop they spill.
+        if (tid == 0) {
+            const bool on = P0.quota_thr && npieces > 1;
+            flag[2] = on ? (npieces | (piece << 16)) : 0u;
+            flag[3] = (uint32_t)(((unsigned long long)P.K * P.nb + P0.nb - 1u) / P0.nb);
+        }
         const unsigned long long pf_t0 = PROF ? __builtin_amdgcn_s_memtime() : 0ull;
         // A operands of this wave's queries, all k, into registers
         float areg[DIM / 2][TMW];
@@ -541,7 +585,11 @@ __global__ void __launch_bounds__(256, WPS) rg_gt_rs_kernel(GtParams P0) {
         const uint32_t lds_w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(lds_ptr_t *)Bq) +
                                (2u * ((uint32_t)w >> 1) + ((uint32_t)w & 1u)) * 1024u;
         auto row_ptr = [&](uint32_t tile) {
-            const uint32_t gr = min(tile * kNB + 64u * ((uint32_t)w & 1u) + (uint32_t)lane, P.nb - 1u);   // clamp: rows past the end are ignored
+            // (the lane number is made here, as in stream_bias below: carried into the tile loop it is spilled in the instantiations with
+            // larger candidate buffers, and the reload of a spill waits for vmcnt(0) -- for every DMA in flight, once per tile)
+            uint32_t ln;
+            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+            const uint32_t gr = min(tile * kNB + 64u * ((uint32_t)w & 1u) + ln, P.nb - 1u);   // clamp: rows past the end are ignored
             return P.base + (size_t)gr * P.bstride + 4u * ((uint32_t)w >> 1);
         };
         auto stream_chunk = [&](auto cc, const float *rowp, uint32_t buf) __attribute__((always_inline)) {
@@ -616,9 +664,28 @@ __global__ void __launch_bounds__(256, WPS) rg_gt_rs_kernel(GtParams P0) {
                                 for (int qi = w; qi < MQB; qi += 4)
                                     if (cnt[qi] + kNB > (uint32_t)C) {
                                         // selection (round 5); RG_GT_DIAG=16: the bitonic sort of rounds 1 - 4 (same lists, A/B)
-                                        if (P.diag & 16u) gt_compact_call<ITEMS>(cand + (size_t)qi * C, &cnt[qi], &thr[qi], P.K, lane);
-                                        else gt_select_call<ITEMS>(cand + (size_t)qi * C, &cnt[qi], &thr[qi], P.K, lane);
+                                        bool sorted_form = false;
+                                        if constexpr ((ITEMS & (ITEMS - 1)) == 0) {
+                                            if (P.diag & 16u) { gt_compact_call<ITEMS>(cand + (size_t)qi * C, &cnt[qi], &thr[qi], P.K, lane); sorted_form = true; }
+                                        }
+                                        if (!sorted_form) {
+                                            const uint32_t pw = (uint32_t)__builtin_amdgcn_readfirstlane((int)flag[2]);
+                                            uint32_t *sl = pw ? P0.quota_thr + (size_t)(q0 / MQB) * P0.nseg * MQB + qi : nullptr;
+                                            gt_select_call<ITEMS>(cand + (size_t)qi * C, &cnt[qi], &thr[qi], P.K, lane, sl, pw,
+                                                                  (uint32_t)__builtin_amdgcn_readfirstlane((int)flag[3]), (uint32_t)MQB);
+                                        }
                                     }
+                                {   // every query of this wave takes up what the other pieces have published since
+                                    const uint32_t pw = (uint32_t)__builtin_amdgcn_readfirstlane((int)flag[2]);
+                                    if (pw && lane < 32) {
+                                        const int qi = w + 4 * lane;
+                                        const uint32_t *sl = P0.quota_thr + (size_t)(q0 / MQB) * P0.nseg * MQB + qi;
+                                        float t = __builtin_inff();
+                                        for (uint32_t j = 0; j < (pw & 0xffffu); ++j)
+                                            t = fminf(t, __uint_as_float(__hip_atomic_load(sl + (size_t)j * MQB, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
+                                        thr[qi] = fmaxf(thr[qi], t);
+                                    }
+                                }
                                 __syncthreads();
                                 if (tid == 0) flag[0] = 0;
                                 if (kThrRegs) {
@@ -752,13 +819,17 @@ __global__ void __launch_bounds__(256, WPS) rg_gt_rs_kernel(GtParams P0) {
         const unsigned long long pf_t1 = PROF ? __builtin_amdgcn_s_memtime() : 0ull;
         // final selection + output
         for (int qi = w; qi < MQB; qi += 4) {
-            gt_compact<ITEMS>(cand + (size_t)qi * C, &cnt[qi], &thr[qi], P.K, lane);
+            const uint32_t kept = min(cnt[qi], P.K);     // (a piece that filtered with the other pieces' bound may end with fewer than K)
+            if constexpr (ITEMS > 4) {     // larger buffers: shed to K with the selection, then the 256-key network orders what is left
+                if (cnt[qi] > P.K) gt_select_call<ITEMS>(cand + (size_t)qi * C, &cnt[qi], &thr[qi], P.K, lane, nullptr, 0u, 0u, 0u);
+                gt_compact<4>(cand + (size_t)qi * C, &cnt[qi], &thr[qi], P.K, lane);
+            } else gt_compact<ITEMS>(cand + (size_t)qi * C, &cnt[qi], &thr[qi], P.K, lane);
             const uint32_t q = q0 + qi;
             if (q < P.nq) {
                 for (uint32_t e = lane; e < P.K; e += 64) {
                     const u64 k = cand[(size_t)qi * C + e];
-                    P.out_ids[(size_t)q * P.K + e] = (uint32_t)k + P.id_base;
-                    P.out_vals[(size_t)q * P.K + e] = key_value(k, true);
+                    P.out_ids[(size_t)q * P.K + e] = e < kept ? (uint32_t)k + P.id_base : 0xffffffffu;      // padding ranks last in K3
+                    P.out_vals[(size_t)q * P.K + e] = e < kept ? key_value(k, true) : -__builtin_inff();
                 }
             }
         }
@@ -786,7 +857,8 @@ __host__ __device__ inline uint64_t gt_cut(uint32_t w, uint32_t slots, uint64_t 
 }
 __global__ void rg_gt_items_kernel(uint32_t slots, uint64_t per, uint64_t total, uint64_t tpb, uint64_t snap, uint32_t nb, uint4 *items, uint32_t *first) {
     if (threadIdx.x || blockIdx.x) return;
-    uint32_t n = 0, cur_blk = 0xffffffffu, cur_list = 0;
+    uint32_t n = 0, cur_blk = 0xffffffffu, cur_list = 0, blk_first = 0;
+    auto close_block = [&]() { for (uint32_t i = blk_first; i < n; ++i) items[i].w |= cur_list << 16; };     // w = list | pieces of the block << 16
     for (uint32_t w = 0; w < slots; ++w) {
         first[w] = n;
         const uint64_t hi = gt_cut(w + 1, slots, per, total, tpb, snap);
@@ -796,11 +868,12 @@ __global__ void rg_gt_items_kernel(uint32_t slots, uint64_t per, uint64_t total,
             const uint32_t row0 = (uint32_t)(t0 * kNB);
             const uint64_t rows64 = nt * kNB;
             const uint32_t rows = rows64 < (uint64_t)nb - row0 ? (uint32_t)rows64 : nb - row0;
-            if (blk != cur_blk) { cur_blk = blk; cur_list = 0; }
+            if (blk != cur_blk) { close_block(); cur_blk = blk; cur_list = 0; blk_first = n; }
             items[n++] = make_uint4(blk, row0, rows, cur_list++);
             c += nt;
         }
     }
+    close_block();
     first[slots] = n;
 }
 
@@ -910,7 +983,7 @@ namespace rg {
 
 void gt_workspace_free(GtWorkspace *ws) {
     if (!ws) return;
-    for (int i = 0; i < 9; ++i) {
+    for (int i = 0; i < 10; ++i) {
         if (ws->p[i]) (void)hipFree(ws->p[i]);
         ws->p[i] = nullptr; ws->cap[i] = 0;
     }
@@ -1005,7 +1078,12 @@ rg_status gt_shard_ws(const float *d_base, uint32_t nb, uint32_t bstride, const 
         // (measured, scripts/exp/gt_small_batch.py: where the equal items fit ONE round the balanced form is 2 % behind -- an idle
         // workgroup slot leaves its CU's MFMA pipes to the neighbour, and more pieces mean more cold thresholds -- 0.730 vs 0.746 of
         // peak at 10,000 queries; with a partial second round it is 16 % ahead: 0.789 vs 0.681 at 100,000)
-        if (total >= slots && (getenv("RG_GT_BALANCE_ONE") || (items_old > slots && per + snap < span_old - span_old / 8)) && per > 2 * snap) {
+        // (round 5: also wherever one round of equal items leaves more than 6 % of the workgroup slots empty -- 391 blocks of 50,000
+        // queries on 512 slots ran at 0.67 of peak against 0.83 balanced, 470 items of 30,000 at 0.79 against 0.82, 474 of 10,000 at 0.770
+        // against 0.777; a full round -- 8,192 or 16,384 queries -- stays as it is: 0.84 / 0.85 against 0.78 / 0.82,
+        // profiles/r05/gt_ab_box11_balance_one.jsonl)
+        const bool poor_fill = items_old <= slots && items_old * 100 < (uint64_t)slots * 94;
+        if (total >= slots && (getenv("RG_GT_BALANCE_ONE") || poor_fill || (items_old > slots && per + snap < span_old - span_old / 8)) && per > 2 * snap) {
             // the loop of rg_gt_items_kernel, to size and validate the table
             uint32_t n = 0, cur_blk = 0xffffffffu, cur_list = 0, max_list = 0;
             bool ok = true;
@@ -1032,7 +1110,7 @@ rg_status gt_shard_ws(const float *d_base, uint32_t nb, uint32_t bstride, const 
     struct Scratch {
         hipStream_t s;
         GtWorkspace *ws;
-        void *p[9] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+        void *p[10] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
         ~Scratch() { if (!ws) for (void *q : p) if (q) (void)hipFreeAsync(q, s); }
         hipError_t get(int i, size_t bytes) {
             bytes = std::max<size_t>(bytes, 64);
@@ -1063,7 +1141,13 @@ rg_status gt_shard_ws(const float *d_base, uint32_t nb, uint32_t bstride, const 
         bias = static_cast<float *>(scratch.p[0]);
         hipLaunchKernelGGL(rg_gt_bias_kernel, dim3((nb * 16 + 255) / 256), dim3(256), 0, s, d_base, nb, bstride, dim, bias);
     }
-    const int rs_items = (rs_tmw && dim == 200 && getenv("RG_GT_CAND") && atoi(getenv("RG_GT_CAND")) == 8) ? 8 : 4;
+    // candidate buffer of the register-stationary kernel in units of 64 keys: 4 (256 keys: a query sheds down to K after every 29
+    // candidates at K = 100), 6 or 8 (d = 200; after 157 / 285) -- RG_GT_CAND
+    const int cand_env = getenv("RG_GT_CAND") ? atoi(getenv("RG_GT_CAND")) : 0;
+    // default (profiles/r05/gt_ab_box12_buffers_256_384_512.jsonl, d = 200, % of the fp32-MFMA peak with 256 / 384 / 512 keys): 77.0 / 79.0 /
+    // 78.1 at 10,000 queries, 80.9 / 81.5 / 80.8 at 30,000, 82.3 / 82.4 / 81.6 at 100,000 -- and 88.6 / 88.2 / 87.3 at 65,536, where a
+    // workgroup streams the whole shard for its block and sheds rarely anyway: 384 keys where a block is searched in pieces, 256 otherwise
+    const int rs_items = (rs_tmw && dim == 200) ? ((cand_env == 8 || cand_env == 6 || cand_env == 4) ? cand_env : (nseg > 1 || bal_lists) ? 6 : 4) : 4;
     RG_HIP(scratch.get(1, (size_t)grid * mq * 64 * (rs_tmw ? rs_items : items) * 8));
     cand = static_cast<u64 *>(scratch.p[1]);
     RG_HIP(scratch.get(2, 128));
@@ -1094,6 +1178,13 @@ rg_status gt_shard_ws(const float *d_base, uint32_t nb, uint32_t bstride, const 
         P.items = static_cast<const uint4 *>(scratch.p[7]);
         P.item_first = static_cast<const uint32_t *>(scratch.p[8]);
     }
+    P.quota_thr = nullptr;
+    if (rs_tmw && nseg > 1 && !getenv("RG_GT_NOSHARE")) {      // quota thresholds between the pieces of a query block (register-stationary kernel)
+        const size_t words = (size_t)nblocks * nseg * mq;
+        RG_HIP(scratch.get(9, words * 4));
+        P.quota_thr = static_cast<uint32_t *>(scratch.p[9]);
+        RG_HIP(hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(P.quota_thr), (int)0xff800000u, words, s));      // -inf: nothing published
+    }
     rg_status st;
     if (rs_tmw) {
         const size_t lds_rs = ((size_t)2 * rs_bk * kNB + 2 * rs_mqb + 8 + 256) * 4;
@@ -1111,6 +1202,7 @@ rg_status gt_shard_ws(const float *d_base, uint32_t nb, uint32_t bstride, const 
                     RG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rs));
                     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_rs, s, P);
                 } else if (rs_items == 8) RG_RS_LAUNCH_I(200, 40, 2, 8)
+                else if (rs_items == 6) RG_RS_LAUNCH_I(200, 40, 2, 6)
                 else RG_RS_LAUNCH(200, 40, 2)
                 break;
             case 512: RG_RS_LAUNCH(512, 64, 1) break;
