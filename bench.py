@@ -1003,6 +1003,19 @@ def main():
             tk = time.perf_counter() - tk0
             gt["k2_device_resident"] = {"queries": int(gq.shape[0]), "seconds": tk, "value": float(gq.shape[0]) * float(args.nb) / tk,
                                         "frac_of_mfma_peak": 2.0 * args.dim * float(gq.shape[0]) * float(args.nb) / tk / 1e12 / 157.3}
+            # ... and at the size of an evaluation-side truth or a tail batch: 10,000 queries in one launch (a query block is searched in
+            # pieces by several workgroups there: balanced split, quota thresholds between the pieces)
+            gs = gq[: min(10_000, int(gq.shape[0]))].contiguous()
+            groundtruth.groundtruth_distributed(shard, lo, gs, args.metric, args.gt_K)
+            torch.cuda.synchronize()
+            ts0 = time.perf_counter()
+            for _ in range(3):
+                groundtruth.groundtruth_distributed(shard, lo, gs, args.metric, args.gt_K)
+            torch.cuda.synchronize()
+            ts = (time.perf_counter() - ts0) / 3
+            gt["k2_small_batch"] = {"queries": int(gs.shape[0]), "seconds": round(ts, 4),
+                                    "frac_of_mfma_peak": round(2.0 * args.dim * float(gs.shape[0]) * float(args.nb) / ts / 1e12 / 157.3, 4)}
+            del gs
             if args.cpu_seconds > 0:
                 try:
                     gt["cpu_baseline"] = gt_cpu_baseline(base, gq, args)
