@@ -337,3 +337,33 @@ print("RESULT rank %%d: ok rccl=%%d" %% (rank, 1))
         assert (got_i == want_i).all() and (got_d.view(np.uint32) == want_d.view(np.uint32)).all()
     else:
         assert all(("refused" in r[0]) or ("unavailable" in r[0]) for r in res), res
+
+
+@pytest.mark.parametrize("metric,d,K", [("ip", 200, 100), ("l2", 200, 100), ("ip", 512, 10), ("ip", 200, 128)])
+@pytest.mark.parametrize("order", ["best_last", "best_first", "best_in_one_piece"])
+def test_quota_thresholds_when_one_piece_holds_every_neighbour(oracle, metric, d, K, order, monkeypatch):
+    """Round 5: a query block whose rows are searched in pieces filters every piece with min_j u_j, u_j = piece j's ceil(K rows_j / nb)-th
+    best -- a lower bound of the shard's K-th best.  The adversarial layouts: the base sorted so that ONE piece holds all true
+    neighbours (the other pieces end with fewer than K entries and pad their lists; K3 must still return the exact top-K), sorted
+    the other way round (the first tiles set a threshold nothing later beats), and every tile better than all before it (all 128
+    rows of a tile pass for every query: the candidate buffers fill at the highest rate).  Few queries, so that the segment form
+    cuts every block into many pieces; the lists equal the fp64 brute force and do not depend on RG_GT_NOSHARE."""
+    from roargraph_amd import groundtruth
+    rng = np.random.default_rng(K + d)
+    nb, nq = 48_000, 200
+    base = rng.standard_normal((nb, d)).astype(np.float32)
+    q = (rng.standard_normal((nq, d)) * 0.2 + 1.0).astype(np.float32)      # queries near (1, ..., 1): the score grows with the row sum
+    key = base.sum(axis=1) if metric == "ip" else -np.linalg.norm(base - 1.0, axis=1)
+    idx = np.argsort(key)
+    if order == "best_first":
+        idx = idx[::-1]
+    elif order == "best_in_one_piece":
+        top = idx[-6000:]; rest = rng.permutation(idx[:-6000])
+        idx = np.concatenate([rest[:20000], top, rest[20000:]])
+    base = np.ascontiguousarray(base[idx])
+    ids, dists = groundtruth.compute_groundtruth(base, q, metric, K)
+    ref_ids, _, ref_s = oracle.groundtruth_f64(base, q, metric, K, nthreads=16)
+    check_gt(base, q, metric, K, ids, dists, ref_ids, ref_s)
+    monkeypatch.setenv("RG_GT_NOSHARE", "1")
+    ids2, dists2 = groundtruth.compute_groundtruth(base, q, metric, K)
+    assert (ids2 == ids).all() and (dists2.view(np.uint32) == dists.view(np.uint32)).all()
