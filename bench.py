@@ -43,6 +43,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+import faulthandler  # noqa: E402
+faulthandler.enable()      # a run that dies (SIGABRT of a GPU fault, SIGSEGV) leaves the Python stack of every thread on stderr
 
 # the reference's evaluation list (README.md:118) thinned to the points that shape the curve
 SWEEP_DEFAULT = "10,20,30,40,50,60,80,100,150,200,300,500,700,1000,1500,2000"
@@ -301,6 +303,14 @@ def reuse_of_last_launch(torch, index, stream, nb, nq, dev, full=False):
 
 
 
+_T0 = time.perf_counter()
+
+
+def progress(what):      # RG_BENCH_PROGRESS=1: stage marks on stderr (where a run that dies was)
+    if os.environ.get("RG_BENCH_PROGRESS"):
+        print("[bench %7.1f s] %s" % (time.perf_counter() - _T0, what), file=sys.stderr, flush=True)
+
+
 def side_config(torch, dev, stream, name, nb, dim, metric, k, rank_latent, ntrain, nq, Ls, target, cpu_seconds, steps, what, frac_hbm_only=None):
     """One smaller workload end to end inside the default run: data -> ground truth of the training queries (K2) ->
     GPU-assisted RoarGraph construction -> a short L_pq sweep -> `steps` timed batches at the smallest L_pq reaching `target`
@@ -308,19 +318,22 @@ def side_config(torch, dev, stream, name, nb, dim, metric, k, rank_latent, ntrai
     asserted equal).  Returns a block with its own `roofline` and `cpu_baseline`."""
     from roargraph_amd import build, groundtruth, synth
     from roargraph_amd.index import IndexBipartite
+    progress("side block %s: start" % name)
     t_all = time.perf_counter()
     base, train, q, desc = synth.make_device_set(dev, 1234, nb, ntrain, nq, dim, data="lowrank", rank=rank_latent, q_seed=99)
     t0 = time.perf_counter()
     ti, _ = groundtruth.groundtruth_distributed(base, 0, train, metric, 100)
     torch.cuda.synchronize()
+    progress("side block %s: training truth done, building" % name)
     t_gt = time.perf_counter() - t0
     t0 = time.perf_counter()
-    h_off, h_nbrs, ep = build.build_roargraph(base.cpu().numpy(), ti.cpu().numpy().view(np.uint32), metric, 100, 35, 500,
+    h_off, h_nbrs, ep = build.build_roargraph(synth.to_host(base), synth.to_host(ti).view(np.uint32), metric, 100, 35, 500,
                                               num_threads=int(os.environ.get("RG_BENCH_BUILD_THREADS", min(128, os.cpu_count() or 1))), device=dev.index or 0)
     t_build = time.perf_counter() - t0
     del train, ti
-    off = torch.from_numpy(h_off.view(np.int64)).to(dev)
-    nbrs = torch.from_numpy(h_nbrs.view(np.int32)).to(dev)
+    off = synth.to_device(h_off.view(np.int64), dev)
+    nbrs = synth.to_device(h_nbrs.view(np.int32), dev)
+    progress("side block %s: built, opening" % name)
     torch.cuda.empty_cache()
     index = IndexBipartite.from_device(base, off, nbrs, ep, metric=metric)
     nbatch = 3
@@ -333,12 +346,14 @@ def side_config(torch, dev, stream, name, nb, dim, metric, k, rank_latent, ntrai
         gts.append(ti_q.cpu().numpy().view(np.uint32).copy())
     t_gtq = time.perf_counter() - t0
     del ti_q, tv_q
+    progress("side block %s: query truth done, sweep" % name)
     S = Searcher(torch, index, qs, k, dim, stream, gts)
     S.recall_k = k if k <= 100 else 10
     sweep = []
     for L in [x for x in Ls if x >= k]:
         ms, used = S.timed(L, reps=2, settle=2)
         sweep.append(S.point(L, ms, used))
+    progress("side block %s: headline" % name)
     ok = [p["L_pq"] for p in sweep if (p["recall_at_k"] or 0.0) >= target]
     L_star = min(ok) if ok else max(p["L_pq"] for p in sweep)
     ms, used = S.timed(L_star, reps=steps, settle=1)
@@ -356,16 +371,18 @@ def side_config(torch, dev, stream, name, nb, dim, metric, k, rank_latent, ntrai
         index.set("lset", -1); index.set("adaptive", 1)
     except Exception:  # noqa: BLE001
         reuse = None
+    progress("side block %s: reuse statistics done" % name)
     cpu = None
     if cpu_seconds > 0:
         try:
-            cpu = cpu_search_baseline(base.cpu().numpy(), h_off, h_nbrs, ep, qs[0].cpu().numpy(), ids_head, metric, k, L_star,
+            cpu = cpu_search_baseline(synth.to_host(base), h_off, h_nbrs, ep, qs[0].cpu().numpy(), ids_head, metric, k, L_star,
                                       [min(16, os.cpu_count() or 1)], cpu_seconds)[0]
             cpu["gpu_over_cpu"] = head["qps"] / cpu["value"] if cpu.get("value") else None
         except AssertionError:
             raise
         except Exception as e:  # noqa: BLE001
             cpu = {"value": None, "unit": "QPS", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
+    progress("side block %s: closing" % name)
     index.close()
     alg = head["mean_evals"] * nq * 4.0 * dim
     tr_, trs = pmc_traffic({"nb": nb, "dim": dim, "nq": nq, "k": k, "metric": metric, "data": "lowrank", "rank": rank_latent, "graph": "roargraph",
@@ -562,6 +579,7 @@ def main():
     else:
         base, train, q, data_desc = synth.make_device_set(dev, 1234, args.nb, ntrain, args.nq, args.dim, data=args.data, rank=args.rank,
                                                           q_seed=99 + rank)
+    progress("data made")
     t_gt = t_build = 0.0
     if file_index is not None:
         h_off, h_nbrs, ep = file_index
@@ -586,20 +604,21 @@ def main():
             ti = torch.cat([p[: b - a] for p, (a, b) in zip(parts, groundtruth.query_ranges(ntrain_used, world))])
         sync_all()
         t_gt = time.perf_counter() - t0
+        progress("training ground truth done")
         t0 = time.perf_counter()
         meta = torch.zeros(2, dtype=torch.int64, device=cdev)
         cached = args.index_cache and os.path.exists(args.index_cache)
         if rank == 0 and cached:
             z = np.load(args.index_cache)
             h_off, h_nbrs, ep = z["off"], z["nbrs"], int(z["ep"])
-            off = torch.from_numpy(h_off.view(np.int64)).to(dev)
-            nbrs = torch.from_numpy(h_nbrs.view(np.int32)).to(dev)
+            off = synth.to_device(h_off.view(np.int64), dev)
+            nbrs = synth.to_device(h_nbrs.view(np.int32), dev)
             meta[0], meta[1] = int(h_nbrs.size), int(ep)
         elif rank == 0:
-            h_off, h_nbrs, ep = build.build_roargraph(base.cpu().numpy(), ti.cpu().numpy().view(np.uint32), args.metric, 100, 35, 500,
+            h_off, h_nbrs, ep = build.build_roargraph(synth.to_host(base), synth.to_host(ti).view(np.uint32), args.metric, 100, 35, 500,
                                                       num_threads=int(os.environ.get("RG_BENCH_BUILD_THREADS", min(128, os.cpu_count() or 1))), device=local)
-            off = torch.from_numpy(h_off.view(np.int64)).to(dev)
-            nbrs = torch.from_numpy(h_nbrs.view(np.int32)).to(dev)
+            off = synth.to_device(h_off.view(np.int64), dev)
+            nbrs = synth.to_device(h_nbrs.view(np.int32), dev)
             meta[0], meta[1] = int(h_nbrs.size), int(ep)
             if args.index_cache:
                 np.savez(args.index_cache, off=h_off, nbrs=h_nbrs, ep=ep)
@@ -630,8 +649,10 @@ def main():
     # the setup phase (ground truth of the training queries, construction) went through torch's caching allocator, which keeps
     # what it is given; the library allocates with hipMalloc -- hand the cached blocks back first, so that its large buffers
     # (adjacency, split rows, id logs, the 19 GiB of visited tags of a wide beam) are cut from whole memory, not from the gaps
+    progress("graph ready")
     torch.cuda.empty_cache()
     index = IndexBipartite.from_device(base, off, nbrs, ep, metric=args.metric)
+    progress("index open")
     for kv in [x for x in args.set.split(",") if x]:
         kname, kval = kv.split("=")
         index.set(kname, int(kval))
@@ -651,12 +672,14 @@ def main():
     del ti_q, tv_q
     torch.cuda.empty_cache()
     S = Searcher(torch, index, qs, args.k, args.dim, stream, gts)
+    progress("query batches and their truth ready")
 
     # ---- L_pq sweep (every rank runs it: it also settles the adaptive default; rank 0 reports) -------------------------
     sweep_Ls = sorted({int(x) for x in args.sweep.split(",") if x} | {500}) if args.sweep else []
     sweep_Ls = [L for L in sweep_Ls if L >= args.k]
     sweep = []
     for L in sweep_Ls:
+        progress("sweep L_pq %d" % L)
         ms, used = S.timed(L, reps=3 if L <= 500 else 2)
         if max(S.last_reps_ms) > 1.5 * min(S.last_reps_ms):
             # one launch far off the others (seen once in the round: 7.7 ms among 1.0 ms launches at L_pq = 10 -- a host stall
@@ -693,6 +716,7 @@ def main():
 
     # ---- the timed headline: exactly --steps batches at L_star between barriers, the wait included; every warm-up and
     # every step searches another batch (rotation over `nbatch` distinct ones)
+    progress("headline")
     for _ in range(args.warmup):
         S.run(L_star)
     S.wait()
@@ -767,6 +791,7 @@ def main():
     wl_key = {"nb": args.nb, "dim": args.dim, "nq": args.nq, "k": args.k, "metric": args.metric, "data": args.data, "rank": args.rank,
               "graph": "roargraph" if roar else "random", "L": L_star, "visited": args.visited}
 
+    progress('headline done: checks, host form')
     # ---- the boundary's host form (rg_search: host buffers in, host buffers out -- PCIe inclusive; never `value`) --------
     host_form = None
     if rank == 0 and world == 1:
@@ -785,6 +810,7 @@ def main():
     # ---- batches alternating over two streams (the boundary allows concurrent searches on one index): the next batch's
     # queries fill the wave slots the previous batch's tail leaves idle.  Reported beside `value`, never as it: `value` and
     # the roofline keep the one-stream form whose per-launch duration rocprofv3 can be held against.
+    progress('two streams')
     two_streams = None
     if rank == 0 and world == 1 and not args.no_two_streams:
         s2 = torch.cuda.Stream(device=dev)
@@ -807,6 +833,7 @@ def main():
         del S2
 
     # ---- opt-in NON-parity modes, reported separately, never as `value` -----------------------------------------------
+    progress('opt-in modes')
     fast = None
     if rank == 0 and not args.no_fast and args.dim in (200, 512):
         fast = []
@@ -847,11 +874,12 @@ def main():
         index.set("shared_frontier", 0)
 
     # ---- CPU baselines on the same index and queries (rank 0, N = 1) ---------------------------------------------------
+    progress('cpu baselines')
     cpu = cpu1 = cpu_cfg1 = gt_check = None
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
-        base_np = base.cpu().numpy()
-        h_off_np = off.cpu().numpy().view(np.uint64)
-        h_nbrs_np = nbrs.cpu().numpy().view(np.uint32)
+        base_np = synth.to_host(base)
+        h_off_np = synth.to_host(off).view(np.uint64)
+        h_nbrs_np = synth.to_host(nbrs).view(np.uint32)
         q_np = qs[0].cpu().numpy()
         try:
             cpu, cpu1 = cpu_search_baseline(base_np, h_off_np, h_nbrs_np, ep, q_np, ids_head, args.metric, args.k, L_star,
@@ -905,6 +933,7 @@ def main():
             del b1, tr1, q1, t1i, t1v, g1i, g1v, S1
 
     # ---- worst case: the same base under a random graph, L_pq = 500 -------------------------------------------------
+    progress('worst case')
     worst = None
     if rank == 0 and world == 1 and roar and not args.no_worstcase:
         g = torch.Generator(device=dev); g.manual_seed(4321)
@@ -930,6 +959,7 @@ def main():
     # exchange of batch b), per-shard top-K lists exchanged with grouped RCCL send/recv on a side stream, K3, rows written
     # to the owner's host array.  Ranks that share a GPU (--backend gloo, control-flow tests) cannot form an RCCL
     # communicator: they take the torch.distributed form (one all_to_all) instead.
+    progress("ground-truth leg")
     gt = None
     if args.gt_nq > 0:
         lo, hi = groundtruth.shard_rows(args.nb, world)[rank]
@@ -1025,6 +1055,7 @@ def main():
 
     # ---- side blocks (rank 0, N = 1): three smaller workloads, each built and searched inside the run, each with its own roofline
     # and cpu_baseline -- the headline's data set is the easiest of the family (latent rank 32), and BASELINE configs[3] / [4] are d = 512
+    progress("side blocks")
     side_blocks = []
     n_query_batches = len(qs)
     if rank == 0 and world == 1 and args.configs:
@@ -1135,6 +1166,7 @@ def main():
             "gt_build": gt,
             "configs": side_blocks,
             "device_memory": mem_stats_main,
+            "host_memory_GB": {"MemAvailable_at_end": round(_mem_available_gb(), 1)},
         }
         # The full record goes to a FILE (--full-out; default bench_full.json beside this script, and a copy under gpurun_out/
         # when that directory exists); stdout carries exactly ONE compact JSON line (a few KB) with the contract's keys, the

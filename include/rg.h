@@ -92,7 +92,11 @@ rg_status rg_index_open_multi(const char *base_fbin, const char *index_path, int
 rg_status rg_index_open_mem(const float *base, uint32_t nd, uint32_t dim, uint32_t stride, const uint64_t *offsets,
                             const uint32_t *nbrs, uint32_t ep, int metric, int device, rg_index **out);
 /* same from buffers already resident in HBM.  d_base is BORROWED (caller keeps it alive and unchanged);
- * the graph is converted to the library's own layout, d_offsets/d_nbrs may be freed after the call. */
+ * the graph is converted to the library's own layout, d_offsets/d_nbrs may be freed after the call.
+ * The searches do not necessarily read d_base itself: for d = 200 the index keeps its own split copy of the rows (7.7 + 4.7 GB at
+ * 10M rows), and a base of 2 GiB or more that would be read directly (d = 512) is copied into a buffer balanced over the memory
+ * classes of the device when twice its size + 8 GiB is free (RG_COPY_BASE=0 in the environment: never) -- so a later change of
+ * d_base is NOT seen by the searches, and freeing it does not free the rows.  rg_index_stat "base_copied" says which it was. */
 rg_status rg_index_open_dev(const float *d_base, uint32_t nd, uint32_t dim, uint32_t stride,
                             const uint64_t *d_offsets, const uint32_t *d_nbrs, uint32_t ep, int metric, int device,
                             rg_index **out);
@@ -150,7 +154,8 @@ rg_status rg_index_set(rg_index *idx, const char *name, int value);
  * "lset_left" (queries that outgrew their exact LDS set), "recounted" (queries whose cmps the host recounted), "hub_levels" (1: the
  * adjacency carries hub levels), "hub_m_last" (log2 of the hub bitmap of the last search launch, 0 = none), "placement_balanced"
  * (1: every large buffer this index allocated so far -- rows, adjacency, visited tags, id logs -- is spread over the memory
- * classes; 0: at least one fell back to a plain allocation, the slower placement), "plain_allocs" (how many). */
+ * classes; 0: at least one fell back to a plain allocation, the slower placement), "plain_allocs" (how many), "base_copied" (1: the
+ * searches read the index's own copy of a caller-owned device base, 2: its split copy for d = 200, 0: the caller's buffer). */
 rg_status rg_index_stat(const rg_index *idx, const char *name, uint64_t *value);
 /* Where the large buffers of the indexes on `device` live (diagnostics; no counterpart in the reference).  The library
  * builds every buffer of 2 GiB and more from 1-GiB granules taken round robin over the memory classes of the device

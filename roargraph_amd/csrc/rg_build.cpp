@@ -56,6 +56,7 @@
 #include "rg.h"
 #include "rg_index_struct.h"
 #include "rg_internal.h"
+#include "rg_mem.h"
 
 namespace rg {
 namespace {
@@ -850,7 +851,7 @@ struct Builder {
         dirty.assign(nd, 1);
         if (d_base_pre) { d_base = d_base_pre; d_base_pre = nullptr; }
         else ok = ok && hipMalloc(&d_base, (size_t)nd * stride * 4) == hipSuccess &&
-                  hipMemcpy(d_base, base, (size_t)nd * stride * 4, hipMemcpyHostToDevice) == hipSuccess;
+                  rg::upload_staged(d_base, base, (size_t)nd * stride * 4) == RG_OK;      // (through pinned chunks: rg_mem.h)
         ok = ok && hipMalloc(&d_exp, (size_t)B * cap * 8) == hipSuccess && hipMalloc(&d_nexp, (size_t)B * 4) == hipSuccess &&
                   hipHostMalloc(&h_exp, (size_t)B * cap * 8) == hipSuccess && hipHostMalloc(&h_nexp, (size_t)B * 4) == hipSuccess &&
                   hipStreamCreate(&st) == hipSuccess && hipEventCreate(&evA) == hipSuccess && hipEventCreate(&evB) == hipSuccess;
@@ -1084,7 +1085,7 @@ struct Builder {
         // is one (rg_projection_ep_dev: the same sums in the same order, checked bit for bit against this loop in the tests)
         if (gpu_device >= 0 && dim % 4 == 0 && stride % 4 == 0 && hipSetDevice(gpu_device) == hipSuccess &&
             hipMalloc(&d_base_pre, (size_t)nd * stride * 4) == hipSuccess) {
-            if (hipMemcpy(d_base_pre, base, (size_t)nd * stride * 4, hipMemcpyHostToDevice) == hipSuccess &&
+            if (rg::upload_staged(d_base_pre, base, (size_t)nd * stride * 4) == RG_OK &&
                 rg_projection_ep_dev(d_base_pre, nd, dim, (uint32_t)stride, gpu_device, &ep) == RG_OK)
                 ep_known = true;
             else { (void)hipFree(d_base_pre); d_base_pre = nullptr; }

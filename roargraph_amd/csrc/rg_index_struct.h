@@ -78,6 +78,7 @@ struct rg_index {
     uint32_t nd = 0, dim = 0, stride = 0, ep = 0;
     float *d_base = nullptr;
     bool own_base = false;
+    bool base_copied = false;    // own_base because a caller-owned device base was copied into a balanced buffer (rg_index_open_dev)
     // graph
     uint64_t *d_offsets = nullptr;
     uint32_t *d_nbrs = nullptr;

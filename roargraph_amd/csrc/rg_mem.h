@@ -24,4 +24,9 @@ void dev_free(void *p);
 void dev_trim(int device);
 // did the calling thread's last dev_alloc of 2 GiB or more fall back to a plain allocation (one memory class)?
 bool dev_last_plain();
+// host (pageable) -> device through two pinned 64-MiB chunks (round 5): gigabytes of pageable memory handed to hipMemcpy are
+// pinned page by page by the runtime for the time of the copy; two bench runs of the round died of a GPU memory access fault a few
+// pages into such a region while the host was under memory pressure.  The library's own large uploads go through memory the
+// driver owns instead.  Synchronous; falls back to a plain hipMemcpy when the chunks cannot be had.
+rg_status upload_staged(void *d_dst, const void *h_src, size_t bytes);
 }  // namespace rg

@@ -307,6 +307,7 @@ void release_cache(Pool &P) {
     if (P.cache.empty()) return;
     (void)hipDeviceSynchronize();
     for (Cached &c : P.cache) {
+        if (g_trace) fprintf(stderr, "[rg_mem] %.2f GiB at %p: released from the cache\n", (double)c.buf.bytes / (1u << 30), c.va);
         for (size_t i = 0; i < c.buf.handles.size(); ++i) {
             va_unmap((char *)c.va + i * kGranule, kGranule);
             (void)hipMemRelease(c.buf.handles[i]);
@@ -468,12 +469,14 @@ void dev_free(void *p) {
         Buffer &b = it->second;
         if (P.cached_bytes + b.bytes <= cache_cap_bytes()) {     // kept mapped for the next request of its size
             (void)hipDeviceSynchronize();                        // (nothing queued reads it any more when it is handed out again)
+            if (g_trace) fprintf(stderr, "[rg_mem] %.2f GiB at %p: freed into the cache\n", (double)b.bytes / (1u << 30), p);
             P.cache.push_back({p, b});
             P.cached_bytes += b.bytes;
             P.live.erase(it);
             return;
         }
         (void)hipDeviceSynchronize();
+        if (g_trace) fprintf(stderr, "[rg_mem] %.2f GiB at %p: freed (unmapped)\n", (double)b.bytes / (1u << 30), p);
         for (size_t i = 0; i < b.handles.size(); ++i) {
             va_unmap((char *)p + i * kGranule, kGranule);
             (void)hipMemRelease(b.handles[i]);
@@ -483,6 +486,40 @@ void dev_free(void *p) {
         return;
     }
     (void)hipFree(p);
+}
+
+rg_status upload_staged(void *d_dst, const void *h_src, size_t bytes) {
+    constexpr size_t kChunk = (size_t)64 << 20;
+    if (bytes <= kChunk) {
+        hipError_t e = hipMemcpy(d_dst, h_src, bytes, hipMemcpyHostToDevice);
+        return e == hipSuccess ? RG_OK : set_error(RG_ERR_DEVICE, std::string("hipMemcpy: ") + hipGetErrorString(e));
+    }
+    void *pin[2] = {nullptr, nullptr};
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    hipStream_t s = nullptr;
+    bool ok = hipHostMalloc(&pin[0], kChunk) == hipSuccess && hipHostMalloc(&pin[1], kChunk) == hipSuccess &&
+              hipEventCreateWithFlags(&ev[0], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&ev[1], hipEventDisableTiming) == hipSuccess &&
+              hipStreamCreateWithFlags(&s, hipStreamNonBlocking) == hipSuccess;
+    hipError_t e = hipSuccess;
+    if (ok) {
+        size_t off = 0;
+        for (int p = 0; off < bytes && e == hipSuccess; p ^= 1) {
+            const size_t n = std::min(kChunk, bytes - off);
+            if (off >= 2 * kChunk) e = hipEventSynchronize(ev[p]);       // the copy that last used this chunk is done
+            if (e != hipSuccess) break;
+            memcpy(pin[p], (const char *)h_src + off, n);
+            e = hipMemcpyAsync((char *)d_dst + off, pin[p], n, hipMemcpyHostToDevice, s);
+            if (e == hipSuccess) e = hipEventRecord(ev[p], s);
+            off += n;
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(s);
+    } else {
+        (void)hipGetLastError();
+        e = hipMemcpy(d_dst, h_src, bytes, hipMemcpyHostToDevice);
+    }
+    if (s) (void)hipStreamDestroy(s);
+    for (int p = 0; p < 2; ++p) { if (ev[p]) (void)hipEventDestroy(ev[p]); if (pin[p]) (void)hipHostFree(pin[p]); }
+    return e == hipSuccess ? RG_OK : set_error(RG_ERR_DEVICE, std::string("staged upload: ") + hipGetErrorString(e));
 }
 
 void dev_trim(int device) {

@@ -606,7 +606,7 @@ static rg_status finish_graph(rg_index *ix, const uint64_t *d_off, const uint32_
             float *copy = nullptr;
             if (dev_alloc_t(ix->device, (size_t)ix->nd * ix->stride, &copy) == RG_OK) {
                 ix->n_plain_allocs += dev_last_plain() ? 1 : 0;
-                if (hipMemcpy(copy, ix->d_base, bytes, hipMemcpyDeviceToDevice) == hipSuccess) { ix->d_base = copy; ix->own_base = true; }
+                if (hipMemcpy(copy, ix->d_base, bytes, hipMemcpyDeviceToDevice) == hipSuccess) { ix->d_base = copy; ix->own_base = true; ix->base_copied = true; }
                 else { (void)hipGetLastError(); dev_free(copy); }
             }
         }
@@ -789,6 +789,7 @@ static rg_status ensure_visited(rg_index *ix, SearchCtx *cx, uint32_t slots, boo
     // over the fabric instead of the 128-byte line the L2 fetches for a 4-byte word it will not see again
     // the old buffer goes first: at 10M nodes the tags of a wide-beam launch are 19 GiB, and the new buffer wants the memory
     // (and the classes) the old one held
+    const uint32_t old_slots = (d_vis && have_words == vwords) ? have_slots : 0u;
     if (d_vis) { dev_free(d_vis); d_vis = nullptr; have_slots = 0; }
     const bool ok_v = ix->visited_uncached ? hipExtMallocWithFlags(reinterpret_cast<void **>(&nv), (size_t)slots * vwords * 4,
                                                                    ix->visited_uncached == 2 ? hipDeviceMallocFinegrained : hipDeviceMallocUncached) == hipSuccess
@@ -798,6 +799,15 @@ static rg_status ensure_visited(rg_index *ix, SearchCtx *cx, uint32_t slots, boo
     if (!ok_v || hipMalloc(&ne, (size_t)slots * 4) != hipSuccess) {
         (void)hipGetLastError();
         dev_free(nv);
+        // (the context must not lose a working buffer to a failed attempt at a larger one: back to the size it had -- the
+        // memory was just released -- so that the launches that fitted before still do)
+        if (old_slots && dev_alloc_t(ix->device, (size_t)old_slots * vwords, &nv) == RG_OK) {
+            dev_trim(ix->device);
+            d_vis = nv;
+            (void)hipMemsetAsync(d_vis, 0, (size_t)old_slots * vwords * 4, s);
+            if (d_ep) (void)hipMemsetAsync(d_ep, 0, (size_t)old_slots * 4, s);
+            have_slots = d_ep ? old_slots : 0;
+        }
         return set_error(RG_ERR_OOM, "no room for the visited words of the exact form");
     }
     if (d_ep) (void)hipFree(d_ep);
@@ -1718,17 +1728,19 @@ rg_status rg_index_open_mem(const float *base, uint32_t nd, uint32_t dim, uint32
         std::vector<float> tmp((size_t)nd * ad, 0.0f);
         for (size_t i = 0; i < nd; ++i) std::memcpy(tmp.data() + i * ad, base + i * (size_t)stride, (size_t)dim * 4);
         if (metric == RG_METRIC_COSINE) rg_normalize_rows(tmp.data(), nd, ad, dim);
-        RG_HIP(hipMemcpy(d_base.p, tmp.data(), tmp.size() * 4, hipMemcpyHostToDevice));
+        st = rg::upload_staged(d_base.p, tmp.data(), tmp.size() * 4);
     } else {
-        RG_HIP(hipMemcpy(d_base.p, base, (size_t)nd * ad * 4, hipMemcpyHostToDevice));
+        st = rg::upload_staged(d_base.p, base, (size_t)nd * ad * 4);
     }
+    if (st != RG_OK) return st;
     const uint64_t ne = offsets[nd];
     rg::DevBuf<uint64_t> d_off;
     rg::DevBuf<uint32_t> d_nb;
     RG_HIP(d_off.alloc((size_t)nd + 1));
     RG_HIP(d_nb.alloc(ne));
-    RG_HIP(hipMemcpy(d_off.p, offsets, ((size_t)nd + 1) * 8, hipMemcpyHostToDevice));
-    RG_HIP(hipMemcpy(d_nb.p, nbrs, ne * 4, hipMemcpyHostToDevice));
+    st = rg::upload_staged(d_off.p, offsets, ((size_t)nd + 1) * 8);
+    if (st == RG_OK) st = rg::upload_staged(d_nb.p, nbrs, ne * 4);
+    if (st != RG_OK) return st;
     rg_index *ix = nullptr;
     st = open_dev_impl(d_base.p, nd, ad, ad, d_off.p, d_nb.p, ep, metric, device, true, &ix);
     if (st != RG_OK) return st;
@@ -1875,6 +1887,7 @@ rg_status rg_index_stat(const rg_index *ixc, const char *name, uint64_t *value) 
     else if (!strcmp(name, "hub_levels")) *value = ix->hub_levels ? 1 : 0;
     else if (!strcmp(name, "placement_balanced")) *value = ix->n_plain_allocs == 0 ? 1 : 0;
     else if (!strcmp(name, "plain_allocs")) *value = ix->n_plain_allocs;
+    else if (!strcmp(name, "base_copied")) *value = ix->d_main ? 2 : (ix->base_copied ? 1 : 0);
     else if (!strcmp(name, "hub_m_last")) *value = ix->hub_m_last;
     else return set_error(RG_ERR_ARG, "unknown counter");
     return RG_OK;

@@ -138,3 +138,54 @@ def make_device_set(dev, seed, nb, ntrain, nq, d, data="gaussian", rank=24, nois
     else:
         raise ValueError("data must be gaussian or lowrank")
     return base, train, q, desc
+
+
+_PIN = {}
+
+
+def _pinned(torch, nbytes=64 << 20):
+    """One pinned staging buffer per process (bench / tests helper)."""
+    if "buf" not in _PIN:
+        _PIN["buf"] = torch.empty(nbytes, dtype=torch.uint8).pin_memory()
+    return _PIN["buf"]
+
+
+def to_host(t):
+    """Device tensor -> numpy array through a pinned 64-MiB staging buffer (round 5).  `t.cpu()` of gigabytes hands pageable memory to
+    the runtime, which pins it page by page for the copy; two bench runs of the round died of a GPU memory access fault a few pages
+    into such a region.  Small tensors take the plain path."""
+    import numpy as np
+    import torch
+    t = t.contiguous()
+    nbytes = t.numel() * t.element_size()
+    if not t.is_cuda or nbytes < (256 << 20):
+        return t.cpu().numpy()
+    out = np.empty(tuple(t.shape), dtype=torch.empty(0, dtype=t.dtype).numpy().dtype)
+    flat_out = out.reshape(-1).view(np.uint8)
+    flat_in = t.reshape(-1).view(torch.uint8)
+    pin = _pinned(torch)
+    step = pin.numel()
+    for off in range(0, nbytes, step):
+        n = min(step, nbytes - off)
+        pin[:n].copy_(flat_in[off:off + n], non_blocking=False)
+        flat_out[off:off + n] = pin[:n].numpy()
+    return out
+
+
+def to_device(a, dev):
+    """numpy array -> device tensor through the same pinned staging buffer (see to_host)."""
+    import numpy as np
+    import torch
+    a = np.ascontiguousarray(a)
+    if a.nbytes < (256 << 20):
+        return torch.from_numpy(a).to(dev)
+    out = torch.empty(tuple(a.shape), dtype=torch.from_numpy(a[:0].reshape(-1)[:0]).dtype, device=dev)
+    flat_out = out.reshape(-1).view(torch.uint8)
+    flat_in = a.reshape(-1).view(np.uint8)
+    pin = _pinned(torch)
+    step = pin.numel()
+    for off in range(0, a.nbytes, step):
+        n = min(step, a.nbytes - off)
+        pin[:n].numpy()[:] = flat_in[off:off + n]
+        flat_out[off:off + n].copy_(pin[:n], non_blocking=False)
+    return out

@@ -405,3 +405,21 @@ def test_compute_groundtruth_cli_multi_rank_leg(bins, oracle, tmp_path, dist_fn,
     assert (i1 == i3).all() and (d1.view(np.uint32) == d3.view(np.uint32)).all()
     ref_ids, _, ref_s = oracle.groundtruth_f64(base, q, metric, 50, nthreads=8)
     check_gt(base, q, metric, 50, i3, d3, ref_ids, ref_s)
+
+
+def test_pinned_staged_host_transfers_round_trip():
+    """synth.to_host / synth.to_device (bench.py's large transfers, round 5): gigabyte tensors cross PCIe through one pinned 64-MiB
+    staging buffer instead of handing pageable memory to the runtime; values and dtypes survive, ragged last chunks included."""
+    import torch
+    from roargraph_amd import synth
+    dev = torch.device("cuda", 0)
+    g = torch.Generator(device=dev); g.manual_seed(3)
+    t = torch.empty((700_001, 101), device=dev).normal_(generator=g)          # 283 MB: the staged path, last chunk ragged
+    h = synth.to_host(t)
+    assert h.dtype == np.float32 and h.shape == (700_001, 101) and (h == t.cpu().numpy()).all()
+    back = synth.to_device(h, dev)
+    assert back.dtype == torch.float32 and torch.equal(back, t)
+    ids = torch.randint(0, 2 ** 31 - 1, (80_000_000,), dtype=torch.int32, device=dev, generator=g)     # 320 MB of int32
+    assert (synth.to_host(ids) == ids.cpu().numpy()).all()
+    small = torch.arange(10, device=dev)
+    assert (synth.to_host(small) == np.arange(10)).all()
