@@ -1,6 +1,7 @@
 #!/bin/bash
 # GPU box, round 5: rocprofv3 passes of the bench workloads at the round's code; text summaries under gpurun_out/prof_r05 for profiles/r05/.
 #   d = 200 (10M, genuine index built once into --index-cache): headline, L_pq 500 / 1000 / 2000 (look-ahead tags with the hub bitmap)
+#   rank128: the headline's shape on latent-rank-128 data (10M x 200, index degree 36), L_pq 300 (the bench's rank128 side block)
 #   d = 512: webvid (2.5M x 512 IP, L_pq 50), laion (2M x 512 L2 top-100, L_pq 150), worst512 (2.5M x 512 under a random graph, L_pq 500)
 #   trace        --kernel-trace --stats                 (average kernel durations)
 #   fetch/write  --pmc FETCH_SIZE / WRITE_SIZE          (fabric traffic; FETCH_SIZE x2 on gfx950)
@@ -27,10 +28,11 @@ for W in ${WORKLOADS:-head L500 L1000 L2000 webvid laion worst512}; do
     webvid) A="--nb 2500000 --dim 512 --metric ip --k 10 --index-cache /tmp/webvid_ix.npz --L 50";;
     laion) A="--nb 2000000 --dim 512 --metric l2 --k 100 --index-cache /tmp/laion_ix.npz --L 150";;
     worst512) A="--nb 2500000 --dim 512 --metric ip --k 10 --graph random --L 500";;
+    rank128) A="--rank 128 --index-cache /tmp/rank128_ix.npz --L 300";;
   esac
   B="python $R/bench.py $COMMON $A"
   # the first command of a workload builds its index into the cache (untimed by rocprof)
-  case $W in head|webvid|laion) $B --full-out $OUT/${W}_build.bench.json > $OUT/${W}_build.log 2>&1; tail -2 $OUT/${W}_build.log;; esac
+  case $W in head|webvid|laion|rank128) $B --full-out $OUT/${W}_build.bench.json > $OUT/${W}_build.log 2>&1; tail -2 $OUT/${W}_build.log;; esac
   for PASS in ${PASSES:-trace fetch write}; do
     case $PASS in
       trace) run ${W}_trace "$B" --kernel-trace --stats;;

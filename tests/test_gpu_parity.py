@@ -674,3 +674,23 @@ def test_exact_set_with_tags_is_not_used_over_rows_with_repeats(rg, oracle, lset
             assert (got[3] == want[3]).all() and (got[0] == want[0]).all() and (bits(got[1]) == bits(want[1])).all(), L
             assert all(len(set(r.tolist())) == k for r in got[0])
     ix.close()
+
+
+def test_large_base_goes_up_through_pinned_chunks(rg, oracle):
+    """rg_index_open_mem with a 230 MB base, a 20 MB graph (round 5: host -> device through two pinned 64-MiB chunks, rg_mem.hip
+    upload_staged -- several chunks, a ragged last one): the searches over what arrived equal the oracle's over the host arrays."""
+    rng = np.random.default_rng(11)
+    nb, d, deg = 287_001, 200, 8
+    base = rng.standard_normal((nb, d)).astype(np.float32)
+    nbrs = rng.integers(0, nb, size=nb * deg, dtype=np.uint32)
+    nbrs.reshape(nb, deg)[:, 0] = (np.arange(nb, dtype=np.uint32) + 1) % nb       # a ring: every node reachable
+    off = (np.arange(nb + 1, dtype=np.uint64) * deg)
+    q = (rng.standard_normal((24, d)) * 0.5 + 0.3).astype(np.float32)
+    ix = rg.IndexBipartite.from_arrays(base, off, nbrs, 7, metric="ip")
+    for k, L in ((10, 30), (10, 300)):
+        got = ix.SearchRoarGraph(q, k, L)
+        want = oracle.search(base, "ip", off, nbrs, 7, q, k, L, nthreads=8)
+        assert (got[2] == want[2]).all() and (got[3] == want[3]).all() and (got[0] == want[0]).all() and (bits(got[1]) == bits(want[1])).all(), (k, L)
+    ids = np.arange(0, nb, 1009, dtype=np.uint32)      # rows from every chunk, the last one included
+    assert (bits(ix.score_batch(q[0], ids)) == bits(oracle.score_batch(base, "ip", q[0], ids))).all()
+    ix.close()
