@@ -758,6 +758,8 @@ __global__ void __launch_bounds__(256, WPS) rg_gt_rs_kernel(GtParams P0) {
                         // 16-bit mask per lane, a hundred vector instructions per tile)
                         const unsigned long long pf_f0 = PROF ? __builtin_amdgcn_s_memtime() : 0ull;
                         if (PROF) ++pf_tiles;
+                        // (round 5, measured and removed: a quick reject in front of the sixteen compares -- one maximum tree against the smallest
+                        // threshold of the lane's rows -- level at 10,000 - 100,000 queries and 1 % SLOWER at 65,536: gt_ab_box25_quick_reject.jsonl)
                         uint64_t any_win = 0;
                         float mx[TMW][16];
 #pragma unroll
@@ -791,7 +793,12 @@ __global__ void __launch_bounds__(256, WPS) rg_gt_rs_kernel(GtParams P0) {
                                                 // chunk and for the previous candidate's store, on every candidate
                                                 __attribute__((address_space(1))) u64 *cb = (__attribute__((address_space(1))) u64 *)P0.cand;
                                                 asm volatile("" : "+s"(cb));
-                                                cb[((uint32_t)blockIdx.x * MQB + (uint32_t)qi) * (uint32_t)C + slot] = make_key(acc[m][n][r], id, true);
+                                                // (and the buffer's index from a lane number made here: with 384-key buffers the product
+                                                // (block * MQB + query) * C is otherwise carried through the tile loop in a spilled register)
+                                                uint32_t ln;
+                                                asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+                                                const uint32_t qi2 = (uint32_t)(qoff + 32 * m + (r & 3) + 8 * (r >> 2)) + 4u * (ln >> 5);
+                                                cb[((uint32_t)blockIdx.x * MQB + qi2) * (uint32_t)C + slot] = make_key(acc[m][n][r], id, true);
                                                 if (slot + 1 + kNB > (uint32_t)C) flag[0] = 1;
                                                 if (PROF) pf_ncand += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(true));
                                             }
