@@ -551,6 +551,13 @@ def main():
         self_launch(args)
     if args.gpus == 1 and "WORLD_SIZE" not in os.environ and "RG_BENCH_CHILD" not in os.environ and not args.no_retry:
         supervise()
+    if "RG_BENCH_CHILD" in os.environ:      # the child of supervise(): it must not outlive a parent that was killed outright
+        try:
+            import ctypes
+            import signal
+            ctypes.CDLL("libc.so.6", use_errno=True).prctl(1, int(signal.SIGTERM), 0, 0, 0)      # PR_SET_PDEATHSIG
+        except Exception:  # noqa: BLE001
+            pass
     import torch
     import torch.distributed as dist
     from roargraph_amd import build, groundtruth, synth
