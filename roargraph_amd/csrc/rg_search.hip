@@ -905,6 +905,13 @@ static rg_status plan_k1(rg_index *ix, int mode, uint32_t nq, uint32_t L, bool w
     // the others goes to the bit screen (more tests of never-marked nodes stay on the CU).  profiles/r04/k1_ab_box17_look_forms.jsonl,
     // % of 8 TB/s at L_pq 300 / 500 / 700: 76.1 / 71.5 / 70.6 as planned before, 76.1 / 73.8 / 71.1 with eight residents
     if (mode == 0 && dimc_of(ix) == 200 && !bf && !bp && ix->waves_per_cu <= 0 && ix->rows_per_pass <= 0 && R == 4 && wpc > 8 && wpc <= 12) wpc = 8;
+    // (round 5, with the hub bitmap: between L_pq 250 and 375 -- where LDS would allow 12 - 14 residents with 16 rows in flight -- eight
+    // residents with 32 rows each do better: 79.5 - 79.9 against 75.0 - 77.6 % of 8 TB/s at 300, 76.7 - 79.5 against 74.3 - 75.2 at 350, 78.6
+    // against 74.9 at 375; from 400 up 16 rows win by a point or two: profiles/r05/k1_ab_box29_rows_in_flight_300_500.txt, k1_ab_box30_*)
+    if (mode == 0 && dimc_of(ix) == 200 && !bf && !bp && ix->waves_per_cu <= 0 && ix->rows_per_pass <= 0 && R == 4 && wpc >= 8 && L >= 250u && L <= 375u) {
+        R = 8; wpc = 8;
+        lds = search_lds_bytes(ix, L, R, mode, bf, filter_auto);
+    }
     if (ix->waves_per_cu > 0) wpc = std::min(wpc, ix->waves_per_cu);
     else wpc = std::min(wpc, 24);
     K1Launch c;
