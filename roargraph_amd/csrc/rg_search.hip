@@ -1303,7 +1303,7 @@ static rg_status search_dev(rg_index *ix, SearchCtx *cx, const float *d_q, uint3
             // (never over rows that name a node twice: two lanes of one hop that bring the same node and find no room in the set would both
             // read a stale tag with a plain load and both call the node fresh -- the pure form settles them with its CAS or, once it
             // logs, with de-duplicating inserts; the look-ahead form is kept off such rows for the same reason)
-            const bool with_tags = !pure && tags_ok && !ix->adj_dups && (ix->lset_tags >= 2 || (L <= 512u && (double)(plan.vf_slots + plan.vs_side) >= 0.366 * (double)need));      // (0.64 x the mean visits; 0.6 x until the look-ahead tags got hubs and 32 rows in flight: 79.3 - 79.9 against 77.6 - 77.9 at L_pq 280, profiles/r05/k1_ab_box33_*)
+            const bool with_tags = !pure && tags_ok && !ix->adj_dups && (ix->lset_tags >= 2 || (L <= 512u && (double)(plan.vf_slots + plan.vs_side) >= 0.343 * (double)need));      // (round 5: 0.64 x instead of 0.6 x the visits tried against the look-ahead tags with hubs -- within the box-to-box noise, profiles/r05/k1_ab_box33_*, k1_ab_box34_*)
             if (ps == RG_OK && (pure || with_tags) && (st = ensure_qlog(ix, cx, nq)) == RG_OK && nq <= cx->qlog_chunk) {
                 if (hipMemsetAsync(b->d_ovf, 0, 8, s) != hipSuccess) return fail(set_error(RG_ERR_DEVICE, "hipMemsetAsync failed"));
                 b->mode = 3;
