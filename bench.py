@@ -44,7 +44,10 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 import faulthandler  # noqa: E402
-faulthandler.enable()      # a run that dies (SIGABRT of a GPU fault, SIGSEGV) leaves the Python stack of every thread on stderr
+try:
+    faulthandler.enable()  # a run that dies (SIGABRT of a GPU fault, SIGSEGV) leaves the Python stack of every thread on stderr
+except Exception:  # noqa: BLE001  (a stderr without a file descriptor: imported under a test's capture)
+    pass
 
 # the reference's evaluation list (README.md:118) thinned to the points that shape the curve
 SWEEP_DEFAULT = "10,20,30,40,50,60,80,100,150,200,300,500,700,1000,1500,2000"

@@ -210,3 +210,52 @@ def test_cli_table_golden_is_current_and_the_twin_prints_it():
                    for x in (m.group(1) if m.group(1) is not None else None
                              for m in re.finditer(r'<<\s*(?:"((?:[^"\\]|\\.)*)"|k\b)', stmt)))
     assert lits == fmt["header"], (lits, fmt["header"])
+
+
+def test_bench_child_is_started_again_only_when_it_was_killed(tmp_path, monkeypatch, capsys):
+    """bench.py's one-GPU runs work in a child process (round 5: two runs died of a GPU memory access fault).  The parent's rule,
+    on stand-in children: a child killed by a signal without a record is started ONCE more and the line then says
+    `bench_attempts: 2`; a child that ends with an error of its own (no GPU, a parity assertion) is final; a child that
+    keeps dying ends the run with its status."""
+    import json
+    import sys
+    import textwrap
+    sys.path.insert(0, ROOT)
+    import bench
+
+    def run(body):
+        fake = tmp_path / "fake_bench.py"
+        fake.write_text(textwrap.dedent(body))
+        marker = tmp_path / "marker"
+        if marker.exists():
+            marker.unlink()
+        monkeypatch.setattr(bench, "__file__", str(fake))
+        monkeypatch.setattr(sys, "argv", [str(fake)])
+        monkeypatch.delenv("RG_BENCH_CHILD", raising=False)
+        with pytest.raises(SystemExit) as e:
+            bench.supervise()
+        out = capsys.readouterr()
+        return e.value.code, out.out, out.err
+
+    code, out, err = run("""
+        import os
+        m = os.path.join(os.path.dirname(__file__), "marker")
+        if not os.path.exists(m):
+            open(m, "w").write("x"); os.abort()
+        print('{"metric": "x", "value": 1}')
+    """)
+    assert code == 0 and json.loads(out.strip()) == {"metric": "x", "value": 1, "bench_attempts": 2} and "starting once more" in err
+    code, out, err = run("""
+        import sys
+        print("bench.py needs an MI355X", file=sys.stderr); sys.exit(3)
+    """)
+    assert code == 3 and out == "" and "starting once more" not in err
+    code, out, err = run("""
+        import os
+        os.abort()
+    """)
+    assert code != 0 and out == "" and err.count("ended with status") == 2
+    code, out, err = run("""
+        print('{"metric": "x", "value": 2}')
+    """)
+    assert code == 0 and json.loads(out.strip())["bench_attempts"] == 1
