@@ -106,8 +106,8 @@ def parse():
     ap.add_argument("--query-file", default="query.10k.fbin")
     ap.add_argument("--train-file", default="query.train.10M.fbin")
     ap.add_argument("--index-file", default="t2i_10M_roar.index")
-    ap.add_argument("--no-retry", action="store_true", help="one-GPU runs: do the work in THIS process (default: in a child process that is "
-                    "started once more if it dies without a record)")
+    ap.add_argument("--no-retry", "--in-process", dest="no_retry", action="store_true", help="one-GPU runs: do the work in THIS process (default: in a "
+                    "child process whose death ends the bench with its status and a post-mortem of the GPU fault; there is no second attempt)")
     ap.add_argument("--full-out", default="", help="file the FULL record is written to (default: bench_full.json beside this script, plus "
                     "gpurun_out/bench_full.json when that directory exists); stdout carries one compact line")
     ap.add_argument("--index-cache", default="", help="file the built graph is kept in (profiling: the rocprofv3 passes of one box "
@@ -487,41 +487,12 @@ def compact_line(line, full_paths):
 
 
 def supervise():
-    """One-GPU runs are carried out by a CHILD process of this script; this (GPU-less) parent passes its one JSON line on.  Two runs of
-    round 5 died of a `Memory access fault by GPU` at different stages (profiles/r05/bench_fault_box15_stderr.txt; not reproduced in a
-    dozen later runs): a child that dies without a line is started once more, and the line says how many attempts it took -- a
-    measurement repeated after a crash, never an edited one.  --no-retry runs in this process as before."""
-    import subprocess
-    env = dict(os.environ, RG_BENCH_CHILD="1")
-    rc = 1
-    for attempt in (1, 2):
-        p = subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=subprocess.PIPE, text=True)
-
-        def forward(signum, _frame, p=p):      # a caller's timeout (SIGTERM) or ^C ends the child too
-            p.terminate()
-            raise SystemExit(128 + signum)
-        import signal
-        for sg in (signal.SIGTERM, signal.SIGINT):
-            signal.signal(sg, forward)
-        out, _ = p.communicate()
-        rc = p.returncode
-        lines = [l for l in out.splitlines() if l.startswith("{")]
-        if rc == 0 and lines:
-            try:
-                rec = json.loads(lines[-1])
-                rec["bench_attempts"] = attempt
-                print(json.dumps(rec, separators=(",", ":")), flush=True)
-            except ValueError:
-                print(lines[-1], flush=True)
-            raise SystemExit(0)
-        # only a child that was KILLED (a signal: the runtime aborts the process on a GPU fault) is started again; an error it reported
-        # itself -- no GPU, a parity assertion, a bad flag -- is final
-        died = rc < 0 or rc in (134, 139)
-        print("[bench] attempt %d ended with status %d and no record%s" % (attempt, rc, ": starting once more" if (died and attempt == 1) else ""),
-              file=sys.stderr, flush=True)
-        if not died:
-            break
-    raise SystemExit(rc if rc else 1)
+    """One-GPU runs are carried out by a CHILD process of this script (roargraph_amd/benchlib/supervise.py); this GPU-less parent passes its one
+    JSON line on.  No second attempt (round 5 had one): a child that dies ends the bench with its status, and the parent prints the
+    post-mortem of a GPU fault -- which buffer the address belonged to -- from the report the library wrote.  --no-retry (kept for older
+    command lines) = --in-process: the work happens in this process."""
+    from roargraph_amd.benchlib import supervise as sv
+    sv.supervise(os.path.abspath(__file__), sys.argv[1:], ROOT)
 
 
 def self_launch(args):

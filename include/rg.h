@@ -172,6 +172,14 @@ rg_status rg_mem_stats(int device, uint64_t *buffers, uint64_t *plain, uint32_t 
  * rg_mem_release hands the cache (and the pool's spare granules) back to the device. */
 rg_status rg_mem_stats_ex(int device, uint64_t *vals, int nvals);
 rg_status rg_mem_release(int device);
+/* Post-mortem of a GPU memory fault (round 6; no counterpart in the reference).  The runtime answers a GPU page fault with one line
+ * on stderr -- "Memory access fault by GPU ... on address 0x..." -- and abort().  rg_mem_fault_report(path) (or RG_FAULT_REPORT=path in
+ * the environment at load time) installs SIGABRT / SIGSEGV / SIGBUS handlers that write, before the process dies, the library's journal
+ * of address-space events (every range mapped, cached, handed out again, unmapped: the last 4096), its live and cached buffers and
+ * /proc/self/maps to `path`, then pass the signal on to the handler that was installed before; roargraph_amd/benchlib/fault.py names
+ * the buffer a fault address belongs to from that file.  rg_mem_journal_dump writes the same report now (tests). */
+rg_status rg_mem_fault_report(const char *path);
+rg_status rg_mem_journal_dump(const char *path);
 /* The device adjacency of an index as the search kernel reads it (diagnostics, tests; no counterpart in the reference):
  * [npts][*stride] words, word 0 of a row = its degree, then the neighbours: id in the low 24 bits and -- on indexes of up to 2^24
  * nodes -- min(15, in-degree of the neighbour) in bits 24..27 and its hub level in bits 28..31 (knob "hub_bits": at 2^m bits the

@@ -26,6 +26,7 @@
 
 #include "rg.h"
 #include "rg_internal.h"
+#include "rg_mem.h"
 
 namespace rg {
 
@@ -1124,7 +1125,7 @@ rg_status gt_shard_ws(const float *d_base, uint32_t nb, uint32_t bstride, const 
             if (!ws) return hipMallocAsync(&p[i], bytes, s);
             if (ws->cap[i] < bytes) {
                 if (ws->p[i]) { (void)hipStreamSynchronize(s); (void)hipFree(ws->p[i]); ws->p[i] = nullptr; ws->cap[i] = 0; }
-                hipError_t e = hipMalloc(&ws->p[i], bytes);
+                hipError_t e = dev_malloc_retry(&ws->p[i], bytes);
                 if (e != hipSuccess) return e;
                 ws->cap[i] = bytes;
             }
@@ -1154,7 +1155,8 @@ rg_status gt_shard_ws(const float *d_base, uint32_t nb, uint32_t bstride, const 
     // default (profiles/r05/gt_ab_box12_buffers_256_384_512.jsonl, d = 200, % of the fp32-MFMA peak with 256 / 384 / 512 keys): 77.0 / 79.0 /
     // 78.1 at 10,000 queries, 80.9 / 81.5 / 80.8 at 30,000, 82.3 / 82.4 / 81.6 at 100,000 -- and 88.6 / 88.2 / 87.3 at 65,536, where a
     // workgroup streams the whole shard for its block and sheds rarely anyway: 384 keys where a block is searched in pieces, 256 otherwise
-    const int rs_items = (rs_tmw && dim == 200) ? ((cand_env == 8 || cand_env == 6 || cand_env == 4) ? cand_env : (nseg > 1 || bal_lists) ? 6 : 4) : 4;
+    const int rs_items = (rs_tmw && dim == 200) ? ((cand_env == 8 || cand_env == 6 || cand_env == 4) ? cand_env : (nseg > 1 || bal_lists) ? 6 : 4)
+                         : (rs_tmw && dim == 512 && cand_env == 6) ? 6 : 4;
     RG_HIP(scratch.get(1, (size_t)grid * mq * 64 * (rs_tmw ? rs_items : items) * 8));
     cand = static_cast<u64 *>(scratch.p[1]);
     RG_HIP(scratch.get(2, 128));
@@ -1212,7 +1214,10 @@ rg_status gt_shard_ws(const float *d_base, uint32_t nb, uint32_t bstride, const 
                 else if (rs_items == 6) RG_RS_LAUNCH_I(200, 40, 2, 6)
                 else RG_RS_LAUNCH(200, 40, 2)
                 break;
-            case 512: RG_RS_LAUNCH(512, 64, 1) break;
+            case 512:
+                if (rs_items == 6) RG_RS_LAUNCH_I(512, 64, 1, 6)
+                else RG_RS_LAUNCH(512, 64, 1)
+                break;
             case 96: RG_RS_LAUNCH(96, 48, 2) break;
             case 128: RG_RS_LAUNCH(128, 64, 2) break;
             case 256: RG_RS_LAUNCH(256, 64, 1) break;

@@ -1,6 +1,8 @@
 // rg_mem.h -- device memory for the large, randomly read buffers of an index, balanced over the memory classes of the
 // device (rg_mem.hip has the measurement and the method).
 #pragma once
+#include <hip/hip_runtime_api.h>
+
 #include <cstddef>
 
 #include "rg.h"
@@ -22,6 +24,8 @@ void dev_free(void *p);
 // hands the pool's spare granules back to the device (freed balanced buffers stay cached, mapped, for the next request of
 // their size: rg_mem_release hands those back too)
 void dev_trim(int device);
+// hipMalloc that, refused, hands the allocator's cache and spare granules back to the (current) device and tries once more
+hipError_t dev_malloc_retry(void **out, size_t bytes);
 // did the calling thread's last dev_alloc of 2 GiB or more fall back to a plain allocation (one memory class)?
 bool dev_last_plain();
 // host (pageable) -> device through two pinned 64-MiB chunks (round 5): gigabytes of pageable memory handed to hipMemcpy are

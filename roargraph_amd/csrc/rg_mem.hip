@@ -19,7 +19,12 @@
 // RG_BALANCED_ALLOC=0 turns the whole thing off.
 #include <hip/hip_runtime.h>
 
+#include <fcntl.h>
+#include <signal.h>
+#include <unistd.h>
+
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cstdint>
 #include <cstdio>
@@ -40,6 +45,28 @@ namespace {
 constexpr size_t kGranule = (size_t)1 << 30;
 constexpr size_t kMinBalanced = (size_t)2 << 30;      // smaller buffers: hipMalloc
 constexpr int kMaxClasses = 4;
+
+// ---- JOURNAL OF ADDRESS-SPACE EVENTS + FAULT REPORT (round 6) ------------------------------------------------------------------
+// The runtime answers a GPU page fault with one line ("Memory access fault by GPU ... on address 0x...") and abort().  Two bench
+// runs of round 5 died that way and the address could not be attributed to anything.  Every range this file maps, caches, hands
+// out again or unmaps is therefore noted in a ring (4096 events, no allocation, one atomic per event), and -- RG_FAULT_REPORT=<path>
+// in the environment, or rg_mem_fault_report(path) -- a SIGABRT / SIGSEGV / SIGBUS handler writes the ring, the live and cached
+// buffers and /proc/self/maps to <path> before the process dies: the fault address then names its buffer and that buffer's life
+// (roargraph_amd/benchlib/fault.py reads the report).  Kinds: g = granule mapped at its pool address (1 GiB), u = granule unmapped
+// there (moved into a buffer, or dropped: aux 1), B = balanced buffer mapped, C = freed into the cache (still mapped), H = handed
+// out again from the cache, F = unmapped (freed, or released from the cache: aux 1), P = plain hipMalloc of a large request,
+// f = hipFree of a pointer the pools do not know.
+struct JEvent { uint64_t t_us, va, bytes; char kind; int8_t device; uint16_t aux; };
+constexpr uint32_t kJournal = 4096;
+JEvent g_journal[kJournal];
+std::atomic<uint64_t> g_jn{0};
+const std::chrono::steady_clock::time_point g_t0 = std::chrono::steady_clock::now();
+void jlog(char kind, const void *va, size_t bytes, int device, int aux = 0) {
+    const uint64_t i = g_jn.fetch_add(1, std::memory_order_relaxed);
+    JEvent &e = g_journal[i % kJournal];
+    e.t_us = (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - g_t0).count();
+    e.va = (uint64_t)(uintptr_t)va; e.bytes = (uint64_t)bytes; e.kind = kind; e.device = (int8_t)device; e.aux = (uint16_t)aux;
+}
 
 __device__ __forceinline__ uint32_t mixu(uint32_t x) {
     x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
@@ -122,10 +149,15 @@ Pool g_pool[16];
 bool g_off = false, g_off_read = false, g_trace = false, g_trace2 = false;
 thread_local bool t_last_plain = false;       // dev_last_plain(): the calling thread's last large request fell back to hipMalloc
 
+// cap of the cache of freed buffers: RG_MEM_CACHE_GIB, default min(64 GiB, a quarter of the device) -- on a 64-GiB part the fixed
+// 64 GiB of round 5 would have kept every closed index on the device
 size_t cache_cap_bytes() {
     static const size_t cap = [] {
         const char *e = getenv("RG_MEM_CACHE_GIB");
-        return (size_t)(e ? std::max(0, atoi(e)) : 64) << 30;
+        if (e) return (size_t)std::max(0, atoi(e)) << 30;
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); total_b = (size_t)256 << 30; }
+        return std::min<size_t>((size_t)64 << 30, total_b / 4);
     }();
     return cap;
 }
@@ -208,11 +240,12 @@ bool new_granule(Pool &P, int device, Granule *g) {
     if (!va_reserve(&g->va, kGranule)) { (void)hipMemRelease(g->h); return false; }
     if (!map_at(g->va, kGranule, g->h, device)) { (void)hipGetLastError(); va_free(g->va, kGranule); (void)hipMemRelease(g->h); return false; }
     g->cls = -1;
+    jlog('g', g->va, kGranule, device);
     return true;
 }
 
 void drop_granule(Granule &g) {
-    if (g.va) { va_unmap(g.va, kGranule); va_free(g.va, kGranule); }
+    if (g.va) { jlog('u', g.va, kGranule, -1, 1); va_unmap(g.va, kGranule); va_free(g.va, kGranule); }
     (void)hipMemRelease(g.h);
     g.va = nullptr;
 }
@@ -308,6 +341,7 @@ void release_cache(Pool &P) {
     (void)hipDeviceSynchronize();
     for (Cached &c : P.cache) {
         if (g_trace) fprintf(stderr, "[rg_mem] %.2f GiB at %p: released from the cache\n", (double)c.buf.bytes / (1u << 30), c.va);
+        jlog('F', c.va, c.buf.bytes, -1, 1);
         for (size_t i = 0; i < c.buf.handles.size(); ++i) {
             va_unmap((char *)c.va + i * kGranule, kGranule);
             (void)hipMemRelease(c.buf.handles[i]);
@@ -333,6 +367,7 @@ rg_status dev_alloc(int device, size_t bytes, void **out) {
         if (Pp) { release_spare(*Pp); release_cache(*Pp); t_last_plain = true; }
         hipError_t e = hipMalloc(out, bytes);
         if (e != hipSuccess) { (void)hipGetLastError(); return set_error(RG_ERR_OOM, std::string("hipMalloc of ") + std::to_string(bytes) + " bytes: " + hipGetErrorString(e)); }
+        if (bytes >= kMinBalanced) jlog('P', *out, bytes, device);
         return RG_OK;
     };
     if (!Pp) return plain();
@@ -352,6 +387,7 @@ rg_status dev_alloc(int device, size_t bytes, void **out) {
             P.cached_bytes -= c.buf.bytes;
             P.live[c.va] = c.buf;
             ++P.n_buffers; ++P.n_cache_hits;
+            jlog('H', c.va, c.buf.bytes, device);
             if (g_trace) fprintf(stderr, "[rg_mem] %.2f GiB at %p: taken from the cache (%d / %d / %d / %d granules of the classes)\n", (double)c.buf.bytes / (1u << 30), c.va,
                                  c.buf.per_class[0], c.buf.per_class[1], c.buf.per_class[2], c.buf.per_class[3]);
             *out = c.va;
@@ -432,6 +468,7 @@ rg_status dev_alloc(int device, size_t bytes, void **out) {
     bool ok = true;
     for (size_t i = 0; i < n && ok; ++i) {
         Granule &g = taken[i];
+        jlog('u', g.va, kGranule, device, 0);
         va_unmap(g.va, kGranule);
         va_free(g.va, kGranule);
         g.va = nullptr;
@@ -455,6 +492,7 @@ rg_status dev_alloc(int device, size_t bytes, void **out) {
                 buf.per_class[0], buf.per_class[1], buf.per_class[2], buf.per_class[3], P.reps.size(), (double)walked / (1u << 30));
     P.live[va] = buf;
     ++P.n_buffers;
+    jlog('B', va, buf.bytes, device);
     *out = va;
     return RG_OK;
 }
@@ -470,6 +508,7 @@ void dev_free(void *p) {
         if (P.cached_bytes + b.bytes <= cache_cap_bytes()) {     // kept mapped for the next request of its size
             (void)hipDeviceSynchronize();                        // (nothing queued reads it any more when it is handed out again)
             if (g_trace) fprintf(stderr, "[rg_mem] %.2f GiB at %p: freed into the cache\n", (double)b.bytes / (1u << 30), p);
+            jlog('C', p, b.bytes, d);
             P.cache.push_back({p, b});
             P.cached_bytes += b.bytes;
             P.live.erase(it);
@@ -477,6 +516,7 @@ void dev_free(void *p) {
         }
         (void)hipDeviceSynchronize();
         if (g_trace) fprintf(stderr, "[rg_mem] %.2f GiB at %p: freed (unmapped)\n", (double)b.bytes / (1u << 30), p);
+        jlog('F', p, b.bytes, d, 0);
         for (size_t i = 0; i < b.handles.size(); ++i) {
             va_unmap((char *)p + i * kGranule, kGranule);
             (void)hipMemRelease(b.handles[i]);
@@ -485,7 +525,29 @@ void dev_free(void *p) {
         P.live.erase(it);
         return;
     }
+    jlog('f', p, 0, -1);
     (void)hipFree(p);
+}
+
+// hipMalloc for the library's plain (small or uncached) buffers: a request the device refuses is tried once more after the cache of
+// freed balanced buffers and the pool's spare granules went back to the device (memory the library itself keeps mapped
+// must not make its own next request fail)
+hipError_t dev_malloc_retry(void **out, size_t bytes) {
+    hipError_t e = hipMalloc(out, bytes);
+    if (e == hipSuccess) return e;
+    (void)hipGetLastError();
+    int device = -1;
+    if (hipGetDevice(&device) != hipSuccess || device < 0 || device >= 16) return e;
+    {
+        Pool &P = g_pool[device];
+        std::lock_guard<std::mutex> lk(P.mu);
+        if (P.cache.empty() && P.walked_epoch == 0) return e;      // nothing of ours to give back
+        release_spare(P);
+        release_cache(P);
+    }
+    e = hipMalloc(out, bytes);
+    if (e != hipSuccess) (void)hipGetLastError();
+    return e;
 }
 
 rg_status upload_staged(void *d_dst, const void *h_src, size_t bytes) {
@@ -538,6 +600,102 @@ extern "C" rg_status rg_mem_release(int device) {
     std::lock_guard<std::mutex> lk(P.mu);
     rg::release_spare(P);
     rg::release_cache(P);
+    return RG_OK;
+}
+
+// ---- fault report -------------------------------------------------------------------------------------------------------------
+namespace rg {
+namespace {
+char g_report_path[512] = {0};
+struct sigaction g_old_act[3];
+const int g_sigs[3] = {SIGABRT, SIGSEGV, SIGBUS};
+void wr(int fd, const char *s, size_t n) { while (n) { ssize_t k = write(fd, s, n); if (k <= 0) return; s += k; n -= (size_t)k; } }
+// (snprintf and the unlocked look at the pools are not async-signal-safe by the letter; the process is about to die, and a report that
+// is right nearly always is worth more than none)
+void write_report(int fd, const char *why) {
+    char line[256];
+    int n = snprintf(line, sizeof line, "rg_mem fault report v1 (%s)\n", why);
+    wr(fd, line, (size_t)n);
+    const uint64_t jn = g_jn.load(std::memory_order_relaxed);
+    const uint64_t t_now = (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - g_t0).count();
+    n = snprintf(line, sizeof line, "now_us %llu\njournal %llu events (the last %u are kept): t_us kind va bytes device aux\n", (unsigned long long)t_now,
+                 (unsigned long long)jn, kJournal);
+    wr(fd, line, (size_t)n);
+    for (uint64_t i = jn > kJournal ? jn - kJournal : 0; i < jn; ++i) {
+        const JEvent &e = g_journal[i % kJournal];
+        n = snprintf(line, sizeof line, "J %llu %c 0x%llx %llu %d %u\n", (unsigned long long)e.t_us, e.kind, (unsigned long long)e.va, (unsigned long long)e.bytes,
+                     (int)e.device, (unsigned)e.aux);
+        wr(fd, line, (size_t)n);
+    }
+    for (int d = 0; d < 16; ++d) {
+        Pool &P = g_pool[d];
+        if (!P.tried) continue;
+        const bool locked = P.mu.try_lock();
+        for (auto &kv : P.live) { n = snprintf(line, sizeof line, "LIVE %d 0x%llx %llu\n", d, (unsigned long long)(uintptr_t)kv.first, (unsigned long long)kv.second.bytes); wr(fd, line, (size_t)n); }
+        for (auto &c : P.cache) { n = snprintf(line, sizeof line, "CACHED %d 0x%llx %llu\n", d, (unsigned long long)(uintptr_t)c.va, (unsigned long long)c.buf.bytes); wr(fd, line, (size_t)n); }
+        for (auto &g : P.reps) { n = snprintf(line, sizeof line, "REP %d 0x%llx %llu\n", d, (unsigned long long)(uintptr_t)g.va, (unsigned long long)kGranule); wr(fd, line, (size_t)n); }
+        for (int k = 0; k < kMaxClasses; ++k)
+            for (auto &g : P.spare[k]) { n = snprintf(line, sizeof line, "SPARE %d 0x%llx %llu\n", d, (unsigned long long)(uintptr_t)g.va, (unsigned long long)kGranule); wr(fd, line, (size_t)n); }
+        if (locked) P.mu.unlock();
+    }
+    wr(fd, "MAPS\n", 5);
+    const int mf = open("/proc/self/maps", O_RDONLY);
+    if (mf >= 0) {
+        char buf[4096];
+        ssize_t k;
+        while ((k = read(mf, buf, sizeof buf)) > 0) wr(fd, buf, (size_t)k);
+        close(mf);
+    }
+    wr(fd, "END\n", 4);
+}
+void on_fatal(int sig, siginfo_t *si, void *uc) {
+    static std::atomic<int> once{0};
+    int idx = 0;
+    for (int i = 0; i < 3; ++i) if (g_sigs[i] == sig) idx = i;
+    if (once.fetch_add(1) == 0 && g_report_path[0]) {
+        const int fd = open(g_report_path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+        if (fd >= 0) {
+            write_report(fd, sig == SIGABRT ? "SIGABRT" : sig == SIGSEGV ? "SIGSEGV" : "SIGBUS");
+            close(fd);
+        }
+    }
+    // the handler that was there before (Python's faulthandler, or the default: die of the signal)
+    const struct sigaction &o = g_old_act[idx];
+    if ((o.sa_flags & SA_SIGINFO) && o.sa_sigaction) { o.sa_sigaction(sig, si, uc); return; }
+    if (!(o.sa_flags & SA_SIGINFO) && o.sa_handler != SIG_DFL && o.sa_handler != SIG_IGN && o.sa_handler) { o.sa_handler(sig); return; }
+    signal(sig, SIG_DFL);
+    raise(sig);
+}
+struct ReportFromEnv {
+    ReportFromEnv() {
+        const char *e = getenv("RG_FAULT_REPORT");
+        if (e && *e) (void)rg_mem_fault_report(e);
+    }
+} g_report_from_env;
+}  // namespace
+}  // namespace rg
+
+extern "C" rg_status rg_mem_fault_report(const char *path) {
+    if (!path || !*path || strlen(path) >= sizeof rg::g_report_path) return rg::set_error(RG_ERR_ARG, "rg_mem_fault_report: bad path");
+    const bool first = rg::g_report_path[0] == 0;
+    strcpy(rg::g_report_path, path);
+    if (first) {
+        struct sigaction a;
+        memset(&a, 0, sizeof a);
+        a.sa_sigaction = rg::on_fatal;
+        a.sa_flags = SA_SIGINFO | SA_ONSTACK;
+        sigemptyset(&a.sa_mask);
+        for (int i = 0; i < 3; ++i) (void)sigaction(rg::g_sigs[i], &a, &rg::g_old_act[i]);
+    }
+    return RG_OK;
+}
+
+extern "C" rg_status rg_mem_journal_dump(const char *path) {
+    if (!path || !*path) return rg::set_error(RG_ERR_ARG, "rg_mem_journal_dump: bad path");
+    const int fd = open(path, O_WRONLY | O_CREAT | O_TRUNC, 0644);
+    if (fd < 0) return rg::set_error(RG_ERR_IO, std::string("cannot write ") + path);
+    rg::write_report(fd, "on request");
+    close(fd);
     return RG_OK;
 }
 

@@ -34,11 +34,15 @@ static void trace_stale(const char *where) {
     if (e != hipSuccess) fprintf(stderr, "[rg] stale HIP error at %s: %s\n", where, hipGetErrorString(e));
 }
 
+// the library's plain allocations: a refused request is tried once more after the allocator's cache went back to the device (rg_mem.hip)
+template <typename T>
+static inline hipError_t rg_malloc(T **p, size_t bytes) { return dev_malloc_retry(reinterpret_cast<void **>(p), bytes); }
+
 // device allocation released on every exit path of a host wrapper
 template <typename T>
 struct DevBuf {
     T *p = nullptr;
-    hipError_t alloc(size_t n) { return hipMalloc(&p, std::max<size_t>(n * sizeof(T), 16)); }
+    hipError_t alloc(size_t n) { return dev_malloc_retry(reinterpret_cast<void **>(&p), std::max<size_t>(n * sizeof(T), 16)); }
     ~DevBuf() { if (p) (void)hipFree(p); }
     T *release() { T *r = p; p = nullptr; return r; }
     DevBuf() = default;
@@ -570,7 +574,7 @@ static rg_status finish_graph(rg_index *ix, const uint64_t *d_off, const uint32_
             ix->n_plain_allocs += ok && dev_last_plain() ? 1 : 0;
             ok = ok && dev_alloc_t(ix->device, (size_t)(ne + 1) * ix->tail_dim, &ix->d_etail) == RG_OK;
             ix->n_plain_allocs += ok && dev_last_plain() ? 1 : 0;
-            ok = ok && hipMalloc(&ix->d_tail_off, (size_t)ix->nd * 4) == hipSuccess;
+            ok = ok && rg_malloc(&ix->d_tail_off, (size_t)ix->nd * 4) == hipSuccess;
             if (ok) {
                 hipLaunchKernelGGL(rg_split_main_kernel, dim3(8192), dim3(256), 0, 0, ix->d_base, ix->nd, ix->stride, ix->main_dim, ix->d_main);
                 hipLaunchKernelGGL(rg_split_tail_kernel, dim3(8192), dim3(256), 0, 0, ix->d_base, ix->stride, ix->main_dim, ix->tail_dim, d_nb,
@@ -588,8 +592,8 @@ static rg_status finish_graph(rg_index *ix, const uint64_t *d_off, const uint32_
             }
         }
     } else {
-        RG_HIP(hipMalloc(&ix->d_offsets, ((size_t)ix->nd + 1) * 8));
-        RG_HIP(hipMalloc(&ix->d_nbrs, std::max<size_t>(ne * 4, 4)));
+        RG_HIP(rg_malloc(&ix->d_offsets, ((size_t)ix->nd + 1) * 8));
+        RG_HIP(rg_malloc(&ix->d_nbrs, std::max<size_t>(ne * 4, 4)));
         RG_HIP(hipMemcpy(ix->d_offsets, d_off, ((size_t)ix->nd + 1) * 8, hipMemcpyDeviceToDevice));
         RG_HIP(hipMemcpy(ix->d_nbrs, d_nb, ne * 4, hipMemcpyDeviceToDevice));
     }
@@ -616,7 +620,7 @@ static rg_status finish_graph(rg_index *ix, const uint64_t *d_off, const uint32_
         RG_HIP(hipMemcpy(o, d_off + ix->ep, 16, hipMemcpyDeviceToHost));
         const uint32_t dg = (uint32_t)(o[1] - o[0]);
         ix->front_n = 1 + dg;
-        RG_HIP(hipMalloc(&ix->d_front_ids, (size_t)ix->front_n * 4));
+        RG_HIP(rg_malloc(&ix->d_front_ids, (size_t)ix->front_n * 4));
         RG_HIP(hipMemcpy(ix->d_front_ids, &ix->ep, 4, hipMemcpyHostToDevice));
         if (dg) RG_HIP(hipMemcpy(ix->d_front_ids + 1, d_nb + o[0], (size_t)dg * 4, hipMemcpyDeviceToDevice));
     }
@@ -656,8 +660,8 @@ static void free_ctx(SearchCtx *cx) {
 
 static rg_status new_ctx(SearchCtx **out) {
     SearchCtx *cx = new SearchCtx();
-    hipError_t e = hipMalloc(&cx->d_counter, 64);
-    if (e == hipSuccess) e = hipMalloc(&cx->d_scratch_stat, 64);
+    hipError_t e = rg_malloc(&cx->d_counter, 64);
+    if (e == hipSuccess) e = rg_malloc(&cx->d_scratch_stat, 64);
     if (e != hipSuccess) { free_ctx(cx); return set_error(RG_ERR_DEVICE, hipGetErrorString(e)); }
     *out = cx;
     return RG_OK;
@@ -703,12 +707,12 @@ static rg_status take_batch(SearchCtx *cx, uint32_t nq, Batch **out) {
     if (!cx->spare.empty()) { b = cx->spare.back(); cx->spare.pop_back(); }
     else b = new Batch();
     hipError_t e = hipSuccess;
-    if (!b->d_stat) e = hipMalloc(&b->d_stat, 64);
+    if (!b->d_stat) e = rg_malloc(&b->d_stat, 64);
     if (e == hipSuccess && !b->h_stat) e = hipHostMalloc(&b->h_stat, 64);
     if (e == hipSuccess && b->ovf_cap < nq + 2) {
         if (b->d_ovf) (void)hipFree(b->d_ovf);
         b->d_ovf = nullptr; b->ovf_cap = 0;
-        e = hipMalloc(&b->d_ovf, ((size_t)nq + 2) * 4);
+        e = rg_malloc(&b->d_ovf, ((size_t)nq + 2) * 4);
         if (e == hipSuccess) b->ovf_cap = nq + 2;
     }
     if (e != hipSuccess) { free_batch(b); return set_error(RG_ERR_DEVICE, hipGetErrorString(e)); }
@@ -796,7 +800,7 @@ static rg_status ensure_visited(rg_index *ix, SearchCtx *cx, uint32_t slots, boo
                                            : dev_alloc_t(ix->device, (size_t)slots * vwords, &nv) == RG_OK;
     if (ok_v && !ix->visited_uncached && dev_last_plain()) { std::lock_guard<std::mutex> lk(ix->mu); ++ix->n_plain_allocs; }
     dev_trim(ix->device);      // (the allocator's pool of classified granules goes back to the device)
-    if (!ok_v || hipMalloc(&ne, (size_t)slots * 4) != hipSuccess) {
+    if (!ok_v || rg_malloc(&ne, (size_t)slots * 4) != hipSuccess) {
         (void)hipGetLastError();
         dev_free(nv);
         // (the context must not lose a working buffer to a failed attempt at a larger one: back to the size it had -- the
@@ -1181,7 +1185,7 @@ static rg_status ensure_qlog(rg_index *ix, SearchCtx *cx, uint32_t nq) {
         dev_trim(ix->device);
         if (as != RG_OK) return as;
     }
-    RG_HIP(hipMalloc(&cx->d_qlog_n, (size_t)chunk * 4));
+    RG_HIP(rg_malloc(&cx->d_qlog_n, (size_t)chunk * 4));
     cx->qlog_nq = chunk;
     cx->qlog_chunk = chunk;
     cx->logcap = cap;
@@ -1220,7 +1224,7 @@ static rg_status search_dev(rg_index *ix, SearchCtx *cx, const float *d_q, uint3
         if (cx->front_cap < (size_t)nq * fs) {
             if (cx->d_front) (void)hipFree(cx->d_front);
             cx->d_front = nullptr; cx->front_cap = 0;
-            if (hipMalloc(&cx->d_front, (size_t)nq * fs * 4) != hipSuccess) return fail(set_error(RG_ERR_OOM, "no room for the shared-frontier scores"));
+            if (rg_malloc(&cx->d_front, (size_t)nq * fs * 4) != hipSuccess) return fail(set_error(RG_ERR_OOM, "no room for the shared-frontier scores"));
             cx->front_cap = (size_t)nq * fs;
         }
         constexpr int FR = 4;
@@ -1535,7 +1539,7 @@ rg_status build_index_create(const float *d_base, uint32_t nd, uint32_t dim, uin
     ix->d_base = const_cast<float *>(d_base);
     ix->ell_stride = ell_stride;
     ix->max_deg = ell_stride - 1;
-    hipError_t e = hipMalloc(&ix->d_ell, (size_t)nd * ell_stride * 4);
+    hipError_t e = rg_malloc(&ix->d_ell, (size_t)nd * ell_stride * 4);
     if (e == hipSuccess) e = hipMemset(ix->d_ell, 0, (size_t)nd * ell_stride * 4);
     hipDeviceProp_t prop;
     if (e == hipSuccess) e = hipGetDeviceProperties(&prop, device);
@@ -1583,16 +1587,16 @@ static rg_status host_search_begin(rg_index *ix, const float *hq, uint32_t n, ui
     if (st != RG_OK) return st;
     SearchCtx *cx = hs->cx;
     const size_t qn = (size_t)n * d, rn = (size_t)n * k, cn = (size_t)n * 2;
-    if (cx->q_cap < qn) { if (cx->d_q) (void)hipFree(cx->d_q); cx->d_q = nullptr; cx->q_cap = 0; RG_HIP(hipMalloc(&cx->d_q, qn * 4)); cx->q_cap = qn; }
+    if (cx->q_cap < qn) { if (cx->d_q) (void)hipFree(cx->d_q); cx->d_q = nullptr; cx->q_cap = 0; RG_HIP(rg_malloc(&cx->d_q, qn * 4)); cx->q_cap = qn; }
     if (cx->res_cap < rn) {
         if (cx->d_ids) (void)hipFree(cx->d_ids);
         if (cx->d_dist) (void)hipFree(cx->d_dist);
         cx->d_ids = nullptr; cx->d_dist = nullptr; cx->res_cap = 0;
-        RG_HIP(hipMalloc(&cx->d_ids, rn * 4));
-        RG_HIP(hipMalloc(&cx->d_dist, rn * 4));
+        RG_HIP(rg_malloc(&cx->d_ids, rn * 4));
+        RG_HIP(rg_malloc(&cx->d_dist, rn * 4));
         cx->res_cap = rn;
     }
-    if (cx->ch_cap < cn) { if (cx->d_ch) (void)hipFree(cx->d_ch); cx->d_ch = nullptr; cx->ch_cap = 0; RG_HIP(hipMalloc(&cx->d_ch, cn * 4)); cx->ch_cap = cn; }
+    if (cx->ch_cap < cn) { if (cx->d_ch) (void)hipFree(cx->d_ch); cx->d_ch = nullptr; cx->ch_cap = 0; RG_HIP(rg_malloc(&cx->d_ch, cn * 4)); cx->ch_cap = cn; }
     hipStream_t s = cx->own;
     // Pinned staging (round 3): the caller's buffers are pageable, and a pageable hipMemcpy stages through the runtime's own
     // bounce buffers one chunk at a time on the calling thread.  The queries are copied into this context's pinned buffer

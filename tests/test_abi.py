@@ -212,11 +212,11 @@ def test_cli_table_golden_is_current_and_the_twin_prints_it():
     assert lits == fmt["header"], (lits, fmt["header"])
 
 
-def test_bench_child_is_started_again_only_when_it_was_killed(tmp_path, monkeypatch, capsys):
-    """bench.py's one-GPU runs work in a child process (round 5: two runs died of a GPU memory access fault).  The parent's rule,
-    on stand-in children: a child killed by a signal without a record is started ONCE more and the line then says
-    `bench_attempts: 2`; a child that ends with an error of its own (no GPU, a parity assertion) is final; a child that
-    keeps dying ends the run with its status."""
+def test_bench_child_that_dies_fails_the_bench(tmp_path, monkeypatch, capsys):
+    """bench.py's one-GPU runs work in a child process.  The parent's rule (round 6: NO second attempt -- a bench that re-runs itself after
+    a GPU fault hides a memory bug of the product), on stand-in children: a child killed by a signal ends the bench with a non-zero status,
+    no line on stdout, and the post-mortem of the library's fault report on stderr; an error the child reports itself keeps its status;
+    a child that prints its line passes it on with `bench_attempts: 1`."""
     import json
     import sys
     import textwrap
@@ -226,36 +226,35 @@ def test_bench_child_is_started_again_only_when_it_was_killed(tmp_path, monkeypa
     def run(body):
         fake = tmp_path / "fake_bench.py"
         fake.write_text(textwrap.dedent(body))
-        marker = tmp_path / "marker"
-        if marker.exists():
-            marker.unlink()
         monkeypatch.setattr(bench, "__file__", str(fake))
+        monkeypatch.setattr(bench, "ROOT", str(tmp_path))
         monkeypatch.setattr(sys, "argv", [str(fake)])
         monkeypatch.delenv("RG_BENCH_CHILD", raising=False)
+        monkeypatch.delenv("RG_FAULT_REPORT", raising=False)
         with pytest.raises(SystemExit) as e:
             bench.supervise()
         out = capsys.readouterr()
         return e.value.code, out.out, out.err
 
+    # a child that dies the way the HIP runtime kills a process after a GPU page fault: the message, the library's report, abort()
     code, out, err = run("""
-        import os
-        m = os.path.join(os.path.dirname(__file__), "marker")
-        if not os.path.exists(m):
-            open(m, "w").write("x"); os.abort()
-        print('{"metric": "x", "value": 1}')
-    """)
-    assert code == 0 and json.loads(out.strip()) == {"metric": "x", "value": 1, "bench_attempts": 2} and "starting once more" in err
+        import os, sys
+        sys.path.insert(0, %r)
+        from roargraph_amd._lib import lib
+        lib()                                      # RG_FAULT_REPORT (set by the parent) installs the report writer
+        a = id(sys)                                # an address of this process: the post-mortem finds it in /proc/self/maps
+        print("Memory access fault by GPU node-2 (Agent handle: 0x1) on address 0x%%x. Reason: Unknown." %% a, file=sys.stderr, flush=True)
+        os.abort()
+    """ % ROOT)
+    assert code != 0 and out == "", (code, out, err)
+    assert err.count("ended with status") == 1 and "no second attempt" in err and "fault address 0x" in err and "/proc/self/maps:" in err, err
+    assert (tmp_path / "bench_fault_report.txt").read_text().startswith("rg_mem fault report v1 (SIGABRT)")
     code, out, err = run("""
         import sys
         print("bench.py needs an MI355X", file=sys.stderr); sys.exit(3)
     """)
-    assert code == 3 and out == "" and "starting once more" not in err
-    code, out, err = run("""
-        import os
-        os.abort()
-    """)
-    assert code != 0 and out == "" and err.count("ended with status") == 2
+    assert code == 3 and out == "" and "post-mortem" not in err
     code, out, err = run("""
         print('{"metric": "x", "value": 2}')
     """)
-    assert code == 0 and json.loads(out.strip())["bench_attempts"] == 1
+    assert code == 0 and json.loads(out.strip()) == {"metric": "x", "value": 2, "bench_attempts": 1}

@@ -185,3 +185,16 @@ def test_fifty_opens_and_closes_reserve_no_new_address_space(oracle):
     assert ix.stat("placement_balanced") == 1 and stats()[5] > s49[5]
     ix.close()
     check(lib().rg_mem_release(0))
+
+
+def test_open_search_close_reopen_200_iterations():
+    """the lifecycle in which two bench runs of round 5 died of a GPU memory fault -- a large index opened, searched at narrow
+    and wide beams in every exact form, closed, another shape opened in the memory the first one left (the allocator's cache of freed
+    buffers, its remapped 1-GiB granules), the cache handed back every third time -- 200 times in one process, with host threads copying
+    pageable memory over PCIe meanwhile.  A stale mapping shows as a GPU fault (the process dies) or as exact forms that disagree.
+    (index_bipartite.h:27,62-64,105,133: the reference's lifecycle is constructor / load / search / destructor, any number of times.)"""
+    import os
+    from roargraph_amd.benchlib.stress import lifecycle_stress
+    iters = int(os.environ.get("RG_STRESS_ITERS", "200"))
+    r = lifecycle_stress(iters, scale=float(os.environ.get("RG_STRESS_SCALE", "0.8")), host_load=2)
+    assert r["iterations"] == iters
