@@ -127,7 +127,8 @@ rg_status rg_index_info(const rg_index *idx, uint32_t *nd, uint32_t *dim, uint32
  * It combines with "visited": 0 = exact HBM words (no repeated evaluations), 1 / 2 = LDS filter only.
  * Round-3 knobs, none of which changes a result: "lookahead" (-1 automatic / 0 / 1 / 2: form of the exact visited words, see
  * rg_search_kernel.h VIS = 2), "gather_form" (0 = 16-byte loads + LDS bounce, otherwise compute-layout loads where
- * instantiated), "filter_min_indeg" (the LDS filter keeps entries only for neighbours of at least this in-degree; default 2),
+ * instantiated), "filter_min_indeg" (the LDS filter keeps entries only for neighbours of at least this in-degree; default 2; the adjacency words carry
+ * min(15, in-degree), so values above 15 mean 15),
  * "count_in_k1" (beams up to this wide count their distinct ids inside the search kernel; default 40, 0 = never),
  * "log_early", "visited_budget_kb" (cap of the exact visited words per stream; default 24 GiB), "visited_uncached",
  * "visited_bytes" (look-ahead form: one epoch byte per node instead of the epoch-tagged words; default on), "filter_fill"
@@ -322,6 +323,15 @@ rg_status rg_build_roargraph_gpu(const float *base, uint32_t nb, uint32_t dim, u
  * nodes one by one, then batches of at most a quarter of what is linked): writes up to `cap` batch sizes, *count = how
  * many there are.  For checkers that restate the construction (oracle/rg_oracle_build.c takes the same list). */
 rg_status rg_build_schedule(uint32_t nb, uint32_t batch, uint32_t *sizes, uint32_t cap, uint32_t *count);
+/* Tests (no counterpart in the reference): ONE call of one occlusion-pruning rule of the construction, so that the rules can be held
+ * against goldens made with the reference's own Distance / Neighbor objects (tests/golden/prune_*.npz, oracle/ref_driver.cpp `prune`).
+ * kind 0 = PruneBiSearchBaseGetBase (index_bipartite.cpp:1612-1694), 1 = PruneProjectionReverseCandidates (:1526-1610), 2 =
+ * PruneProjectionInternalReverseCandidates (:1434-1524), 3 = PruneProjectionBaseSearchCandidates (:1846-1940, have = the pivot's
+ * projection list).  ids / dists [np] = the candidate pool (kinds 1, 2: the list, dists unused); out has room for max(M, np) ids.
+ * use_gpu 0 = the builder's host routine, 1 = the pruning kernel of the GPU-assisted build (kinds 0 and 3). */
+rg_status rg_build_prune_debug(const float *base, uint32_t nb, uint32_t dim, uint32_t stride, int metric, uint32_t M, int kind, uint32_t pivot,
+                               const uint32_t *ids, const float *dists, uint32_t np, const uint32_t *have, uint32_t nhave, uint32_t *out,
+                               uint32_t *nout, int use_gpu, int device);
 
 #ifdef __cplusplus
 }

@@ -333,3 +333,46 @@ def ref_search(base_fbin, index_path, query_fbin, metric, k, L, threads=1, repea
         if line.startswith("QPS "):
             qps = float(line.split()[1])
     return ids, ds, cmps, hops, qps
+
+
+PRUNE_KINDS = {"get_base": 0, "reverse": 1, "reverse_phantoms": 2, "search": 3}
+
+
+def prune(base, metric, M, kind, pivot, ids, dists=None, have=None):
+    """rgo_prune: one call of one pruning rule of the restated construction (oracle/rg_oracle_build.c)."""
+    base = np.ascontiguousarray(base, np.float32)
+    ids = np.ascontiguousarray(ids, np.uint32)
+    dists = np.ascontiguousarray(dists if dists is not None else np.zeros(ids.size), np.float32)
+    have = np.ascontiguousarray(have if have is not None else np.zeros(0), np.uint32)
+    out = np.zeros(max(int(M), ids.size) + 1, np.uint32)
+    n = C.c_uint32()
+    lib().rgo_prune(_p(base), C.c_size_t(base.shape[1]), C.c_uint32(base.shape[0]), C.c_uint(base.shape[1]), METRIC[metric], C.c_uint32(M),
+                    C.c_int(PRUNE_KINDS[kind]), C.c_uint32(pivot), _p(ids), _p(dists), C.c_uint32(ids.size), _p(have), C.c_uint32(have.size),
+                    _p(out), C.byref(n))
+    return out[: n.value].copy()
+
+
+def prune_calls_pack(calls):
+    """calls = [(kind, pivot, ids, dists or None, have or None)] -> the bytes `rg_ref prune` reads"""
+    parts = [np.array([len(calls)], np.uint32).tobytes()]
+    for kind, pivot, ids, dists, have in calls:
+        ids = np.ascontiguousarray(ids, np.uint32)
+        dists = np.ascontiguousarray(dists if dists is not None else np.zeros(ids.size), np.float32)
+        have = np.ascontiguousarray(have if have is not None else np.zeros(0), np.uint32)
+        parts += [np.array([PRUNE_KINDS[kind], pivot, ids.size, have.size], np.uint32).tobytes(), ids.tobytes(), dists.tobytes(), have.tobytes()]
+    return b"".join(parts)
+
+
+def ref_prune(base_fbin, metric, M, calls):
+    """The same calls through oracle/_ref/rg_ref prune (the reference's own Distance / Neighbor objects); list of id arrays."""
+    import tempfile
+    with tempfile.TemporaryDirectory() as td:
+        cin, cout = os.path.join(td, "calls.bin"), os.path.join(td, "out.bin")
+        open(cin, "wb").write(prune_calls_pack(calls))
+        ref_run("prune", base_fbin, metric, str(M), cin, cout)
+        w = np.fromfile(cout, np.uint32)
+    res, pos = [], 0
+    for _ in calls:
+        n = int(w[pos]); res.append(w[pos + 1: pos + 1 + n].copy()); pos += 1 + n
+    assert pos == w.size
+    return res

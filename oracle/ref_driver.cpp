@@ -21,6 +21,7 @@
 // with oracle/rg_oracle.c.
 #include <omp.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstdint>
 #include <cstdio>
@@ -297,8 +298,137 @@ static int cmd_ep(int argc, char **argv) {
     return 0;
 }
 
+// prune base.fbin <l2|ip> M calls.bin out.bin : the four occlusion-pruning rules of the construction, one call after the other.
+// src/index_bipartite.cpp cannot be compiled here (see the header), so the rules are restated around the reference's genuine
+// objects -- Distance::compare for every distance, Neighbor with ITS operator< under std::sort and ITS operator== under std::find:
+//   kind 0  PruneBiSearchBaseGetBase                     (:1612-1694)  pool = (id, distance) pairs in search order, pivot = tgt_base
+//   kind 1  PruneProjectionReverseCandidates             (:1526-1610)  pool = ids of the list (distances are computed), pivot = src_node
+//   kind 2  PruneProjectionInternalReverseCandidates     (:1434-1524)  the same with the queue starting as list.size() value-initialised
+//                                                                      Neighbors (:1438) and no top-up
+//   kind 3  PruneProjectionBaseSearchCandidates          (:1846-1940)  pool = (id, distance) pairs, pivot = qid, have = projection_graph_[qid]
+// calls.bin = u32 ncalls, then per call: u32 kind, pivot, np, nhave; u32 ids[np]; f32 dists[np]; u32 have[nhave]
+// out.bin   = per call: u32 n; u32 ids[n]
+namespace prune_rules {
+struct Ctx {
+    const efanna2e::Distance *dist;
+    const float *data;
+    size_t dim;
+    uint32_t M;
+    float d(uint32_t a, uint32_t b) const { return dist->compare(data + dim * a, data + dim * b, (unsigned)dim); }
+};
+// one occlusion sweep over q[start + 1 ..): a candidate joins unless it is in the result, or some member of the result is
+// closer to it than it is to the pivot; `self` never joins; refuse_dup = the extra std::find of the second sweeps
+static void sweep(const Ctx &c, std::vector<Neighbor> &q, uint32_t &start, uint32_t self, std::vector<uint32_t> &result, bool refuse_dup) {
+    while (result.size() < c.M && (++start) < q.size()) {
+        Neighbor &p = q[start];
+        bool occlude = false;
+        for (size_t t = 0; t < result.size() && !occlude; ++t) {
+            if (p.id == result[t]) { occlude = true; break; }
+            const float djk = c.d(p.id, result[t]);
+            if (refuse_dup ? (1.0 * djk < p.distance) : (djk < p.distance)) occlude = true;
+        }
+        if (occlude || p.id == self) continue;
+        if (refuse_dup && std::find(result.begin(), result.end(), p.id) != result.end()) continue;
+        result.push_back(p.id);
+    }
+}
+static std::vector<uint32_t> get_base(const Ctx &c, std::vector<Neighbor> &search_pool, uint32_t tgt) {
+    std::vector<Neighbor> base_pool;
+    std::vector<uint32_t> seen;
+    for (auto &b : search_pool) {
+        if (std::find(seen.begin(), seen.end(), b.id) != seen.end() || b.id == tgt) continue;
+        base_pool.push_back(b);
+        seen.push_back(b.id);
+    }
+    std::sort(base_pool.begin(), base_pool.end());
+    std::vector<uint32_t> result;
+    uint32_t start = 0;
+    result.push_back(base_pool[start].id);
+    sweep(c, base_pool, start, tgt, result, false);
+    start = 0;                                   // the second sweep walks the search pool as it came, and skips members first
+    while (result.size() < c.M && (++start) < search_pool.size()) {
+        Neighbor &p = search_pool[start];
+        if (std::find(result.begin(), result.end(), p.id) != result.end()) continue;
+        bool occlude = false;
+        for (size_t t = 0; t < result.size() && !occlude; ++t) {
+            if (p.id == result[t]) { occlude = true; break; }
+            if (1.0 * c.d(p.id, result[t]) < p.distance) occlude = true;
+        }
+        if (!occlude && p.id != tgt && std::find(result.begin(), result.end(), p.id) == result.end()) result.push_back(p.id);
+    }
+    for (size_t i = 1; i < base_pool.size() && result.size() < c.M; ++i)
+        if (std::find(result.begin(), result.end(), base_pool[i].id) == result.end() && base_pool[i].id != tgt) result.push_back(base_pool[i].id);
+    return result;
+}
+static std::vector<uint32_t> reverse(const Ctx &c, uint32_t src, const std::vector<uint32_t> &list, bool phantoms) {
+    std::vector<Neighbor> q(phantoms ? list.size() : 0);          // (:1438: value-initialised entries, id 0 / distance 0)
+    for (uint32_t id : list) {
+        const Neighbor nn(id, c.d(src, id), false);
+        if (std::find(q.begin(), q.end(), nn) == q.end()) q.push_back(nn);
+    }
+    std::sort(q.begin(), q.end());
+    std::vector<uint32_t> result;
+    uint32_t start = 0;
+    if (q[start].id == src) ++start;
+    result.push_back(q[start].id);
+    sweep(c, q, start, src, result, false);
+    start = 0;
+    sweep(c, q, start, src, result, true);
+    if (!phantoms)
+        for (size_t i = 0; i < list.size() && result.size() < c.M; ++i)
+            if (std::find(result.begin(), result.end(), list[i]) == result.end()) result.push_back(list[i]);
+    return result;
+}
+static std::vector<uint32_t> search(const Ctx &c, std::vector<Neighbor> &pool, uint32_t qid, const std::vector<uint32_t> &have) {
+    std::sort(pool.begin(), pool.end());
+    std::vector<uint32_t> result;
+    uint32_t start = 0;
+    if (pool[start].id == qid) ++start;
+    while (std::find(have.begin(), have.end(), pool[start].id) != have.end()) ++start;
+    result.push_back(pool[start].id);
+    sweep(c, pool, start, qid, result, false);
+    start = 0;
+    sweep(c, pool, start, qid, result, true);
+    return result;
+}
+}  // namespace prune_rules
+
+static int cmd_prune(int argc, char **argv) {
+    if (argc < 7) return 2;
+    uint32_t n = 0, d = 0;
+    float *data = nullptr;
+    efanna2e::load_meta<float>(argv[2], n, d);
+    efanna2e::load_data<float>(argv[2], n, d, data);
+    data = efanna2e::data_align(data, n, d);
+    std::unique_ptr<efanna2e::Distance> dist(make_distance(argv[3]));
+    prune_rules::Ctx c{dist.get(), data, d, (uint32_t)atoi(argv[4])};
+    auto buf = slurp(argv[5]);
+    const uint32_t *w = (const uint32_t *)buf.data();
+    const uint32_t ncalls = *w++;
+    std::ofstream out(argv[6], std::ios::binary);
+    for (uint32_t i = 0; i < ncalls; ++i) {
+        const uint32_t kind = w[0], pivot = w[1], np = w[2], nhave = w[3];
+        const uint32_t *ids = w + 4;
+        const float *ds = (const float *)(ids + np);
+        const uint32_t *have = (const uint32_t *)(ds + np);
+        w = have + nhave;
+        std::vector<uint32_t> res;
+        if (kind == 1 || kind == 2) res = prune_rules::reverse(c, pivot, std::vector<uint32_t>(ids, ids + np), kind == 2);
+        else {
+            std::vector<Neighbor> pool;
+            for (uint32_t j = 0; j < np; ++j) pool.push_back(Neighbor(ids[j], ds[j], false));
+            res = kind == 0 ? prune_rules::get_base(c, pool, pivot) : prune_rules::search(c, pool, pivot, std::vector<uint32_t>(have, have + nhave));
+        }
+        const uint32_t m = (uint32_t)res.size();
+        out.write((const char *)&m, 4);
+        out.write((const char *)res.data(), (std::streamsize)m * 4);
+    }
+    std::cout << "OK " << ncalls << std::endl;
+    return 0;
+}
+
 int main(int argc, char **argv) {
-    if (argc < 2) { std::cerr << "usage: rg_ref <dist|queue|search|meta|gtload|fbinload|ep> ..." << std::endl; return 2; }
+    if (argc < 2) { std::cerr << "usage: rg_ref <dist|queue|search|meta|gtload|fbinload|ep|prune> ..." << std::endl; return 2; }
     std::string c = argv[1];
     try {
         if (c == "dist") return cmd_dist(argc, argv);
@@ -308,6 +438,7 @@ int main(int argc, char **argv) {
         if (c == "gtload") return cmd_gtload(argc, argv);
         if (c == "fbinload") return cmd_fbinload(argc, argv);
         if (c == "ep") return cmd_ep(argc, argv);
+        if (c == "prune") return cmd_prune(argc, argv);
     } catch (const std::exception &e) {
         std::cout << "EXC: " << e.what() << std::endl;
         return 3;

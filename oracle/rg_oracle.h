@@ -109,6 +109,9 @@ int rgo_build_roargraph(const float *base, size_t stride, uint32_t nb, unsigned 
 int rgo_build_roargraph_sched(const float *base, size_t stride, uint32_t nb, unsigned d, int metric, const uint32_t *knn, uint32_t nq,
                               uint32_t knn_k, uint32_t M_sq, uint32_t M_pjbp, uint32_t L_pjpq, const uint32_t *sched, uint32_t nsched,
                               uint32_t *out_ep, uint64_t **out_off, uint32_t **out_nbrs);
+/* one call of one occlusion-pruning rule of the construction (rg_oracle_build.c; kinds as in `rg_ref prune`) */
+int rgo_prune(const float *base, size_t stride, uint32_t nb, unsigned d, int metric, uint32_t M, int kind, uint32_t pivot, const uint32_t *ids,
+              const float *dists, uint32_t np, const uint32_t *have, uint32_t nhave, uint32_t *out, uint32_t *nout);
 
 /* a10: exact top-K ground truth (DiskANN compute_groundtruth; source absent, README.md:62-75).
  * fp64 accumulation; order: mips = score desc then id asc, l2 = dist asc then id asc.

@@ -324,3 +324,38 @@ int rgo_build_roargraph(const float *base_in, size_t stride, uint32_t nb, unsign
                         uint32_t **out_nbrs) {
     return rgo_build_roargraph_sched(base_in, stride, nb, d, metric, knn, nq, knn_k, M_sq, M_pjbp, L_pjpq, NULL, 0, out_ep, out_off, out_nbrs);
 }
+
+
+/* One call of one pruning rule (tests: the rules against the goldens `rg_ref prune` made with the reference's own Distance / Neighbor
+ * objects -- tests/golden/prune_*.npz).  kind 0 = PruneBiSearchBaseGetBase, 1 = PruneProjectionReverseCandidates, 2 =
+ * PruneProjectionInternalReverseCandidates, 3 = PruneProjectionBaseSearchCandidates (`have` = projection_graph_[pivot]).
+ * out has room for max(M, np) ids; returns 0. */
+int rgo_prune(const float *base, size_t stride, uint32_t nb, unsigned d, int metric, uint32_t M, int kind, uint32_t pivot, const uint32_t *ids,
+              const float *dists, uint32_t np, const uint32_t *have, uint32_t nhave, uint32_t *out, uint32_t *nout) {
+    B b;
+    memset(&b, 0, sizeof b);
+    b.base = base; b.stride = stride; b.d = d; b.metric = metric; b.nd = nb; b.M = M;
+    list_t res = {0};
+    if (kind == 1 || kind == 2) {
+        for (uint32_t i = 0; i < np; ++i) list_push(&res, ids[i]);
+        prune_reverse(&b, pivot, &res, kind == 2);
+    } else {
+        nb_t *pool = (nb_t *)malloc(((size_t)np + 1) * sizeof(nb_t));
+        for (uint32_t i = 0; i < np; ++i) { pool[i].id = ids[i]; pool[i].dist = dists[i]; }
+        if (kind == 0) prune_get_base(&b, pool, np, pivot, &res);
+        else {
+            list_t hv = {0};
+            for (uint32_t i = 0; i < nhave; ++i) list_push(&hv, have[i]);
+            b.proj = (list_t *)calloc((size_t)pivot + 1, sizeof(list_t));
+            b.proj[pivot] = hv;
+            prune_search(&b, pool, np, pivot, &res);
+            free(hv.v);
+            free(b.proj);
+        }
+        free(pool);
+    }
+    for (uint32_t i = 0; i < res.n; ++i) out[i] = res.v[i];
+    *nout = res.n;
+    free(res.v);
+    return 0;
+}

@@ -39,3 +39,25 @@ def build_schedule(nb, batch=0):
     out = np.zeros(max(n.value, 1), np.uint32)
     check(lib().rg_build_schedule(C.c_uint32(nb), C.c_uint32(batch), out.ctypes.data_as(C.c_void_p), C.c_uint32(out.size), C.byref(n)))
     return out[: n.value]
+
+
+PRUNE_KINDS = {"get_base": 0, "reverse": 1, "reverse_phantoms": 2, "search": 3}
+
+
+def prune_debug(base, metric, M, kind, pivot, ids, dists=None, have=None, use_gpu=False, device=0):
+    """rg_build_prune_debug: ONE call of one occlusion-pruning rule of the construction (index_bipartite.cpp:1434-1694, 1846-1940) through
+    the builder's host routine (use_gpu=False: no GPU needed) or the pruning kernel of the GPU-assisted build (kinds get_base / search)."""
+    import ctypes as C
+    import numpy as np
+    from ._lib import METRIC, check, lib
+    base = np.ascontiguousarray(base, np.float32)
+    ids = np.ascontiguousarray(ids, np.uint32)
+    dists = np.ascontiguousarray(dists if dists is not None else np.zeros(ids.size), np.float32)
+    have = np.ascontiguousarray(have if have is not None else np.zeros(0), np.uint32)
+    out = np.zeros(max(int(M), ids.size) + 1, np.uint32)
+    n = C.c_uint32()
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    check(lib().rg_build_prune_debug(vp(base), C.c_uint32(base.shape[0]), C.c_uint32(base.shape[1]), C.c_uint32(base.shape[1]), METRIC[metric], C.c_uint32(M),
+                                     C.c_int(kind if isinstance(kind, int) else PRUNE_KINDS[kind]), C.c_uint32(pivot), vp(ids), vp(dists), C.c_uint32(ids.size),
+                                     vp(have), C.c_uint32(have.size), vp(out), C.byref(n), C.c_int(1 if use_gpu else 0), C.c_int(device)))
+    return out[: n.value].copy()

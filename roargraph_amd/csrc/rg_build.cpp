@@ -1381,3 +1381,98 @@ extern "C" rg_status rg_build_schedule(uint32_t nb, uint32_t batch, uint32_t *si
     *count = (uint32_t)s.size();
     return RG_OK;
 }
+
+/* One call of one pruning rule of the construction (tests: the product's rules against tests/golden/prune_*.npz, which `rg_ref prune`
+ * made with the reference's own Distance / Neighbor objects).  kind 0 = PruneBiSearchBaseGetBase (:1612-1694), 1 =
+ * PruneProjectionReverseCandidates (:1526-1610), 2 = PruneProjectionInternalReverseCandidates (:1434-1524), 3 =
+ * PruneProjectionBaseSearchCandidates (:1846-1940; `have` = projection_graph_[pivot]).  use_gpu = 0: the host routines of the builder
+ * (no GPU needed); 1: the pruning kernel (rg_build_prune.hip) as the GPU-assisted build launches it -- kind 3 from an expansion list,
+ * kind 0 from a knn row whose first entry is the pivot (the distances are then computed on the device and `dists` is ignored). */
+extern "C" rg_status rg_build_prune_debug(const float *base, uint32_t nb, uint32_t dim, uint32_t stride, int metric, uint32_t M, int kind, uint32_t pivot,
+                                          const uint32_t *ids, const float *dists, uint32_t np, const uint32_t *have, uint32_t nhave, uint32_t *out,
+                                          uint32_t *nout, int use_gpu, int device) {
+    using rg::set_error;
+    if (!base || !ids || !out || !nout || (np && kind != 1 && kind != 2 && !dists) || (nhave && !have)) return set_error(RG_ERR_ARG, "null argument");
+    if (kind < 0 || kind > 3 || pivot >= nb || M == 0 || stride < dim) return set_error(RG_ERR_ARG, "bad argument");
+    if (metric != RG_METRIC_L2 && metric != RG_METRIC_IP) return set_error(RG_ERR_ARG, "Unknown distance type");
+    for (uint32_t i = 0; i < np; ++i) if (ids[i] >= nb) return set_error(RG_ERR_ARG, "id >= npts");
+    try {
+        if (!use_gpu) {
+            rg::Builder b;
+            b.base = base; b.stride = stride; b.dim = dim; b.nd = nb;
+            b.l2 = metric == RG_METRIC_L2;
+#if defined(__x86_64__)
+            b.avx512 = __builtin_cpu_supports("avx512f") && __builtin_cpu_supports("fma");
+#else
+            b.avx512 = false;
+#endif
+            b.M = M;
+            std::vector<uint32_t> res;
+            if (kind == 1 || kind == 2) {
+                res.assign(ids, ids + np);
+                b.prune_reverse(pivot, res, kind == 2);
+            } else {
+                std::vector<rg::Nb> pool(np);
+                for (uint32_t i = 0; i < np; ++i) pool[i] = rg::Nb{ids[i], dists[i]};
+                if (kind == 0) b.prune_get_base(pool, pivot, res);
+                else {
+                    b.proj.resize((size_t)pivot + 1);
+                    b.proj[pivot].assign(have, have + nhave);
+                    b.prune_search(pool, pivot, res);
+                }
+            }
+            for (size_t i = 0; i < res.size(); ++i) out[i] = res[i];
+            *nout = (uint32_t)res.size();
+            return RG_OK;
+        }
+        if (kind != 0 && kind != 3) return set_error(RG_ERR_ARG, "the GPU prunes kinds 0 and 3 only");
+        if (dim % 8 || stride % 4) return set_error(RG_ERR_ARG, "GPU pruning needs dim % 8 == 0 and stride % 4 == 0");
+        int ndev = 0;
+        if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return set_error(RG_ERR_DEVICE, "no HIP device visible: the gfx950 path cannot run (there is no CPU fallback)");
+        if (hipSetDevice(device) != hipSuccess) return set_error(RG_ERR_DEVICE, "cannot select the device");
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, device) != hipSuccess) return set_error(RG_ERR_DEVICE, "hipGetDeviceProperties");
+        const uint32_t cap = std::max<uint32_t>(np, 1);
+        struct Dev { void *p = nullptr; ~Dev() { if (p) (void)hipFree(p); } };
+        Dev d_base, d_exp, d_nexp, d_have, d_out, d_knn, d_piv;
+        bool ok = hipMalloc(&d_base.p, (size_t)nb * stride * 4) == hipSuccess && hipMalloc(&d_exp.p, (size_t)cap * 8) == hipSuccess &&
+                  hipMalloc(&d_nexp.p, 4) == hipSuccess && hipMalloc(&d_have.p, ((size_t)nhave + 1) * 4) == hipSuccess &&
+                  hipMalloc(&d_out.p, ((size_t)M + 1) * 4) == hipSuccess && hipMalloc(&d_knn.p, (size_t)cap * 4) == hipSuccess && hipMalloc(&d_piv.p, 4) == hipSuccess;
+        if (!ok) return set_error(RG_ERR_OOM, "no device memory for the pruning test");
+        ok = hipMemcpy(d_base.p, base, (size_t)nb * stride * 4, hipMemcpyHostToDevice) == hipSuccess;
+        std::vector<uint32_t> h_out((size_t)M + 1, 0);
+        rg_status st = RG_OK;
+        if (kind == 3) {
+            std::vector<rg::uint2_pod> ex(cap);
+            for (uint32_t i = 0; i < np; ++i) { uint32_t bits; std::memcpy(&bits, &dists[i], 4); ex[i] = rg::uint2_pod{bits, ids[i]}; }
+            std::vector<uint32_t> hv((size_t)nhave + 1);
+            hv[0] = nhave;
+            for (uint32_t i = 0; i < nhave; ++i) hv[1 + i] = have[i];
+            ok = ok && hipMemcpy(d_exp.p, ex.data(), (size_t)cap * 8, hipMemcpyHostToDevice) == hipSuccess &&
+                 hipMemcpy(d_nexp.p, &np, 4, hipMemcpyHostToDevice) == hipSuccess && hipMemcpy(d_have.p, hv.data(), hv.size() * 4, hipMemcpyHostToDevice) == hipSuccess;
+            if (!ok) return set_error(RG_ERR_DEVICE, "upload failed");
+            rg_index ix;
+            ix.d_base = (float *)d_base.p; ix.nd = nb; ix.dim = dim; ix.stride = stride; ix.metric = metric; ix.device = device;
+            ix.num_cu = prop.multiProcessorCount;
+            if (!rg::build_prune_supported(&ix, M, cap)) return set_error(RG_ERR_ARG, "pruning kernel: shape not supported");
+            st = rg::build_prune_dev(&ix, pivot, 1, M, (const rg::uint2_pod *)d_exp.p, cap, (const uint32_t *)d_nexp.p, (const uint32_t *)d_have.p, nhave + 1,
+                                     (uint32_t *)d_out.p, nullptr);
+        } else {
+            if (np == 0 || ids[0] != pivot) return set_error(RG_ERR_ARG, "GPU kind 0: the pool is a knn row whose first entry is the pivot");
+            ok = ok && hipMemcpy(d_knn.p, ids, (size_t)np * 4, hipMemcpyHostToDevice) == hipSuccess;
+            if (!ok) return set_error(RG_ERR_DEVICE, "upload failed");
+            if (!rg::build_prune_knn_supported(dim, M, np, 160 * 1024)) return set_error(RG_ERR_ARG, "pruning kernel: shape not supported");
+            st = rg::build_prune_knn_dev((const float *)d_base.p, dim, stride, metric, device, prop.multiProcessorCount, 160 * 1024, (const uint32_t *)d_knn.p, 1, np, np, M,
+                                         (rg::uint2_pod *)d_exp.p, cap, (uint32_t *)d_piv.p, (uint32_t *)d_out.p, nullptr);
+        }
+        if (st != RG_OK) return st;
+        if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(h_out.data(), d_out.p, h_out.size() * 4, hipMemcpyDeviceToHost) != hipSuccess)
+            return set_error(RG_ERR_DEVICE, "the pruning kernel failed");
+        if (h_out[0] == 0xffffffffu) return set_error(RG_ERR_ARG, "the pruning kernel left this list to the host (a repeated id, or a list beyond its capacity)");
+        *nout = h_out[0];
+        for (uint32_t i = 0; i < h_out[0]; ++i) out[i] = h_out[1 + i];
+        return RG_OK;
+    } catch (const std::bad_alloc &) {
+        return set_error(RG_ERR_OOM, "out of host memory");
+    }
+}

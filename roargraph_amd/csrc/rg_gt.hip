@@ -196,12 +196,23 @@ struct QuotaRef {
     uint32_t *slots = nullptr;     // null = off
     uint32_t npieces = 0, piece = 0, pstride = 0, quota = 0;
 };
-// min over the pieces of what they published (-inf while some piece has published nothing); `mine` stands in for this piece's own slot
+// The largest float below f (f itself for -inf).  The bound the pieces SHARE goes through this: the tile filter admits
+// `score > threshold`, strictly -- right for a piece's OWN K-th value, whose holder is already in the buffer, but a row of another piece
+// that ties with min_j u_j exactly (duplicated base rows in different segments) must still pass, or which of two equal rows survives
+// would depend on when the bound arrived, and not on the id as the unsegmented path and K3 have it.
+__device__ __forceinline__ float next_below(float f) {
+    if (f == -__builtin_inff()) return f;
+    f += 0.0f;                                                   // -0 -> +0
+    if (f == 0.0f) return __uint_as_float(0x80000001u);          // the largest float below zero
+    return ord2f(f2ord(f) - 1u);
+}
+// min over the pieces of what they published (-inf while some piece has published nothing); `mine` stands in for this piece's own slot.
+// Any number of pieces (the balanced form allows 1024 / K of them: more than a wave's 64 lanes only at K <= 15)
 __device__ __forceinline__ float quota_min(const QuotaRef &qr, float mine, int lane) {
     float t = __builtin_inff();
-    if ((uint32_t)lane < qr.npieces)
-        t = (uint32_t)lane == qr.piece ? mine
-                                       : __uint_as_float(__hip_atomic_load(qr.slots + (size_t)lane * qr.pstride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    for (uint32_t j = (uint32_t)lane; j < qr.npieces; j += 64u)
+        t = fminf(t, j == qr.piece ? mine
+                                   : __uint_as_float(__hip_atomic_load(qr.slots + (size_t)j * qr.pstride, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
     for (int o = 32; o; o >>= 1) t = fminf(t, __shfl_xor(t, o, 64));
     return t;
 }
@@ -281,7 +292,7 @@ __device__ __forceinline__ void gt_select(u64 *buf, uint32_t *cnt, float *thr, u
             mine = ord2f(~kth_value(qr.quota, lo, v));
             if (lane == 0) __hip_atomic_store(qr.slots + (size_t)qr.piece * qr.pstride, __float_as_uint(mine), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        t = fmaxf(own, quota_min(qr, mine, lane));
+        t = fmaxf(own, next_below(quota_min(qr, mine, lane)));
     }
     if (lane == 0) {
         if (n > K) *cnt = K;
@@ -684,7 +695,7 @@ __global__ void __launch_bounds__(256, WPS) rg_gt_rs_kernel(GtParams P0) {
                                         float t = __builtin_inff();
                                         for (uint32_t j = 0; j < (pw & 0xffffu); ++j)
                                             t = fminf(t, __uint_as_float(__hip_atomic_load(sl + (size_t)j * MQB, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
-                                        thr[qi] = fmaxf(thr[qi], t);
+                                        thr[qi] = fmaxf(thr[qi], next_below(t));      // (strictly below the bound: its ties must pass)
                                     }
                                 }
                                 __syncthreads();

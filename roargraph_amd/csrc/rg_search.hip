@@ -1157,7 +1157,8 @@ static rg_status launch_k1(rg_index *ix, SearchCtx *cx, int mode, const float *d
         if (tb >= 8 && id_bits_of(ix->nd) <= tb - 2 + 15) { P.count_tbits = tb; P.count_mode = mode == 3 ? 0u : 1u; }
     }
     P.id_mask = (ix->ell_tagged && !bp) ? 0x00ffffffu : 0xffffffffu;
-    P.vf_min_indeg = (uint32_t)std::max(0, std::min(255, ix->filter_min_indeg));
+    // (the in-degree tag of a neighbour word is a nibble since round 5 -- min(15, in-degree): a knob above 15 means 15)
+    P.vf_min_indeg = (uint32_t)std::max(0, std::min(15, ix->filter_min_indeg));
 #ifdef RG_K1_PROF
     P.prof = (qlist || bp) ? nullptr : g_prof_buf;
 #endif

@@ -12,10 +12,14 @@ can check both the oracle and the HIP path against them.
                               (genuine queue + visited pool + distance, loop restated -- see oracle/ref_driver.cpp)
   G4 formats.npz              bytes of small .fbin / gt files (good and truncated) + what util.h's loaders said
 
+  G6 prune_<name>.npz         calls of the four occlusion-pruning rules of the construction (index_bipartite.cpp:1434-1694, 1846-1940) over the
+                              base of search_<name>.npz: pools with the reference's own distance bits, and the lists `rg_ref prune` returned
+                              (genuine Distance::compare, Neighbor::operator< under std::sort, operator== under std::find; rules restated)
+
   G5 cli_table.json           the stdout header / row / CSV row FORMATS of tests/test_search_roargraph.cpp (:190, :231-236):
                               the string literals of its stream statements evaluated, variables left as {name}
 
-usage: python scripts/make_golden.py [g1 g2 g3 g3c g4 g5]   (default: all)
+usage: python scripts/make_golden.py [g1 g2 g3 g3c g4 g5 g6]   (default: all)
 """
 import os
 import subprocess
@@ -196,13 +200,93 @@ def g5():
     json.dump(out, open(os.path.join(OUT, "cli_table.json"), "w"), indent=1)
 
 
+def prune_calls(base, metric, rng, M):
+    """Seeded calls of the four rules with pools shaped like the construction's: near neighbours of the pivot (so that occlusion
+    happens), a few far rows, ties, repeated ids, the pivot itself, node 0, lists longer and shorter than M."""
+    nb = base.shape[0]
+    sc = (base @ base.T) if metric == "ip" else -((base[:, None, :2] - base[None, :, :2]) ** 2).sum(-1)      # a cheap notion of "near"
+    if metric != "ip":
+        g = base @ base.T
+        n2 = (base * base).sum(1)
+        sc = -(n2[:, None] + n2[None, :] - 2 * g)
+    calls = []
+
+    def dists_to(pivot, ids):
+        return po.ref_dist(metric, base[np.asarray(ids, np.int64)], np.repeat(base[pivot][None], len(ids), 0))
+    for _ in range(40):      # kind 0: a training query's knn row scored against its nearest base point (:1074-1082)
+        qv = rng.standard_normal(base.shape[1]).astype(np.float32) * 0.5 + 0.3
+        s_q = base @ qv if metric == "ip" else -((base - qv) ** 2).sum(1)
+        row = np.argsort(-s_q)[: int(rng.integers(5, 101))].astype(np.uint32)
+        pivot = int(row[0])
+        if rng.random() < 0.25:      # repeated ids / the pivot again (the rule keeps first occurrences; host only in the product)
+            row = np.concatenate([row, row[rng.integers(0, row.size, 3)], [pivot]]).astype(np.uint32)
+        calls.append(("get_base", pivot, row, dists_to(pivot, row), None))
+    for kind in ("reverse", "reverse_phantoms"):      # a list that grew beyond its limit by one reverse edge (:1391-1432, :1352-1389)
+        for _ in range(40):
+            src = int(rng.integers(0, nb))
+            near = np.argsort(-sc[src])[: 3 * M]
+            n = int(rng.integers(2, 2 * M + 2))
+            lst = rng.choice(near, size=min(n, near.size), replace=False).astype(np.uint32)
+            extra = rng.integers(0, nb, int(rng.integers(0, 4))).astype(np.uint32)
+            lst = np.concatenate([lst, extra])
+            if rng.random() < 0.3:
+                lst = np.concatenate([lst, [0]]).astype(np.uint32)          # node 0 meets the phantoms of :1438
+            if rng.random() < 0.2:
+                lst = np.concatenate([lst, lst[:2]]).astype(np.uint32)      # repeated ids (std::find drops them)
+            if rng.random() < 0.2:
+                lst = np.concatenate([[src], lst]).astype(np.uint32)        # the pivot itself in its list
+            calls.append((kind, src, rng.permutation(lst).astype(np.uint32), None, None))
+    for _ in range(40):      # kind 3: the expansion list of a node's own search (:1192-1220) against its projection list
+        node = int(rng.integers(0, nb))
+        order = np.argsort(-sc[node])
+        order = order[order != node]
+        np_ = int(rng.integers(3, 400))
+        pool = np.concatenate([order[: np_ // 2], rng.choice(order[np_ // 2: 8 * np_], size=np_ - np_ // 2, replace=False)]).astype(np.uint32)
+        if rng.random() < 0.3:
+            pool = np.concatenate([pool, [node]]).astype(np.uint32)         # (the entry point can be the node)
+        pool = rng.permutation(pool).astype(np.uint32)
+        ds = dists_to(node, pool)
+        srt = pool[np.lexsort((pool, ds))]
+        nh = int(rng.integers(0, min(M, srt.size - 2) + 1))
+        have = np.concatenate([srt[srt != node][: nh // 2], rng.integers(0, nb, nh - nh // 2)]).astype(np.uint32)     # the nearest ones are neighbours already
+        calls.append(("search", node, pool, ds, have))
+    return calls
+
+
+def g6():
+    with tempfile.TemporaryDirectory() as td:
+        for name, seed in (("ip200", 61), ("l2_512", 62)):
+            z = np.load(os.path.join(OUT, "search_%s.npz" % name))
+            base, metric = z["base"], str(z["metric"])
+            bf = os.path.join(td, "b.fbin")
+            io.write_fbin(bf, base)
+            rng = np.random.default_rng(seed)
+            rec = {"kind": [], "pivot": [], "M": [], "pool_off": [0], "pool_ids": [], "pool_dist_bits": [], "have_off": [0], "have": [], "out_off": [0], "out": []}
+            for M in (8, 35):
+                calls = prune_calls(base, metric, rng, M)
+                res = po.ref_prune(bf, metric, M, calls)
+                for (kind, pivot, ids, ds, have), r in zip(calls, res):
+                    rec["kind"].append(po.PRUNE_KINDS[kind]); rec["pivot"].append(pivot); rec["M"].append(M)
+                    rec["pool_ids"].append(np.asarray(ids, np.uint32))
+                    rec["pool_dist_bits"].append((np.asarray(ds, np.float32) if ds is not None else np.zeros(len(ids), np.float32)).view(np.uint32))
+                    rec["have"].append(np.asarray(have if have is not None else [], np.uint32))
+                    rec["out"].append(np.asarray(r, np.uint32))
+                    rec["pool_off"].append(rec["pool_off"][-1] + len(ids)); rec["have_off"].append(rec["have_off"][-1] + rec["have"][-1].size)
+                    rec["out_off"].append(rec["out_off"][-1] + len(r))
+            np.savez_compressed(os.path.join(OUT, "prune_%s.npz" % name), base_of="search_%s.npz" % name, metric=metric,
+                                kind=np.array(rec["kind"], np.uint32), pivot=np.array(rec["pivot"], np.uint32), M=np.array(rec["M"], np.uint32),
+                                pool_off=np.array(rec["pool_off"], np.uint64), pool_ids=np.concatenate(rec["pool_ids"]),
+                                pool_dist_bits=np.concatenate(rec["pool_dist_bits"]), have_off=np.array(rec["have_off"], np.uint64),
+                                have=np.concatenate(rec["have"]), out_off=np.array(rec["out_off"], np.uint64), out=np.concatenate(rec["out"]))
+
+
 if __name__ == "__main__":
     subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle")])
     if not po.have_ref():
         sys.exit("oracle/_ref/rg_ref is not available (needs /root/reference and an AVX-512 host)")
     os.makedirs(OUT, exist_ok=True)
     only = sys.argv[1:]
-    for name, fn in (("g1", g1), ("g2", g2), ("g3", g3), ("g3c", g3_cosine), ("g4", g4), ("g5", g5)):
+    for name, fn in (("g1", g1), ("g2", g2), ("g3", g3), ("g3c", g3_cosine), ("g4", g4), ("g5", g5), ("g6", g6)):
         if not only or name in only:
             fn()
     tot = sum(os.path.getsize(os.path.join(OUT, f)) for f in os.listdir(OUT))

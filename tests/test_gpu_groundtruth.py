@@ -367,3 +367,29 @@ def test_quota_thresholds_when_one_piece_holds_every_neighbour(oracle, metric, d
     monkeypatch.setenv("RG_GT_NOSHARE", "1")
     ids2, dists2 = groundtruth.compute_groundtruth(base, q, metric, K)
     assert (ids2 == ids).all() and (dists2.view(np.uint32) == dists.view(np.uint32)).all()
+
+
+def test_ties_across_the_pieces_of_a_query_block_keep_the_smaller_id(oracle, monkeypatch):
+    """the bound the pieces of a query block share (min_j u_j, quota thresholds) reaches a piece's filter as a STRICT threshold.
+    Duplicated base rows in different pieces score exactly alike; if the bound equals that score, the piece that hears of it first would
+    drop its twin -- possibly the one with the SMALLER id -- and the result would depend on timing.  The shared bound is therefore the
+    next float below min_j u_j.  48,000 rows in pieces of a few thousand, every row duplicated 24,000 rows further on, few queries:
+    equal scores must come out id-ascending, and the lists must not depend on RG_GT_NOSHARE (every piece on its own) -- five times."""
+    from roargraph_amd import groundtruth
+    rng = np.random.default_rng(77)
+    nb, nq, K, d = 48_000, 96, 100, 200
+    half = rng.standard_normal((nb // 2, d)).astype(np.float32)
+    base = np.concatenate([half, half])
+    q = rng.standard_normal((nq, d)).astype(np.float32)
+    ref_ids, _, ref_s = oracle.groundtruth_f64(base, q, "ip", K, nthreads=16)
+    runs = []
+    for _ in range(5):
+        ids, dists = groundtruth.compute_groundtruth(base, q, "ip", K)
+        assert (ids[:, 0::2] + nb // 2 == ids[:, 1::2]).all(), "equal scores must be ordered by id"
+        assert (dists[:, 0::2].view(np.uint32) == dists[:, 1::2].view(np.uint32)).all()
+        runs.append(ids)
+    assert all((r == runs[0]).all() for r in runs)
+    check_gt(base, q, "ip", K, runs[0], dists, ref_ids, ref_s)
+    monkeypatch.setenv("RG_GT_NOSHARE", "1")
+    ids2, dists2 = groundtruth.compute_groundtruth(base, q, "ip", K)
+    assert (ids2 == runs[0]).all() and (dists2.view(np.uint32) == dists.view(np.uint32)).all()
