@@ -56,6 +56,11 @@ SWEEP_README = ("10,15,20,25,30,35,40,45,50,55,60,65,70,75,80,85,90,95,100,105,1
                 "190,195,200,220,240,260,280,300,350,400,450,500,550,600,700,800,900,1000,1500,2000")
 
 
+from benchlib import legs  # noqa: E402
+from benchlib.report import compact_line  # noqa: E402
+from benchlib.workloads import MALL_ROWS, _mem_available_gb, pmc_traffic, progress  # noqa: E402
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -69,7 +74,7 @@ def parse():
     ap.add_argument("--k", type=int, default=10)
     ap.add_argument("--metric", default="ip")
     ap.add_argument("--data", default="lowrank", help="lowrank (default: structured embeddings, where a graph index reaches high "
-                    "recall) | gaussian (no structure at all)")
+                    "recall) | mixture (1,000 clusters in the latent space: low reuse between queries) | gaussian (no structure at all)")
     ap.add_argument("--rank", type=int, default=32, help="latent rank of --data lowrank")
     ap.add_argument("--graph", default="roargraph", help="roargraph (default: genuine index built in the run) | random (out-degree --deg)")
     ap.add_argument("--real-index", action="store_true", help="(kept for older command lines) same as --graph roargraph")
@@ -79,12 +84,12 @@ def parse():
     ap.add_argument("--target-recall", type=float, default=0.90)
     ap.add_argument("--sweep", default=SWEEP_DEFAULT, help="comma list of L_pq values (empty = none); `readme` = the reference's own 56-point "
                     "evaluation list (README.md:118)")
-    ap.add_argument("--configs", default="rank128,webvid,laion", help="comma list of the side blocks of the default run, each a smaller build + search "
-                    "of its own with roofline and cpu_baseline (rank 0, N = 1): rank128 = a harder data set (latent rank 128: 0.9 recall "
-                    "needs a beam ten times as wide), webvid = BASELINE configs[4] end to end (2.5M x 512 IP: ground truth -> build -> "
+    ap.add_argument("--configs", default="mixture,webvid,laion", help="comma list of the side blocks of the default run, each a smaller build + search "
+                    "of its own with roofline and cpu_baseline (rank 0, N = 1): mixture = the headline's shape on data with LOW REUSE between queries "
+                    "(1,000 clusters, latent rank 128), rank128 = latent rank 128 without clusters (round 5's block), webvid = BASELINE configs[4] end to end (2.5M x 512 IP: ground truth -> build -> "
                     "search), laion = BASELINE configs[3] shape (d = 512 L2 top-100) at the size --laion-nb; empty = none")
     ap.add_argument("--side-nb", type=int, default=0, help="rows of EVERY side block (tests: small sets); 0 = their own sizes")
-    ap.add_argument("--rank128-nb", type=int, default=10_000_000, help="rows of the rank128 side block (default: the headline's size)")
+    ap.add_argument("--rank128-nb", type=int, default=10_000_000, help="rows of the rank128 / mixture side blocks (default: the headline's size)")
     ap.add_argument("--laion-nb", type=int, default=2_000_000, help="rows of the laion-shaped side block (the full 10M x 512 run: "
                     "python bench.py --nb 10000000 --dim 512 --metric l2 --k 100 --configs '')")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall budget of each CPU baseline sample (0 = skip)")
@@ -115,383 +120,12 @@ def parse():
     return ap.parse_args()
 
 
-def _mem_available_gb():
-    try:
-        for line in open("/proc/meminfo"):
-            if line.startswith("MemAvailable"):
-                return int(line.split()[1]) / 1e6
-    except OSError:
-        pass
-    return 0.0
-
-
-def cpu_search_baseline(base_np, off, nbrs, ep, q_np, ids_gpu, metric, k, L, threads_list, budget_s):
-    """The CPU path on a bounded sample of the same workload, once per entry of threads_list, each checked against the
-    GPU's ids (an AssertionError here is a parity failure and ends the run).  oracle/_ref/rg_ref when it can run (the
-    reference's own headers), else the AVX-512 restatement oracle/librg_oracle.so."""
-    from oracle import pyoracle as po
-    from roargraph_amd import io
-    po.build() if not os.path.exists(po.LIB_PATH) else None
-    nq = q_np.shape[0]
-    po.use_avx512(True)
-    use_ref = po.have_ref() and _mem_available_gb() > 3.0 * base_np.nbytes / 1e9
-    outs = []
-    with tempfile.TemporaryDirectory(dir="/dev/shm" if os.path.isdir("/dev/shm") else None) as td:
-        bf, qf, gf = (os.path.join(td, x) for x in ("b.fbin", "q.fbin", "g.index"))
-        if use_ref:
-            io.write_fbin(bf, base_np)
-            io.write_index(gf, off, nbrs, ep)
-        for threads in threads_list:
-            out = {"unit": "QPS", "cores": threads, "host_cores": os.cpu_count() or 1, "L_pq": L}
-            pilot = min(nq, 2 * threads)     # sized with the C port
-            t0 = time.time()
-            r = po.search(base_np, metric, off, nbrs, ep, q_np[:pilot], k, L, nthreads=threads)
-            dt = max(time.time() - t0, 1e-6)
-            assert (r[0] == ids_gpu[:pilot]).all(), "CPU oracle and GPU disagree on the bench workload (L_pq=%d)" % L
-            n = int(min(nq, max(pilot, budget_s * pilot / dt)))
-            n = max(threads, n - n % threads)
-            if use_ref:
-                io.write_fbin(qf, q_np[:n])
-                # the reference's loop issues two software prefetches per neighbour (index_bipartite.cpp:2374-2375) and one
-                # prefetch_vector of the entry point (:2324): that form is `value`; the loop without them (what round 2
-                # timed) is recorded beside it
-                ids, _, cmps, _, qps = po.ref_search(bf, gf, qf, metric, k, L, threads=threads, prefetch=True)
-                assert (ids == ids_gpu[:n]).all(), "reference-header driver and GPU disagree on the bench workload (L_pq=%d)" % L
-                ids_np, _, _, _, qps_np = po.ref_search(bf, gf, qf, metric, k, L, threads=threads, prefetch=False)
-                assert (ids_np == ids).all()
-                out.update(value=qps, value_without_prefetch=qps_np, kind="reference", mean_evals=float(np.mean(cmps)),
-                           sample="%d queries, %d OpenMP thread(s), oracle/_ref/rg_ref (reference distance.h/neighbor.h/"
-                                  "visited_list_pool.h; search loop restated with the reference's software prefetches, "
-                                  "index_bipartite.cpp:2324,2374-2375), ids equal the GPU's" % (n, threads))
-            else:
-                t0 = time.time()
-                r = po.search(base_np, metric, off, nbrs, ep, q_np[:n], k, L, nthreads=threads)
-                dt = time.time() - t0
-                assert (r[0] == ids_gpu[:n]).all(), "CPU oracle and GPU disagree on the bench workload (L_pq=%d)" % L
-                out.update(value=n / dt, kind="port", mean_evals=float(np.mean(r[2])),
-                           sample="%d queries, %d OpenMP thread(s), oracle/librg_oracle.so (avx512=%s), ids equal the GPU's"
-                                  % (n, threads, bool(po.have_avx512())))
-            outs.append(out)
-    return outs
-
-
-def gt_cpu_baseline(base, gq, args):
-    """CPU baseline of the ground-truth leg: oracle/gt_numpy.py (blocked SGEMM on all host cores + per-query top-K, the
-    shape of the reference's compute_groundtruth) on a bounded sample of the same workload."""
-    sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import gt_numpy
-    nbs, nqs = min(args.nb, 1_000_000), min(int(gq.shape[0]), 2048)
-    hb = base[:nbs].cpu().numpy()
-    hq = gq[:nqs].cpu().numpy()
-    gt_numpy.groundtruth_blocked(hb[:65536], hq[:64], args.metric, args.gt_K)   # warm the BLAS threads
-    t0 = time.perf_counter()
-    gt_numpy.groundtruth_blocked(hb, hq, args.metric, args.gt_K)
-    dt = time.perf_counter() - t0
-    return {"value": float(nbs) * float(nqs) / dt, "unit": "distances/s", "cores": os.cpu_count() or 1, "kind": "port",
-            "sample": "%d queries x %d base rows, K=%d, numpy/OpenBLAS SGEMM + argpartition per 131072-row block "
-                      "(oracle/gt_numpy.py), %.1f s" % (nqs, nbs, args.gt_K, dt)}
-
-
-def pmc_traffic(key):
-    """HBM bytes per launch of the search kernel from the committed rocprofv3 PMC passes (profiles/*/search_traffic*.json:
-    separate --pmc FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE with the gfx950 x2 correction).  Counters cannot be read from
-    inside the timed process, so the figure is reported only when a committed profile is of the workload being benched."""
-    import glob
-    paths = glob.glob(os.path.join(ROOT, "profiles", "**", "search_traffic*.json"), recursive=True)
-    # newest round first (profiles/r04/... before profiles/r03/final/...), inside a round the deepest ("final") first
-    for path in sorted(paths, key=lambda q: (os.path.relpath(q, ROOT).split(os.sep)[1], q.count(os.sep), q), reverse=True):
-        try:
-            t = json.load(open(path))
-        except Exception:
-            continue
-        for ent in (t if isinstance(t, list) else [t]):
-            if ent.get("workload") == key and ent.get("fetch_bytes_corrected"):
-                total = float(ent["fetch_bytes_corrected"]) + float(ent.get("write_bytes") or 0.0)
-                return total, "%s (rocprofv3 --pmc FETCH_SIZE x2 gfx950 correction %.4g B + WRITE_SIZE %.4g B per launch)" % (
-                    os.path.relpath(path, ROOT), ent["fetch_bytes_corrected"], ent.get("write_bytes") or 0.0)
-    return None, None
-
-
-class Searcher:
-    """One index + B distinct query batches, each with its own result buffers; timing helpers.  run() without a batch
-    number takes the next one in rotation, so consecutive launches never search the same queries."""
-
-    def __init__(self, torch, index, qs, k, dim, stream, gts):
-        self.t, self.ix, self.qs, self.k, self.dim, self.stream = torch, index, list(qs), k, dim, stream
-        self.gts = list(gts) if gts is not None else [None] * len(self.qs)
-        dev, nq = self.qs[0].device, self.qs[0].shape[0]
-        self.nq = nq
-        self.out = [dict(ids=torch.zeros((nq, k), dtype=torch.int32, device=dev), dists=torch.zeros((nq, k), dtype=torch.float32, device=dev),
-                         cmps=torch.zeros(nq, dtype=torch.int32, device=dev), hops=torch.zeros(nq, dtype=torch.int32, device=dev)) for _ in self.qs]
-        self.cursor = 0
-        self.depth_settled = {}
-
-    def run(self, L, b=None):
-        if b is None:
-            b = self.cursor
-            self.cursor = (self.cursor + 1) % len(self.qs)
-        o = self.out[b]
-        self.ix.search_dev(self.qs[b], self.k, L, o["ids"], o["dists"], o["cmps"], o["hops"], stream=self.stream)
-        return b
-
-    def wait(self):
-        self.ix.search_wait(self.stream)
-
-    def timed(self, L, reps=3, settle=3):
-        """(average milliseconds per batch, batches timed) over `reps` launches (HIP events on the launch stream), after
-        `settle` untimed batches (that is where the adaptive default decides between its two exact forms)."""
-        t = self.t
-        for _ in range(settle):
-            self.run(L); self.wait()
-        if L not in self.depth_settled or self.depth_settled[L] < reps:
-            # the timed launches below are enqueued back to back: the first time `reps` batches are in flight on the stream the
-            # library allocates the per-batch state of the 2nd, 3rd ... (a hipMalloc between the event records of that batch:
-            # 2.4 - 6.7 ms once) -- let that happen here
-            for _ in range(reps):
-                self.run(L)
-            self.wait()
-            self.depth_settled[L] = reps
-        ev = [(t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)) for _ in range(reps)]
-        used = []
-        names = ("batches_lset", "batches_filter_log", "batches_exact_hbm", "batches_filter_only")
-        before = [self.ix.stat(n_) for n_ in names]
-        e0, e1 = t.cuda.Event(enable_timing=True), t.cuda.Event(enable_timing=True)
-        e0.record()
-        for a, b in ev:
-            a.record(); used.append(self.run(L)); b.record()
-        self.wait()
-        # the figure is the whole region -- first enqueue to the end of rg_search_wait (whatever the library ran for these
-        # batches, on the launch stream or beside it, is done when the closing event is recorded) -- over the batches in it
-        e1.record(); e1.synchronize()
-        self.last_reps_ms = [a.elapsed_time(b) for a, b in ev]          # per enqueue, on the launch stream (K1 and what it waited for)
-        # which kernel form the timed launches ran in (counters of the library) and the hub bitmap of the last one
-        self.last_forms = {n_[8:]: self.ix.stat(n_) - b0 for n_, b0 in zip(names, before) if self.ix.stat(n_) - b0}
-        self.last_forms["hub_bits_log2"] = self.ix.stat("hub_m_last")
-        return e0.elapsed_time(e1) / reps, used
-
-    def point(self, L, ms, used):
-        """One row of the report: `used` = the batches the timing ran (their buffers hold the results at this L)."""
-        from roargraph_amd import index as ixmod
-        used = sorted(set(used))
-        mc = float(np.mean([self.out[b]["cmps"].float().mean().item() for b in used]))
-        mh = float(np.mean([self.out[b]["hops"].float().mean().item() for b in used]))
-        rec = rec_k = None
-        if self.k >= 10 and all(self.gts[b] is not None for b in used):
-            rec = float(np.mean([ixmod.recall(self.out[b]["ids"].cpu().numpy().view(np.uint32), self.gts[b], 10) for b in used]))
-            rk = getattr(self, "recall_k", 10)      # the reference's recall@k over all k results (test_search_roargraph.cpp:23-36)
-            rec_k = rec if rk == 10 else float(np.mean([ixmod.recall(self.out[b]["ids"].cpu().numpy().view(np.uint32), self.gts[b], rk) for b in used]))
-        gbps = self.nq * mc * 4 * self.dim / (ms / 1e3) / 1e9
-        return {"L_pq": L, "qps": self.nq / (ms / 1e3), "ms_per_batch": ms, "recall_at_10": rec, "recall_at_k": rec_k, "mean_evals": mc, "mean_hops": mh,
-                "distinct_batches": len(used), "GBps": gbps, "pct_of_8000": 100.0 * gbps / 8000.0, "pct_of_6290": 100.0 * gbps / 6290.0}
-
-
-MALL_ROWS = 349525      # rows of 768 B the 256-MiB Infinity Cache can hold
-
-
-def reuse_of_last_launch(torch, index, stream, nb, nq, dev, full=False):
-    """First touches and popularity of the rows the last default-mode launch on `stream` read (rg_search_reuse_stats over its
-    id logs); None when that launch ran on the exact words (no logs)."""
-    try:
-        counts = torch.zeros(nb, dtype=torch.int32, device=dev)
-        ev_n, dr_n = index.reuse_stats(stream, counts)
-    except Exception:  # noqa: BLE001
-        return None
-    srt = torch.sort(counts, descending=True).values.double()
-    cum = torch.cumsum(srt, 0) / max(float(ev_n), 1.0)
-    out = {"distinct_rows_frac": dr_n / max(ev_n, 1), "share_of_reads_to_top_%d_rows" % MALL_ROWS: float(cum[min(MALL_ROWS, nb) - 1].item())}
-    if full:
-        out.update({"evaluations_performed": ev_n, "distinct_rows": dr_n,
-                    # popularity: share of the launch's row reads that go to its H most read rows (H rows = H x 768 B)
-                    "share_of_reads_to_top_rows": {str(h): float(cum[min(h, nb) - 1].item()) for h in (64, 1024, 16384, 131072, MALL_ROWS, 1048576)},
-                    "rows_read_by_every_query": int((counts >= nq).sum().item())})
-    return out
-
-
-
-_T0 = time.perf_counter()
-
-
-def progress(what):      # RG_BENCH_PROGRESS=1: stage marks on stderr (where a run that dies was)
-    if os.environ.get("RG_BENCH_PROGRESS"):
-        print("[bench %7.1f s] %s" % (time.perf_counter() - _T0, what), file=sys.stderr, flush=True)
-
-
-def side_config(torch, dev, stream, name, nb, dim, metric, k, rank_latent, ntrain, nq, Ls, target, cpu_seconds, steps, what, frac_hbm_only=None):
-    """One smaller workload end to end inside the default run: data -> ground truth of the training queries (K2) ->
-    GPU-assisted RoarGraph construction -> a short L_pq sweep -> `steps` timed batches at the smallest L_pq reaching `target`
-    recall@10 (recall@k for the top-100 shape) -> the reference loop on 16 host threads over the same index and queries (ids
-    asserted equal).  Returns a block with its own `roofline` and `cpu_baseline`."""
-    from roargraph_amd import build, groundtruth, synth
-    from roargraph_amd.index import IndexBipartite
-    progress("side block %s: start" % name)
-    t_all = time.perf_counter()
-    base, train, q, desc = synth.make_device_set(dev, 1234, nb, ntrain, nq, dim, data="lowrank", rank=rank_latent, q_seed=99)
-    t0 = time.perf_counter()
-    ti, _ = groundtruth.groundtruth_distributed(base, 0, train, metric, 100)
-    torch.cuda.synchronize()
-    progress("side block %s: training truth done, building" % name)
-    t_gt = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    h_off, h_nbrs, ep = build.build_roargraph(synth.to_host(base), synth.to_host(ti).view(np.uint32), metric, 100, 35, 500,
-                                              num_threads=int(os.environ.get("RG_BENCH_BUILD_THREADS", min(128, os.cpu_count() or 1))), device=dev.index or 0)
-    t_build = time.perf_counter() - t0
-    del train, ti
-    off = synth.to_device(h_off.view(np.int64), dev)
-    nbrs = synth.to_device(h_nbrs.view(np.int32), dev)
-    progress("side block %s: built, opening" % name)
-    torch.cuda.empty_cache()
-    index = IndexBipartite.from_device(base, off, nbrs, ep, metric=metric)
-    nbatch = 3
-    qs = [q] + [synth.make_device_set(dev, 1234, 1024, 0, nq, dim, data="lowrank", rank=rank_latent, q_seed=99 + 7919 * b)[2] for b in range(1, nbatch)]
-    gts = []
-    ti_q = torch.zeros((nq, 100), dtype=torch.int32, device=dev); tv_q = torch.zeros((nq, 100), device=dev)
-    t0 = time.perf_counter()
-    for qb in qs:
-        groundtruth.gt_shard_dev(base, qb, metric, 100, 0, ti_q, tv_q, stream=stream); torch.cuda.synchronize()
-        gts.append(ti_q.cpu().numpy().view(np.uint32).copy())
-    t_gtq = time.perf_counter() - t0
-    del ti_q, tv_q
-    progress("side block %s: query truth done, sweep" % name)
-    S = Searcher(torch, index, qs, k, dim, stream, gts)
-    S.recall_k = k if k <= 100 else 10
-    sweep = []
-    for L in [x for x in Ls if x >= k]:
-        ms, used = S.timed(L, reps=2, settle=2)
-        sweep.append(S.point(L, ms, used))
-    progress("side block %s: headline" % name)
-    ok = [p["L_pq"] for p in sweep if (p["recall_at_k"] or 0.0) >= target]
-    L_star = min(ok) if ok else max(p["L_pq"] for p in sweep)
-    ms, used = S.timed(L_star, reps=steps, settle=1)
-    head = S.point(L_star, ms, used)
-    forms = {n_: index.stat(n_) for n_ in ("batches_lset", "batches_filter_log", "batches_exact_hbm")}
-    head_forms = dict(S.last_forms)
-    S.run(L_star, 0); S.wait()
-    ids_head = S.out[0]["ids"].cpu().numpy().view(np.uint32).copy()
-    # share of the headline launch's row reads that go to rows a 256-MiB cache can hold (one untimed launch in the logging form)
-    reuse = None
-    try:
-        index.set("lset", 0); index.set("adaptive", 0)
-        S.run(L_star, 0); S.wait()
-        reuse = reuse_of_last_launch(torch, index, stream, nb, nq, dev)
-        index.set("lset", -1); index.set("adaptive", 1)
-    except Exception:  # noqa: BLE001
-        reuse = None
-    progress("side block %s: reuse statistics done" % name)
-    cpu = None
-    if cpu_seconds > 0:
-        try:
-            cpu = cpu_search_baseline(synth.to_host(base), h_off, h_nbrs, ep, qs[0].cpu().numpy(), ids_head, metric, k, L_star,
-                                      [min(16, os.cpu_count() or 1)], cpu_seconds)[0]
-            cpu["gpu_over_cpu"] = head["qps"] / cpu["value"] if cpu.get("value") else None
-        except AssertionError:
-            raise
-        except Exception as e:  # noqa: BLE001
-            cpu = {"value": None, "unit": "QPS", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
-    progress("side block %s: closing" % name)
-    index.close()
-    alg = head["mean_evals"] * nq * 4.0 * dim
-    tr_, trs = pmc_traffic({"nb": nb, "dim": dim, "nq": nq, "k": k, "metric": metric, "data": "lowrank", "rank": rank_latent, "graph": "roargraph",
-                            "L": L_star, "visited": 2})
-    out = {"name": name, "what": what, "nb": nb, "dim": dim,
-           "workload": "base %dx%d fp32 %s (%s), %d training queries, own RoarGraph index (M_sq=100 M_pjbp=35 L_pjpq=500, avg degree %.1f), %d queries/batch "
-                       "(%d distinct batches), top-%d, L_pq=%d" % (nb, dim, metric, desc, ntrain, float(h_nbrs.size) / nb, nq, nbatch, k, L_star),
-           "metric": "QPS @ recall@%d >= %.2f" % (S.recall_k, target), "value": head["qps"], "unit": "queries/s",
-           "L_pq": L_star, "recall_at_k": head["recall_at_k"], "recall_k": S.recall_k, "mean_evals": head["mean_evals"], "mean_hops": head["mean_hops"],
-           "seconds": {"train_ground_truth": t_gt, "construction": t_build, "query_ground_truth": t_gtq, "block_total": time.perf_counter() - t_all},
-           "roofline": {"bound": "hbm", "achieved": head["GBps"], "peak": 8000.0, "unit": "GB/s", "frac": head["GBps"] / 8000.0,
-                        "kernel_ms_avg": ms, "algorithmic_bytes_per_launch": alg, "traffic": tr_, "traffic_source": trs,
-                        "frac_hbm_only": frac_hbm_only,
-                        "frac_cache_served": reuse.get("share_of_reads_to_top_%d_rows" % MALL_ROWS) if reuse else None,
-                        "distinct_rows_frac": reuse.get("distinct_rows_frac") if reuse else None,
-                        "kernel_forms_of_the_timed_launches": head_forms,
-                        "frac_of_measured_stream_ceiling_6290": head["GBps"] / 6290.0},
-           "cpu_baseline": cpu, "kernel_forms_of_the_batches": forms,
-           "L_pq_sweep": [{"L_pq": p["L_pq"], "qps": p["qps"], "recall_at_k": p["recall_at_k"], "mean_evals": p["mean_evals"], "pct_of_8000": p["pct_of_8000"]}
-                          for p in sweep]}
-    del S, index, base, off, nbrs, qs
-    torch.cuda.empty_cache()
-    return out
-
-
-def _r(x, nd=4):
-    """Round a float to nd significant digits (None and non-floats pass through): the compact line carries figures, not noise."""
-    if isinstance(x, bool) or x is None or not isinstance(x, (int, float)):
-        return x
-    if isinstance(x, int) or x == 0.0 or x != x:
-        return x
-    from math import floor, log10
-    return round(x, max(0, nd - 1 - int(floor(log10(abs(x))))))
-
-
-def compact_line(line, full_paths):
-    """The one line stdout carries: every key of the bench contract, `roofline` and `cpu_baseline` with the fields the
-    judge reads, and one short row per sweep point / side block.  Everything else is in the full record (`full_record`)."""
-    def pick(d, keys, nd=4):
-        return {k: _r(d.get(k), nd) for k in keys if d is not None and k in d} if d else None
-    out = {k: line[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-                                "vs_baseline", "dtype", "data")}
-    out["value"], out["ms_per_step"] = _r(line["value"], 6), _r(line["ms_per_step"], 6)
-    cfg = line["config"]
-    wl = cfg["workload"]
-    out["config"] = {"workload": wl if len(wl) <= 420 else wl[:417] + "...", "parallelism": cfg["parallelism"], "L_pq": cfg["L_pq"],
-                     "recall_at_10": _r(cfg["recall_at_10"]), "target_recall": cfg["target_recall"],
-                     "distinct_query_batches": cfg["distinct_query_batches"], "mean_evals_per_query": _r(cfg["mean_evals_per_query"], 6),
-                     "mean_hops": _r(cfg["mean_hops"], 5), "setup_seconds": {k: _r(v, 3) for k, v in cfg["setup_seconds"].items()}}
-    rf = line["roofline"]
-    out["roofline"] = pick(rf, ("bound", "achieved", "peak", "unit", "frac", "traffic", "frac_hbm_only", "frac_cache_served", "kernel",
-                                "kernel_ms_avg", "algorithmic_bytes_per_launch", "distinct_rows_frac", "frac_of_measured_stream_ceiling_6290"), 5)
-    ts = rf.get("traffic_source")
-    out["roofline"]["traffic_source"] = ts.split(" (")[0] if ts else None
-    cb = line.get("cpu_baseline")
-    if cb:
-        out["cpu_baseline"] = pick(cb, ("value", "unit", "cores", "kind", "host_cores", "L_pq", "value_without_prefetch", "gpu_over_cpu"), 5)
-        smp = cb.get("sample") or ""
-        out["cpu_baseline"]["sample"] = smp if len(smp) <= 200 else smp[:197] + "..."
-    else:
-        out["cpu_baseline"] = None
-    c1 = line.get("cpu_baseline_1_thread")
-    if c1:
-        out["cpu_baseline_1_thread_qps"] = _r(c1.get("value"))
-    c0 = line.get("cpu_baseline_config1")
-    if c0:
-        out["cpu_baseline_config1"] = pick(c0, ("value", "cores", "kind", "recall_at_10", "gpu_qps_same_inputs"))
-    # sweep rows: [L_pq, QPS, recall@10, % of 8 TB/s]
-    out["sweep_cols"] = ["L_pq", "qps", "recall_at_10", "pct_of_8000"]
-    out["sweep"] = [[p["L_pq"], _r(p["qps"]), _r(p["recall_at_10"]), _r(p["pct_of_8000"], 3)] for p in line.get("L_pq_sweep") or []]
-    w = line.get("roofline_worstcase")
-    if w:
-        out["worstcase"] = pick(w, ("qps", "frac", "kernel_ms_avg", "traffic"))
-    g = line.get("gt_build")
-    if g:
-        out["gt_build"] = {"value": _r(g["value"]), "unit": "distances/s", "frac_of_mfma_peak": _r(g["roofline"]["frac"]),
-                           "k2_resident_frac": _r((g.get("k2_device_resident") or {}).get("frac_of_mfma_peak")),
-                           "cpu_value": _r((g.get("cpu_baseline") or {}).get("value"))}
-        if g.get("k2_small_batch"):
-            out["gt_build"]["k2_small_batch"] = g["k2_small_batch"]
-    for name, key in (("two_streams_qps", "two_streams_pipelined"), ("host_form_qps", "host_form_pcie_inclusive")):
-        if line.get(key):
-            out[name] = _r(line[key].get("qps"))
-    out["configs_summary"] = []
-    for c in line.get("configs") or []:
-        r_ = c.get("roofline") or {}
-        out["configs_summary"].append({"name": c["name"], "nb": c.get("nb"), "dim": c.get("dim"), "L_pq": c["L_pq"], "qps": _r(c["value"]),
-                                       "recall": _r(c["recall_at_k"]), "recall_k": c["recall_k"], "frac": _r(r_.get("frac")),
-                                       "frac_hbm_only": _r(r_.get("frac_hbm_only")), "frac_cache_served": _r(r_.get("frac_cache_served")),
-                                       "traffic": _r(r_.get("traffic")), "cpu_qps": _r((c.get("cpu_baseline") or {}).get("value")),
-                                       "sweep": [[p["L_pq"], _r(p["pct_of_8000"], 3), _r(p["recall_at_k"], 3)] for p in c.get("L_pq_sweep") or []]})
-    dm = line.get("device_memory")
-    if dm:
-        out["device_memory"] = dm
-    out["full_record"] = full_paths
-    return out
-
-
 def supervise():
-    """One-GPU runs are carried out by a CHILD process of this script (roargraph_amd/benchlib/supervise.py); this GPU-less parent passes its one
+    """One-GPU runs are carried out by a CHILD process of this script (benchlib/supervise.py); this GPU-less parent passes its one
     JSON line on.  No second attempt (round 5 had one): a child that dies ends the bench with its status, and the parent prints the
     post-mortem of a GPU fault -- which buffer the address belonged to -- from the report the library wrote.  --no-retry (kept for older
     command lines) = --in-process: the work happens in this process."""
-    from roargraph_amd.benchlib import supervise as sv
+    from benchlib import supervise as sv
     sv.supervise(os.path.abspath(__file__), sys.argv[1:], ROOT)
 
 
@@ -566,176 +200,14 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    # ---- synthetic t2i-10M-shaped inputs: the same base (and index) on every rank, one query batch per rank ---------
-    ntrain = (args.train or args.nb // 5) if roar else 0
-    file_index = None
-    if args.data_root:
-        # the reference's own files: every rank reads the base; rank r takes the r-th slice of the query file, wrapped
-        from roargraph_amd import index as ixmod
-
-        def read_fbin(path):     # the library's loader (load_data + data_align, util.h:179-211, 37-75)
-            arr, d = ixmod.fbin_load(path)
-            return arr if arr.shape[1] == d else np.ascontiguousarray(arr[:, :d])
-        fp = lambda name: os.path.join(args.data_root, name)
-        for need in (args.base_file, args.query_file):
-            if not os.path.exists(fp(need)):
-                raise SystemExit("--data-root: %s not found" % fp(need))
-        hb = read_fbin(fp(args.base_file))
-        hq = read_fbin(fp(args.query_file))
-        args.nb, args.dim = int(hb.shape[0]), int(hb.shape[1])
-        args.nq = min(args.nq, int(hq.shape[0]))
-        sel = (np.arange(args.nq) + rank * args.nq) % hq.shape[0]
-        base = torch.from_numpy(hb).to(dev); q = torch.from_numpy(np.ascontiguousarray(hq[sel])).to(dev)
-        del hb, hq
-        train = None
-        if roar and os.path.exists(fp(args.index_file)):
-            file_index = ixmod.graph_load(fp(args.index_file))
-        elif roar:
-            if not os.path.exists(fp(args.train_file)):
-                raise SystemExit("--data-root: neither %s nor %s found" % (fp(args.index_file), fp(args.train_file)))
-            ht = read_fbin(fp(args.train_file))
-            ntrain = min(args.train or int(ht.shape[0]), int(ht.shape[0]))
-            train = torch.from_numpy(np.ascontiguousarray(ht[:ntrain])).to(dev)
-            del ht
-        data_desc = "files of %s (%s, %s)" % (args.data_root, args.base_file, args.query_file)
-        args.data = "files"
-    else:
-        base, train, q, data_desc = synth.make_device_set(dev, 1234, args.nb, ntrain, args.nq, args.dim, data=args.data, rank=args.rank,
-                                                          q_seed=99 + rank)
-    progress("data made")
-    t_gt = t_build = 0.0
-    if file_index is not None:
-        h_off, h_nbrs, ep = file_index
-        off = torch.from_numpy(np.ascontiguousarray(h_off).view(np.int64)).to(dev)
-        nbrs = torch.from_numpy(np.ascontiguousarray(h_nbrs).view(np.int32)).to(dev)
-        graph_desc = "index file %s (avg degree %.1f)" % (args.index_file, float(nbrs.numel()) / args.nb)
-        del file_index
-    elif roar:
-        # training-query ground truth: base rows sharded over the ranks, one all-to-all, K3 (the multi-GPU form of K2)
-        t0 = time.perf_counter()
-        lo, hi = groundtruth.shard_rows(args.nb, world)[rank]
-        if args.index_cache and os.path.exists(args.index_cache):
-            train = train[:1024]      # graph comes from the cache: a token ground truth keeps the code path
-        ti, _ = groundtruth.groundtruth_distributed(base[lo:hi], lo, train, args.metric, 100)
-        ntrain_used = train.shape[0]
-        if world > 1:   # every rank holds the lists of the query range it owns: collect them on all ranks, rank 0 uses them
-            per = max(b - a for a, b in groundtruth.query_ranges(ntrain_used, world))
-            pad = torch.zeros((per, 100), dtype=torch.int32, device=cdev)
-            pad[: ti.shape[0]] = ti.to(cdev)
-            parts = [torch.zeros_like(pad) for _ in range(world)]
-            dist.all_gather(parts, pad)
-            ti = torch.cat([p[: b - a] for p, (a, b) in zip(parts, groundtruth.query_ranges(ntrain_used, world))])
-        sync_all()
-        t_gt = time.perf_counter() - t0
-        progress("training ground truth done")
-        t0 = time.perf_counter()
-        meta = torch.zeros(2, dtype=torch.int64, device=cdev)
-        cached = args.index_cache and os.path.exists(args.index_cache)
-        if rank == 0 and cached:
-            z = np.load(args.index_cache)
-            h_off, h_nbrs, ep = z["off"], z["nbrs"], int(z["ep"])
-            off = synth.to_device(h_off.view(np.int64), dev)
-            nbrs = synth.to_device(h_nbrs.view(np.int32), dev)
-            meta[0], meta[1] = int(h_nbrs.size), int(ep)
-        elif rank == 0:
-            h_off, h_nbrs, ep = build.build_roargraph(synth.to_host(base), synth.to_host(ti).view(np.uint32), args.metric, 100, 35, 500,
-                                                      num_threads=int(os.environ.get("RG_BENCH_BUILD_THREADS", min(128, os.cpu_count() or 1))), device=local)
-            off = synth.to_device(h_off.view(np.int64), dev)
-            nbrs = synth.to_device(h_nbrs.view(np.int32), dev)
-            meta[0], meta[1] = int(h_nbrs.size), int(ep)
-            if args.index_cache:
-                np.savez(args.index_cache, off=h_off, nbrs=h_nbrs, ep=ep)
-        if world > 1:   # the finished graph goes to every rank (replicated index)
-            dist.broadcast(meta, 0)
-            if rank != 0:
-                off = torch.zeros(args.nb + 1, dtype=torch.int64, device=dev)
-                nbrs = torch.zeros(int(meta[0]), dtype=torch.int32, device=dev)
-            if args.backend == "nccl":
-                dist.broadcast(off, 0); dist.broadcast(nbrs, 0)
-            else:
-                ho, hn = off.cpu(), nbrs.cpu()
-                dist.broadcast(ho, 0); dist.broadcast(hn, 0)
-                off, nbrs = ho.to(dev), hn.to(dev)
-        ep = int(meta[1]) if world > 1 else ep
-        sync_all()
-        t_build = time.perf_counter() - t0
-        graph_desc = ("genuine RoarGraph index built in the run (K2 truth of %d training queries %.0f s on %d GPU(s), GPU-assisted "
-                      "construction %.0f s, M_sq=100 M_pjbp=35 L_pjpq=500, avg degree %.1f)"
-                      % (ntrain, t_gt, world, t_build, float(nbrs.numel()) / args.nb))
-        del train, ti
-    else:
-        g = torch.Generator(device=dev); g.manual_seed(4321)
-        nbrs = torch.randint(0, args.nb, (args.nb * args.deg,), dtype=torch.int32, device=dev, generator=g)
-        off = torch.arange(0, args.nb + 1, dtype=torch.int64, device=dev) * args.deg
-        ep = 0
-        graph_desc = "random out-degree-%d graph (recall is meaningless on it)" % args.deg
-    # the setup phase (ground truth of the training queries, construction) went through torch's caching allocator, which keeps
-    # what it is given; the library allocates with hipMalloc -- hand the cached blocks back first, so that its large buffers
-    # (adjacency, split rows, id logs, the 19 GiB of visited tags of a wide beam) are cut from whole memory, not from the gaps
-    progress("graph ready")
-    torch.cuda.empty_cache()
-    index = IndexBipartite.from_device(base, off, nbrs, ep, metric=args.metric)
-    progress("index open")
-    for kv in [x for x in args.set.split(",") if x]:
-        kname, kval = kv.split("=")
-        index.set(kname, int(kval))
-    index.set("visited", args.visited)
-
-    # distinct query batches of this rank: one per timed step and warm-up (at most 32), every one with its exact truth (K2)
-    nbatch = max(1, min(32, args.steps + args.warmup)) if not args.data_root else 1
-    qs = [q]
-    for b in range(1, nbatch):
-        qs.append(synth.make_device_set(dev, 1234, 1024, 0, args.nq, args.dim, data=args.data, rank=args.rank,
-                                        q_seed=99 + rank + 7919 * b)[2])
-    gts = []
-    ti_q = torch.zeros((args.nq, 100), dtype=torch.int32, device=dev); tv_q = torch.zeros((args.nq, 100), device=dev)
-    for qb in qs:
-        groundtruth.gt_shard_dev(base, qb, args.metric, 100, 0, ti_q, tv_q, stream=stream); torch.cuda.synchronize()
-        gts.append(ti_q.cpu().numpy().view(np.uint32).copy())
-    del ti_q, tv_q
-    torch.cuda.empty_cache()
-    S = Searcher(torch, index, qs, args.k, args.dim, stream, gts)
-    progress("query batches and their truth ready")
-
-    # ---- L_pq sweep (every rank runs it: it also settles the adaptive default; rank 0 reports) -------------------------
-    sweep_Ls = sorted({int(x) for x in args.sweep.split(",") if x} | {500}) if args.sweep else []
-    sweep_Ls = [L for L in sweep_Ls if L >= args.k]
-    sweep = []
-    for L in sweep_Ls:
-        progress("sweep L_pq %d" % L)
-        ms, used = S.timed(L, reps=3 if L <= 500 else 2)
-        if max(S.last_reps_ms) > 1.5 * min(S.last_reps_ms):
-            # one launch far off the others (seen once in the round: 7.7 ms among 1.0 ms launches at L_pq = 10 -- a host stall
-            # between the two event records of a batch, not kernel time): measure the point again and say so
-            first = list(S.last_reps_ms)
-            ms, used = S.timed(L, reps=5 if L <= 500 else 3, settle=1)
-            pt = S.point(L, ms, used)
-            pt["remeasured"] = {"first_attempt_ms": first, "second_attempt_ms": list(S.last_reps_ms)}
-        else:
-            pt = S.point(L, ms, used)
-        pt["ms_reps"] = [round(x, 4) for x in S.last_reps_ms]
-        pt["forms"] = dict(S.last_forms)
-        if args.visited == 2 and rank == 0:
-            # what explains a point above the 6.29 TB/s streaming-copy ceiling: how few of the launch's row reads are first
-            # touches, and how many go to rows a 256-MiB cache could hold (null: the launch ran on the exact words)
-            ru = reuse_of_last_launch(torch, index, stream, args.nb, args.nq, dev)
-            if ru is None:     # narrow beams run on the exact LDS set (no id logs): one untimed launch in the logging form, for the statistics only
-                index.set("lset", 0); index.set("adaptive", 0)      # (the exact-tag form keeps no logs either)
-                S.run(L, 0); S.wait()
-                ru = reuse_of_last_launch(torch, index, stream, args.nb, args.nq, dev)
-                index.set("lset", -1); index.set("adaptive", 1)
-            pt["distinct_rows_frac"] = ru["distinct_rows_frac"] if ru else None
-            pt["share_of_reads_to_rows_a_256MiB_cache_can_hold"] = ru["share_of_reads_to_top_%d_rows" % MALL_ROWS] if ru else None
-        sweep.append(pt)
-    if args.L > 0:
-        L_star = args.L
-    else:
-        ok = [p["L_pq"] for p in sweep if (p["recall_at_10"] or 0.0) >= args.target_recall]
-        L_star = min(ok) if ok else (max(sweep_Ls) if sweep_Ls else 500)
-    if world > 1:   # all ranks time the same beam width
-        t = torch.tensor([L_star], dtype=torch.int64, device=cdev)
-        dist.broadcast(t, 0)
-        L_star = int(t.item())
+    # everything the legs share (benchlib/legs.py: each leg reads its inputs from C and leaves its results there)
+    from types import SimpleNamespace
+    C = SimpleNamespace(args=args, torch=torch, dist=dist, dev=dev, cdev=cdev, stream=stream, rank=rank, world=world, local=local, roar=roar,
+                        sync_all=sync_all, synth=synth, groundtruth=groundtruth, build=build, lib=lib, IndexBipartite=IndexBipartite, t_all=t_all)
+    legs.make_data_and_graph(C)
+    legs.open_index_and_batches(C)
+    legs.sweep_leg(C)
+    S, L_star, sweep = C.S, C.L_star, C.sweep
 
     # ---- the timed headline: exactly --steps batches at L_star between barriers, the wait included; every warm-up and
     # every step searches another batch (rotation over `nbatch` distinct ones)
@@ -767,353 +239,22 @@ def main():
         elapsed = float(t.item())
     qps = args.nq * args.steps * world / elapsed
     head = S.point(L_star, float(np.mean(kernel_ms)), used)
-    # what the same launch gains when it REPLAYS one batch (round 2's protocol: the rows of the previous launch are still
-    # in the Infinity Cache) -- reported, never `value`
-    for _ in range(3):
-        S.run(L_star, 0)
-    S.wait()
-    n_replay = min(10, args.steps)
-    er0, er1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    er0.record()
-    for _ in range(n_replay):
-        S.run(L_star, 0)
-    S.wait()
-    er1.record(); er1.synchronize()
-    replay_ms = er0.elapsed_time(er1) / n_replay
-    replay_alg = float(S.out[0]["cmps"].float().sum().item()) * 4.0 * args.dim
-    # first touches: distinct base rows among the evaluations of one launch (the id logs of the default visited mode)
-    reuse = None
-    if args.visited == 2:
-        reuse = reuse_of_last_launch(torch, index, stream, args.nb, args.nq, dev, full=True)
-        if reuse is None:      # the headline ran on the exact LDS set (no id logs): one untimed launch in the logging form, for the statistics only
-            index.set("lset", 0); index.set("adaptive", 0)
-            S.run(L_star, 0); S.wait()
-            reuse = reuse_of_last_launch(torch, index, stream, args.nb, args.nq, dev, full=True)
-            index.set("lset", -1); index.set("adaptive", 1)
-            S.run(L_star, 0); S.wait()
-        reuse = reuse or {"unavailable": "the launch ran on the exact words: no id logs"}
-    forms_head = {n_: index.stat(n_) for n_ in ("batches_lset", "batches_filter_log", "batches_exact_hbm", "batches_filter_only", "lset_left", "recounted")}
-    ids_head = S.out[0]["ids"].cpu().numpy().view(np.uint32).copy()
-    # the exact HBM-visited form returns the same bits (parity between the two exact forms, checked every run)
-    if args.visited != 0:
-        o = S.out[0]
-        keep = [o[x].clone() for x in ("ids", "dists", "cmps", "hops")]
-        index.set("visited", 0)
-        for look in (1, 0):      # both kernel forms of the exact words
-            index.set("lookahead", look)
-            S.run(L_star, 0); S.wait()
-            assert torch.equal(o["ids"], keep[0]) and torch.equal(o["hops"], keep[3]), "visited modes disagree on ids/hops"
-            assert torch.equal(o["dists"].view(torch.int32), keep[1].view(torch.int32)), "visited modes disagree on distances"
-            if args.visited == 2:
-                assert torch.equal(o["cmps"], keep[2]), "cmps differ from the exact visited mode"
-        index.set("lookahead", -1)
-        index.set("visited", args.visited)
+    C.qps, C.head, C.elapsed = qps, head, elapsed
+    legs.replay_and_checks(C)
+    replay_ms, replay_alg, reuse, forms_head = C.replay_ms, C.replay_alg, C.reuse, C.forms_head
     kavg = float(np.mean(kernel_ms)) / 1e3
     alg_bytes = head["mean_evals"] * args.nq * 4.0 * args.dim
     achieved = alg_bytes / kavg / 1e9
     wl_key = {"nb": args.nb, "dim": args.dim, "nq": args.nq, "k": args.k, "metric": args.metric, "data": args.data, "rank": args.rank,
               "graph": "roargraph" if roar else "random", "L": L_star, "visited": args.visited}
-
-    progress('headline done: checks, host form')
-    # ---- the boundary's host form (rg_search: host buffers in, host buffers out -- PCIe inclusive; never `value`) --------
-    host_form = None
-    if rank == 0 and world == 1:
-        qh = qs[0].cpu().numpy()
-        index.SearchRoarGraph(qh, args.k, L_star)
-        t1 = time.perf_counter()
-        for _ in range(5):
-            hres = index.SearchRoarGraph(qh, args.k, L_star)
-        dt = (time.perf_counter() - t1) / 5
-        assert (hres[0] == ids_head).all(), "host form and device form disagree"
-        host_form = {"what": "rg_search with pageable host buffers (queries up, ids/dists/cmps/hops down, one synchronous call per "
-                             "%d-query batch), L_pq=%d" % (args.nq, L_star),
-                     "qps": args.nq / dt, "ms_per_batch": dt * 1e3, "vs_device_resident": args.nq / dt / qps}
-        del qh
-
-    # ---- batches alternating over two streams (the boundary allows concurrent searches on one index): the next batch's
-    # queries fill the wave slots the previous batch's tail leaves idle.  Reported beside `value`, never as it: `value` and
-    # the roofline keep the one-stream form whose per-launch duration rocprofv3 can be held against.
-    progress('two streams')
-    two_streams = None
-    if rank == 0 and world == 1 and not args.no_two_streams:
-        s2 = torch.cuda.Stream(device=dev)
-        S2 = Searcher(torch, index, qs, args.k, args.dim, s2.cuda_stream, None)
-        S2.cursor = len(qs) // 2
-        for _ in range(2):
-            S.run(L_star); S2.run(L_star)
-        S.wait(); S2.wait()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for i in range(args.steps):
-            (S if i % 2 == 0 else S2).run(L_star)
-        S.wait(); S2.wait()
-        torch.cuda.synchronize()
-        dt = time.perf_counter() - t1
-        S.run(L_star, 0); S2.run(L_star, 0); S.wait(); S2.wait()
-        assert torch.equal(S2.out[0]["ids"], S.out[0]["ids"]) and torch.equal(S2.out[0]["cmps"], S.out[0]["cmps"]), "the two streams disagree"
-        two_streams = {"what": "%d batches of %d queries (distinct, rotated) alternating over two streams of one index, L_pq=%d" % (args.steps, args.nq, L_star),
-                       "qps": args.nq * args.steps / dt, "vs_one_stream": args.nq * args.steps / dt / qps}
-        del S2
-
-    # ---- opt-in NON-parity modes, reported separately, never as `value` -----------------------------------------------
-    progress('opt-in modes')
-    fast = None
-    if rank == 0 and not args.no_fast and args.dim in (200, 512):
-        fast = []
-        for name, knob in (("fast_bf16 (bf16 traversal + exact fp32 re-rank of the beam)", "fast_bf16"),
-                           ("multi_expand (the speculated second expansion of a hop is merged unconditionally)", "multi_expand")):
-            try:
-                index.set(knob, 1)
-                rows = []
-                for L in sorted({L_star, 500}):
-                    ms, used_f = S.timed(L, reps=2, settle=1)
-                    p = S.point(L, ms, used_f)
-                    rows.append({"L_pq": L, "qps": p["qps"], "recall_at_10": p["recall_at_10"], "mean_evals_performed": p["mean_evals"]})
-                fast.append({"mode": name + " -- opt-in, NOT parity", "points": rows})
-            except Exception as e:  # noqa: BLE001
-                fast.append({"mode": name, "error": repr(e)})
-            index.set(knob, 0)
-
-    # ---- opt-in EXACT mode (results bit-identical, checked here): the first hop scored once for the batch ----
-    shared = None
-    if rank == 0 and not args.no_fast:
-        try:
-            index.set("shared_frontier", 1)
-            rows = []
-            for L in sorted({L_star, 500}):
-                ms, used_s = S.timed(L, reps=3, settle=1)
-                p = S.point(L, ms, used_s)
-                rows.append({"L_pq": L, "qps": p["qps"], "recall_at_10": p["recall_at_10"], "mean_evals": p["mean_evals"], "pct_of_8000": p["pct_of_8000"]})
-            S.run(L_star, 0); S.wait()
-            same = (S.out[0]["ids"].cpu().numpy().view(np.uint32) == ids_head).all()
-            shared = {"mode": "shared_frontier: the entry point and its neighbours scored once per batch with the exact routine "
-                              "(rg_front_score_kernel), the first hop reads the scores -- opt-in, results bit-identical", "points": rows,
-                      "ids_equal_default": bool(same)}
-            assert same, "shared_frontier changed a result"
-        except AssertionError:
-            raise
-        except Exception as e:  # noqa: BLE001
-            shared = {"mode": "shared_frontier", "error": repr(e)}
-        index.set("shared_frontier", 0)
-
-    # ---- CPU baselines on the same index and queries (rank 0, N = 1) ---------------------------------------------------
-    progress('cpu baselines')
-    cpu = cpu1 = cpu_cfg1 = gt_check = None
-    if rank == 0 and world == 1 and args.cpu_seconds > 0:
-        base_np = synth.to_host(base)
-        h_off_np = synth.to_host(off).view(np.uint64)
-        h_nbrs_np = synth.to_host(nbrs).view(np.uint32)
-        q_np = qs[0].cpu().numpy()
-        try:
-            cpu, cpu1 = cpu_search_baseline(base_np, h_off_np, h_nbrs_np, ep, q_np, ids_head, args.metric, args.k, L_star,
-                                            [min(16, os.cpu_count() or 1), 1], args.cpu_seconds)   # README.md:110 evaluates with 16 threads
-        except AssertionError:
-            raise
-        except Exception as e:  # noqa: BLE001  (environmental: no room in /dev/shm, ...); a parity failure is never folded in here
-            cpu = cpu or {"value": None, "unit": "QPS", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
-        # the recall column rests on the product's own K2 truth: a sample of it against the fp64 brute force of the checker (CPU, part of
-        # this baseline leg) -- ids equal wherever the fp64 scores of neighbouring ranks differ by more than 1e-5 relative
-        gt_check = None
-        try:
-            from oracle import pyoracle as po
-            ns = 32
-            ref_i, _, ref_s = po.groundtruth_f64(base_np, q_np[:ns], args.metric, 100, nthreads=min(16, os.cpu_count() or 1))
-            mine = gts[0][:ns]
-            same = mine == ref_i
-            sc = np.abs(ref_s).max(axis=1, keepdims=True) + 1e-30
-            # a differing id is legitimate only inside a tie band of the fp64 scores at that rank
-            gap_ok = np.zeros_like(same)
-            gap_ok[:, 1:] |= np.abs(np.diff(ref_s, axis=1)) <= 1e-5 * sc
-            gap_ok[:, :-1] |= np.abs(np.diff(ref_s, axis=1)) <= 1e-5 * sc
-            gt_check = {"queries": ns, "K": 100, "ids_equal_frac": float(same.mean()), "differences_outside_fp64_tie_bands": int((~same & ~gap_ok).sum()),
-                        "what": "K2 truth of the first %d queries of batch 0 against oracle fp64 brute force over the %d-row base" % (ns, args.nb)}
-            assert gt_check["differences_outside_fp64_tie_bands"] == 0, "the bench's ground truth disagrees with fp64 brute force: %r" % (gt_check,)
-        except AssertionError:
-            raise
-        except Exception as e:  # noqa: BLE001
-            gt_check = {"error": repr(e)}
-        del base_np
-        # BASELINE configs[0]: 100K-row subset with its own index, L_pq = 50, one CPU thread (and the GPU on the same inputs)
-        if args.config1_nb and roar and args.nb >= args.config1_nb:
-            nb1, nt1 = args.config1_nb, args.config1_nb
-            b1, tr1, q1, _ = synth.make_device_set(dev, 4321, nb1, nt1, 2000, args.dim, data=args.data, rank=args.rank)
-            t1i = torch.zeros((nt1, 100), dtype=torch.int32, device=dev); t1v = torch.zeros((nt1, 100), device=dev)
-            groundtruth.gt_shard_dev(b1, tr1, args.metric, 100, 0, t1i, t1v, stream=stream); torch.cuda.synchronize()
-            o1, n1, e1 = build.build_roargraph(b1.cpu().numpy(), t1i.cpu().numpy().view(np.uint32), args.metric, 100, 35, 500,
-                                               num_threads=min(64, os.cpu_count() or 1), device=local)
-            ix1 = IndexBipartite.from_device(b1, torch.from_numpy(o1.view(np.int64)).to(dev), torch.from_numpy(n1.view(np.int32)).to(dev), e1,
-                                             metric=args.metric)
-            g1i = torch.zeros((2000, 100), dtype=torch.int32, device=dev); g1v = torch.zeros((2000, 100), device=dev)
-            groundtruth.gt_shard_dev(b1, q1, args.metric, 100, 0, g1i, g1v, stream=stream); torch.cuda.synchronize()
-            S1 = Searcher(torch, ix1, [q1], args.k, args.dim, stream, [g1i.cpu().numpy().view(np.uint32)])
-            ms1, u1 = S1.timed(50)
-            p1 = S1.point(50, ms1, u1)
-            cpu_cfg1 = cpu_search_baseline(b1.cpu().numpy(), o1, n1, e1, q1.cpu().numpy(), S1.out[0]["ids"].cpu().numpy().view(np.uint32), args.metric,
-                                           args.k, 50, [1], args.cpu_seconds / 2)[0]
-            cpu_cfg1.update(workload="%d-row subset, own RoarGraph index, 2000 queries, top-%d, L_pq=50" % (nb1, args.k),
-                            recall_at_10=p1["recall_at_10"], gpu_qps_same_inputs=p1["qps"])
-            ix1.close()
-            del b1, tr1, q1, t1i, t1v, g1i, g1v, S1
-
-    # ---- worst case: the same base under a random graph, L_pq = 500 -------------------------------------------------
-    progress('worst case')
-    worst = None
-    if rank == 0 and world == 1 and roar and not args.no_worstcase:
-        g = torch.Generator(device=dev); g.manual_seed(4321)
-        rn = torch.randint(0, args.nb, (args.nb * args.deg,), dtype=torch.int32, device=dev, generator=g)
-        ro = torch.arange(0, args.nb + 1, dtype=torch.int64, device=dev) * args.deg
-        ixr = IndexBipartite.from_device(base, ro, rn, 0, metric=args.metric)
-        Sr = Searcher(torch, ixr, qs, args.k, args.dim, stream, None)
-        msr, ur = Sr.timed(500, reps=min(5, args.steps), settle=2)
-        pr = Sr.point(500, msr, ur)
-        tr_, trs = pmc_traffic({"nb": args.nb, "dim": args.dim, "nq": args.nq, "k": args.k, "metric": args.metric, "data": args.data, "rank": args.rank,
-                                "graph": "random", "L": 500, "visited": 2})
-        worst = {"workload": "same base, random out-degree-%d graph, %d queries, top-%d, L_pq=500 (every neighbour fresh: pure random "
-                             "%d-byte row reads; recall meaningless)" % (args.deg, args.nq, args.k, 4 * args.dim),
-                 "qps": pr["qps"], "mean_evals": pr["mean_evals"], "mean_hops": pr["mean_hops"],
-                 "bound": "hbm", "achieved": pr["GBps"], "peak": 8000.0, "unit": "GB/s", "frac": pr["GBps"] / 8000.0,
-                 "frac_of_measured_stream_ceiling_6290": pr["GBps"] / 6290.0, "kernel_ms_avg": msr, "traffic": tr_, "traffic_source": trs}
-        ixr.close()
-        del rn, ro, Sr
-
-    # ---- second BASELINE metric: ground-truth build, distances/s, through the NATIVE multi-rank path the CLI twin ships
-    # (rg_comm + rg_groundtruth_rank, csrc/rg_gt_dist.hip): base rows sharded over the ranks and resident in HBM, the
-    # queries streamed from host memory in batches of 65,536 (>= 4 batches, so that K2 of batch b+1 runs under the
-    # exchange of batch b), per-shard top-K lists exchanged with grouped RCCL send/recv on a side stream, K3, rows written
-    # to the owner's host array.  Ranks that share a GPU (--backend gloo, control-flow tests) cannot form an RCCL
-    # communicator: they take the torch.distributed form (one all_to_all) instead.
-    progress("ground-truth leg")
-    gt = None
-    if args.gt_nq > 0:
-        lo, hi = groundtruth.shard_rows(args.nb, world)[rank]
-        g = torch.Generator(device=dev); g.manual_seed(4242)
-        shard = base[lo:hi]
-        native = world == 1 or args.backend == "nccl"
-        gt_batch = 65536
-        if native and world > 1:     # every rank must be able to join the RCCL communicator, or none takes the native path
-            ok = torch.tensor([1], dtype=torch.int32, device=cdev)
-            try:
-                comm = groundtruth.Comm.from_torch_dist(local)
-            except Exception as e:  # noqa: BLE001
-                print("[bench] rank %d: native ground-truth path unavailable (%r): torch.distributed form instead" % (rank, e), file=sys.stderr)
-                comm = None
-                ok[0] = 0
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if int(ok.item()) == 0:
-                if comm is not None:
-                    comm.destroy()
-                native = False
-        elif native:
-            comm = groundtruth.Comm.local([local])[0]
-        if native:
-            nq_gt = max(args.gt_nq, 4 * gt_batch) if args.gt_nq >= gt_batch else args.gt_nq
-            gq_h = (torch.empty((nq_gt, args.dim), dtype=torch.float32, device=dev).normal_(generator=g) * 0.5 + 0.3).cpu().numpy()
-            out_i = np.zeros((nq_gt, args.gt_K), np.uint32); out_d = np.zeros((nq_gt, args.gt_K), np.float32)
-            # warm-up: a small call (allocations, module load, communicator), then one batch of the timed size -- the leg
-            # follows half a minute of CPU-only baselines, and the first seconds of MFMA work after that idle run slower
-            groundtruth.groundtruth_rank(comm, shard, lo, gq_h[:4096], args.metric, args.gt_K, out_i[:4096], out_d[:4096], batch=2048)
-            groundtruth.groundtruth_rank(comm, shard, lo, gq_h[:gt_batch], args.metric, args.gt_K, out_i[:gt_batch], out_d[:gt_batch], batch=gt_batch)
-            sync_all()
-            tg0 = time.perf_counter()
-            groundtruth.groundtruth_rank(comm, shard, lo, gq_h, args.metric, args.gt_K, out_i, out_d, batch=gt_batch)
-            sync_all()
-            tg = time.perf_counter() - tg0
-            form = ("rg_groundtruth_rank over %s: %d query batches of %d streamed from host memory, per-shard K-lists exchanged on a "
-                    "side stream under the next batch's K2" % ("RCCL (ncclSend/ncclRecv, xGMI)" if comm.uses_rccl() else "the in-process transport",
-                                                              (nq_gt + gt_batch - 1) // gt_batch, gt_batch))
-            comm.destroy()
-            del out_i, out_d
-        else:
-            nq_gt = args.gt_nq
-            gq = torch.empty((nq_gt, args.dim), dtype=torch.float32, device=dev).normal_(generator=g) * 0.5 + 0.3
-            groundtruth.groundtruth_distributed(shard[: min(hi - lo, 65536)], lo, gq[:2048], args.metric, args.gt_K)
-            groundtruth.groundtruth_distributed(shard, lo, gq, args.metric, args.gt_K)
-            sync_all()
-            tg0 = time.perf_counter()
-            gi, gv = groundtruth.groundtruth_distributed(shard, lo, gq, args.metric, args.gt_K)
-            sync_all()
-            tg = time.perf_counter() - tg0
-            form = "torch.distributed form (K2 per rank, one all_to_all, K3): ranks share a GPU, no RCCL communicator possible"
-            gq_h = gq.cpu().numpy()
-            del gi, gv, gq
-        if world > 1:
-            t = torch.tensor([tg], dtype=torch.float64, device=cdev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            tg = float(t.item())
-        dps = float(nq_gt) * float(args.nb) / tg
-        gt = {"metric": "GT-build distances/sec (K=%d, %d queries x %d base rows, base sharded x%d)" % (args.gt_K, nq_gt, args.nb, world),
-              "value": dps, "seconds": tg, "form": form, "TFLOPs_fp32_mfma": 2.0 * args.dim * dps / 1e12,
-              "roofline": {"bound": "mfma", "achieved": 2.0 * args.dim * dps / 1e12, "peak": 157.3 * world, "unit": "TFLOP/s",
-                           "frac": 2.0 * args.dim * dps / 1e12 / (157.3 * world)}}
-        if rank == 0 and world == 1:
-            # the kernel alone, queries and results resident in HBM (one K2 launch over 65,536 queries): what profiles/*/gt_* profile
-            gq = torch.from_numpy(gq_h[: min(nq_gt, gt_batch)]).to(dev)
-            groundtruth.groundtruth_distributed(shard, lo, gq, args.metric, args.gt_K)
-            torch.cuda.synchronize()
-            tk0 = time.perf_counter()
-            groundtruth.groundtruth_distributed(shard, lo, gq, args.metric, args.gt_K)
-            torch.cuda.synchronize()
-            tk = time.perf_counter() - tk0
-            gt["k2_device_resident"] = {"queries": int(gq.shape[0]), "seconds": tk, "value": float(gq.shape[0]) * float(args.nb) / tk,
-                                        "frac_of_mfma_peak": 2.0 * args.dim * float(gq.shape[0]) * float(args.nb) / tk / 1e12 / 157.3}
-            # ... and at the size of an evaluation-side truth or a tail batch: 10,000 queries in one launch (a query block is searched in
-            # pieces by several workgroups there: balanced split, quota thresholds between the pieces)
-            gs = gq[: min(10_000, int(gq.shape[0]))].contiguous()
-            groundtruth.groundtruth_distributed(shard, lo, gs, args.metric, args.gt_K)
-            torch.cuda.synchronize()
-            ts0 = time.perf_counter()
-            for _ in range(3):
-                groundtruth.groundtruth_distributed(shard, lo, gs, args.metric, args.gt_K)
-            torch.cuda.synchronize()
-            ts = (time.perf_counter() - ts0) / 3
-            gt["k2_small_batch"] = {"queries": int(gs.shape[0]), "seconds": round(ts, 4),
-                                    "frac_of_mfma_peak": round(2.0 * args.dim * float(gs.shape[0]) * float(args.nb) / ts / 1e12 / 157.3, 4)}
-            del gs
-            if args.cpu_seconds > 0:
-                try:
-                    gt["cpu_baseline"] = gt_cpu_baseline(base, gq, args)
-                except Exception as e:  # noqa: BLE001
-                    gt["cpu_baseline"] = {"value": None, "unit": "distances/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
-            del gq
-
-    # ---- side blocks (rank 0, N = 1): three smaller workloads, each built and searched inside the run, each with its own roofline
-    # and cpu_baseline -- the headline's data set is the easiest of the family (latent rank 32), and BASELINE configs[3] / [4] are d = 512
-    progress("side blocks")
-    side_blocks = []
-    n_query_batches = len(qs)
-    if rank == 0 and world == 1 and args.configs:
-        mem_stats_main = index.mem_stats()
-        index.close()
-        del S, index, base, off, nbrs, qs
-        torch.cuda.empty_cache()
-        lib().rg_mem_release(local)      # the library's cache of freed buffers (the side blocks have other sizes)
-        defs = {
-            # (round 5: at the headline's own size -- 10M x 200 -- so that the driver's clock sees the headline shape on data where
-            # recall 0.9 needs a four times wider beam and the index has more than twice the degree)
-            "rank128": dict(nb=args.rank128_nb, dim=200, metric="ip", k=10, rank_latent=128, Ls=[50, 100, 200, 300, 500, 1000],
-                            what="a harder data set of the headline's family and SIZE: latent rank 128 instead of 32 (four times the intrinsic "
-                                 "dimension), %d x 200 IP, top-10; frac_hbm_only = the headline block's random-graph figure (same base shape)" % args.rank128_nb),
-            "webvid": dict(nb=2_500_000, dim=512, metric="ip", k=10, rank_latent=32, Ls=[10, 20, 30, 50, 100, 200, 500],
-                           what="BASELINE configs[4] shape, end to end in the run: webvid-2.5M-shaped 2.5M x 512 IP, ground truth of 500k training "
-                                "queries (K2) -> GPU-assisted RoarGraph construction -> search, top-10"),
-            "laion": dict(nb=args.laion_nb, dim=512, metric="l2", k=100, rank_latent=32, Ls=[100, 150, 200, 300, 500, 1000],
-                          what="BASELINE configs[3] shape at %d rows (the full 10M x 512 run takes the whole default budget by itself: --nb 10000000 "
-                               "--dim 512 --metric l2 --k 100): laion-shaped d = 512 L2, top-100, recall@100" % args.laion_nb),
-        }
-        for cname in [c for c in args.configs.split(",") if c]:
-            if cname not in defs:
-                raise SystemExit("--configs: unknown block %r (rank128, webvid, laion)" % cname)
-            d_ = defs[cname]
-            if args.side_nb:
-                d_["nb"] = args.side_nb
-            side_blocks.append(side_config(torch, dev, stream, cname, d_["nb"], d_["dim"], d_["metric"], d_["k"], d_["rank_latent"], d_["nb"] // 5, args.nq,
-                                           d_["Ls"], args.target_recall, min(args.cpu_seconds, 6.0), min(args.steps, 5), d_["what"],
-                                           frac_hbm_only=worst["frac"] if (worst and cname == "rank128" and d_["nb"] == args.nb and d_["dim"] == args.dim) else None))
-    else:
-        mem_stats_main = index.mem_stats() if rank == 0 else None
-    if mem_stats_main and not mem_stats_main.get("placement_balanced", True):
-        print("[bench] WARNING: %d large buffer(s) of the index fell back to plain allocations (one memory class): wide beams run "
-              "up to 10 %% slower in that placement" % mem_stats_main.get("plain_allocs_of_this_index", -1), file=sys.stderr)
+    del S      # (the side blocks close the main index and hand its memory back: nothing here may keep it alive)
+    for leg in (legs.host_form_leg, legs.two_streams_leg, legs.opt_in_modes_leg, legs.cpu_baselines_leg, legs.worst_case_leg,
+                legs.ground_truth_leg, legs.side_blocks_leg):
+        leg(C)
+    host_form, two_streams, fast, shared = C.host_form, C.two_streams, C.fast, C.shared
+    cpu, cpu1, cpu_cfg1, gt_check, worst, gt = C.cpu, C.cpu1, C.cpu_cfg1, C.gt_check, C.worst, C.gt
+    side_blocks, mem_stats_main, n_query_batches = C.side_blocks, C.mem_stats_main, C.n_query_batches
+    data_desc, graph_desc, t_gt, t_build = C.data_desc, C.graph_desc, C.t_gt, C.t_build
     traffic, traffic_src = pmc_traffic(wl_key) if rank == 0 else (None, None)
     shape_name = {(10_000_000, 200, "ip"): "t2i-10M-shaped", (10_000_000, 512, "l2"): "laion-10M-shaped",
                   (2_500_000, 512, "ip"): "webvid-2.5M-shaped"}.get((args.nb, args.dim, args.metric), "%dx%d" % (args.nb, args.dim))
@@ -1214,3 +355,4 @@ def main():
 
 if __name__ == "__main__":
     main()
+

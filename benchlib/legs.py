@@ -1,0 +1,639 @@
+"""The legs of the default bench run around its timed region, each a function over the run's context `C` (a namespace: flags, device, the
+base / graph / index / searcher of this rank, what earlier legs found).  Bodies moved out of bench.py's main() unchanged in round 6 (VERDICT r5
+#9); bench.py keeps the flags, the timed headline and the line."""
+import os
+import sys
+import time
+
+import numpy as np
+
+from .workloads import (MALL_ROWS, Searcher, cpu_search_baseline, gt_cpu_baseline, pmc_traffic, progress, reuse_of_last_launch,  # noqa: F401
+                        side_config)
+
+
+_NAMES = ("args torch dist dev cdev stream rank world local roar sync_all synth groundtruth build lib IndexBipartite t_all base train off nbrs ep q qs gts "
+          "index S data_desc graph_desc t_gt t_build ntrain sweep L_star qps head ids_head worst elapsed kernel_ms used").split()
+
+
+def _ctx(C):
+    """the shared names of a run as locals of a leg (None where no earlier leg has set one)"""
+    return tuple(getattr(C, n, None) for n in _NAMES)
+
+
+def make_data_and_graph(C):
+    """the data set of this rank (synthetic, or the reference's files under --data-root) and the graph over it: a genuine RoarGraph index built in the run (K2 truth of the training queries sharded over the ranks, GPU-assisted construction on rank 0, broadcast), an index file, or a random graph"""
+    (args, torch, dist, dev, cdev, stream, rank, world, local, roar, sync_all, synth, groundtruth, build, lib, IndexBipartite, t_all, base, train, off, nbrs,
+     ep, q, qs, gts, index, S, data_desc, graph_desc, t_gt, t_build, ntrain, sweep, L_star, qps, head, ids_head, worst, elapsed, kernel_ms, used) = _ctx(C)
+    # ---- synthetic t2i-10M-shaped inputs: the same base (and index) on every rank, one query batch per rank ---------
+    ntrain = (args.train or args.nb // 5) if roar else 0
+    file_index = None
+    if args.data_root:
+        # the reference's own files: every rank reads the base; rank r takes the r-th slice of the query file, wrapped
+        from roargraph_amd import index as ixmod
+
+        def read_fbin(path):     # the library's loader (load_data + data_align, util.h:179-211, 37-75)
+            arr, d = ixmod.fbin_load(path)
+            return arr if arr.shape[1] == d else np.ascontiguousarray(arr[:, :d])
+        fp = lambda name: os.path.join(args.data_root, name)
+        for need in (args.base_file, args.query_file):
+            if not os.path.exists(fp(need)):
+                raise SystemExit("--data-root: %s not found" % fp(need))
+        hb = read_fbin(fp(args.base_file))
+        hq = read_fbin(fp(args.query_file))
+        args.nb, args.dim = int(hb.shape[0]), int(hb.shape[1])
+        args.nq = min(args.nq, int(hq.shape[0]))
+        sel = (np.arange(args.nq) + rank * args.nq) % hq.shape[0]
+        base = torch.from_numpy(hb).to(dev); q = torch.from_numpy(np.ascontiguousarray(hq[sel])).to(dev)
+        del hb, hq
+        train = None
+        if roar and os.path.exists(fp(args.index_file)):
+            file_index = ixmod.graph_load(fp(args.index_file))
+        elif roar:
+            if not os.path.exists(fp(args.train_file)):
+                raise SystemExit("--data-root: neither %s nor %s found" % (fp(args.index_file), fp(args.train_file)))
+            ht = read_fbin(fp(args.train_file))
+            ntrain = min(args.train or int(ht.shape[0]), int(ht.shape[0]))
+            train = torch.from_numpy(np.ascontiguousarray(ht[:ntrain])).to(dev)
+            del ht
+        data_desc = "files of %s (%s, %s)" % (args.data_root, args.base_file, args.query_file)
+        args.data = "files"
+    else:
+        base, train, q, data_desc = synth.make_device_set(dev, 1234, args.nb, ntrain, args.nq, args.dim, data=args.data, rank=args.rank,
+                                                          q_seed=99 + rank)
+    progress("data made")
+    t_gt = t_build = 0.0
+    if file_index is not None:
+        h_off, h_nbrs, ep = file_index
+        off = torch.from_numpy(np.ascontiguousarray(h_off).view(np.int64)).to(dev)
+        nbrs = torch.from_numpy(np.ascontiguousarray(h_nbrs).view(np.int32)).to(dev)
+        graph_desc = "index file %s (avg degree %.1f)" % (args.index_file, float(nbrs.numel()) / args.nb)
+        del file_index
+    elif roar:
+        # training-query ground truth: base rows sharded over the ranks, one all-to-all, K3 (the multi-GPU form of K2)
+        t0 = time.perf_counter()
+        lo, hi = groundtruth.shard_rows(args.nb, world)[rank]
+        if args.index_cache and os.path.exists(args.index_cache):
+            train = train[:1024]      # graph comes from the cache: a token ground truth keeps the code path
+        ti, _ = groundtruth.groundtruth_distributed(base[lo:hi], lo, train, args.metric, 100)
+        ntrain_used = train.shape[0]
+        if world > 1:   # every rank holds the lists of the query range it owns: collect them on all ranks, rank 0 uses them
+            per = max(b - a for a, b in groundtruth.query_ranges(ntrain_used, world))
+            pad = torch.zeros((per, 100), dtype=torch.int32, device=cdev)
+            pad[: ti.shape[0]] = ti.to(cdev)
+            parts = [torch.zeros_like(pad) for _ in range(world)]
+            dist.all_gather(parts, pad)
+            ti = torch.cat([p[: b - a] for p, (a, b) in zip(parts, groundtruth.query_ranges(ntrain_used, world))])
+        sync_all()
+        t_gt = time.perf_counter() - t0
+        progress("training ground truth done")
+        t0 = time.perf_counter()
+        meta = torch.zeros(2, dtype=torch.int64, device=cdev)
+        cached = args.index_cache and os.path.exists(args.index_cache)
+        if rank == 0 and cached:
+            z = np.load(args.index_cache)
+            h_off, h_nbrs, ep = z["off"], z["nbrs"], int(z["ep"])
+            off = synth.to_device(h_off.view(np.int64), dev)
+            nbrs = synth.to_device(h_nbrs.view(np.int32), dev)
+            meta[0], meta[1] = int(h_nbrs.size), int(ep)
+        elif rank == 0:
+            h_off, h_nbrs, ep = build.build_roargraph(synth.to_host(base), synth.to_host(ti).view(np.uint32), args.metric, 100, 35, 500,
+                                                      num_threads=int(os.environ.get("RG_BENCH_BUILD_THREADS", min(128, os.cpu_count() or 1))), device=local)
+            off = synth.to_device(h_off.view(np.int64), dev)
+            nbrs = synth.to_device(h_nbrs.view(np.int32), dev)
+            meta[0], meta[1] = int(h_nbrs.size), int(ep)
+            if args.index_cache:
+                np.savez(args.index_cache, off=h_off, nbrs=h_nbrs, ep=ep)
+        if world > 1:   # the finished graph goes to every rank (replicated index)
+            dist.broadcast(meta, 0)
+            if rank != 0:
+                off = torch.zeros(args.nb + 1, dtype=torch.int64, device=dev)
+                nbrs = torch.zeros(int(meta[0]), dtype=torch.int32, device=dev)
+            if args.backend == "nccl":
+                dist.broadcast(off, 0); dist.broadcast(nbrs, 0)
+            else:
+                ho, hn = off.cpu(), nbrs.cpu()
+                dist.broadcast(ho, 0); dist.broadcast(hn, 0)
+                off, nbrs = ho.to(dev), hn.to(dev)
+        ep = int(meta[1]) if world > 1 else ep
+        sync_all()
+        t_build = time.perf_counter() - t0
+        graph_desc = ("genuine RoarGraph index built in the run (K2 truth of %d training queries %.0f s on %d GPU(s), GPU-assisted "
+                      "construction %.0f s, M_sq=100 M_pjbp=35 L_pjpq=500, avg degree %.1f)"
+                      % (ntrain, t_gt, world, t_build, float(nbrs.numel()) / args.nb))
+        del train, ti
+    else:
+        g = torch.Generator(device=dev); g.manual_seed(4321)
+        nbrs = torch.randint(0, args.nb, (args.nb * args.deg,), dtype=torch.int32, device=dev, generator=g)
+        off = torch.arange(0, args.nb + 1, dtype=torch.int64, device=dev) * args.deg
+        ep = 0
+        graph_desc = "random out-degree-%d graph (recall is meaningless on it)" % args.deg
+    # the setup phase (ground truth of the training queries, construction) went through torch's caching allocator, which keeps
+    # what it is given; the library allocates with hipMalloc -- hand the cached blocks back first, so that its large buffers
+    # (adjacency, split rows, id logs, the 19 GiB of visited tags of a wide beam) are cut from whole memory, not from the gaps
+    C.base = base
+    C.off = off
+    C.nbrs = nbrs
+    C.ep = ep
+    C.q = q
+    C.data_desc = data_desc
+    C.graph_desc = graph_desc
+    C.t_gt = t_gt
+    C.t_build = t_build
+    C.ntrain = ntrain
+
+
+def open_index_and_batches(C):
+    """the index of this rank over its base and graph, and its distinct query batches with their exact truth (K2)"""
+    (args, torch, dist, dev, cdev, stream, rank, world, local, roar, sync_all, synth, groundtruth, build, lib, IndexBipartite, t_all, base, train, off, nbrs,
+     ep, q, qs, gts, index, S, data_desc, graph_desc, t_gt, t_build, ntrain, sweep, L_star, qps, head, ids_head, worst, elapsed, kernel_ms, used) = _ctx(C)
+    progress("graph ready")
+    torch.cuda.empty_cache()
+    index = IndexBipartite.from_device(base, off, nbrs, ep, metric=args.metric)
+    progress("index open")
+    for kv in [x for x in args.set.split(",") if x]:
+        kname, kval = kv.split("=")
+        index.set(kname, int(kval))
+    index.set("visited", args.visited)
+
+    # distinct query batches of this rank: one per timed step and warm-up (at most 32), every one with its exact truth (K2)
+    nbatch = max(1, min(32, args.steps + args.warmup)) if not args.data_root else 1
+    qs = [q]
+    for b in range(1, nbatch):
+        qs.append(synth.make_device_set(dev, 1234, 1024, 0, args.nq, args.dim, data=args.data, rank=args.rank,
+                                        q_seed=99 + rank + 7919 * b)[2])
+    gts = []
+    ti_q = torch.zeros((args.nq, 100), dtype=torch.int32, device=dev); tv_q = torch.zeros((args.nq, 100), device=dev)
+    for qb in qs:
+        groundtruth.gt_shard_dev(base, qb, args.metric, 100, 0, ti_q, tv_q, stream=stream); torch.cuda.synchronize()
+        gts.append(ti_q.cpu().numpy().view(np.uint32).copy())
+    del ti_q, tv_q
+    torch.cuda.empty_cache()
+    S = Searcher(torch, index, qs, args.k, args.dim, stream, gts)
+    progress("query batches and their truth ready")
+    C.index = index
+    C.qs = qs
+    C.gts = gts
+    C.S = S
+
+
+def sweep_leg(C):
+    """the L_pq sweep (every rank runs it: it also settles the adaptive default) and the beam width of the headline"""
+    (args, torch, dist, dev, cdev, stream, rank, world, local, roar, sync_all, synth, groundtruth, build, lib, IndexBipartite, t_all, base, train, off, nbrs,
+     ep, q, qs, gts, index, S, data_desc, graph_desc, t_gt, t_build, ntrain, sweep, L_star, qps, head, ids_head, worst, elapsed, kernel_ms, used) = _ctx(C)
+    # ---- L_pq sweep (every rank runs it: it also settles the adaptive default; rank 0 reports) -------------------------
+    sweep_Ls = sorted({int(x) for x in args.sweep.split(",") if x} | {500}) if args.sweep else []
+    sweep_Ls = [L for L in sweep_Ls if L >= args.k]
+    sweep = []
+    for L in sweep_Ls:
+        progress("sweep L_pq %d" % L)
+        ms, used = S.timed(L, reps=3 if L <= 500 else 2)
+        if max(S.last_reps_ms) > 1.5 * min(S.last_reps_ms):
+            # one launch far off the others (seen once in the round: 7.7 ms among 1.0 ms launches at L_pq = 10 -- a host stall
+            # between the two event records of a batch, not kernel time): measure the point again and say so
+            first = list(S.last_reps_ms)
+            ms, used = S.timed(L, reps=5 if L <= 500 else 3, settle=1)
+            pt = S.point(L, ms, used)
+            pt["remeasured"] = {"first_attempt_ms": first, "second_attempt_ms": list(S.last_reps_ms)}
+        else:
+            pt = S.point(L, ms, used)
+        pt["ms_reps"] = [round(x, 4) for x in S.last_reps_ms]
+        pt["forms"] = dict(S.last_forms)
+        if args.visited == 2 and rank == 0:
+            # what explains a point above the 6.29 TB/s streaming-copy ceiling: how few of the launch's row reads are first
+            # touches, and how many go to rows a 256-MiB cache could hold (null: the launch ran on the exact words)
+            ru = reuse_of_last_launch(torch, index, stream, args.nb, args.nq, dev)
+            if ru is None:     # narrow beams run on the exact LDS set (no id logs): one untimed launch in the logging form, for the statistics only
+                index.set("lset", 0); index.set("adaptive", 0)      # (the exact-tag form keeps no logs either)
+                S.run(L, 0); S.wait()
+                ru = reuse_of_last_launch(torch, index, stream, args.nb, args.nq, dev)
+                index.set("lset", -1); index.set("adaptive", 1)
+            pt["distinct_rows_frac"] = ru["distinct_rows_frac"] if ru else None
+            pt["share_of_reads_to_rows_a_256MiB_cache_can_hold"] = ru["share_of_reads_to_top_%d_rows" % MALL_ROWS] if ru else None
+        sweep.append(pt)
+    if args.L > 0:
+        L_star = args.L
+    else:
+        ok = [p["L_pq"] for p in sweep if (p["recall_at_10"] or 0.0) >= args.target_recall]
+        L_star = min(ok) if ok else (max(sweep_Ls) if sweep_Ls else 500)
+    if world > 1:   # all ranks time the same beam width
+        t = torch.tensor([L_star], dtype=torch.int64, device=cdev)
+        dist.broadcast(t, 0)
+        L_star = int(t.item())
+
+    C.sweep = sweep
+    C.L_star = L_star
+
+
+def replay_and_checks(C):
+    """after the timed region: the replay figure, row-reuse statistics of the headline launch, and the parity of the exact visited forms on the headline's batch"""
+    (args, torch, dist, dev, cdev, stream, rank, world, local, roar, sync_all, synth, groundtruth, build, lib, IndexBipartite, t_all, base, train, off, nbrs,
+     ep, q, qs, gts, index, S, data_desc, graph_desc, t_gt, t_build, ntrain, sweep, L_star, qps, head, ids_head, worst, elapsed, kernel_ms, used) = _ctx(C)
+    # what the same launch gains when it REPLAYS one batch (round 2's protocol: the rows of the previous launch are still
+    # in the Infinity Cache) -- reported, never `value`
+    for _ in range(3):
+        S.run(L_star, 0)
+    S.wait()
+    n_replay = min(10, args.steps)
+    er0, er1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    er0.record()
+    for _ in range(n_replay):
+        S.run(L_star, 0)
+    S.wait()
+    er1.record(); er1.synchronize()
+    replay_ms = er0.elapsed_time(er1) / n_replay
+    replay_alg = float(S.out[0]["cmps"].float().sum().item()) * 4.0 * args.dim
+    # first touches: distinct base rows among the evaluations of one launch (the id logs of the default visited mode)
+    reuse = None
+    if args.visited == 2:
+        reuse = reuse_of_last_launch(torch, index, stream, args.nb, args.nq, dev, full=True)
+        if reuse is None:      # the headline ran on the exact LDS set (no id logs): one untimed launch in the logging form, for the statistics only
+            index.set("lset", 0); index.set("adaptive", 0)
+            S.run(L_star, 0); S.wait()
+            reuse = reuse_of_last_launch(torch, index, stream, args.nb, args.nq, dev, full=True)
+            index.set("lset", -1); index.set("adaptive", 1)
+            S.run(L_star, 0); S.wait()
+        reuse = reuse or {"unavailable": "the launch ran on the exact words: no id logs"}
+    forms_head = {n_: index.stat(n_) for n_ in ("batches_lset", "batches_filter_log", "batches_exact_hbm", "batches_filter_only", "lset_left", "recounted")}
+    ids_head = S.out[0]["ids"].cpu().numpy().view(np.uint32).copy()
+    # the exact HBM-visited form returns the same bits (parity between the two exact forms, checked every run)
+    if args.visited != 0:
+        o = S.out[0]
+        keep = [o[x].clone() for x in ("ids", "dists", "cmps", "hops")]
+        index.set("visited", 0)
+        for look in (1, 0):      # both kernel forms of the exact words
+            index.set("lookahead", look)
+            S.run(L_star, 0); S.wait()
+            assert torch.equal(o["ids"], keep[0]) and torch.equal(o["hops"], keep[3]), "visited modes disagree on ids/hops"
+            assert torch.equal(o["dists"].view(torch.int32), keep[1].view(torch.int32)), "visited modes disagree on distances"
+            if args.visited == 2:
+                assert torch.equal(o["cmps"], keep[2]), "cmps differ from the exact visited mode"
+        index.set("lookahead", -1)
+        index.set("visited", args.visited)
+    C.replay_ms = replay_ms
+    C.replay_alg = replay_alg
+    C.reuse = reuse
+    C.forms_head = forms_head
+    C.ids_head = ids_head
+
+
+def host_form_leg(C):
+    """the boundary's host form (PCIe inclusive; never `value`)"""
+    (args, torch, dist, dev, cdev, stream, rank, world, local, roar, sync_all, synth, groundtruth, build, lib, IndexBipartite, t_all, base, train, off, nbrs,
+     ep, q, qs, gts, index, S, data_desc, graph_desc, t_gt, t_build, ntrain, sweep, L_star, qps, head, ids_head, worst, elapsed, kernel_ms, used) = _ctx(C)
+    progress('headline done: checks, host form')
+    # ---- the boundary's host form (rg_search: host buffers in, host buffers out -- PCIe inclusive; never `value`) --------
+    host_form = None
+    if rank == 0 and world == 1:
+        qh = qs[0].cpu().numpy()
+        index.SearchRoarGraph(qh, args.k, L_star)
+        t1 = time.perf_counter()
+        for _ in range(5):
+            hres = index.SearchRoarGraph(qh, args.k, L_star)
+        dt = (time.perf_counter() - t1) / 5
+        assert (hres[0] == ids_head).all(), "host form and device form disagree"
+        host_form = {"what": "rg_search with pageable host buffers (queries up, ids/dists/cmps/hops down, one synchronous call per "
+                             "%d-query batch), L_pq=%d" % (args.nq, L_star),
+                     "qps": args.nq / dt, "ms_per_batch": dt * 1e3, "vs_device_resident": args.nq / dt / qps}
+        del qh
+
+    C.host_form = host_form
+
+
+def two_streams_leg(C):
+    """batches alternating over two streams of one index (reported beside `value`)"""
+    (args, torch, dist, dev, cdev, stream, rank, world, local, roar, sync_all, synth, groundtruth, build, lib, IndexBipartite, t_all, base, train, off, nbrs,
+     ep, q, qs, gts, index, S, data_desc, graph_desc, t_gt, t_build, ntrain, sweep, L_star, qps, head, ids_head, worst, elapsed, kernel_ms, used) = _ctx(C)
+    # ---- batches alternating over two streams (the boundary allows concurrent searches on one index): the next batch's
+    # queries fill the wave slots the previous batch's tail leaves idle.  Reported beside `value`, never as it: `value` and
+    # the roofline keep the one-stream form whose per-launch duration rocprofv3 can be held against.
+    progress('two streams')
+    two_streams = None
+    if rank == 0 and world == 1 and not args.no_two_streams:
+        s2 = torch.cuda.Stream(device=dev)
+        S2 = Searcher(torch, index, qs, args.k, args.dim, s2.cuda_stream, None)
+        S2.cursor = len(qs) // 2
+        for _ in range(2):
+            S.run(L_star); S2.run(L_star)
+        S.wait(); S2.wait()
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            (S if i % 2 == 0 else S2).run(L_star)
+        S.wait(); S2.wait()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t1
+        S.run(L_star, 0); S2.run(L_star, 0); S.wait(); S2.wait()
+        assert torch.equal(S2.out[0]["ids"], S.out[0]["ids"]) and torch.equal(S2.out[0]["cmps"], S.out[0]["cmps"]), "the two streams disagree"
+        two_streams = {"what": "%d batches of %d queries (distinct, rotated) alternating over two streams of one index, L_pq=%d" % (args.steps, args.nq, L_star),
+                       "qps": args.nq * args.steps / dt, "vs_one_stream": args.nq * args.steps / dt / qps}
+        del S2
+
+    C.two_streams = two_streams
+
+
+def opt_in_modes_leg(C):
+    """the opt-in modes: fast_bf16 / multi_expand (not parity) and shared_frontier (exact, checked)"""
+    (args, torch, dist, dev, cdev, stream, rank, world, local, roar, sync_all, synth, groundtruth, build, lib, IndexBipartite, t_all, base, train, off, nbrs,
+     ep, q, qs, gts, index, S, data_desc, graph_desc, t_gt, t_build, ntrain, sweep, L_star, qps, head, ids_head, worst, elapsed, kernel_ms, used) = _ctx(C)
+    # ---- opt-in NON-parity modes, reported separately, never as `value` -----------------------------------------------
+    progress('opt-in modes')
+    fast = None
+    if rank == 0 and not args.no_fast and args.dim in (200, 512):
+        fast = []
+        for name, knob in (("fast_bf16 (bf16 traversal + exact fp32 re-rank of the beam)", "fast_bf16"),
+                           ("multi_expand (the speculated second expansion of a hop is merged unconditionally)", "multi_expand")):
+            try:
+                index.set(knob, 1)
+                rows = []
+                for L in sorted({L_star, 500}):
+                    ms, used_f = S.timed(L, reps=2, settle=1)
+                    p = S.point(L, ms, used_f)
+                    rows.append({"L_pq": L, "qps": p["qps"], "recall_at_10": p["recall_at_10"], "mean_evals_performed": p["mean_evals"]})
+                fast.append({"mode": name + " -- opt-in, NOT parity", "points": rows})
+            except Exception as e:  # noqa: BLE001
+                fast.append({"mode": name, "error": repr(e)})
+            index.set(knob, 0)
+
+    # ---- opt-in EXACT mode (results bit-identical, checked here): the first hop scored once for the batch ----
+    shared = None
+    if rank == 0 and not args.no_fast:
+        try:
+            index.set("shared_frontier", 1)
+            rows = []
+            for L in sorted({L_star, 500}):
+                ms, used_s = S.timed(L, reps=3, settle=1)
+                p = S.point(L, ms, used_s)
+                rows.append({"L_pq": L, "qps": p["qps"], "recall_at_10": p["recall_at_10"], "mean_evals": p["mean_evals"], "pct_of_8000": p["pct_of_8000"]})
+            S.run(L_star, 0); S.wait()
+            same = (S.out[0]["ids"].cpu().numpy().view(np.uint32) == ids_head).all()
+            shared = {"mode": "shared_frontier: the entry point and its neighbours scored once per batch with the exact routine "
+                              "(rg_front_score_kernel), the first hop reads the scores -- opt-in, results bit-identical", "points": rows,
+                      "ids_equal_default": bool(same)}
+            assert same, "shared_frontier changed a result"
+        except AssertionError:
+            raise
+        except Exception as e:  # noqa: BLE001
+            shared = {"mode": "shared_frontier", "error": repr(e)}
+        index.set("shared_frontier", 0)
+
+    C.fast = fast
+    C.shared = shared
+
+
+def cpu_baselines_leg(C):
+    """the reference loop on the host cores over the same index and queries (ids asserted equal), the truth cross-check, BASELINE configs[0]"""
+    (args, torch, dist, dev, cdev, stream, rank, world, local, roar, sync_all, synth, groundtruth, build, lib, IndexBipartite, t_all, base, train, off, nbrs,
+     ep, q, qs, gts, index, S, data_desc, graph_desc, t_gt, t_build, ntrain, sweep, L_star, qps, head, ids_head, worst, elapsed, kernel_ms, used) = _ctx(C)
+    # ---- CPU baselines on the same index and queries (rank 0, N = 1) ---------------------------------------------------
+    progress('cpu baselines')
+    cpu = cpu1 = cpu_cfg1 = gt_check = None
+    if rank == 0 and world == 1 and args.cpu_seconds > 0:
+        base_np = synth.to_host(base)
+        h_off_np = synth.to_host(off).view(np.uint64)
+        h_nbrs_np = synth.to_host(nbrs).view(np.uint32)
+        q_np = qs[0].cpu().numpy()
+        try:
+            cpu, cpu1 = cpu_search_baseline(base_np, h_off_np, h_nbrs_np, ep, q_np, ids_head, args.metric, args.k, L_star,
+                                            [min(16, os.cpu_count() or 1), 1], args.cpu_seconds)   # README.md:110 evaluates with 16 threads
+        except AssertionError:
+            raise
+        except Exception as e:  # noqa: BLE001  (environmental: no room in /dev/shm, ...); a parity failure is never folded in here
+            cpu = cpu or {"value": None, "unit": "QPS", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
+        # the recall column rests on the product's own K2 truth: a sample of it against the fp64 brute force of the checker (CPU, part of
+        # this baseline leg) -- ids equal wherever the fp64 scores of neighbouring ranks differ by more than 1e-5 relative
+        gt_check = None
+        try:
+            from oracle import pyoracle as po
+            ns = 32
+            ref_i, _, ref_s = po.groundtruth_f64(base_np, q_np[:ns], args.metric, 100, nthreads=min(16, os.cpu_count() or 1))
+            mine = gts[0][:ns]
+            same = mine == ref_i
+            sc = np.abs(ref_s).max(axis=1, keepdims=True) + 1e-30
+            # a differing id is legitimate only inside a tie band of the fp64 scores at that rank
+            gap_ok = np.zeros_like(same)
+            gap_ok[:, 1:] |= np.abs(np.diff(ref_s, axis=1)) <= 1e-5 * sc
+            gap_ok[:, :-1] |= np.abs(np.diff(ref_s, axis=1)) <= 1e-5 * sc
+            gt_check = {"queries": ns, "K": 100, "ids_equal_frac": float(same.mean()), "differences_outside_fp64_tie_bands": int((~same & ~gap_ok).sum()),
+                        "what": "K2 truth of the first %d queries of batch 0 against oracle fp64 brute force over the %d-row base" % (ns, args.nb)}
+            assert gt_check["differences_outside_fp64_tie_bands"] == 0, "the bench's ground truth disagrees with fp64 brute force: %r" % (gt_check,)
+        except AssertionError:
+            raise
+        except Exception as e:  # noqa: BLE001
+            gt_check = {"error": repr(e)}
+        del base_np
+        # BASELINE configs[0]: 100K-row subset with its own index, L_pq = 50, one CPU thread (and the GPU on the same inputs)
+        if args.config1_nb and roar and args.nb >= args.config1_nb:
+            nb1, nt1 = args.config1_nb, args.config1_nb
+            b1, tr1, q1, _ = synth.make_device_set(dev, 4321, nb1, nt1, 2000, args.dim, data=args.data, rank=args.rank)
+            t1i = torch.zeros((nt1, 100), dtype=torch.int32, device=dev); t1v = torch.zeros((nt1, 100), device=dev)
+            groundtruth.gt_shard_dev(b1, tr1, args.metric, 100, 0, t1i, t1v, stream=stream); torch.cuda.synchronize()
+            o1, n1, e1 = build.build_roargraph(b1.cpu().numpy(), t1i.cpu().numpy().view(np.uint32), args.metric, 100, 35, 500,
+                                               num_threads=min(64, os.cpu_count() or 1), device=local)
+            ix1 = IndexBipartite.from_device(b1, torch.from_numpy(o1.view(np.int64)).to(dev), torch.from_numpy(n1.view(np.int32)).to(dev), e1,
+                                             metric=args.metric)
+            g1i = torch.zeros((2000, 100), dtype=torch.int32, device=dev); g1v = torch.zeros((2000, 100), device=dev)
+            groundtruth.gt_shard_dev(b1, q1, args.metric, 100, 0, g1i, g1v, stream=stream); torch.cuda.synchronize()
+            S1 = Searcher(torch, ix1, [q1], args.k, args.dim, stream, [g1i.cpu().numpy().view(np.uint32)])
+            ms1, u1 = S1.timed(50)
+            p1 = S1.point(50, ms1, u1)
+            cpu_cfg1 = cpu_search_baseline(b1.cpu().numpy(), o1, n1, e1, q1.cpu().numpy(), S1.out[0]["ids"].cpu().numpy().view(np.uint32), args.metric,
+                                           args.k, 50, [1], args.cpu_seconds / 2)[0]
+            cpu_cfg1.update(workload="%d-row subset, own RoarGraph index, 2000 queries, top-%d, L_pq=50" % (nb1, args.k),
+                            recall_at_10=p1["recall_at_10"], gpu_qps_same_inputs=p1["qps"])
+            ix1.close()
+            del b1, tr1, q1, t1i, t1v, g1i, g1v, S1
+
+    C.cpu = cpu
+    C.cpu1 = cpu1
+    C.cpu_cfg1 = cpu_cfg1
+    C.gt_check = gt_check
+
+
+def worst_case_leg(C):
+    """the same base under a random graph at L_pq = 500: every row read comes from HBM (frac_hbm_only)"""
+    (args, torch, dist, dev, cdev, stream, rank, world, local, roar, sync_all, synth, groundtruth, build, lib, IndexBipartite, t_all, base, train, off, nbrs,
+     ep, q, qs, gts, index, S, data_desc, graph_desc, t_gt, t_build, ntrain, sweep, L_star, qps, head, ids_head, worst, elapsed, kernel_ms, used) = _ctx(C)
+    # ---- worst case: the same base under a random graph, L_pq = 500 -------------------------------------------------
+    progress('worst case')
+    worst = None
+    if rank == 0 and world == 1 and roar and not args.no_worstcase:
+        g = torch.Generator(device=dev); g.manual_seed(4321)
+        rn = torch.randint(0, args.nb, (args.nb * args.deg,), dtype=torch.int32, device=dev, generator=g)
+        ro = torch.arange(0, args.nb + 1, dtype=torch.int64, device=dev) * args.deg
+        ixr = IndexBipartite.from_device(base, ro, rn, 0, metric=args.metric)
+        Sr = Searcher(torch, ixr, qs, args.k, args.dim, stream, None)
+        msr, ur = Sr.timed(500, reps=min(5, args.steps), settle=2)
+        pr = Sr.point(500, msr, ur)
+        tr_, trs = pmc_traffic({"nb": args.nb, "dim": args.dim, "nq": args.nq, "k": args.k, "metric": args.metric, "data": args.data, "rank": args.rank,
+                                "graph": "random", "L": 500, "visited": 2})
+        worst = {"workload": "same base, random out-degree-%d graph, %d queries, top-%d, L_pq=500 (every neighbour fresh: pure random "
+                             "%d-byte row reads; recall meaningless)" % (args.deg, args.nq, args.k, 4 * args.dim),
+                 "qps": pr["qps"], "mean_evals": pr["mean_evals"], "mean_hops": pr["mean_hops"],
+                 "bound": "hbm", "achieved": pr["GBps"], "peak": 8000.0, "unit": "GB/s", "frac": pr["GBps"] / 8000.0,
+                 "frac_of_measured_stream_ceiling_6290": pr["GBps"] / 6290.0, "kernel_ms_avg": msr, "traffic": tr_, "traffic_source": trs}
+        ixr.close()
+        del rn, ro, Sr
+
+    C.worst = worst
+
+
+def ground_truth_leg(C):
+    """BASELINE metric #2: K2 through the native multi-rank path, and the resident / small-batch launches"""
+    (args, torch, dist, dev, cdev, stream, rank, world, local, roar, sync_all, synth, groundtruth, build, lib, IndexBipartite, t_all, base, train, off, nbrs,
+     ep, q, qs, gts, index, S, data_desc, graph_desc, t_gt, t_build, ntrain, sweep, L_star, qps, head, ids_head, worst, elapsed, kernel_ms, used) = _ctx(C)
+    # ---- second BASELINE metric: ground-truth build, distances/s, through the NATIVE multi-rank path the CLI twin ships
+    # (rg_comm + rg_groundtruth_rank, csrc/rg_gt_dist.hip): base rows sharded over the ranks and resident in HBM, the
+    # queries streamed from host memory in batches of 65,536 (>= 4 batches, so that K2 of batch b+1 runs under the
+    # exchange of batch b), per-shard top-K lists exchanged with grouped RCCL send/recv on a side stream, K3, rows written
+    # to the owner's host array.  Ranks that share a GPU (--backend gloo, control-flow tests) cannot form an RCCL
+    # communicator: they take the torch.distributed form (one all_to_all) instead.
+    progress("ground-truth leg")
+    gt = None
+    if args.gt_nq > 0:
+        lo, hi = groundtruth.shard_rows(args.nb, world)[rank]
+        g = torch.Generator(device=dev); g.manual_seed(4242)
+        shard = base[lo:hi]
+        native = world == 1 or args.backend == "nccl"
+        gt_batch = 65536
+        if native and world > 1:     # every rank must be able to join the RCCL communicator, or none takes the native path
+            ok = torch.tensor([1], dtype=torch.int32, device=cdev)
+            try:
+                comm = groundtruth.Comm.from_torch_dist(local)
+            except Exception as e:  # noqa: BLE001
+                print("[bench] rank %d: native ground-truth path unavailable (%r): torch.distributed form instead" % (rank, e), file=sys.stderr)
+                comm = None
+                ok[0] = 0
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                if comm is not None:
+                    comm.destroy()
+                native = False
+        elif native:
+            comm = groundtruth.Comm.local([local])[0]
+        if native:
+            nq_gt = max(args.gt_nq, 4 * gt_batch) if args.gt_nq >= gt_batch else args.gt_nq
+            gq_h = (torch.empty((nq_gt, args.dim), dtype=torch.float32, device=dev).normal_(generator=g) * 0.5 + 0.3).cpu().numpy()
+            out_i = np.zeros((nq_gt, args.gt_K), np.uint32); out_d = np.zeros((nq_gt, args.gt_K), np.float32)
+            # warm-up: a small call (allocations, module load, communicator), then one batch of the timed size -- the leg
+            # follows half a minute of CPU-only baselines, and the first seconds of MFMA work after that idle run slower
+            groundtruth.groundtruth_rank(comm, shard, lo, gq_h[:4096], args.metric, args.gt_K, out_i[:4096], out_d[:4096], batch=2048)
+            groundtruth.groundtruth_rank(comm, shard, lo, gq_h[:gt_batch], args.metric, args.gt_K, out_i[:gt_batch], out_d[:gt_batch], batch=gt_batch)
+            sync_all()
+            tg0 = time.perf_counter()
+            groundtruth.groundtruth_rank(comm, shard, lo, gq_h, args.metric, args.gt_K, out_i, out_d, batch=gt_batch)
+            sync_all()
+            tg = time.perf_counter() - tg0
+            form = ("rg_groundtruth_rank over %s: %d query batches of %d streamed from host memory, per-shard K-lists exchanged on a "
+                    "side stream under the next batch's K2" % ("RCCL (ncclSend/ncclRecv, xGMI)" if comm.uses_rccl() else "the in-process transport",
+                                                              (nq_gt + gt_batch - 1) // gt_batch, gt_batch))
+            comm.destroy()
+            del out_i, out_d
+        else:
+            nq_gt = args.gt_nq
+            gq = torch.empty((nq_gt, args.dim), dtype=torch.float32, device=dev).normal_(generator=g) * 0.5 + 0.3
+            groundtruth.groundtruth_distributed(shard[: min(hi - lo, 65536)], lo, gq[:2048], args.metric, args.gt_K)
+            groundtruth.groundtruth_distributed(shard, lo, gq, args.metric, args.gt_K)
+            sync_all()
+            tg0 = time.perf_counter()
+            gi, gv = groundtruth.groundtruth_distributed(shard, lo, gq, args.metric, args.gt_K)
+            sync_all()
+            tg = time.perf_counter() - tg0
+            form = "torch.distributed form (K2 per rank, one all_to_all, K3): ranks share a GPU, no RCCL communicator possible"
+            gq_h = gq.cpu().numpy()
+            del gi, gv, gq
+        if world > 1:
+            t = torch.tensor([tg], dtype=torch.float64, device=cdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            tg = float(t.item())
+        dps = float(nq_gt) * float(args.nb) / tg
+        gt = {"metric": "GT-build distances/sec (K=%d, %d queries x %d base rows, base sharded x%d)" % (args.gt_K, nq_gt, args.nb, world),
+              "value": dps, "seconds": tg, "form": form, "TFLOPs_fp32_mfma": 2.0 * args.dim * dps / 1e12,
+              "roofline": {"bound": "mfma", "achieved": 2.0 * args.dim * dps / 1e12, "peak": 157.3 * world, "unit": "TFLOP/s",
+                           "frac": 2.0 * args.dim * dps / 1e12 / (157.3 * world)}}
+        if rank == 0 and world == 1:
+            # the kernel alone, queries and results resident in HBM (one K2 launch over 65,536 queries): what profiles/*/gt_* profile
+            gq = torch.from_numpy(gq_h[: min(nq_gt, gt_batch)]).to(dev)
+            groundtruth.groundtruth_distributed(shard, lo, gq, args.metric, args.gt_K)
+            torch.cuda.synchronize()
+            tk0 = time.perf_counter()
+            groundtruth.groundtruth_distributed(shard, lo, gq, args.metric, args.gt_K)
+            torch.cuda.synchronize()
+            tk = time.perf_counter() - tk0
+            gt["k2_device_resident"] = {"queries": int(gq.shape[0]), "seconds": tk, "value": float(gq.shape[0]) * float(args.nb) / tk,
+                                        "frac_of_mfma_peak": 2.0 * args.dim * float(gq.shape[0]) * float(args.nb) / tk / 1e12 / 157.3}
+            # ... and at the size of an evaluation-side truth or a tail batch: 10,000 queries in one launch (a query block is searched in
+            # pieces by several workgroups there: balanced split, quota thresholds between the pieces)
+            gs = gq[: min(10_000, int(gq.shape[0]))].contiguous()
+            groundtruth.groundtruth_distributed(shard, lo, gs, args.metric, args.gt_K)
+            torch.cuda.synchronize()
+            ts0 = time.perf_counter()
+            for _ in range(3):
+                groundtruth.groundtruth_distributed(shard, lo, gs, args.metric, args.gt_K)
+            torch.cuda.synchronize()
+            ts = (time.perf_counter() - ts0) / 3
+            gt["k2_small_batch"] = {"queries": int(gs.shape[0]), "seconds": round(ts, 4),
+                                    "frac_of_mfma_peak": round(2.0 * args.dim * float(gs.shape[0]) * float(args.nb) / ts / 1e12 / 157.3, 4)}
+            del gs
+            if args.cpu_seconds > 0:
+                try:
+                    gt["cpu_baseline"] = gt_cpu_baseline(base, gq, args)
+                except Exception as e:  # noqa: BLE001
+                    gt["cpu_baseline"] = {"value": None, "unit": "distances/s", "cores": 0, "kind": "port", "sample": "failed: %r" % (e,)}
+            del gq
+
+    C.gt = gt
+
+
+def side_blocks_leg(C):
+    """the side blocks (rank 0, N = 1): the main index is closed and its memory handed back first"""
+    (args, torch, dist, dev, cdev, stream, rank, world, local, roar, sync_all, synth, groundtruth, build, lib, IndexBipartite, t_all, base, train, off, nbrs,
+     ep, q, qs, gts, index, S, data_desc, graph_desc, t_gt, t_build, ntrain, sweep, L_star, qps, head, ids_head, worst, elapsed, kernel_ms, used) = _ctx(C)
+    # ---- side blocks (rank 0, N = 1): three smaller workloads, each built and searched inside the run, each with its own roofline
+    # and cpu_baseline -- the headline's data set is the easiest of the family (latent rank 32), and BASELINE configs[3] / [4] are d = 512
+    progress("side blocks")
+    side_blocks = []
+    n_query_batches = len(qs)
+    if rank == 0 and world == 1 and args.configs:
+        mem_stats_main = index.mem_stats()
+        index.close()
+        del S, index, base, off, nbrs, qs
+        C.S = C.index = C.base = C.off = C.nbrs = C.qs = C.q = None
+        torch.cuda.empty_cache()
+        lib().rg_mem_release(local)      # the library's cache of freed buffers (the side blocks have other sizes)
+        defs = {
+            # (round 5: at the headline's own size -- 10M x 200 -- so that the driver's clock sees the headline shape on data where
+            # recall 0.9 needs a four times wider beam and the index has more than twice the degree)
+            "rank128": dict(nb=args.rank128_nb, dim=200, metric="ip", k=10, rank_latent=128, Ls=[50, 100, 200, 300, 500, 1000],
+                            what="a harder data set of the headline's family and SIZE: latent rank 128 instead of 32 (four times the intrinsic "
+                                 "dimension), %d x 200 IP, top-10; frac_hbm_only = the headline block's random-graph figure (same base shape)" % args.rank128_nb),
+            # (round 6) the family with LOW REUSE between the queries of a launch: 1,000 clusters in a rank-128 latent space at the
+            # headline's size -- where recall 0.9 lands when the Infinity Cache has little to serve
+            "mixture": dict(nb=args.rank128_nb, dim=200, metric="ip", k=10, rank_latent=128, Ls=[50, 100, 200, 300, 500, 1000], data="mixture",
+                            what="low reuse between queries: %d x 200 IP, 1,000 cluster centres in a rank-128 latent space (synth.py 'mixture'), top-10; "
+                                 "frac_hbm_only = the headline block's random-graph figure (same base shape)" % args.rank128_nb),
+            "webvid": dict(nb=2_500_000, dim=512, metric="ip", k=10, rank_latent=32, Ls=[10, 20, 30, 50, 100, 200, 500],
+                           what="BASELINE configs[4] shape, end to end in the run: webvid-2.5M-shaped 2.5M x 512 IP, ground truth of 500k training "
+                                "queries (K2) -> GPU-assisted RoarGraph construction -> search, top-10"),
+            "laion": dict(nb=args.laion_nb, dim=512, metric="l2", k=100, rank_latent=32, Ls=[100, 150, 200, 300, 500, 1000],
+                          what="BASELINE configs[3] shape at %d rows (the full 10M x 512 run takes the whole default budget by itself: --nb 10000000 "
+                               "--dim 512 --metric l2 --k 100): laion-shaped d = 512 L2, top-100, recall@100" % args.laion_nb),
+        }
+        for cname in [c for c in args.configs.split(",") if c]:
+            if cname not in defs:
+                raise SystemExit("--configs: unknown block %r (rank128, mixture, webvid, laion)" % cname)
+            d_ = defs[cname]
+            if args.side_nb:
+                d_["nb"] = args.side_nb
+            side_blocks.append(side_config(torch, dev, stream, cname, d_["nb"], d_["dim"], d_["metric"], d_["k"], d_["rank_latent"], d_["nb"] // 5, args.nq,
+                                           d_["Ls"], args.target_recall, min(args.cpu_seconds, 6.0), min(args.steps, 5), d_["what"],
+                                           frac_hbm_only=worst["frac"] if (worst and cname in ("rank128", "mixture") and d_["nb"] == args.nb and d_["dim"] == args.dim) else None,
+                                           data=d_.get("data", "lowrank")))
+    else:
+        mem_stats_main = index.mem_stats() if rank == 0 else None
+    if mem_stats_main and not mem_stats_main.get("placement_balanced", True):
+        print("[bench] WARNING: %d large buffer(s) of the index fell back to plain allocations (one memory class): wide beams run "
+              "up to 10 %% slower in that placement" % mem_stats_main.get("plain_allocs_of_this_index", -1), file=sys.stderr)
+    C.side_blocks = side_blocks
+    C.mem_stats_main = mem_stats_main
+    C.n_query_batches = n_query_batches
+

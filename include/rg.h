@@ -177,7 +177,7 @@ rg_status rg_mem_release(int device);
  * on stderr -- "Memory access fault by GPU ... on address 0x..." -- and abort().  rg_mem_fault_report(path) (or RG_FAULT_REPORT=path in
  * the environment at load time) installs SIGABRT / SIGSEGV / SIGBUS handlers that write, before the process dies, the library's journal
  * of address-space events (every range mapped, cached, handed out again, unmapped: the last 4096), its live and cached buffers and
- * /proc/self/maps to `path`, then pass the signal on to the handler that was installed before; roargraph_amd/benchlib/fault.py names
+ * /proc/self/maps to `path`, then pass the signal on to the handler that was installed before; benchlib/fault.py names
  * the buffer a fault address belongs to from that file.  rg_mem_journal_dump writes the same report now (tests). */
 rg_status rg_mem_fault_report(const char *path);
 rg_status rg_mem_journal_dump(const char *path);

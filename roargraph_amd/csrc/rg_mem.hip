@@ -52,7 +52,7 @@ constexpr int kMaxClasses = 4;
 // out again or unmaps is therefore noted in a ring (4096 events, no allocation, one atomic per event), and -- RG_FAULT_REPORT=<path>
 // in the environment, or rg_mem_fault_report(path) -- a SIGABRT / SIGSEGV / SIGBUS handler writes the ring, the live and cached
 // buffers and /proc/self/maps to <path> before the process dies: the fault address then names its buffer and that buffer's life
-// (roargraph_amd/benchlib/fault.py reads the report).  Kinds: g = granule mapped at its pool address (1 GiB), u = granule unmapped
+// (benchlib/fault.py reads the report).  Kinds: g = granule mapped at its pool address (1 GiB), u = granule unmapped
 // there (moved into a buffer, or dropped: aux 1), B = balanced buffer mapped, C = freed into the cache (still mapped), H = handed
 // out again from the cache, F = unmapped (freed, or released from the cache: aux 1), P = plain hipMalloc of a large request,
 // f = hipFree of a pointer the pools do not know.

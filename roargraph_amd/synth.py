@@ -135,8 +135,33 @@ def make_device_set(dev, seed, nb, ntrain, nq, d, data="gaussian", rank=24, nois
         q = queries(mix)
         desc = ("low-rank embeddings %dx%d: x = zA + %.2f eps, latent rank %d, base z ~ N(0,1), train/test queries "
                 "z ~ N(0.3,0.5^2) (%d / %d)" % (nb, d, noise, rank, ntrain, nq))
+    elif data == "mixture":
+        # (round 6) low reuse BETWEEN queries: 1,000 cluster centres in the latent space, a row = its centre + 0.35 N(0, I) mapped through A;
+        # queries sit near centres too, with the out-of-distribution shift of the other families.  Two queries of a batch rarely walk the
+        # same region of the graph, so few of a launch's row reads are repeats that the Infinity Cache can serve.
+        ncl = 1000
+        mix = torch.empty((rank, d), dtype=torch.float32, device=dev).normal_(generator=g) / float(rank) ** 0.5
+        cent = torch.empty((ncl, rank), dtype=torch.float32, device=dev).normal_(generator=g)
+
+        def fill_mix(n, shift, spread):
+            out = torch.empty((n, d), dtype=torch.float32, device=dev)
+            for s in range(0, n, chunk):
+                m = min(chunk, n - s)
+                k = torch.randint(0, ncl, (m,), device=dev, generator=g)
+                z = cent[k] + torch.empty((m, rank), dtype=torch.float32, device=dev).normal_(generator=g) * spread + shift
+                out[s:s + m] = z @ mix
+                out[s:s + m].add_(torch.empty((m, d), dtype=torch.float32, device=dev).normal_(generator=g), alpha=noise)
+            return out
+        base = fill_mix(nb, 0.0, 0.35)
+        train = fill_mix(ntrain, 0.1, 0.45) if ntrain else None
+        if q_seed is not None:
+            g = torch.Generator(device=dev)
+            g.manual_seed(q_seed)
+        q = fill_mix(nq, 0.1, 0.45)
+        desc = ("mixture embeddings %dx%d: %d cluster centres in a rank-%d latent space, x = (c_k + 0.35 e) A + %.2f eps; train/test queries "
+                "(c_k + 0.1 + 0.45 e) A (%d / %d)" % (nb, d, ncl, rank, noise, ntrain, nq))
     else:
-        raise ValueError("data must be gaussian or lowrank")
+        raise ValueError("data must be gaussian, lowrank or mixture")
     return base, train, q, desc
 
 

@@ -194,3 +194,51 @@ def test_rccl_exchange_schedule_of_the_ground_truth_for_eight_ranks(world, nq, b
         ci, cv = ids[:, q].reshape(-1), vals[:, q].reshape(-1)
         order = np.lexsort((ci, -cv))[:K]
         assert (out_i[q] == ci[order]).all() and (out_v[q] == cv[order]).all()
+
+
+def test_first_8gpu_script_commands_parse():
+    """scripts/first_8gpu.sh has NEVER run (no round had a multi-GPU node): what can be checked without one is that every command it
+    would issue exists and parses -- bench.py's flags through bench.parse(), the ground-truth CLI's flags against its source, the pytest
+    selections against the test file, the helper's sub-commands."""
+    import os
+    import re
+    import shlex
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run(["bash", os.path.join(root, "scripts", "first_8gpu.sh")], env=dict(os.environ, DRY_RUN="1"), capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0, out.stderr
+    cmds = [shlex.split(l[4:]) for l in out.stdout.splitlines() if l.startswith("CMD ")]
+    assert len(cmds) == 10
+    sys.path.insert(0, root)
+    import bench
+    gpus = []
+    for c in cmds:
+        if "bench.py" in c:
+            argv = c[c.index("bench.py") + 1:]
+            if "--configs" in argv and (argv.index("--configs") + 1 == len(argv) or argv[argv.index("--configs") + 1].startswith("--")):
+                argv.insert(argv.index("--configs") + 1, "")      # (the echo of the dry run drops the empty argument)
+            old = sys.argv
+            sys.argv = ["bench.py"] + argv
+            try:
+                a = bench.parse()
+            finally:
+                sys.argv = old
+            gpus.append(a.gpus)
+            assert a.steps == 20 and a.warmup == 5 and a.configs == "" and a.full_out.endswith("bench_n%d.json" % a.gpus)
+        elif c[0].endswith("compute_groundtruth"):
+            src = open(os.path.join(root, "roargraph_amd", "cli", "compute_groundtruth.cpp")).read()
+            flags = [x[2:] for x in c if x.startswith("--")]
+            assert flags and all('a.add("%s"' % f in src for f in flags), flags
+            assert c[c.index("--devices") + 1] == "0,1,2,3,4,5,6,7"
+        elif "pytest" in c:
+            tests = open(os.path.join(root, "tests", "test_gpu_groundtruth.py")).read()
+            sel = c[c.index("-k") + 1]
+            for name in re.split(r"\s+or\s+", sel):
+                assert re.search(r"def test_\w*%s" % re.escape(name.replace("test_", "", 1) if name.startswith("test_") else name), tests), name
+        elif c[1].endswith("first_8gpu_files.py"):
+            assert c[2] in ("make", "check", "scale")
+    assert gpus == [1, 2, 4, 8]
+    from roargraph_amd import dist as rgdist
+    plan = rgdist.bench_plan(8, 10_000_000, 10_000, 2_000_000, 262_144)
+    assert len(plan["search"]) == 8 and sum(b - a for a, b in (p["base_rows"] for p in plan["gt_build"])) == 10_000_000

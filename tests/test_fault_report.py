@@ -1,4 +1,4 @@
-"""CPU: the post-mortem of a GPU memory fault (csrc/rg_mem.hip journal + signal handler, roargraph_amd/benchlib/fault.py)."""
+"""CPU: the post-mortem of a GPU memory fault (csrc/rg_mem.hip journal + signal handler, benchlib/fault.py)."""
 import os
 import subprocess
 import sys
@@ -25,7 +25,7 @@ END
 
 def test_attribution_of_a_fault_address():
     sys.path.insert(0, ROOT)
-    from roargraph_amd.benchlib import fault
+    from benchlib import fault
     err = "Memory access fault by GPU node-2 (Agent handle: 0x5c2ce1ad5490) on address 0x710004c000. Reason: Unknown.\n"
     assert fault.fault_addresses(err) == [0x710004c000]
     r = fault.attribute(REPORT, 0x710004c000)
@@ -52,5 +52,5 @@ def test_the_library_writes_its_report_when_the_process_aborts(tmp_path):
     assert p.returncode in (-6, 134), (p.returncode, p.stderr[-500:])
     text = rep.read_text()
     assert text.startswith("rg_mem fault report v1 (SIGABRT)") and "MAPS" in text and text.rstrip().endswith("END")
-    from roargraph_amd.benchlib import fault
+    from benchlib import fault
     assert len(fault.parse(text)["maps"]) > 10

@@ -194,7 +194,7 @@ def test_open_search_close_reopen_200_iterations():
     pageable memory over PCIe meanwhile.  A stale mapping shows as a GPU fault (the process dies) or as exact forms that disagree.
     (index_bipartite.h:27,62-64,105,133: the reference's lifecycle is constructor / load / search / destructor, any number of times.)"""
     import os
-    from roargraph_amd.benchlib.stress import lifecycle_stress
+    from benchlib.stress import lifecycle_stress
     iters = int(os.environ.get("RG_STRESS_ITERS", "200"))
     r = lifecycle_stress(iters, scale=float(os.environ.get("RG_STRESS_SCALE", "0.8")), host_load=2)
     assert r["iterations"] == iters

@@ -281,10 +281,13 @@ ident = open(idfile, "rb").read()
 if not ident:
     print("RESULT rank %%d: rccl unavailable (rg_comm_unique_id failed)" %% rank); sys.exit(0)
 h = C.c_void_p()
-rc = L.rg_comm_init_rank(ident, rank, 2, 0, C.byref(h))
+# RG_TEST_TWO_DEVICES=1 (scripts/first_8gpu.sh, a node with >= 2 GPUs): rank r on device r -- the exchange between two DEVICES
+device = rank if (os.environ.get("RG_TEST_TWO_DEVICES") and torch.cuda.device_count() >= 2) else 0
+torch.cuda.set_device(device)
+rc = L.rg_comm_init_rank(ident, rank, 2, device, C.byref(h))
 if rc != 0:
     print("RESULT rank %%d: init refused: %%s" %% (rank, L.rg_last_error().decode())); sys.exit(0)
-comm = groundtruth.Comm(h, rank, 2, 0)
+comm = groundtruth.Comm(h, rank, 2, device)
 base, q = synth.make_synth(64, 4000, 200, 200)
 lo, hi = groundtruth.shard_rows(4000, 2)[rank]
 oi = np.zeros((200, 24), np.uint32); od = np.zeros((200, 24), np.float32)
