@@ -97,6 +97,8 @@ def parse():
                     help="2 = library default (LDS visited filter + id log + exact distinct count, adaptive to the exact HBM words; "
                          "every output bit-exact); 1 = LDS filter only (cmps = evaluations performed); 0 = visited words in HBM")
     ap.add_argument("--set", default="", help="comma list of knob=value passed to rg_index_set (tuning experiments)")
+    ap.add_argument("--row-stride", type=int, default=0, help="experiment: base rows padded to this many floats (256 with RG_SPLIT_ROWS=0: eight whole "
+                    "128-B lines per d = 200 row instead of the split copy); 0 = dim")
     ap.add_argument("--no-worstcase", action="store_true", help="skip the random-graph block")
     ap.add_argument("--no-fast", action="store_true", help="skip the opt-in non-parity modes")
     ap.add_argument("--no-two-streams", action="store_true", help="skip the two-stream block (profiling: its overlapped launches would "

@@ -147,8 +147,13 @@ def open_index_and_batches(C):
     (args, torch, dist, dev, cdev, stream, rank, world, local, roar, sync_all, synth, groundtruth, build, lib, IndexBipartite, t_all, base, train, off, nbrs,
      ep, q, qs, gts, index, S, data_desc, graph_desc, t_gt, t_build, ntrain, sweep, L_star, qps, head, ids_head, worst, elapsed, kernel_ms, used) = _ctx(C)
     progress("graph ready")
+    if args.row_stride > args.dim:      # experiment: rows padded to a stride of their own (256 floats = eight whole 128-B lines per row)
+        padded = torch.zeros((args.nb, args.row_stride), dtype=torch.float32, device=dev)
+        padded[:, : args.dim] = base
+        base = padded
+        del padded
     torch.cuda.empty_cache()
-    index = IndexBipartite.from_device(base, off, nbrs, ep, metric=args.metric)
+    index = IndexBipartite.from_device(base, off, nbrs, ep, metric=args.metric, dim=args.dim)
     progress("index open")
     for kv in [x for x in args.set.split(",") if x]:
         kname, kval = kv.split("=")
@@ -164,12 +169,13 @@ def open_index_and_batches(C):
     gts = []
     ti_q = torch.zeros((args.nq, 100), dtype=torch.int32, device=dev); tv_q = torch.zeros((args.nq, 100), device=dev)
     for qb in qs:
-        groundtruth.gt_shard_dev(base, qb, args.metric, 100, 0, ti_q, tv_q, stream=stream); torch.cuda.synchronize()
+        groundtruth.gt_shard_dev(base, qb, args.metric, 100, 0, ti_q, tv_q, dim=args.dim, stream=stream); torch.cuda.synchronize()
         gts.append(ti_q.cpu().numpy().view(np.uint32).copy())
     del ti_q, tv_q
     torch.cuda.empty_cache()
     S = Searcher(torch, index, qs, args.k, args.dim, stream, gts)
     progress("query batches and their truth ready")
+    C.base = base
     C.index = index
     C.qs = qs
     C.gts = gts

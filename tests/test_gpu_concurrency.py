@@ -140,9 +140,12 @@ def test_fifty_opens_and_closes_reserve_no_new_address_space(oracle):
     runs, every open is served from the cache, the placement is reported balanced, and the searches return the same bits; the
     cache goes back to the device on request."""
     import ctypes as C
+    import os
     import torch
     from roargraph_amd._lib import check, lib
     from roargraph_amd.index import IndexBipartite
+    if os.environ.get("RG_BALANCED_ALLOC") == "0":
+        pytest.skip("the balanced allocator is switched off: there is no cache of mapped buffers to test")
     dev = torch.device("cuda", 0)
     g = torch.Generator(device=dev); g.manual_seed(77)
     nb, d, deg, nq = 1_500_000, 512, 16, 256
@@ -198,3 +201,23 @@ def test_open_search_close_reopen_200_iterations():
     iters = int(os.environ.get("RG_STRESS_ITERS", "200"))
     r = lifecycle_stress(iters, scale=float(os.environ.get("RG_STRESS_SCALE", "0.8")), host_load=2)
     assert r["iterations"] == iters
+
+
+def test_kill_switch_of_the_balanced_allocator():
+    """RG_BALANCED_ALLOC=0 must leave a working library that never touches the virtual-memory API -- every large buffer
+    a plain hipMalloc, no probe launched, no address space reserved -- through the same lifecycle (its own process: the switch is read once)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys, json, ctypes as C; sys.path.insert(0, %r)\n"
+            "from benchlib.stress import lifecycle_stress\n"
+            "from roargraph_amd._lib import lib\n"
+            "r = lifecycle_stress(6, scale=0.8, host_load=0)\n"
+            "ex = (C.c_uint64 * 10)(); lib().rg_mem_stats_ex(0, ex, 10)\n"
+            "print('RESULT ' + json.dumps({'iterations': r['iterations'], 'balanced': int(ex[0]), 'probes': int(ex[3]), 'va': int(ex[5]), 'cached': int(ex[7])}))\n" % root)
+    p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, RG_BALANCED_ALLOC="0"), capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-1500:]
+    r = json.loads([l for l in p.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    assert r == {"iterations": 6, "balanced": 0, "probes": 0, "va": 0, "cached": 0}, r

@@ -39,7 +39,7 @@ def check_gt(base, q, metric, K, ids, dists, ref_ids, ref_s64, tol=1e-5, min_sam
     assert (np.abs(dists.astype(np.float64) - s) <= 1e-4 * np.abs(s) + 1e-4 * scale * 1e-2).all(), "stored distances off"
 
 
-@pytest.mark.parametrize("metric,d,nb,nq,K", [("ip", 200, 20000, 300, 100), ("l2", 512, 6000, 130, 100),
+@pytest.mark.parametrize("metric,d,nb,nq,K", [("ip", 200, 20000, 300, 100), ("l2", 512, 6000, 130, 100), ("ip", 512, 9000, 200, 100),
                                               ("ip", 200, 1000, 5, 10), ("l2", 24, 3000, 257, 1),
                                               ("ip", 104, 5000, 64, 100), ("ip", 200, 130, 128, 128),
                                               ("l2", 200, 4000, 100, 300),
