@@ -580,6 +580,23 @@ def ground_truth_leg(C):
             gt["k2_small_batch"] = {"queries": int(gs.shape[0]), "seconds": round(ts, 4),
                                     "frac_of_mfma_peak": round(2.0 * args.dim * float(gs.shape[0]) * float(args.nb) / ts / 1e12 / 157.3, 4)}
             del gs
+            # (round 6, VERDICT r5 #2 / missing #4) K2 at d = 512, the ground truth of BASELINE configs[3] (laion: L2) and [4] (webvid: IP): one
+            # launch over 65,536 and over 10,000 queries x a 2M x 512 base per metric, fraction of the fp32-MFMA peak
+            if args.k2_d512_nb > 0:
+                g5 = torch.Generator(device=dev); g5.manual_seed(512)
+                b5 = torch.empty((args.k2_d512_nb, 512), dtype=torch.float32, device=dev).normal_(generator=g5)
+                q5 = torch.empty((65536, 512), dtype=torch.float32, device=dev).normal_(generator=g5) * 0.5 + 0.3
+                i5 = torch.zeros((65536, args.gt_K), dtype=torch.int32, device=dev); v5 = torch.zeros((65536, args.gt_K), device=dev)
+                gt["k2_d512"] = {"base_rows": args.k2_d512_nb, "K": args.gt_K}
+                for m5 in ("ip", "l2"):
+                    for n5 in (65536, 10000):
+                        groundtruth.gt_shard_dev(b5, q5[:n5], m5, args.gt_K, 0, i5[:n5], v5[:n5], stream=stream); torch.cuda.synchronize()
+                        t50 = time.perf_counter()
+                        groundtruth.gt_shard_dev(b5, q5[:n5], m5, args.gt_K, 0, i5[:n5], v5[:n5], stream=stream); torch.cuda.synchronize()
+                        t5 = time.perf_counter() - t50
+                        gt["k2_d512"]["%s_%d" % (m5, n5)] = round(2.0 * 512 * float(n5) * float(args.k2_d512_nb) / t5 / 1e12 / 157.3, 4)
+                del b5, q5, i5, v5
+                torch.cuda.empty_cache()
             if args.cpu_seconds > 0:
                 try:
                     gt["cpu_baseline"] = gt_cpu_baseline(base, gq, args)

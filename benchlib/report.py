@@ -63,6 +63,8 @@ def compact_line(line, full_paths):
                            "cpu_value": _r((g.get("cpu_baseline") or {}).get("value"))}
         if g.get("k2_small_batch"):
             out["gt_build"]["k2_small_batch"] = g["k2_small_batch"]
+        if g.get("k2_d512"):      # fractions of the fp32-MFMA peak at d = 512: {ip,l2}_{65536,10000}
+            out["gt_build"]["k2_d512"] = g["k2_d512"]
     for name, key in (("two_streams_qps", "two_streams_pipelined"), ("host_form_qps", "host_form_pcie_inclusive")):
         if line.get(key):
             out[name] = _r(line[key].get("qps"))

@@ -291,6 +291,7 @@ def test_bench_one_gpu_small_run_reports_every_block(tmp_path):
     import sys
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "4", "--warmup", "2", "--nb", "300000", "--nq", "1000", "--gt-nq", "65536",
            "--cpu-seconds", "1", "--sweep", "20,100", "--no-worstcase", "--no-fast", "--config1-nb", "0", "--configs", "webvid,laion", "--side-nb", "40000",
+           "--k2-d512-nb", "200000",
            "--full-out", str(tmp_path / "full.json")]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
@@ -318,6 +319,9 @@ def test_bench_one_gpu_small_run_reports_every_block(tmp_path):
     assert cb["value"] > 0 and (cb["kind"] != "reference" or cb["value_without_prefetch"] > 0)
     g = d["gt_build"]
     assert g["value"] > 0 and "4 query batches" in g["form"] and g["k2_device_resident"]["value"] > 0
+    # (round 6) K2 at d = 512 in the record: both metrics, both batch sizes
+    assert set(g["k2_d512"]) >= {"ip_65536", "ip_10000", "l2_65536", "l2_10000"} and all(g["k2_d512"][k] > 0 for k in ("ip_65536", "l2_10000"))
+    assert c["gt_build"]["k2_d512"]["l2_65536"] > 0
 
 
 def test_bench_on_the_reference_file_layout(tmp_path):
