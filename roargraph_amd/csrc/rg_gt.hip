@@ -645,13 +645,19 @@ __global__ void __launch_bounds__(256, WPS) rg_gt_rs_kernel(GtParams P0) {
                 for (int n = 0; n < 4; ++n) b0[n] = bq[2 * (32 * n)];
             }
             for (uint32_t tile = 0; tile < ntiles; ++tile) {
+                // accumulators of a tile start as the rows' bias (L2: -|b|^2/2).  Without a bias (IP) nothing is written here: the first MFMA of
+                // the tile takes the constant 0 as its C operand instead (round 6) -- the 64 v_mov of the initialisation sat between the filter
+                // of one tile and the first MFMA of the next, with nothing in the matrix pipe
+                const bool has_bias = P.bias != nullptr;
+                if (has_bias) {
 #pragma unroll
-                for (int n = 0; n < 4; ++n) {
-                    const float b = P.bias ? bias_l[(tile & 1u) * 128u + 32 * n + (lane & 31)] : 0.0f;
+                    for (int n = 0; n < 4; ++n) {
+                        const float b = bias_l[(tile & 1u) * 128u + 32 * n + (lane & 31)];
 #pragma unroll
-                    for (int m = 0; m < TMW; ++m)
+                        for (int m = 0; m < TMW; ++m)
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) acc[m][n][r] = b;
+                            for (int r = 0; r < 16; ++r) acc[m][n][r] = b;
+                    }
                 }
                 auto chunk = [&](auto cc) __attribute__((always_inline)) {
                     constexpr int c = decltype(cc)::value;
@@ -750,11 +756,20 @@ __global__ void __launch_bounds__(256, WPS) rg_gt_rs_kernel(GtParams P0) {
                         }
                         __builtin_amdgcn_sched_barrier(0);
                         const int kk = 2 * (c * KQC + kq);
+                        if (c == 0 && kq == 0 && !has_bias) {      // first k pair of the tile, no bias: C = 0
+                            const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-                        for (int n = 0; n < 4; ++n)
+                            for (int n = 0; n < 4; ++n)
 #pragma unroll
-                            for (int m = 0; m < TMW; ++m)
-                                acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[kk][m], bc[n].x, acc[m][n], 0, 0, 0);
+                                for (int m = 0; m < TMW; ++m)
+                                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[kk][m], bc[n].x, zero, 0, 0, 0);
+                        } else {
+#pragma unroll
+                            for (int n = 0; n < 4; ++n)
+#pragma unroll
+                                for (int m = 0; m < TMW; ++m)
+                                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(areg[kk][m], bc[n].x, acc[m][n], 0, 0, 0);
+                        }
 #pragma unroll
                         for (int n = 0; n < 4; ++n)
 #pragma unroll
@@ -860,270 +875,6 @@ __global__ void __launch_bounds__(256, WPS) rg_gt_rs_kernel(GtParams P0) {
         atomicAdd(pf + 0, pf_item); atomicAdd(pf + 1, pf_filter); atomicAdd(pf + 2, pf_slow); atomicAdd(pf + 3, pf_compact);
         atomicAdd(pf + 4, (unsigned long long)pf_tiles); atomicAdd(pf + 5, (unsigned long long)pf_nslow);
         atomicAdd(pf + 6, (unsigned long long)pf_nev); atomicAdd(pf + 7, (unsigned long long)pf_ncand);
-    }
-}
-
-// K2-RS16 (round 6): the register-stationary form with 16-ROW query tiles (v_mfma_f32_16x16x4_f32) for d = 512.  The 32-row form keeps
-// DIM / 2 = 256 A registers per wave at d = 512: one wave per SIMD, one workgroup per CU -- whenever that wave waits (a chunk barrier, the
-// DMA in front of it, the tile filter, a compaction) its SIMD's matrix pipe has nothing to do (0.84 of peak for IP, 0.69 for L2 at 65,536
-// queries against 0.88 at d = 200, where two workgroups share a CU).  With 16 queries per wave the A operands are DIM / 4 = 128
-// registers (lane l holds Q[q = l & 15][4 kq + (l >> 4)] for every k-quad kq), the accumulators of the eight 16-column tiles of a base
-// tile 32, and TWO workgroups of 64 queries fit a CU: the stalls of one are covered by the other, as at d = 200.  The MFMA rate is the
-// same (2,048 flops per 32 cycles against 4,096 per 64); the price is one B fragment read (ds_read_b32) per MFMA instead of one
-// ds_read_b64 per two, and a base stream shared by 64 queries instead of 128 (twice the L2 -> LDS traffic per flop).
-// Pipeline, LDS-DMA, barriers, filter, candidate buffers, selection: those of rg_gt_rs_kernel.
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-template <int DIM, int BK, int ITEMS, int WPS>
-__global__ void __launch_bounds__(256, WPS) rg_gt_rs16_kernel(GtParams P0) {
-    constexpr int C = 64 * ITEMS;
-    constexpr int MQB = 64;                   // queries per workgroup (4 waves x 16)
-    constexpr int NKC = DIM / BK;             // k-chunks per base tile
-    constexpr int KQC = BK / 4;               // k-quads per chunk
-    static_assert(DIM % BK == 0 && BK % 8 == 0 && NKC >= 2 && NKC <= 8 && KQC / 2 <= 8, "chunking");
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int qoff = 16 * w;
-    const int lcol = lane & 15, lk = lane >> 4;      // column of a 16-column tile / k slot of a quad (= query row group of the accumulators)
-
-    float4 *Bq = reinterpret_cast<float4 *>(smem);                               // [2][KQC][128]
-    float *thr = reinterpret_cast<float *>(Bq + 2 * (size_t)KQC * kNB);          // [MQB]
-    uint32_t *cnt = reinterpret_cast<uint32_t *>(thr + MQB);                     // [MQB]
-    uint32_t *flag = cnt + MQB;                                                  // [4]
-    float *bias_l = reinterpret_cast<float *>(flag + 4);                         // [2][128] -|b|^2/2 of the tile's rows (L2)
-    u64 *cand = P0.cand + (size_t)blockIdx.x * MQB * C;
-
-    uint32_t cursor = P0.items ? P0.item_first[blockIdx.x] : 0u;
-    const uint32_t cursor_end = P0.items ? P0.item_first[blockIdx.x + 1] : 0u;
-    for (;;) {
-        uint32_t item;
-        if (P0.items) {
-            if (cursor >= cursor_end) break;
-            item = cursor++;
-            __syncthreads();
-        } else {
-            if (tid == 0) flag[1] = atomicAdd(P0.counter, 1u);
-            __syncthreads();
-            item = flag[1];
-            __syncthreads();
-        }
-        uint32_t blk;
-        uint32_t piece, npieces;
-        const GtParams P = gt_segment(P0, item, blk, piece, npieces);
-        if ((uint64_t)blk * MQB >= P.nq) break;
-        const uint32_t ntiles = (P.nb + kNB - 1) / kNB;
-        const uint32_t q0 = blk * MQB;
-        if (tid == 0) {
-            const bool on = P0.quota_thr && npieces > 1;
-            flag[2] = on ? (npieces | (piece << 16)) : 0u;
-            flag[3] = (uint32_t)(((unsigned long long)P.K * P.nb + P0.nb - 1u) / P0.nb);
-        }
-        // A operands of this wave's 16 queries, all k, into registers
-        float areg[DIM / 4];
-        {
-            const uint32_t q = q0 + qoff + lcol;
-            const float *qrow = P.queries + (size_t)min(q, P.nq - 1u) * P.qstride + lk;
-            const float scale = q < P.nq ? 1.0f : 0.0f;
-#pragma unroll
-            for (int kq = 0; kq < DIM / 4; ++kq) areg[kq] = qrow[4 * kq] * scale;
-        }
-        for (int i = tid; i < MQB; i += 256) { thr[i] = -__builtin_inff(); cnt[i] = 0; }
-        if (tid == 0) flag[0] = 0;
-        float thr_r[4];       // thresholds of this lane's four query rows (rows 4 lk + r of the wave's tile)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) thr_r[r] = -__builtin_inff();
-
-        const uint32_t lds_w = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(lds_ptr_t *)Bq) +
-                               (2u * ((uint32_t)w >> 1) + ((uint32_t)w & 1u)) * 1024u;
-        auto row_ptr = [&](uint32_t tile) {
-            uint32_t ln;
-            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
-            const uint32_t gr = min(tile * kNB + 64u * ((uint32_t)w & 1u) + ln, P.nb - 1u);   // clamp: rows past the end are ignored
-            return P.base + (size_t)gr * P.bstride + 4u * ((uint32_t)w >> 1);
-        };
-        auto stream_chunk = [&](auto cc, const float *rowp, uint32_t buf) __attribute__((always_inline)) {
-            constexpr int c = decltype(cc)::value;
-            glds_run<0, KQC / 2>(lds_w + buf * (uint32_t)(KQC * kNB * 16), rowp + c * BK);
-        };
-        const float *rowp = row_ptr(0);
-
-        f32x4 acc[8];
-        uint32_t step = 0;
-        {
-            float b0[8], b1[8];
-            const uint32_t lds_bias = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(lds_ptr_t *)bias_l);
-            auto stream_bias = [&](uint32_t tile, uint32_t slot) __attribute__((always_inline)) {
-                if (P.bias && w < 2) {
-                    uint32_t ln;
-                    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
-                    const uint32_t id = min(tile * kNB + 64u * (uint32_t)w + ln, P.nb - 1u);
-                    const float *src = P.bias + id;
-                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off"
-                                 :: "s"(lds_bias + slot * 512u + 256u * (uint32_t)w), "v"(src) : "memory");
-                }
-            };
-            // fragment of column tile n for k-quad kq of the chunk in `buf`: B[k = 4 kq + lk][row 16 n + lcol]
-            const float *bf0 = reinterpret_cast<const float *>(Bq) + 4 * lcol + lk;
-            const float *rowp_next = rowp;
-            stream_chunk(std::integral_constant<int, 0>{}, rowp, 0);
-            stream_bias(0, 0);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            stream_chunk(std::integral_constant<int, 1>{}, rowp, 1);
-#pragma unroll
-            for (int n = 0; n < 8; ++n) b0[n] = bf0[64 * n];
-            for (uint32_t tile = 0; tile < ntiles; ++tile) {
-#pragma unroll
-                for (int n = 0; n < 8; ++n) {
-                    const float b = P.bias ? bias_l[(tile & 1u) * 128u + 16 * n + lcol] : 0.0f;
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[n][r] = b;
-                }
-                auto chunk = [&](auto cc) __attribute__((always_inline)) {
-                    constexpr int c = decltype(cc)::value;
-                    const uint32_t buf = step & 1u;
-                    const float *bq = bf0 + (size_t)buf * KQC * kNB * 4;
-                    const float *bqn = bf0 + (size_t)(buf ^ 1u) * KQC * kNB * 4;
-#pragma unroll
-                    for (int kq = 0; kq < KQC; ++kq) {
-                        float (&bc)[8] = (kq & 1) ? b1 : b0;
-                        float (&bn)[8] = (kq & 1) ? b0 : b1;
-                        if (kq + 1 < KQC) {
-#pragma unroll
-                            for (int n = 0; n < 8; ++n) bn[n] = bq[(kq + 1) * kNB * 4 + 64 * n];
-                        } else {
-                            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-                            __syncthreads();
-                            if (c == 0 && flag[0]) {   // set by the previous tile's filter
-                                for (int qi = w; qi < MQB; qi += 4)
-                                    if (cnt[qi] + kNB > (uint32_t)C) {
-                                        const uint32_t pw = (uint32_t)__builtin_amdgcn_readfirstlane((int)flag[2]);
-                                        uint32_t *sl = pw ? P0.quota_thr + (size_t)(q0 / MQB) * P0.nseg * MQB + qi : nullptr;
-                                        gt_select_call<ITEMS>(cand + (size_t)qi * C, &cnt[qi], &thr[qi], P.K, lane, sl, pw,
-                                                              (uint32_t)__builtin_amdgcn_readfirstlane((int)flag[3]), (uint32_t)MQB);
-                                    }
-                                {   // every query of this wave takes up what the other pieces have published since
-                                    const uint32_t pw = (uint32_t)__builtin_amdgcn_readfirstlane((int)flag[2]);
-                                    if (pw && lane < MQB / 4) {
-                                        const int qi = w + 4 * lane;
-                                        const uint32_t *sl = P0.quota_thr + (size_t)(q0 / MQB) * P0.nseg * MQB + qi;
-                                        float t = __builtin_inff();
-                                        for (uint32_t j = 0; j < (pw & 0xffffu); ++j)
-                                            t = fminf(t, __uint_as_float(__hip_atomic_load(sl + (size_t)j * MQB, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)));
-                                        thr[qi] = fmaxf(thr[qi], next_below(t));
-                                    }
-                                }
-                                __syncthreads();
-                                if (tid == 0) flag[0] = 0;
-#pragma unroll
-                                for (int r = 0; r < 4; ++r) thr_r[r] = thr[qoff + 4 * lk + r];
-                                __syncthreads();
-                            }
-                            const float *dsrc = nullptr;
-                            if (!(P.diag & 1u)) {
-                                if constexpr (c + 2 < NKC) {
-                                    dsrc = rowp + (c + 2) * BK;
-                                } else if (tile + 1 < ntiles) {
-                                    if constexpr (c + 2 == NKC) {
-                                        rowp_next = row_ptr(tile + 1);
-                                        stream_bias(tile + 1, (tile + 1) & 1u);
-                                    }
-                                    dsrc = rowp_next + (c + 2 - NKC) * BK;
-                                }
-                            }
-                            const uint32_t dlds = lds_w + buf * (uint32_t)(KQC * kNB * 16);
-                            const bool next_frags = c + 1 < NKC || tile + 1 < ntiles;
-                            const int kkt = c * KQC + kq;
-                            auto tail_step = [&](auto jj) __attribute__((always_inline)) {
-                                constexpr int j = decltype(jj)::value;
-                                acc[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[kkt], bc[j], acc[j], 0, 0, 0);
-                                __builtin_amdgcn_sched_barrier(0);
-                                if constexpr (j < KQC / 2) {
-                                    if (dsrc) glds16<32 * j>(dlds + 4096u * j, dsrc);
-                                }
-                                if (next_frags) bn[j] = bqn[64 * j];      // first quad of the next chunk (bn is free: its quad is done)
-                                __builtin_amdgcn_sched_barrier(0);
-                            };
-                            __builtin_amdgcn_sched_barrier(0);
-                            tail_step(std::integral_constant<int, 0>{}); tail_step(std::integral_constant<int, 1>{});
-                            tail_step(std::integral_constant<int, 2>{}); tail_step(std::integral_constant<int, 3>{});
-                            tail_step(std::integral_constant<int, 4>{}); tail_step(std::integral_constant<int, 5>{});
-                            tail_step(std::integral_constant<int, 6>{}); tail_step(std::integral_constant<int, 7>{});
-                            continue;
-                        }
-                        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                        for (int n = 0; n < 8; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(areg[c * KQC + kq], bc[n], acc[n], 0, 0, 0);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                    ++step;
-                    if (c + 1 == NKC && !(P.diag & 2u)) {
-                        // tile finished: threshold filter (the compaction check rides on the next barrier)
-                        uint64_t any_win = 0;
-                        float mx[4];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            float m3a, m3b, m3c;
-                            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m3a) : "v"(acc[0][r]), "v"(acc[1][r]), "v"(acc[2][r]));
-                            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m3b) : "v"(acc[3][r]), "v"(acc[4][r]), "v"(acc[5][r]));
-                            asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m3c) : "v"(acc[6][r]), "v"(acc[7][r]), "v"(m3a));
-                            asm("v_max_f32 %0, %1, %2" : "=v"(mx[r]) : "v"(m3b), "v"(m3c));
-                            any_win |= __builtin_amdgcn_ballot_w64(mx[r] > thr_r[r]);
-                        }
-                        if (any_win) {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const float t = thr_r[r];
-                                if (mx[r] > t) {
-#pragma unroll
-                                    for (int n = 0; n < 8; ++n) {
-                                        const uint32_t id = tile * kNB + 16 * n + lcol;
-                                        if (acc[n][r] > t && id < P.nb && !(P.diag & 8u)) {
-                                            uint32_t ln;
-                                            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
-                                            const uint32_t qi2 = (uint32_t)(qoff + r) + 4u * (ln >> 4);
-                                            const uint32_t slot = atomicAdd(&cnt[qi2], 1u);
-                                            __attribute__((address_space(1))) u64 *cb = (__attribute__((address_space(1))) u64 *)P0.cand;
-                                            asm volatile("" : "+s"(cb));
-                                            cb[((uint32_t)blockIdx.x * MQB + qi2) * (uint32_t)C + slot] = make_key(acc[n][r], id, true);
-                                            if (slot + 1 + kNB > (uint32_t)C) flag[0] = 1;
-                                        }
-                                    }
-                                }
-                            }
-                        }
-                    }
-                    if (c + 1 == NKC) rowp = rowp_next;
-                };
-                if constexpr (0 < NKC) chunk(std::integral_constant<int, 0>{});
-                if constexpr (1 < NKC) chunk(std::integral_constant<int, 1>{});
-                if constexpr (2 < NKC) chunk(std::integral_constant<int, 2>{});
-                if constexpr (3 < NKC) chunk(std::integral_constant<int, 3>{});
-                if constexpr (4 < NKC) chunk(std::integral_constant<int, 4>{});
-                if constexpr (5 < NKC) chunk(std::integral_constant<int, 5>{});
-                if constexpr (6 < NKC) chunk(std::integral_constant<int, 6>{});
-                if constexpr (7 < NKC) chunk(std::integral_constant<int, 7>{});
-            }
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the last tile's candidate stores
-            __syncthreads();
-        }
-        // final selection + output
-        for (int qi = w; qi < MQB; qi += 4) {
-            const uint32_t kept = min(cnt[qi], P.K);
-            if constexpr (ITEMS > 4) {
-                if (cnt[qi] > P.K) gt_select_call<ITEMS>(cand + (size_t)qi * C, &cnt[qi], &thr[qi], P.K, lane, nullptr, 0u, 0u, 0u);
-                gt_compact<4>(cand + (size_t)qi * C, &cnt[qi], &thr[qi], P.K, lane);
-            } else gt_compact<ITEMS>(cand + (size_t)qi * C, &cnt[qi], &thr[qi], P.K, lane);
-            const uint32_t q = q0 + qi;
-            if (q < P.nq) {
-                for (uint32_t e = lane; e < P.K; e += 64) {
-                    const u64 k = cand[(size_t)qi * C + e];
-                    P.out_ids[(size_t)q * P.K + e] = e < kept ? (uint32_t)k + P.id_base : 0xffffffffu;
-                    P.out_vals[(size_t)q * P.K + e] = e < kept ? key_value(k, true) : -__builtin_inff();
-                }
-            }
-        }
-        __syncthreads();
     }
 }
 
@@ -1326,11 +1077,10 @@ rg_status gt_shard_ws(const float *d_base, uint32_t nb, uint32_t bstride, const 
             if (c.dim == dim) { rs_tmw = 1; rs_bk = c.bk; rs_per_cu = c.per_cu; }
         rs_mqb = 128 * rs_tmw;
     }
-    // d = 512 (round 6): 16-row query tiles, 64 queries per workgroup, two workgroups per CU (rg_gt_rs16_kernel); RG_GT_RS16=0: the 32-row form
-    // (d = 200, RG_GT_RS16=1, experiment: 50 A registers, THREE workgroups per CU)
-    const int rs16_env = getenv("RG_GT_RS16") ? atoi(getenv("RG_GT_RS16")) : -1;
-    const bool rs16 = rs_tmw && ((dim == 512 && rs16_env != 0) || (dim == 200 && rs16_env == 1));
-    if (rs16) { rs_mqb = 64; rs_per_cu = dim == 512 ? 2 : 3; }
+    // (round 6, measured and removed: 16-row query tiles -- v_mfma_f32_16x16x4_f32, 128 A registers at d = 512, two workgroups of 64 queries
+    // per CU; three at d = 200.  SLOWER everywhere: 0.834 against 0.882 of peak at d = 512 IP / 65,536 queries, 0.72 against 0.78 at 10,000,
+    // 0.73 against 0.88 at d = 200 -- one B-fragment read per MFMA and a base stream shared by half as many queries cost more than the
+    // second workgroup covers: profiles/r06/gt_ab_box2_*.jsonl)
     if (rs_tmw) mq = rs_mqb;
     const uint32_t nblocks = (nq + mq - 1) / mq;
     const uint32_t per_cu = rs_tmw ? rs_per_cu : 1;   // matches the kernel's launch bounds
@@ -1435,10 +1185,12 @@ rg_status gt_shard_ws(const float *d_base, uint32_t nb, uint32_t bstride, const 
     // default (profiles/r05/gt_ab_box12_buffers_256_384_512.jsonl, d = 200, % of the fp32-MFMA peak with 256 / 384 / 512 keys): 77.0 / 79.0 /
     // 78.1 at 10,000 queries, 80.9 / 81.5 / 80.8 at 30,000, 82.3 / 82.4 / 81.6 at 100,000 -- and 88.6 / 88.2 / 87.3 at 65,536, where a
     // workgroup streams the whole shard for its block and sheds rarely anyway: 384 keys where a block is searched in pieces, 256 otherwise
-    const int rs_items = (rs16 && dim == 200) ? 6 : (rs_tmw && dim == 200) ? ((cand_env == 8 || cand_env == 6 || cand_env == 4) ? cand_env : (nseg > 1 || bal_lists) ? 6 : 4)
-                         // d = 512: 384 keys where a 256-key buffer would shed after fewer than 16 candidates -- L2's K + 28 = 128 survivors left it
-                         // NONE: a compaction event per candidate (round 6; 0.69 of peak against 0.84 for IP at 65,536 queries)
-                         : (rs_tmw && dim == 512 && (cand_env == 6 || (cand_env != 4 && 256u - kNB < K + 16u))) ? 6 : 4;
+    const int rs_items = (rs_tmw && dim == 200) ? ((cand_env == 8 || cand_env == 6 || cand_env == 4) ? cand_env : (nseg > 1 || bal_lists) ? 6 : 4)
+                         // d = 512 (round 6): 384 keys.  L2 ranks K + 28 = 128 survivors, which left a 256-key buffer NO room at all -- a
+                         // compaction event per candidate: 0.71 -> 0.85 of peak at 65,536 queries, 0.56 -> 0.82 at 30,000, 0.45 -> 0.77 at 10,000; IP
+                         // (K = 100) gains too where a block is searched in pieces: 0.78 -> 0.80 at 10,000, 0.827 -> 0.839 at 30,000, level at 65,536
+                         // (profiles/r06/gt_ab_box2_d512_{ip,l2}.jsonl).  RG_GT_CAND=4: 256 keys
+                         : (rs_tmw && dim == 512 && cand_env != 4) ? 6 : 4;
     RG_HIP(scratch.get(1, (size_t)grid * mq * 64 * (rs_tmw ? rs_items : items) * 8));
     cand = static_cast<u64 *>(scratch.p[1]);
     RG_HIP(scratch.get(2, 128));
@@ -1488,11 +1240,7 @@ rg_status gt_shard_ws(const float *d_base, uint32_t nb, uint32_t bstride, const 
 #define RG_RS_LAUNCH(D, BKV, WPSV) RG_RS_LAUNCH_I(D, BKV, WPSV, 4)
         switch (dim) {
             case 200:
-                if (rs16) {
-                    auto kern = rg_gt_rs16_kernel<200, 40, 6, 3>;
-                    RG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rs));
-                    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_rs, s, P);
-                } else if (rs_prof) {
+                if (rs_prof) {
                     auto kern = rg_gt_rs_kernel<200, 40, 1, 4, 2, true>;
                     RG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rs));
                     hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_rs, s, P);
@@ -1501,16 +1249,7 @@ rg_status gt_shard_ws(const float *d_base, uint32_t nb, uint32_t bstride, const 
                 else RG_RS_LAUNCH(200, 40, 2)
                 break;
             case 512:
-                if (rs16) {
-#define RG_RS16_LAUNCH(IT)                                                                                                   \
-    {                                                                                                                        \
-        auto kern = rg_gt_rs16_kernel<512, 64, IT, 2>;                                                                       \
-        RG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_rs)); \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds_rs, s, P);                                                       \
-    }
-                    if (rs_items == 6) RG_RS16_LAUNCH(6) else RG_RS16_LAUNCH(4)
-#undef RG_RS16_LAUNCH
-                } else if (rs_items == 6) RG_RS_LAUNCH_I(512, 64, 1, 6)
+                if (rs_items == 6) RG_RS_LAUNCH_I(512, 64, 1, 6)
                 else RG_RS_LAUNCH(512, 64, 1)
                 break;
             case 96: RG_RS_LAUNCH(96, 48, 2) break;

@@ -86,6 +86,10 @@ def random_regular_csr(nd, deg, seed=11):
     return offsets, nbrs.reshape(-1)
 
 
+# the "mixture" family: (cluster centres, spread of the base rows around their centre, shift and spread of the queries) in the latent space
+MIXTURE_DEFAULT = (1000, 0.35, 0.1, 0.45)
+
+
 def make_device_set(dev, seed, nb, ntrain, nq, d, data="gaussian", rank=24, noise=0.05, q_seed=None):
     """Base / training queries / test queries as torch tensors on `dev` (bench.py, scripts/e2e_pipeline.py).
 
@@ -139,7 +143,11 @@ def make_device_set(dev, seed, nb, ntrain, nq, d, data="gaussian", rank=24, nois
         # (round 6) low reuse BETWEEN queries: 1,000 cluster centres in the latent space, a row = its centre + 0.35 N(0, I) mapped through A;
         # queries sit near centres too, with the out-of-distribution shift of the other families.  Two queries of a batch rarely walk the
         # same region of the graph, so few of a launch's row reads are repeats that the Infinity Cache can serve.
-        ncl = 1000
+        import os
+        ncl, b_spread, q_shift, q_spread = MIXTURE_DEFAULT
+        if os.environ.get("RG_MIXTURE"):      # experiments: "clusters,base spread,query shift,query spread"
+            v = os.environ["RG_MIXTURE"].split(",")
+            ncl, b_spread, q_shift, q_spread = int(v[0]), float(v[1]), float(v[2]), float(v[3])
         mix = torch.empty((rank, d), dtype=torch.float32, device=dev).normal_(generator=g) / float(rank) ** 0.5
         cent = torch.empty((ncl, rank), dtype=torch.float32, device=dev).normal_(generator=g)
 
@@ -152,14 +160,14 @@ def make_device_set(dev, seed, nb, ntrain, nq, d, data="gaussian", rank=24, nois
                 out[s:s + m] = z @ mix
                 out[s:s + m].add_(torch.empty((m, d), dtype=torch.float32, device=dev).normal_(generator=g), alpha=noise)
             return out
-        base = fill_mix(nb, 0.0, 0.35)
-        train = fill_mix(ntrain, 0.1, 0.45) if ntrain else None
+        base = fill_mix(nb, 0.0, b_spread)
+        train = fill_mix(ntrain, q_shift, q_spread) if ntrain else None
         if q_seed is not None:
             g = torch.Generator(device=dev)
             g.manual_seed(q_seed)
-        q = fill_mix(nq, 0.1, 0.45)
-        desc = ("mixture embeddings %dx%d: %d cluster centres in a rank-%d latent space, x = (c_k + 0.35 e) A + %.2f eps; train/test queries "
-                "(c_k + 0.1 + 0.45 e) A (%d / %d)" % (nb, d, ncl, rank, noise, ntrain, nq))
+        q = fill_mix(nq, q_shift, q_spread)
+        desc = ("mixture embeddings %dx%d: %d cluster centres in a rank-%d latent space, x = (c_k + %.2f e) A + %.2f eps; train/test queries "
+                "(c_k + %.2f + %.2f e) A (%d / %d)" % (nb, d, ncl, rank, b_spread, noise, q_shift, q_spread, ntrain, nq))
     else:
         raise ValueError("data must be gaussian, lowrank or mixture")
     return base, train, q, desc

@@ -242,14 +242,15 @@ def prune_calls(base, metric, rng, M):
         order = order[order != node]
         np_ = int(rng.integers(3, 400))
         pool = np.concatenate([order[: np_ // 2], rng.choice(order[np_ // 2: 8 * np_], size=np_ - np_ // 2, replace=False)]).astype(np.uint32)
-        if rng.random() < 0.3:
-            pool = np.concatenate([pool, [node]]).astype(np.uint32)         # (the entry point can be the node)
         pool = rng.permutation(pool).astype(np.uint32)
         ds = dists_to(node, pool)
         srt = pool[np.lexsort((pool, ds))]
         nh = int(rng.integers(0, min(M, srt.size - 2) + 1))
-        have = np.concatenate([srt[srt != node][: nh // 2], rng.integers(0, nb, nh - nh // 2)]).astype(np.uint32)     # the nearest ones are neighbours already
-        calls.append(("search", node, pool, ds, have))
+        have = np.concatenate([srt[: nh // 2], rng.integers(0, nb, nh - nh // 2)]).astype(np.uint32)     # the nearest ones are neighbours already
+        calls.append(("search", node, pool, ds, have))      # as LinkProjection calls the rule: the node erased from the pool (:1203-1208)
+        if rng.random() < 0.3:      # the bare rule with the node still in its pool (its own `start++`, :1858-1860; the product's GPU kernel folds the erase in)
+            pool2 = rng.permutation(np.concatenate([pool, [node]])).astype(np.uint32)
+            calls.append(("search", node, pool2, dists_to(node, pool2), have))
     return calls
 
 

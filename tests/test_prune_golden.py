@@ -1,7 +1,7 @@
 """The four occlusion-pruning rules of the construction (src/index_bipartite.cpp:1434-1694, 1846-1940) against goldens made with the
 reference's OWN Distance::compare, Neighbor::operator< (under std::sort) and operator== (under std::find): tests/golden/prune_*.npz,
 scripts/make_golden.py g6, oracle/ref_driver.cpp `prune` (the TU itself cannot be compiled in this image, so the rules are restated
-around the genuine objects -- the standing `rg_ref search` has for SearchRoarGraph).  320 calls per base: knn rows, lists that grew by a
+around the genuine objects -- the standing `rg_ref search` has for SearchRoarGraph).  330-odd calls per base: knn rows, lists that grew by a
 reverse edge (with and without the phantom entries of :1438), expansion lists against a projection list; repeated ids, the pivot in its
 own pool, node 0, ties.  Checked here: the oracle's rules (CPU), the product's host rules (CPU: the builder is host code), the product's
 pruning kernel (-m gpu), and -- where /root/reference is present -- the goldens regenerated live.  What stays UNPINNED: the order in
@@ -31,7 +31,7 @@ def calls_of(name):
 @pytest.mark.parametrize("name", ["ip200", "l2_512"])
 def test_oracle_rules_equal_the_goldens(name):
     base, metric, calls = calls_of(name)
-    assert len(calls) == 320 and {c["kind"] for c in calls} == {0, 1, 2, 3}
+    assert len(calls) >= 320 and {c["kind"] for c in calls} == {0, 1, 2, 3}
     for i, c in enumerate(calls):
         got = po.prune(base, metric, c["M"], KIND_NAMES[c["kind"]], c["pivot"], c["ids"], c["dists"], c["have"])
         assert got.tolist() == c["want"].tolist(), (name, i, KIND_NAMES[c["kind"]])
@@ -63,6 +63,8 @@ def test_product_gpu_pruning_kernel_equals_the_goldens(name):
         dup = len(set(c["ids"].tolist())) != c["ids"].size
         if c["kind"] == 0 and (dup or c["ids"][0] != c["pivot"]):
             continue
+        if c["kind"] == 3 and c["pivot"] in c["ids"].tolist():
+            continue      # the bare rule with the node in its pool: LinkProjection erases the node first (:1203-1208), and the kernel folds that erase in
         try:
             got = build.prune_debug(base, metric, c["M"], c["kind"], c["pivot"], c["ids"], c["dists"], c["have"], use_gpu=True)
         except RgError as e:
@@ -71,7 +73,7 @@ def test_product_gpu_pruning_kernel_equals_the_goldens(name):
             continue
         ran += 1
         assert got.tolist() == c["want"].tolist(), (name, i, KIND_NAMES[c["kind"]])
-    assert ran >= 100 and left <= 10, (ran, left)
+    assert ran >= 120 and left <= 10, (ran, left)
 
 
 @pytest.mark.skipif(not po.have_ref() or not os.path.isdir("/root/reference"), reason="needs oracle/_ref/rg_ref and the reference tree")
