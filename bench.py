@@ -84,9 +84,10 @@ def parse():
     ap.add_argument("--target-recall", type=float, default=0.90)
     ap.add_argument("--sweep", default=SWEEP_DEFAULT, help="comma list of L_pq values (empty = none); `readme` = the reference's own 56-point "
                     "evaluation list (README.md:118)")
-    ap.add_argument("--configs", default="mixture,webvid,laion", help="comma list of the side blocks of the default run, each a smaller build + search "
-                    "of its own with roofline and cpu_baseline (rank 0, N = 1): mixture = the headline's shape on data with LOW REUSE between queries "
-                    "(1,000 clusters, latent rank 128), rank128 = latent rank 128 without clusters (round 5's block), webvid = BASELINE configs[4] end to end (2.5M x 512 IP: ground truth -> build -> "
+    ap.add_argument("--configs", default="rank128,webvid,laion", help="comma list of the side blocks of the default run, each a smaller build + search "
+                    "of its own with roofline and cpu_baseline (rank 0, N = 1): rank128 = the headline's shape on harder data (latent rank 128: 0.9 recall "
+                    "needs L_pq 300), mixture = the headline's shape on data with LOW REUSE between queries (10,000 clusters in a rank-128 latent space; "
+                    "easy for the search: not in the default run), webvid = BASELINE configs[4] end to end (2.5M x 512 IP: ground truth -> build -> "
                     "search), laion = BASELINE configs[3] shape (d = 512 L2 top-100) at the size --laion-nb; empty = none")
     ap.add_argument("--side-nb", type=int, default=0, help="rows of EVERY side block (tests: small sets); 0 = their own sizes")
     ap.add_argument("--rank128-nb", type=int, default=10_000_000, help="rows of the rank128 / mixture side blocks (default: the headline's size)")

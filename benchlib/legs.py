@@ -629,10 +629,10 @@ def side_blocks_leg(C):
             "rank128": dict(nb=args.rank128_nb, dim=200, metric="ip", k=10, rank_latent=128, Ls=[50, 100, 200, 300, 500, 1000],
                             what="a harder data set of the headline's family and SIZE: latent rank 128 instead of 32 (four times the intrinsic "
                                  "dimension), %d x 200 IP, top-10; frac_hbm_only = the headline block's random-graph figure (same base shape)" % args.rank128_nb),
-            # (round 6) the family with LOW REUSE between the queries of a launch: 1,000 clusters in a rank-128 latent space at the
-            # headline's size -- where recall 0.9 lands when the Infinity Cache has little to serve
+            # (round 6) the family with LOW REUSE between the queries of a launch: clusters in a rank-128 latent space at the
+            # headline's size -- where recall 0.9 lands when the Infinity Cache has little to serve (not in the default run: --configs mixture,...)
             "mixture": dict(nb=args.rank128_nb, dim=200, metric="ip", k=10, rank_latent=128, Ls=[50, 100, 200, 300, 500, 1000], data="mixture",
-                            what="low reuse between queries: %d x 200 IP, 1,000 cluster centres in a rank-128 latent space (synth.py 'mixture'), top-10; "
+                            what="low reuse between queries: %d x 200 IP, cluster centres in a rank-128 latent space (synth.py 'mixture'), top-10; "
                                  "frac_hbm_only = the headline block's random-graph figure (same base shape)" % args.rank128_nb),
             "webvid": dict(nb=2_500_000, dim=512, metric="ip", k=10, rank_latent=32, Ls=[10, 20, 30, 50, 100, 200, 500],
                            what="BASELINE configs[4] shape, end to end in the run: webvid-2.5M-shaped 2.5M x 512 IP, ground truth of 500k training "

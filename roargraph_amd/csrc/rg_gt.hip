@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "rg.h"
+#include "rg_device.h"
 #include "rg_internal.h"
 #include "rg_mem.h"
 
@@ -956,6 +957,61 @@ __global__ void __launch_bounds__(64) rg_gt_rescore_kernel(const float *base, ui
     }
 }
 
+// The same finalisation with the rows GATHERED COOPERATIVELY (round 6): the kernel above gives every lane a candidate of its own and walks
+// that row with scalar loads -- 128 candidates x 2 KB per query at d = 512 read four bytes per lane at a time: 50 ms for 65,536 queries,
+// 3.3 % of the whole L2 ground truth (rocprofv3: profiles/r06/gt_d512_l2_65536_trace.txt).  Here a wave takes one query, stages it in LDS,
+// and streams the Kin candidate rows four at a time through a ring of R LDS-DMA passes into the scoring routine K1 / K1b use
+// (rg_device.h: gather_issue / gather_score) -- 16 lanes per row, coalesced 16-byte loads.  The distance written is therefore exactly
+// DistanceL2::compare(row, query, dim) of the reference (distance.h:39-89: its lane order, its folds), the value SearchRoarGraph itself
+// would report for that pair.  dim % 8 == 0.
+template <int ITEMS, int R>
+__global__ void __launch_bounds__(64) rg_gt_rescore_gather_kernel(const float *base, uint32_t bstride, const float *queries, uint32_t qstride, uint32_t dim,
+                                                                  uint32_t nq, uint32_t Kin, uint32_t K, uint32_t id_base, const uint32_t *ids_in, uint32_t *ids,
+                                                                  float *vals, uint32_t stage_floats) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int lane = threadIdx.x, g = lane >> 4;
+    float *stage = reinterpret_cast<float *>(smem);                 // R passes of stage_floats
+    float *qv = stage + (size_t)R * stage_floats;                   // dim
+    float *dist = qv + dim;                                         // 64 * ITEMS
+    uint32_t *cid = reinterpret_cast<uint32_t *>(dist + 64 * ITEMS);  // 64 * ITEMS
+    const uint32_t npass = (Kin + 3u) >> 2, lpp = loads_per_pass(dim);
+    for (uint32_t q = blockIdx.x; q < nq; q += gridDim.x) {
+        for (uint32_t i = lane; i < dim; i += kWave) qv[i] = queries[(size_t)q * qstride + i];
+        for (uint32_t e = lane; e < Kin; e += kWave) cid[e] = ids_in[(size_t)q * Kin + e];
+        lds_sync();
+        auto issue = [&](uint32_t p, float *buf) {
+            const uint32_t c = 4 * p + (uint32_t)g;
+            const bool act = c < Kin;
+            gather_issue(base + (size_t)(act ? cid[c] - id_base : 0u) * bstride, dim, act, buf, lane);
+        };
+        for (uint32_t p = 0; p < (uint32_t)R && p < npass; ++p) issue(p, stage + (size_t)p * stage_floats);
+        for (uint32_t p = 0; p < npass; ++p) {
+            const uint32_t last = min(npass, p + (uint32_t)R) - 1u;
+            gather_wait((last - p) * lpp);
+            float *buf = stage + (size_t)(p & (R - 1)) * stage_floats;
+            const uint32_t c = 4 * p + (uint32_t)g;
+            const float d = gather_score<true>(buf, qv, dim, lane);
+            if (c < Kin && (lane & 15) == 0) dist[c] = d;
+            lds_sync();
+            if (p + R < npass) issue(p + R, buf);
+        }
+        lds_sync();
+        u64 key[ITEMS];
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+            const uint32_t e = it * 64 + lane;
+            key[it] = e < Kin ? make_key(dist[e], cid[e], false) : ~0ull;
+        }
+        wave_sort<ITEMS>(key, lane);
+#pragma unroll
+        for (int it = 0; it < ITEMS; ++it) {
+            const uint32_t e = it * 64 + lane;
+            if (e < K) { ids[(size_t)q * K + e] = (uint32_t)key[it]; vals[(size_t)q * K + e] = key_value(key[it], false); }
+        }
+        lds_sync();
+    }
+}
+
 // K3: merge nlists sorted K-lists per query; one wave per query
 template <int ITEMS>
 __global__ void __launch_bounds__(64) rg_gt_merge_kernel(const uint32_t *ids_in, const float *vals_in, uint32_t nlists,
@@ -1283,6 +1339,23 @@ rg_status gt_shard_ws(const float *d_base, uint32_t nb, uint32_t bstride, const 
     if (st == RG_OK && metric == RG_METRIC_L2) {
         const uint32_t g2 = std::min<uint32_t>(nq, (uint32_t)prop.multiProcessorCount * 16u);
         const int it2 = items_for(K);
+        const uint32_t stage_floats = ((dim + 63) / 64) * 256;
+        constexpr int RR = 4;
+        const size_t lds2 = ((size_t)RR * stage_floats + dim + 2 * 64 * (size_t)it2) * 4;
+        if (!getenv("RG_GT_RESCORE_SCALAR") && lds2 <= 64 * 1024) {      // rows gathered cooperatively, the reference's compare() bit for bit
+#define RG_RESCORE(IT)                                                                                                                          \
+    {                                                                                                                                           \
+        auto kern = rg_gt_rescore_gather_kernel<IT, RR>;                                                                                        \
+        RG_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2));                 \
+        hipLaunchKernelGGL(kern, dim3(g2), dim3(64), lds2, s, d_base, bstride, d_queries, qstride, dim, nq, K, K_out, id_base, ids_k2, d_ids, d_dists, stage_floats); \
+    }
+            switch (it2) {
+                case 4: RG_RESCORE(4) break;
+                case 8: RG_RESCORE(8) break;
+                default: RG_RESCORE(16) break;
+            }
+#undef RG_RESCORE
+        } else
         switch (it2) {
             case 4: hipLaunchKernelGGL((rg_gt_rescore_kernel<4>), dim3(g2), dim3(64), 0, s, d_base, bstride, d_queries, qstride, dim, nq, K, K_out, id_base, ids_k2, d_ids, d_dists); break;
             case 8: hipLaunchKernelGGL((rg_gt_rescore_kernel<8>), dim3(g2), dim3(64), 0, s, d_base, bstride, d_queries, qstride, dim, nq, K, K_out, id_base, ids_k2, d_ids, d_dists); break;

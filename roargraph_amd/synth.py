@@ -87,7 +87,10 @@ def random_regular_csr(nd, deg, seed=11):
 
 
 # the "mixture" family: (cluster centres, spread of the base rows around their centre, shift and spread of the queries) in the latent space
-MIXTURE_DEFAULT = (1000, 0.35, 0.1, 0.45)
+# (round 6, scripts/r06/mixture_scan.py at 1M rows: 1,000 tight clusters (0.35) give a degenerate index -- average degree 3.8 at 10M rows, a fifth
+# of the nodes with two edges or fewer -- 10,000 wider ones an index of degree 33 like a real one; every variant is EASY for a graph search,
+# recall@10 >= 0.99 at L_pq 50: what the family offers is low reuse between the queries of a launch, not difficulty)
+MIXTURE_DEFAULT = (10000, 0.5, 0.2, 0.6)
 
 
 def make_device_set(dev, seed, nb, ntrain, nq, d, data="gaussian", rank=24, noise=0.05, q_seed=None):
@@ -140,7 +143,7 @@ def make_device_set(dev, seed, nb, ntrain, nq, d, data="gaussian", rank=24, nois
         desc = ("low-rank embeddings %dx%d: x = zA + %.2f eps, latent rank %d, base z ~ N(0,1), train/test queries "
                 "z ~ N(0.3,0.5^2) (%d / %d)" % (nb, d, noise, rank, ntrain, nq))
     elif data == "mixture":
-        # (round 6) low reuse BETWEEN queries: 1,000 cluster centres in the latent space, a row = its centre + 0.35 N(0, I) mapped through A;
+        # (round 6) low reuse BETWEEN queries: cluster centres in the latent space, a row = its centre + spread x N(0, I) mapped through A;
         # queries sit near centres too, with the out-of-distribution shift of the other families.  Two queries of a batch rarely walk the
         # same region of the graph, so few of a launch's row reads are repeats that the Infinity Cache can serve.
         import os

@@ -296,6 +296,7 @@ def test_bench_one_gpu_small_run_reports_every_block(tmp_path):
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     c, d = _bench_records(r.stdout, str(tmp_path / "full.json"))
+    compact = c
     # the compact line: roofline.frac, cpu_baseline.value and one summary row per side block (what the driver records)
     assert c["cpu_baseline"]["value"] > 0 and c["cpu_baseline"]["kind"] in ("reference", "port") and c["cpu_baseline"]["cores"] >= 1
     assert [x["name"] for x in c["configs_summary"]] == ["webvid", "laion"] and all(x["frac"] > 0 and x["qps"] > 0 for x in c["configs_summary"])
@@ -321,7 +322,7 @@ def test_bench_one_gpu_small_run_reports_every_block(tmp_path):
     assert g["value"] > 0 and "4 query batches" in g["form"] and g["k2_device_resident"]["value"] > 0
     # (round 6) K2 at d = 512 in the record: both metrics, both batch sizes
     assert set(g["k2_d512"]) >= {"ip_65536", "ip_10000", "l2_65536", "l2_10000"} and all(g["k2_d512"][k] > 0 for k in ("ip_65536", "l2_10000"))
-    assert c["gt_build"]["k2_d512"]["l2_65536"] > 0
+    assert compact["gt_build"]["k2_d512"]["l2_65536"] > 0
 
 
 def test_bench_on_the_reference_file_layout(tmp_path):
