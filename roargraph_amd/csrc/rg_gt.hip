@@ -1241,7 +1241,9 @@ rg_status gt_shard_ws(const float *d_base, uint32_t nb, uint32_t bstride, const 
     // default (profiles/r05/gt_ab_box12_buffers_256_384_512.jsonl, d = 200, % of the fp32-MFMA peak with 256 / 384 / 512 keys): 77.0 / 79.0 /
     // 78.1 at 10,000 queries, 80.9 / 81.5 / 80.8 at 30,000, 82.3 / 82.4 / 81.6 at 100,000 -- and 88.6 / 88.2 / 87.3 at 65,536, where a
     // workgroup streams the whole shard for its block and sheds rarely anyway: 384 keys where a block is searched in pieces, 256 otherwise
-    const int rs_items = (rs_tmw && dim == 200) ? ((cand_env == 8 || cand_env == 6 || cand_env == 4) ? cand_env : (nseg > 1 || bal_lists) ? 6 : 4)
+    // (round 6: 384 keys also wherever 256 would shed after fewer than 16 candidates -- L2's K + 28 = 128 survivors: 0.79 of peak at d = 200 /
+    // 65,536 queries against 0.88 for IP, box 3b)
+    const int rs_items = (rs_tmw && dim == 200) ? ((cand_env == 8 || cand_env == 6 || cand_env == 4) ? cand_env : (nseg > 1 || bal_lists || K + 16u > 256u - kNB) ? 6 : 4)
                          // d = 512 (round 6): 384 keys.  L2 ranks K + 28 = 128 survivors, which left a 256-key buffer NO room at all -- a
                          // compaction event per candidate: 0.71 -> 0.85 of peak at 65,536 queries, 0.56 -> 0.82 at 30,000, 0.45 -> 0.77 at 10,000; IP
                          // (K = 100) gains too where a block is searched in pieces: 0.78 -> 0.80 at 10,000, 0.827 -> 0.839 at 30,000, level at 65,536
