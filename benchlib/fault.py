@@ -8,7 +8,7 @@ import re
 
 KINDS = {"g": "granule mapped at its pool address", "u": "granule unmapped at its pool address", "B": "balanced buffer mapped",
          "C": "buffer freed into the cache (still mapped)", "H": "buffer handed out again from the cache", "F": "buffer unmapped",
-         "P": "plain hipMalloc of a large request", "f": "hipFree of a pointer the pools do not know"}
+         "P": "plain hipMalloc of a large request", "f": "hipFree of a pointer the pools do not know", "A": "arena of address space reserved (no memory)"}
 
 FAULT_RE = re.compile(r"Memory access fault by GPU.*?on address (0x[0-9a-fA-F]+)")
 
@@ -57,6 +57,8 @@ def attribute(report_text, address):
                 res["state"] = label
                 res["range"] = (hex(va), nbytes, address - va)
     for e in rep["journal"]:
+        if e["kind"] == "A":
+            continue
         span = e["bytes"] if e["bytes"] else 1
         if e["va"] <= address < e["va"] + span:
             res["history"].append({"t_us": e["t_us"], "kind": e["kind"], "what": KINDS.get(e["kind"], "?"), "va": hex(e["va"]), "bytes": e["bytes"],

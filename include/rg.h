@@ -181,6 +181,9 @@ rg_status rg_mem_release(int device);
  * the buffer a fault address belongs to from that file.  rg_mem_journal_dump writes the same report now (tests). */
 rg_status rg_mem_fault_report(const char *path);
 rg_status rg_mem_journal_dump(const char *path);
+/* Diagnostics (round 6): the allocator's walk in a loop -- per_round granules created, mapped at fresh addresses, zeroed, probed, dropped,
+ * `rounds` times; the step both GPU faults on record sit in (scripts/r06/walk_stress.py).  *granules = how many were mapped and touched. */
+rg_status rg_mem_walk_stress(int device, uint32_t per_round, uint32_t rounds, uint64_t *granules);
 /* The device adjacency of an index as the search kernel reads it (diagnostics, tests; no counterpart in the reference):
  * [npts][*stride] words, word 0 of a row = its degree, then the neighbours: id in the low 24 bits and -- on indexes of up to 2^24
  * nodes -- min(15, in-degree of the neighbour) in bits 24..27 and its hub level in bits 28..31 (knob "hub_bits": at 2^m bits the

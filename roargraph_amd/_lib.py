@@ -20,7 +20,7 @@ SYMBOLS = [
     "rg_last_error", "rg_version", "rg_device_count", "rg_free",
     "rg_fbin_meta", "rg_fbin_load", "rg_fbin_save", "rg_gt_meta", "rg_gt_load", "rg_gt_save", "rg_knn_ids_load",
     "rg_graph_load", "rg_graph_save", "rg_recall", "rg_normalize_rows",
-    "rg_index_open", "rg_index_open_multi", "rg_index_open_mem", "rg_index_open_dev", "rg_index_close", "rg_index_info", "rg_index_set", "rg_index_stat", "rg_mem_stats", "rg_mem_stats_ex", "rg_mem_release", "rg_mem_fault_report", "rg_mem_journal_dump", "rg_index_debug_ell",
+    "rg_index_open", "rg_index_open_multi", "rg_index_open_mem", "rg_index_open_dev", "rg_index_close", "rg_index_info", "rg_index_set", "rg_index_stat", "rg_mem_stats", "rg_mem_stats_ex", "rg_mem_release", "rg_mem_fault_report", "rg_mem_journal_dump", "rg_mem_walk_stress", "rg_index_debug_ell",
     "rg_score_batch", "rg_score_batch_dev", "rg_search", "rg_search_sharded", "rg_search_dev", "rg_search_wait", "rg_search_prepare", "rg_search_reuse_stats",
     "rg_gt_shard_dev", "rg_gt_merge_dev", "rg_groundtruth_mem", "rg_groundtruth",
     "rg_comm_unique_id", "rg_comm_init_rank", "rg_comm_init_local", "rg_comm_uses_rccl", "rg_comm_destroy", "rg_gt_exchange_plan", "rg_groundtruth_rank", "rg_build_roargraph", "rg_build_roargraph_gpu", "rg_build_schedule", "rg_build_prune_debug", "rg_projection_ep", "rg_projection_ep_dev",

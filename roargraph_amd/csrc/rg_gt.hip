@@ -619,7 +619,7 @@ __global__ void __launch_bounds__(256, WPS) rg_gt_rs_kernel(GtParams P0) {
             // only then multiplies its last quad: DMA issue, LDS latency and barrier skew hide behind 8 MFMAs instead
             // of opening every chunk.  The compaction check rides on the barrier of a tile's first chunk; the L2 bias of
             // a tile arrives with its first chunk (one more DMA instruction) instead of a per-tile global load.
-            static_assert(NKC >= 2 && NKC <= 8 && KQC % 2 == 0, "chunking");
+            static_assert(NKC >= 2 && NKC <= 8 && KQC % 2 == 0 && KQC / 2 <= 16, "chunking");
             float2 b0[4], b1[4];
             const uint32_t lds_bias = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(lds_ptr_t *)bias_l);
             auto stream_bias = [&](uint32_t tile, uint32_t slot) __attribute__((always_inline)) {
@@ -742,6 +742,9 @@ __global__ void __launch_bounds__(256, WPS) rg_gt_rs_kernel(GtParams P0) {
                                 __builtin_amdgcn_sched_barrier(0);
                                 if constexpr (j < KQC / 2) {
                                     if (dsrc) glds16<32 * j>(dlds + 4096u * j, dsrc);
+                                }
+                                if constexpr (j + 8 < KQC / 2) {      // (chunks of more than 16 k-quads: two DMA instructions per step)
+                                    if (dsrc) glds16<32 * (j + 8)>(dlds + 4096u * (j + 8), dsrc);
                                 }
                                 if constexpr (j >= 4) {   // the .x halves of bc are consumed: refill that register set's slot n
                                     if (next_frags) bn[n] = bqn[2 * (32 * n)];
@@ -1132,6 +1135,7 @@ rg_status gt_shard_ws(const float *d_base, uint32_t nb, uint32_t bstride, const 
         for (const RsCfg &c : kRs)
             if (c.dim == dim) { rs_tmw = 1; rs_bk = c.bk; rs_per_cu = c.per_cu; }
         rs_mqb = 128 * rs_tmw;
+        if (rs_tmw && dim == 512 && getenv("RG_GT_BK") && atoi(getenv("RG_GT_BK")) == 128) rs_bk = 128;
     }
     // (round 6, measured and removed: 16-row query tiles -- v_mfma_f32_16x16x4_f32, 128 A registers at d = 512, two workgroups of 64 queries
     // per CU; three at d = 200.  SLOWER everywhere: 0.834 against 0.882 of peak at d = 512 IP / 65,536 queries, 0.72 against 0.78 at 10,000,
@@ -1307,7 +1311,8 @@ rg_status gt_shard_ws(const float *d_base, uint32_t nb, uint32_t bstride, const 
                 else RG_RS_LAUNCH(200, 40, 2)
                 break;
             case 512:
-                if (rs_items == 6) RG_RS_LAUNCH_I(512, 64, 1, 6)
+                if (rs_items == 6 && rs_bk == 128) RG_RS_LAUNCH_I(512, 128, 1, 6)      // RG_GT_BK=128 (experiment: four chunk barriers per tile instead of eight)
+                else if (rs_items == 6) RG_RS_LAUNCH_I(512, 64, 1, 6)
                 else RG_RS_LAUNCH(512, 64, 1)
                 break;
             case 96: RG_RS_LAUNCH(96, 48, 2) break;

@@ -55,7 +55,7 @@ constexpr int kMaxClasses = 4;
 // (benchlib/fault.py reads the report).  Kinds: g = granule mapped at its pool address (1 GiB), u = granule unmapped
 // there (moved into a buffer, or dropped: aux 1), B = balanced buffer mapped, C = freed into the cache (still mapped), H = handed
 // out again from the cache, F = unmapped (freed, or released from the cache: aux 1), P = plain hipMalloc of a large request,
-// f = hipFree of a pointer the pools do not know.
+// f = hipFree of a pointer the pools do not know, A = an arena of address space reserved (round 6: every g / B address lies inside one).
 struct JEvent { uint64_t t_us, va, bytes; char kind; int8_t device; uint16_t aux; };
 constexpr uint32_t kJournal = 4096;
 JEvent g_journal[kJournal];
@@ -189,24 +189,61 @@ void va_unmap(void *va, size_t bytes) {
 // synchronisation around every map / unmap changes nothing).  RG_MEM_VA: "leak" (default) = a range is used once;
 // "reuse" = ranges of equal size are kept in a list of the library's own and mapped again (experiment);
 // "free" = hipMemAddressFree (the behaviour that corrupts: only to reproduce it).
-enum VaMode { kVaLeak, kVaReuse, kVaFree };
+// ROUND 6: "arena" (the default now).  The fault report of the one GPU abort of round 6 (profiles/r06/fault_report_box4_pytest_abort.txt: a
+// full -m gpu run hung for 207 s and was aborted while the allocator was classifying the 13th freshly mapped granule of a walk) shows what
+// "leak" still allowed: hipMemAddressReserve hands out address ranges that plain hipMalloc'ed buffers occupied SECONDS earlier (a buffer
+// freed at t = 56.69 s lies inside a granule reserved and mapped at t = 59.44 s) -- the runtime recycles addresses between hipFree and the
+// virtual-memory API, and a range is "used once" only as far as this file's own reservations go.  Both faults on record (round 5's address was
+// 76 pages into a granule-sized region; round 6's hang sits on a granule's first touch) are FIRST TOUCHES OF A FRESH MAPPING.  In the arena
+// mode one large range (RG_MEM_ARENA_GIB, default 4096 GiB of address space, no memory) is reserved when a device's pool is first used, and
+// every granule and buffer address is carved from it by a bump pointer with a 2-MiB guard gap: no address of a mapping this file makes
+// was ever a hipMalloc'ed buffer's after that moment, and none is used twice.  A spent arena is followed by another.
+enum VaMode { kVaLeak, kVaReuse, kVaFree, kVaArena };
 VaMode va_mode() {
     static const VaMode m = [] {
         const char *e = getenv("RG_MEM_VA");
         if (e && !strcmp(e, "reuse")) return kVaReuse;
         if (e && !strcmp(e, "free")) return kVaFree;
-        return kVaLeak;
+        if (e && !strcmp(e, "leak")) return kVaLeak;
+        return kVaArena;
     }();
     return m;
 }
 std::mutex g_va_mu;
 std::map<size_t, std::vector<void *>> g_va_spare;
 uint64_t g_va_reserved = 0;        // bytes of virtual address space reserved so far (rg_mem_stats)
+char *g_arena = nullptr;           // current arena: [g_arena, g_arena + g_arena_bytes), next free address g_arena + g_arena_used
+size_t g_arena_bytes = 0, g_arena_used = 0;
 void va_free(void *va, size_t bytes) {
     if (va_mode() == kVaFree) (void)hipMemAddressFree(va, bytes);
     else if (va_mode() == kVaReuse) { std::lock_guard<std::mutex> lk(g_va_mu); g_va_spare[bytes].push_back(va); }
 }
 bool va_reserve(void **va, size_t bytes) {
+    if (va_mode() == kVaArena) {
+        std::lock_guard<std::mutex> lk(g_va_mu);
+        constexpr size_t kGuard = (size_t)2 << 20;
+        const size_t need = (bytes + kGuard + kGuard - 1) / kGuard * kGuard;
+        if (!g_arena || g_arena_used + need > g_arena_bytes) {
+            static const size_t arena_bytes = [] {
+                const char *e = getenv("RG_MEM_ARENA_GIB");
+                return (size_t)std::max(64, e ? atoi(e) : 4096) << 30;
+            }();
+            void *a = nullptr;
+            size_t got = 0;
+            for (size_t sz = arena_bytes; sz >= need && sz >= ((size_t)64 << 30) && !got; sz /= 4) {      // (a smaller arena where the address space is short)
+                if (g_va_reserved + sz > ((uint64_t)64 << 40)) continue;
+                if (hipMemAddressReserve(&a, sz, kGranule, nullptr, 0) == hipSuccess) got = sz;
+                else (void)hipGetLastError();
+            }
+            if (!got) return false;
+            g_arena = (char *)a; g_arena_bytes = got; g_arena_used = 0;
+            g_va_reserved += got;
+            jlog('A', a, got, -1);
+        }
+        *va = g_arena + g_arena_used;
+        g_arena_used += need;
+        return true;
+    }
     if (va_mode() == kVaReuse) {
         std::lock_guard<std::mutex> lk(g_va_mu);
         auto it = g_va_spare.find(bytes);
@@ -724,6 +761,35 @@ extern "C" rg_status rg_mem_stats(int device, uint64_t *buffers, uint64_t *plain
         for (int k = 0; k < 4; ++k) granules_per_class[k] = 0;
         for (auto &kv : P.live)
             for (int k = 0; k < 4; ++k) granules_per_class[k] += (uint64_t)kv.second.per_class[k];
+    }
+    return RG_OK;
+}
+
+// diagnostics (scripts/r06/walk_stress.py): the allocator's WALK in a loop -- `per_round` granules created, mapped at fresh addresses, zeroed and
+// probed against the class representatives (classify), then all dropped (unmapped, released) -- `rounds` times.  This is the step both GPU
+// faults on record sit in (the first touch of a freshly mapped granule); the caller churns plain allocations between calls so that the
+// runtime has freed addresses to recycle.  *granules = how many were mapped and touched.
+extern "C" rg_status rg_mem_walk_stress(int device, uint32_t per_round, uint32_t rounds, uint64_t *granules) {
+    if (device < 0 || device >= 16 || !granules) return rg::set_error(RG_ERR_ARG, "bad argument");
+    if (hipSetDevice(device) != hipSuccess) return rg::set_error(RG_ERR_DEVICE, "cannot select the device");
+    if (rg::off()) return rg::set_error(RG_ERR_ARG, "the balanced allocator is switched off");
+    rg::Pool &P = rg::g_pool[device];
+    std::lock_guard<std::mutex> lk(P.mu);
+    if (!rg::init_pool(P, device)) return rg::set_error(RG_ERR_DEVICE, "the virtual-memory pool cannot be set up on this device");
+    *granules = 0;
+    for (uint32_t r = 0; r < rounds; ++r) {
+        std::vector<rg::Granule> got;
+        for (uint32_t i = 0; i < per_round; ++i) {
+            rg::Granule g;
+            if (!rg::new_granule(P, device, &g)) break;
+            bool is_rep = false;
+            const int c = rg::classify(P, g, &is_rep);
+            ++*granules;
+            if (c < 0) { rg::drop_granule(g); return rg::set_error(RG_ERR_DEVICE, "a probe failed"); }
+            if (is_rep) { g.cls = c; P.reps.push_back(g); continue; }
+            got.push_back(g);
+        }
+        for (rg::Granule &g : got) rg::drop_granule(g);
     }
     return RG_OK;
 }
