@@ -166,8 +166,9 @@ rg_status rg_index_stat(const rg_index *idx, const char *name, uint64_t *value);
  * live buffers per class.  RG_BALANCED_ALLOC=0 in the environment turns the balancing off. */
 rg_status rg_mem_stats(int device, uint64_t *buffers, uint64_t *plain, uint32_t *classes, uint64_t *granules_per_class);
 /* More of the same (round 5), vals[0 .. nvals): balanced buffers handed out, plain fallbacks, classes found, probe launches, wall time
- * spent classifying granules (microseconds), bytes of virtual address space reserved so far (a range is used once: a runtime defect
- * hands freed ranges back with stale translations), requests served from the cache of freed buffers, bytes cached, bytes live,
+ * spent classifying granules (microseconds), bytes of virtual address space reserved so far (round 6: one ARENA per process, 4 TiB of
+ * addresses and no memory, from which every mapping's address is carved once -- the runtime recycles the addresses of freed buffers
+ * into new reservations, and first touches of mappings made there faulted: csrc/rg_mem.hip), requests served from the cache of freed buffers, bytes cached, bytes live,
  * classes a buffer is spread over.  A freed balanced buffer stays mapped and cached (RG_MEM_CACHE_GIB, default 64 GiB per device) and
  * serves the next request of its size -- an index opened again reserves no new address space and runs no probe;
  * rg_mem_release hands the cache (and the pool's spare granules) back to the device. */

@@ -198,6 +198,9 @@ void va_unmap(void *va, size_t bytes) {
 // mode one large range (RG_MEM_ARENA_GIB, default 4096 GiB of address space, no memory) is reserved when a device's pool is first used, and
 // every granule and buffer address is carved from it by a bump pointer with a 2-MiB guard gap: no address of a mapping this file makes
 // was ever a hipMalloc'ed buffer's after that moment, and none is used twice.  A spent arena is followed by another.
+// A/B on one box (scripts/r06/walk_stress.py: the walk in a loop, torch and plain allocations churned between rounds;
+// profiles/r06/walk_stress_box4b_summary.txt): "leak" 2 of 2 runs died of `Memory access fault by GPU` after 1,257 / 969 granules, 57 / 121 pages
+// into the granule mapped seconds earlier; arena 0 faults in 11,376 granules.
 enum VaMode { kVaLeak, kVaReuse, kVaFree, kVaArena };
 VaMode va_mode() {
     static const VaMode m = [] {
