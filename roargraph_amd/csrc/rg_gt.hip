@@ -1135,7 +1135,6 @@ rg_status gt_shard_ws(const float *d_base, uint32_t nb, uint32_t bstride, const 
         for (const RsCfg &c : kRs)
             if (c.dim == dim) { rs_tmw = 1; rs_bk = c.bk; rs_per_cu = c.per_cu; }
         rs_mqb = 128 * rs_tmw;
-        if (rs_tmw && dim == 512 && getenv("RG_GT_BK") && atoi(getenv("RG_GT_BK")) == 128) rs_bk = 128;
     }
     // (round 6, measured and removed: 16-row query tiles -- v_mfma_f32_16x16x4_f32, 128 A registers at d = 512, two workgroups of 64 queries
     // per CU; three at d = 200.  SLOWER everywhere: 0.834 against 0.882 of peak at d = 512 IP / 65,536 queries, 0.72 against 0.78 at 10,000,
@@ -1311,8 +1310,9 @@ rg_status gt_shard_ws(const float *d_base, uint32_t nb, uint32_t bstride, const 
                 else RG_RS_LAUNCH(200, 40, 2)
                 break;
             case 512:
-                if (rs_items == 6 && rs_bk == 128) RG_RS_LAUNCH_I(512, 128, 1, 6)      // RG_GT_BK=128 (experiment: four chunk barriers per tile instead of eight)
-                else if (rs_items == 6) RG_RS_LAUNCH_I(512, 64, 1, 6)
+                // (round 6, measured and removed: chunks of 128 floats -- four chunk barriers per tile instead of eight, 128 KB of LDS -- 0.735 against
+                // 0.894 of peak at 65,536 queries, 0.65 / 0.79 at 10,000: profiles/r06/gt_ab_box5_d512_bk128_*.jsonl)
+                if (rs_items == 6) RG_RS_LAUNCH_I(512, 64, 1, 6)
                 else RG_RS_LAUNCH(512, 64, 1)
                 break;
             case 96: RG_RS_LAUNCH(96, 48, 2) break;

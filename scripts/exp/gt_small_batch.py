@@ -28,7 +28,7 @@ for nq in nqs:
         else:
             forms = tuple(f for f in forms if f[0] in spec.split(","))
     for form, env in forms:
-        for k_ in ("RG_GT_NOSHARE", "RG_GT_NOBALANCE", "RG_GT_CAND", "RG_GT_BALANCE_ONE", "RG_GT_DIAG", "RG_GT_PROF", "RG_GT_NO_MARGIN", "RG_GT_RESCORE_SCALAR", "RG_GT_BK"):
+        for k_ in ("RG_GT_NOSHARE", "RG_GT_NOBALANCE", "RG_GT_CAND", "RG_GT_BALANCE_ONE", "RG_GT_DIAG", "RG_GT_PROF", "RG_GT_NO_MARGIN", "RG_GT_RESCORE_SCALAR"):
             os.environ.pop(k_, None)
         os.environ.update(env)
         groundtruth.gt_shard_dev(base, q, metric, K, 0, ids, vals); torch.cuda.synchronize()
