@@ -106,7 +106,7 @@ def parse():
                     "blur the per-launch kernel durations of the trace)")
     ap.add_argument("--gt-nq", type=int, default=65536, help="queries of the ground-truth (K2) leg; 0 = skip")
     ap.add_argument("--gt-K", type=int, default=100)
-    ap.add_argument("--k2-d512-nb", type=int, default=2_000_000, help="base rows of the d = 512 K2 launches of the ground-truth leg (ip and l2, 65,536 and "
+    ap.add_argument("--k2-d512-nb", type=int, default=3_000_000, help="base rows of the d = 512 K2 launches of the ground-truth leg (ip and l2, 65,536 and "
                     "10,000 queries each: the truth of BASELINE configs[3] / [4]); 0 = skip")
     ap.add_argument("--config1-nb", type=int, default=100_000, help="rows of the BASELINE configs[0] subset (0 = skip)")
     ap.add_argument("--data-root", default="", help="directory with the reference's files (README.md:93-117): base.10M.fbin, "

@@ -581,7 +581,7 @@ def ground_truth_leg(C):
                                     "frac_of_mfma_peak": round(2.0 * args.dim * float(gs.shape[0]) * float(args.nb) / ts / 1e12 / 157.3, 4)}
             del gs
             # (round 6, VERDICT r5 #2 / missing #4) K2 at d = 512, the ground truth of BASELINE configs[3] (laion: L2) and [4] (webvid: IP): one
-            # launch over 65,536 and over 10,000 queries x a 2M x 512 base per metric, fraction of the fp32-MFMA peak
+            # launch over 65,536 and over 10,000 queries x a 3M x 512 base per metric (the shape of profiles/r06/gt_d512_*), fraction of the fp32-MFMA peak
             if args.k2_d512_nb > 0:
                 g5 = torch.Generator(device=dev); g5.manual_seed(512)
                 b5 = torch.empty((args.k2_d512_nb, 512), dtype=torch.float32, device=dev).normal_(generator=g5)
