@@ -199,8 +199,9 @@ void va_unmap(void *va, size_t bytes) {
 // every granule and buffer address is carved from it by a bump pointer with a 2-MiB guard gap: no address of a mapping this file makes
 // was ever a hipMalloc'ed buffer's after that moment, and none is used twice.  A spent arena is followed by another.
 // A/B on one box (scripts/r06/walk_stress.py: the walk in a loop, torch and plain allocations churned between rounds;
-// profiles/r06/walk_stress_box4b_summary.txt): "leak" 2 of 2 runs died of `Memory access fault by GPU` after 1,257 / 969 granules, 57 / 121 pages
-// into the granule mapped seconds earlier; arena 0 faults in 11,376 granules.
+// profiles/r06/walk_stress_summary.txt): "leak" 5 of 5 runs died of `Memory access fault by GPU` within 2,100 granules, every time on a
+// granule whose address is 1-GiB aligned (one reservation in 512 is; large plain allocations sit at such addresses too: the signature of a
+// stale huge-page translation of the buffer that had the address before); arena 0 faults in 28,560 granules, ~55 of them GiB-aligned.
 enum VaMode { kVaLeak, kVaReuse, kVaFree, kVaArena };
 VaMode va_mode() {
     static const VaMode m = [] {

@@ -227,9 +227,9 @@ def test_kill_switch_of_the_balanced_allocator():
 def test_allocator_walk_under_address_churn():
     """The root cause of the GPU memory faults of rounds 5 and 6, as far as user space can see it: the runtime hands hipMemAddressReserve
     address ranges that plain hipMalloc'ed buffers occupied moments earlier, and the FIRST TOUCH of a granule mapped into such a range can
-    fault (scripts/r06/walk_stress.py with RG_MEM_VA=leak, the address policy of rounds 4 - 5: 2 of 2 runs died within 1,300 granules,
-    `Memory access fault by GPU` 57 / 121 pages into the granule just mapped -- profiles/r06/walk_leak_*.txt; with the arena of round 6 --
-    every address carved once from one range reserved when the pool is first used -- 0 faults in 11,376 granules).  Here: the same loop in
+    fault (scripts/r06/walk_stress.py with RG_MEM_VA=leak, the address policy of rounds 4 - 5: 5 of 5 runs died within 2,100 granules,
+    `Memory access fault by GPU` on a 1-GiB-aligned granule just mapped -- profiles/r06/walk_stress_summary.txt; with the arena of round 6 --
+    every address carved once from one range reserved when the pool is first used -- 0 faults in 28,560 granules).  Here: the same loop in
     the default (arena) mode for 30 s -- torch and plain allocations churned between rounds of 48 granules created, mapped, zeroed, probed
     and dropped.  A regression of the address policy kills the process."""
     import ctypes as C
