@@ -109,7 +109,7 @@ struct GtParams {
     u64 *cand;          // [grid][MQ][64*ITEMS]
     uint32_t *counter;
     uint32_t BK;
-    uint32_t diag;  // ablation switches for profiling only (wrong results): 1 no base streaming, 2 no epilogue, 4 no per-chunk barrier; 16 (right results): mid-stream compaction by the bitonic sort instead of the selection; 32 (right results): the selection query by query, without the look-ahead of the event form
+    uint32_t diag;  // ablation switches for profiling only (wrong results): 1 no base streaming, 2 no epilogue, 4 no per-chunk barrier; 16 (right results): mid-stream compaction by the bitonic sort instead of the selection
     // few query blocks for the chip: the base shard is also cut in nseg row segments, a work item is (query block, segment),
     // per-segment lists go to seg_ids / seg_vals [nseg][nq][K] and K3 merges them
     uint32_t nseg, seg_rows;
@@ -217,10 +217,9 @@ __device__ __forceinline__ float quota_min(const QuotaRef &qr, float mine, int l
     for (int o = 32; o; o >>= 1) t = fminf(t, __shfl_xor(t, o, 64));
     return t;
 }
-// (`pre`: the buffer's keys already in registers -- lane's element it * 64 + lane, ~0 beyond n -- loaded by the caller ahead of time)
 template <int ITEMS>
 __device__ __forceinline__ void gt_select(u64 *buf, uint32_t *cnt, float *thr, uint32_t K, int lane, uint32_t *q_slots, uint32_t q_pw, uint32_t q_quota,
-                                          uint32_t q_pstride, const u64 *pre = nullptr) {
+                                          uint32_t q_pstride) {
     QuotaRef qr;      // (scalars at the call boundary: a struct by value goes through the stack)
     qr.slots = q_slots; qr.npieces = q_pw & 0xffffu; qr.piece = q_pw >> 16; qr.quota = q_quota; qr.pstride = q_pstride;
     const uint32_t n = *cnt;
@@ -230,7 +229,7 @@ __device__ __forceinline__ void gt_select(u64 *buf, uint32_t *cnt, float *thr, u
 #pragma unroll
     for (int it = 0; it < ITEMS; ++it) {
         const uint32_t e = it * 64 + lane;
-        key[it] = pre ? pre[it] : (e < n ? buf[e] : ~0ull);
+        key[it] = e < n ? buf[e] : ~0ull;
         h[it] = (uint32_t)(key[it] >> 32);
         if (e < n) { lo = min(lo, h[it]); hi = max(hi, h[it]); }
     }
@@ -305,37 +304,6 @@ template <int ITEMS>
 __device__ __attribute__((noinline)) void gt_select_call(u64 *buf, uint32_t *cnt, float *thr, uint32_t K, int lane, uint32_t *q_slots, uint32_t q_pw,
                                                          uint32_t q_quota, uint32_t q_pstride) {
     gt_select<ITEMS>(buf, cnt, thr, K, lane, q_slots, q_pw, q_quota, q_pstride);
-}
-
-// One compaction EVENT of a wave (round 6): every query of the wave (w, w + 4, ...) whose buffer is nearly full is shed to its K best, one after
-// the other -- with the keys of the NEXT such query requested from global memory before the current one is bisected.  The instrumented
-// kernel (profiles/r06/gt_prof_box6.txt) charges an event ~80,000 - 96,000 cycles, a fifth of a workgroup's time at 10,000 queries (cold
-// thresholds: almost every query of the wave compacts in an event): per query a dependent global load of its 256 / 384 keys in front of ~30
-// bisection steps.  Out of line, once per event (the tile loop keeps its registers); the selections and their order are those of the loop
-// of gt_select_call it replaces.
-template <int ITEMS>
-__device__ __attribute__((noinline)) void gt_select_event(u64 *cand, uint32_t *cnt, float *thr, uint32_t K, int lane, int w, int mqb, uint32_t *q_base,
-                                                          uint32_t q_pw, uint32_t q_quota, uint32_t q_pstride) {
-    constexpr uint32_t C = 64 * ITEMS;
-    auto next_full = [&](int from) { int q = from; while (q < mqb && !(cnt[q] + kNB > C)) q += 4; return q; };
-    auto load = [&](int q, u64 (&k)[ITEMS]) {
-        const uint32_t n = cnt[q];
-        const u64 *buf = cand + (size_t)q * C;
-#pragma unroll
-        for (int it = 0; it < ITEMS; ++it) { const uint32_t e = it * 64 + lane; k[it] = e < n ? buf[e] : ~0ull; }
-    };
-    int qi = next_full(w);
-    if (qi >= mqb) return;
-    u64 cur[ITEMS], nxt[ITEMS];
-    load(qi, cur);
-    while (qi < mqb) {
-        const int qn = next_full(qi + 4);
-        if (qn < mqb) load(qn, nxt);
-        gt_select<ITEMS>(cand + (size_t)qi * C, &cnt[qi], &thr[qi], K, lane, q_base ? q_base + qi : nullptr, q_pw, q_quota, q_pstride, cur);
-#pragma unroll
-        for (int it = 0; it < ITEMS; ++it) cur[it] = nxt[it];
-        qi = qn;
-    }
 }
 
 typedef __attribute__((address_space(3))) void lds_ptr_t;
@@ -712,28 +680,20 @@ __global__ void __launch_bounds__(256, WPS) rg_gt_rs_kernel(GtParams P0) {
                             if (c == 0 && flag[0]) {   // set by the previous tile's filter
                                 const unsigned long long pf_c0 = PROF ? __builtin_amdgcn_s_memtime() : 0ull;
                                 if (PROF) ++pf_nev;
-                                {
-                                    // selection (round 5), the wave's queries in one out-of-line event with the next query's keys requested ahead (round 6);
-                                    // RG_GT_DIAG=16: the bitonic sort of rounds 1 - 4, RG_GT_DIAG=32: the selection query by query (same lists, A/B)
-                                    bool done = false;
-                                    if constexpr ((ITEMS & (ITEMS - 1)) == 0) {
-                                        if (P.diag & 16u) {
-                                            for (int qi = w; qi < MQB; qi += 4)
-                                                if (cnt[qi] + kNB > (uint32_t)C) gt_compact_call<ITEMS>(cand + (size_t)qi * C, &cnt[qi], &thr[qi], P.K, lane);
-                                            done = true;
+                                for (int qi = w; qi < MQB; qi += 4)
+                                    if (cnt[qi] + kNB > (uint32_t)C) {
+                                        // selection (round 5); RG_GT_DIAG=16: the bitonic sort of rounds 1 - 4 (same lists, A/B)
+                                        bool sorted_form = false;
+                                        if constexpr ((ITEMS & (ITEMS - 1)) == 0) {
+                                            if (P.diag & 16u) { gt_compact_call<ITEMS>(cand + (size_t)qi * C, &cnt[qi], &thr[qi], P.K, lane); sorted_form = true; }
+                                        }
+                                        if (!sorted_form) {
+                                            const uint32_t pw = (uint32_t)__builtin_amdgcn_readfirstlane((int)flag[2]);
+                                            uint32_t *sl = pw ? P0.quota_thr + (size_t)(q0 / MQB) * P0.nseg * MQB + qi : nullptr;
+                                            gt_select_call<ITEMS>(cand + (size_t)qi * C, &cnt[qi], &thr[qi], P.K, lane, sl, pw,
+                                                                  (uint32_t)__builtin_amdgcn_readfirstlane((int)flag[3]), (uint32_t)MQB);
                                         }
                                     }
-                                    const uint32_t pw = (uint32_t)__builtin_amdgcn_readfirstlane((int)flag[2]);
-                                    uint32_t *qb = pw ? P0.quota_thr + (size_t)(q0 / MQB) * P0.nseg * MQB : nullptr;
-                                    const uint32_t quota = (uint32_t)__builtin_amdgcn_readfirstlane((int)flag[3]);
-                                    if (!done && (P.diag & 32u)) {
-                                        for (int qi = w; qi < MQB; qi += 4)
-                                            if (cnt[qi] + kNB > (uint32_t)C)
-                                                gt_select_call<ITEMS>(cand + (size_t)qi * C, &cnt[qi], &thr[qi], P.K, lane, qb ? qb + qi : nullptr, pw, quota, (uint32_t)MQB);
-                                        done = true;
-                                    }
-                                    if (!done) gt_select_event<ITEMS>(cand, cnt, thr, P.K, lane, w, MQB, qb, pw, quota, (uint32_t)MQB);
-                                }
                                 {   // every query of this wave takes up what the other pieces have published since
                                     const uint32_t pw = (uint32_t)__builtin_amdgcn_readfirstlane((int)flag[2]);
                                     if (pw && lane < 32) {
@@ -856,11 +816,7 @@ __global__ void __launch_bounds__(256, WPS) rg_gt_rs_kernel(GtParams P0) {
                                     if (mx[m][r] > t) {
 #pragma unroll
                                         for (int n = 0; n < 4; ++n) {
-                                            // (the lane number is made here, as below: `lane & 31` carried through the tile loop is spilled at this register
-                                            // pressure, and the reload of a spill waits for vmcnt(0) -- for the DMA in flight -- in every tile that has a candidate)
-                                            uint32_t ln0;
-                                            asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln0));
-                                            const uint32_t id = tile * kNB + 32 * n + (ln0 & 31u);
+                                            const uint32_t id = tile * kNB + 32 * n + (lane & 31);
                                             if (acc[m][n][r] > t && id < P.nb && !(P.diag & 8u)) {
                                                 const uint32_t slot = atomicAdd(&cnt[qi], 1u);
                                                 // the buffer's address is made HERE from the kernel argument: hoisted out of the loop it
