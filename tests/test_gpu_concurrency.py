@@ -194,13 +194,14 @@ def test_fifty_opens_and_closes_reserve_no_new_address_space(oracle):
 def test_open_search_close_reopen_200_iterations():
     """the lifecycle in which two bench runs of round 5 died of a GPU memory fault -- a large index opened, searched at narrow
     and wide beams in every exact form, closed, another shape opened in the memory the first one left (the allocator's cache of freed
-    buffers, its remapped 1-GiB granules), the cache handed back every third time -- 200 times in one process, with host threads copying
-    pageable memory over PCIe meanwhile.  A stale mapping shows as a GPU fault (the process dies) or as exact forms that disagree.
+    buffers, its remapped 1-GiB granules), the cache handed back every third time -- 200 times in one process.  A stale mapping shows as a GPU fault (the process dies) or as exact forms that disagree.
     (index_bipartite.h:27,62-64,105,133: the reference's lifecycle is constructor / load / search / destructor, any number of times.)"""
     import os
     from benchlib.stress import lifecycle_stress
     iters = int(os.environ.get("RG_STRESS_ITERS", "200"))
-    r = lifecycle_stress(iters, scale=float(os.environ.get("RG_STRESS_SCALE", "0.8")), host_load=2)
+    # (host threads copying pageable memory meanwhile: RG_STRESS_HOST=N -- part of round 5's hypothesis, which round 6 ruled out; the default run
+    # does without them: they triple the test's time through the interpreter lock)
+    r = lifecycle_stress(iters, scale=float(os.environ.get("RG_STRESS_SCALE", "0.8")), host_load=int(os.environ.get("RG_STRESS_HOST", "0")))
     assert r["iterations"] == iters
 
 
