@@ -100,6 +100,11 @@ rg_status rg_index_open_mem(const float *base, uint32_t nd, uint32_t dim, uint32
 rg_status rg_index_open_dev(const float *d_base, uint32_t nd, uint32_t dim, uint32_t stride,
                             const uint64_t *d_offsets, const uint32_t *d_nbrs, uint32_t ep, int metric, int device,
                             rg_index **out);
+/* Empty destructor of the reference (index_bipartite.cpp:40); here the index's device buffers are released.  RETENTION: its large buffers
+ * (>= 2 GiB, built from 1-GiB granules spread over the memory classes) stay MAPPED in the allocator's cache -- up to min(64 GiB, a quarter
+ * of the device) per device, RG_MEM_CACHE_GIB -- so that the same index opened again maps nothing anew; rg_mem_release(device) hands that
+ * memory back to the device (another allocator in the process, e.g. torch's, cannot see it), and so does any allocation of this library
+ * that the device refuses. */
 void rg_index_close(rg_index *idx);
 rg_status rg_index_info(const rg_index *idx, uint32_t *nd, uint32_t *dim, uint32_t *stride, uint32_t *ep,
                         float *avg_degree, uint32_t *max_degree, int *device);

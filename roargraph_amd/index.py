@@ -80,6 +80,12 @@ class IndexBipartite:
             lib().rg_index_close(self.handle)
             self.handle = C.c_void_p()
 
+    @staticmethod
+    def release_device_cache(device=0):
+        """rg_mem_release: closed indexes leave their large buffers mapped in the library's cache (rg.h: rg_index_close); this hands that
+        memory back to the device -- call it before another allocator of the process (torch) needs the room."""
+        check(lib().rg_mem_release(C.c_int(device)))
+
     def __del__(self):
         try:
             self.close()
