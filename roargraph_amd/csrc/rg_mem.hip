@@ -201,7 +201,7 @@ void va_unmap(void *va, size_t bytes) {
 // A/B on one box (scripts/r06/walk_stress.py: the walk in a loop, torch and plain allocations churned between rounds;
 // profiles/r06/walk_stress_summary.txt): "leak" 5 of 5 runs died of `Memory access fault by GPU` within 2,100 granules, every time on a
 // granule whose address is 1-GiB aligned (one reservation in 512 is; large plain allocations sit at such addresses too: the signature of a
-// stale huge-page translation of the buffer that had the address before); arena 0 faults in 28,560 granules, ~55 of them GiB-aligned.
+// stale huge-page translation of the buffer that had the address before); arena 0 faults in 57,024 granules, ~110 of them GiB-aligned.
 enum VaMode { kVaLeak, kVaReuse, kVaFree, kVaArena };
 VaMode va_mode() {
     static const VaMode m = [] {

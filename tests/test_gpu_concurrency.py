@@ -230,7 +230,7 @@ def test_allocator_walk_under_address_churn():
     address ranges that plain hipMalloc'ed buffers occupied moments earlier, and the FIRST TOUCH of a granule mapped into such a range can
     fault (scripts/r06/walk_stress.py with RG_MEM_VA=leak, the address policy of rounds 4 - 5: 5 of 5 runs died within 2,100 granules,
     `Memory access fault by GPU` on a 1-GiB-aligned granule just mapped -- profiles/r06/walk_stress_summary.txt; with the arena of round 6 --
-    every address carved once from one range reserved when the pool is first used -- 0 faults in 28,560 granules).  Here: the same loop in
+    every address carved once from one range reserved when the pool is first used -- 0 faults in 57,024 granules).  Here: the same loop in
     the default (arena) mode for 30 s -- torch and plain allocations churned between rounds of 48 granules created, mapped, zeroed, probed
     and dropped.  A regression of the address policy kills the process."""
     import ctypes as C
